@@ -1,0 +1,31 @@
+# Build the gfx950 C-ABI library (the product) and the C oracle (test infrastructure).
+#   make lib      -> spatten_amd/lib/libspatten_hip.so
+#   make oracle   -> oracle/liboracle.so
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+CSRC := $(wildcard spatten_amd/csrc/*.hip)
+OBJS := $(patsubst spatten_amd/csrc/%.hip,build/%.o,$(CSRC))
+LIB := spatten_amd/lib/libspatten_hip.so
+
+all: lib oracle
+
+lib: $(LIB)
+
+build/%.o: spatten_amd/csrc/%.hip spatten_amd/csrc/common.h include/spatten.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p spatten_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle: oracle/liboracle.so
+
+oracle/liboracle.so: oracle/oracle.c
+	gcc -O3 -march=native -fopenmp -fPIC -shared -o $@ $< -lm
+
+clean:
+	rm -rf build $(LIB) oracle/liboracle.so
+
+.PHONY: all lib oracle clean

@@ -1,0 +1,187 @@
+/*
+ * spatten.h — C ABI of libspatten_hip.so: the MI355X (gfx950) implementation of the
+ * SpAtten cascade-pruned attention hot path.
+ *
+ * Every entry point takes plain device pointers, explicit shapes/strides (in ELEMENTS), a dtype
+ * enum and a hipStream_t (passed as void*).  Functions never allocate, never synchronise and never
+ * throw; they return 0 on success or a negative spatten_status_t.  All work is enqueued on `stream`.
+ *
+ * Reference interfaces each entry point replaces (paths relative to mit-han-lab/spatten):
+ *
+ *   spatten_attn_decode      spatten_llm/pos_shift/modify_llama.py:86-147 at q_len == 1
+ *                            (cache-relative RoPE of Q and of the whole un-rotated K cache, KV append,
+ *                            Q.K^T/sqrt(d), score stash :116-119, +mask, fp32 softmax, P.V, head merge)
+ *   spatten_attn_prefill     the same lines at q_len > 1 (causal or explicit additive mask)
+ *   spatten_rope_single      spatten_llm/pos_shift/modify_llama.py:21-28 (apply_rotary_pos_emb_single)
+ *   spatten_importance       spatten_llm/kv_cache_token_pruning.py:51   (stash.sum(0).sum(1))
+ *   spatten_topk_select      spatten_llm/kv_cache_token_pruning.py:59-63 (window top-k, sort, +start)
+ *   spatten_kv_compact       spatten_llm/kv_cache_token_pruning.py:64-96 (mask gather + 3-way concat)
+ *   spatten_prune_layers     the per-layer loop kv_cache_token_pruning.py:55-96 as ONE batched launch pair
+ *
+ * Entry points with no numeric counterpart in the reference ("parity unpinned": restated from the
+ * RTL control flow): spatten_importance_accumulate (cascade importance),
+ * spatten_head_scores, spatten_pq_pack / spatten_attn_decode_pq (progressive quantisation).
+ */
+#ifndef SPATTEN_H_
+#define SPATTEN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPATTEN_ABI_VERSION 1
+
+typedef enum {
+  SPATTEN_F32 = 0,
+  SPATTEN_F16 = 1,
+  SPATTEN_BF16 = 2
+} spatten_dtype_t;
+
+typedef enum {
+  SPATTEN_OK = 0,
+  SPATTEN_ERR_INVALID = -1,     /* bad pointer / shape / stride / dtype */
+  SPATTEN_ERR_UNSUPPORTED = -2, /* head_dim or size outside the compiled range */
+  SPATTEN_ERR_WINDOW = -3,      /* top-k window holds fewer than k candidates (reference: torch.topk RuntimeError) */
+  SPATTEN_ERR_LAUNCH = -4       /* hipLaunch failed; see hipGetLastError on the caller side */
+} spatten_status_t;
+
+int spatten_abi_version(void);
+const char* spatten_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------------
+ * Workspace.  Split-N decode keeps per-(b,h,split) partials (fp32) and one arrival counter per
+ * (b,h).  The caller allocates `spatten_decode_workspace_bytes` bytes ONCE, zero-fills it once
+ * (hipMemset) and may reuse it for every launch on the same stream (the kernel re-arms the
+ * counters itself).
+ * ---------------------------------------------------------------------------------------------- */
+size_t spatten_decode_workspace_bytes(int batch, int heads, int head_dim, int max_splits);
+/* Split count the library would pick for this shape (>=1).  `n_splits` <= 0 in the calls below means "auto". */
+int spatten_decode_auto_splits(int batch, int heads, int head_dim, int kv_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Decode attention (q_len == 1), fused:  modify_llama.py:86-147.
+ *
+ *   q        [B, H, d]            un-rotated query of the new token      (strides q_sb, q_sh; d contiguous)
+ *   k_cache  [B, Hkv, cap, d]     UN-rotated keys (modify_llama.py:100)  (strides kv_sb, kv_sh; rows contiguous, pitch d)
+ *   v_cache  [B, Hkv, cap, d]     values, same strides
+ *   k_new, v_new [B, Hkv, d]      optional (may be NULL): the new token's K/V rows; when given they are
+ *                                 appended IN PLACE at slot kv_len-1 (replaces torch.cat, :95-98) and used
+ *                                 for that slot; strides new_sb, new_sh
+ *   cos, sin [>= max(kv_len, pos_q+1), d/2]  rotary table in the model dtype (transformers 4.33
+ *                                 LlamaRotaryEmbedding rounds it with .to(x.dtype)); only the first half of
+ *                                 the d columns is stored because emb = cat(freqs, freqs)
+ *   table_rows  number of rows of cos/sin (positions are clamped to it for memory safety)
+ *   pos_q    rotary position of the query (HF passes past_len); key j is rotated at position j (:103-104)
+ *   position_ids optional int64 [B] (stride pos_sb) DEVICE pointer: per-batch query position, overrides
+ *            pos_q (what HF hands the forward as position_ids[:, 0]; no host sync needed to honour it)
+ *   mask     optional additive mask [B, kv_len] in the model dtype (the [B,1,1,N] HF mask squeezed), stride mask_sb
+ *   out      [B, H*d]             attn_output before o_proj, model dtype (:138-147), stride out_sb
+ *   scores   optional [B, H, kv_len] the stash: raw scaled logits BEFORE mask/softmax, rounded like the
+ *                                 reference (matmul -> dtype, /sqrt(d) -> dtype) (:111-119), strides sc_sb, sc_sh
+ *   lse      optional [B, H, 2] fp32: (row max of masked logits, sum exp(logit - max))  -> max prob = 1/sum
+ * ---------------------------------------------------------------------------------------------- */
+int spatten_attn_decode(int dtype,
+                        const void* q, int64_t q_sb, int64_t q_sh,
+                        void* k_cache, void* v_cache, int64_t kv_sb, int64_t kv_sh,
+                        const void* k_new, const void* v_new, int64_t new_sb, int64_t new_sh,
+                        const void* cos, const void* sin, int table_rows,
+                        const int64_t* position_ids, int64_t pos_sb,
+                        const void* mask, int64_t mask_sb,
+                        void* out, int64_t out_sb,
+                        void* scores, int64_t sc_sb, int64_t sc_sh,
+                        float* lse,
+                        void* workspace,
+                        int batch, int heads, int kv_heads, int head_dim,
+                        int kv_len, int pos_q, int n_splits,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Prefill attention (q_len >= 1), flash-style, same semantics as above for a block of queries.
+ * Two stages on `stream`: (1) rotate Q and the whole K cache into the workspace and lay V out
+ * key-contiguous for the matrix cores, (2) MFMA flash attention with online softmax.
+ *
+ *   q            [B, H, q_len, d]   un-rotated (strides q_sb, q_sh, q_sq; d contiguous) — the [B,q,H*d]
+ *                                   projection output viewed as [B,H,q,d] is accepted without a copy
+ *   k_cache/v_cache [B,Hkv,cap,d]   must ALREADY hold the q_len new rows at slots [kv_len-q_len, kv_len)
+ *   pos_q0       rotary position of query row 0 (row i uses pos_q0 + i) unless
+ *   position_ids optional int64 [B, q_len] DEVICE pointer (stride pos_sb, rows contiguous)
+ *   causal       1: HF causal mask (key j visible to row i iff j <= kv_len - q_len + i); 0: none
+ *   mask         optional additive [B, q_len, kv_len] in the model dtype (the [B,1,q,N] HF mask), strides
+ *                mask_sb, mask_sq; applied in addition to `causal`
+ *   out          [B, q_len, H*d]    (strides out_sb, out_sq)
+ *   scores       optional [B,H,q_len,kv_len] stash (strides sc_sb, sc_sh, sc_sq) — pre-mask, like the reference
+ *   col_importance optional [B,H,kv_len] fp32, ZERO-FILLED by the caller: += sum over query rows of the
+ *                stash column = the reference importance (kv_cache_token_pruning.py:51) without the stash
+ *   workspace    spatten_prefill_workspace_bytes(...) bytes of device scratch
+ * ---------------------------------------------------------------------------------------------- */
+size_t spatten_prefill_workspace_bytes(int dtype, int batch, int heads, int kv_heads, int head_dim,
+                                       int q_len, int kv_len);
+int spatten_attn_prefill(int dtype,
+                         const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sq,
+                         const void* k_cache, const void* v_cache, int64_t kv_sb, int64_t kv_sh,
+                         const void* cos, const void* sin, int table_rows,
+                         const int64_t* position_ids, int64_t pos_sb,
+                         const void* mask, int64_t mask_sb, int64_t mask_sq,
+                         void* out, int64_t out_sb, int64_t out_sq,
+                         void* scores, int64_t sc_sb, int64_t sc_sh, int64_t sc_sq,
+                         float* col_importance,
+                         void* workspace,
+                         int batch, int heads, int kv_heads, int head_dim,
+                         int q_len, int kv_len, int pos_q0, int causal,
+                         void* stream);
+
+/* apply_rotary_pos_emb_single (modify_llama.py:21-28): x [B,H,n,d] (strides x_sb, x_sh, x_sn; d contiguous)
+ * -> y [B,H,n,d] (strides y_sb, y_sh, y_sn); position_ids int64 [B,n] DEVICE pointer (stride pos_sb; pass
+ * pos_sb = 0 to broadcast one row; NULL = positions pos0 + i).  cos/sin are the [table_rows, d/2] half tables. */
+int spatten_rope_single(int dtype, const void* x, int64_t x_sb, int64_t x_sh, int64_t x_sn,
+                        void* y, int64_t y_sb, int64_t y_sh, int64_t y_sn,
+                        const void* cos, const void* sin, int table_rows,
+                        const int64_t* position_ids, int64_t pos_sb, int pos0,
+                        int batch, int heads, int n, int head_dim, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Prune event.
+ * ---------------------------------------------------------------------------------------------- */
+/* importance = stash.sum(0).sum(1): stash [B,H,q,L] (strides sb, sh, sq; L contiguous) -> out [H,L] (stride out_sh),
+ * model dtype, each of the two reductions accumulated in fp32 and rounded to the dtype (kv_cache_token_pruning.py:51). */
+int spatten_importance(int dtype, const void* stash, int64_t sb, int64_t sh, int64_t sq,
+                       void* out, int64_t out_sh, int batch, int heads, int q_len, int kv_len, void* stream);
+
+/* Per head h: the k largest of score[h, lo:hi) (ties at the k-th value: lowest index first), returned as
+ * ASCENDING absolute positions idx[h, 0..k) (int32, stride idx_sh).  score [H, >=hi] (stride score_sh).
+ * NaN ranks largest, -0 == +0 (torch.topk order).  Requires hi - lo >= k > 0 (else SPATTEN_ERR_WINDOW). */
+int spatten_topk_select(int dtype, const void* score, int64_t score_sh, int heads,
+                        int lo, int hi, int k, int32_t* idx, int64_t idx_sh, void* stream);
+
+/* Fused gather + concat (kv_cache_token_pruning.py:64-96): for X in (K, V)
+ *   dst[b,h,0:start]              = src[b,h,0:start]
+ *   dst[b,h,start:start+k]        = src[b,h,idx[h,:]]
+ *   dst[b,h,start+k:start+k+tail] = src[b,h,tail_lo:tail_lo+tail_len]
+ * src [B,H,L,d] (strides src_sb, src_sh), dst [B,H,cap',d] (strides dst_sb, dst_sh), rows contiguous (pitch d).
+ * v_src/v_dst may be NULL to move K only. */
+int spatten_kv_compact(int dtype, const void* k_src, const void* v_src, int64_t src_sb, int64_t src_sh,
+                       void* k_dst, void* v_dst, int64_t dst_sb, int64_t dst_sh,
+                       const int32_t* idx, int64_t idx_sh,
+                       int batch, int heads, int head_dim,
+                       int start, int k, int tail_lo, int tail_len, void* stream);
+
+/* The whole per-layer loop of apply_token_pruning (kv_cache_token_pruning.py:55-96) for `layers` layers in
+ * two launches (select, then gather).  Arrays of `layers` device pointers, themselves in DEVICE memory:
+ *   score_ptrs[l] -> [H, >=hi] model dtype (importance of layer l, stride score_sh)
+ *   k_src_ptrs/v_src_ptrs[l] -> [B,H,L,d] ; k_dst_ptrs/v_dst_ptrs[l] -> [B,H,cap',d]
+ *   idx [layers, H, k] int32 scratch/output (contiguous). */
+int spatten_prune_layers(int dtype, int layers,
+                         const void* const* score_ptrs, int64_t score_sh,
+                         const void* const* k_src_ptrs, const void* const* v_src_ptrs, int64_t src_sb, int64_t src_sh,
+                         void* const* k_dst_ptrs, void* const* v_dst_ptrs, int64_t dst_sb, int64_t dst_sh,
+                         int32_t* idx,
+                         int batch, int heads, int head_dim,
+                         int lo, int hi, int k, int tail_lo, int tail_len, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPATTEN_H_ */

@@ -1,0 +1,119 @@
+"""SpAttenKVCache — host-side mirror of the reference's KV-cache pruning object.
+
+Reference: spatten_llm/kv_cache_token_pruning.py:23-96.  Same constructor, attributes, method name,
+argument meaning and return conventions (None -> None, passthrough returns the SAME object, otherwise
+a new ``list[[K', V'], ...]``); the per-layer Python loop of torch.topk / sort / scatter / .cpu() /
+boolean gather / cat is replaced by two HIP launches covering every layer (``ops.prune_layers``):
+radix-select top-k that emits ascending positions directly, and one fused gather+concat of K and V.
+
+Documented divergences (reference quirks):
+  * batch > 1 and num_heads == 1 work (the reference's ``.squeeze()[mask]`` raises IndexError);
+  * ``important_size == 0`` raises ValueError (reference: TypeError at :63);
+  * a candidate window shorter than ``important_size`` raises ValueError (reference: torch.topk RuntimeError);
+  * ties exactly at the k-th score keep the LOWEST positions (torch's order there is unspecified);
+  * the returned tensors are views of slabs with spare capacity for ``num_coming`` tokens so the
+    attention forward can append in place instead of re-``cat``-ing the whole cache every token.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+
+def slice2d(x, start, end):
+    return x[:, :, start:end, ...]
+
+
+def slice3d(x, start, end):
+    return x[:, :, :, start:end, ...]
+
+
+def slice1d(x, start, end):
+    return x[:, start:end, ...]
+
+
+DIM_TO_SLICE = {1: slice1d, 2: slice2d, 3: slice3d}
+
+
+class SpAttenKVCache:
+    def __init__(self, start_size=4, recent_size=128, important_size=128, k_seq_dim=2, v_seq_dim=2):
+        # the reference prints this banner from its constructor (kv_cache_token_pruning.py:32)
+        print(f"SpAttenKVCache: keep start: {start_size}, keep recent: {recent_size}, keep important: {important_size}")
+        self.start_size = start_size
+        self.recent_size = recent_size
+        self.important_size = important_size
+        self.cache_size = start_size + important_size + recent_size
+        self.k_seq_dim = k_seq_dim
+        self.v_seq_dim = v_seq_dim
+        self.k_slice = DIM_TO_SLICE[k_seq_dim]
+        self.v_slice = DIM_TO_SLICE[v_seq_dim]
+        self.importance_score: Optional[List[torch.Tensor]] = None
+        self.keep_indices: Optional[torch.Tensor] = None      # int32 [layers, H, important] of the last prune
+        self.n_pruned_last = 0
+        self.n_pruned_total = 0
+
+    # -- pure host logic (unit-tested without a GPU) --------------------------------------------
+    def window(self, seq_len: int, num_coming: int):
+        """(lo, hi, tail_lo, new_len) of a prune at this length, Python-slice semantics of
+        ``score[:, start : seq_len - recent + num_coming]`` (kv_cache_token_pruning.py:59, 80-82)."""
+        lo = self.start_size
+        hi = min(seq_len - self.recent_size + num_coming, seq_len)
+        new_len = self.start_size + self.important_size + (seq_len - hi)
+        return lo, hi, hi, new_len
+
+    def needs_pruning(self, seq_len: int, num_coming: int) -> bool:
+        return seq_len + num_coming > self.cache_size                         # :46
+
+    def apply_token_pruning(self, past_key_values, num_coming, attn_score_all):
+        if past_key_values is None:                                           # :43-44
+            return None
+        seq_len = past_key_values[0][0].size(self.k_seq_dim)
+        if not self.needs_pruning(seq_len, num_coming):                       # :46-47
+            return past_key_values
+        if self.k_seq_dim != 2 or self.v_seq_dim != 2:
+            raise NotImplementedError("the HIP path implements the llama layout [B, H, L, d] (seq dim 2)")
+        if self.important_size <= 0:
+            raise ValueError("important_size must be > 0 on the pruning branch")
+        lo, hi, tail_lo, new_len = self.window(seq_len, num_coming)
+        if hi - lo < self.important_size:
+            raise ValueError(
+                f"top-k window [{lo},{hi}) holds fewer than important_size={self.important_size} candidates "
+                f"(seq_len={seq_len}, num_coming={num_coming})")
+        n_layers = len(past_key_values)
+        if len(attn_score_all) != n_layers:
+            raise ValueError("attn_score_all must hold one stash per layer")
+
+        # importance = stash.sum(0).sum(1)  (:51) — a view when B == q == 1 (decode stash)
+        self.importance_score = [ops.importance(s) for s in attn_score_all]
+        for s in self.importance_score:
+            if s.shape[1] < hi:
+                raise ValueError("attention-score stash is shorter than the KV cache")
+        scores = _common_rows(self.importance_score)
+        Ks = [_rows(kv[0]) for kv in past_key_values]
+        Vs = [_rows(kv[1]) for kv in past_key_values]
+        Ks, Vs = _common_strides(Ks, Vs)
+        Kn, Vn, idx = ops.prune_layers(scores, Ks, Vs, seq_len, lo, hi, self.important_size,
+                                       capacity=new_len + max(int(num_coming), 0))
+        self.keep_indices = idx
+        self.n_pruned_last = seq_len - new_len
+        self.n_pruned_total += self.n_pruned_last
+        return [[k, v] for k, v in zip(Kn, Vn)]                               # list of lists (:72-96)
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    return t if (t.stride(3) == 1 and t.stride(2) == t.shape[3]) else t.contiguous()
+
+
+def _common_strides(Ks: Sequence[torch.Tensor], Vs: Sequence[torch.Tensor]):
+    ref = Ks[0].stride()
+    if all(t.stride() == ref for t in list(Ks) + list(Vs)):
+        return list(Ks), list(Vs)
+    return [t.contiguous() for t in Ks], [t.contiguous() for t in Vs]
+
+
+def _common_rows(scores: Sequence[torch.Tensor]):
+    ok = all(s.stride(1) == 1 and s.stride(0) == scores[0].stride(0) for s in scores)
+    return list(scores) if ok else [s.contiguous() for s in scores]

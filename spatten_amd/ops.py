@@ -1,0 +1,298 @@
+"""torch-tensor front end of the C ABI (``include/spatten.h``).
+
+PyTorch is plumbing here: it owns device memory and the stream; every op below passes raw
+``data_ptr()``s, strides and ``torch.cuda.current_stream().cuda_stream`` to libspatten_hip.so.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"spatten_amd supports float32/float16/bfloat16, got {t.dtype}") from None
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("spatten_amd ops need ROCm device tensors (there is no CPU path in the product)")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+# rotary table in the model dtype, first d/2 columns (transformers 4.33 LlamaRotaryEmbedding)
+# ------------------------------------------------------------------------------------------------
+def rope_table(n: int, d: int, dtype: torch.dtype, device, base: float = 10000.0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """cos, sin [n, d/2] = the distinct half of the 4.33 table ``emb = cat(freqs, freqs)``
+    (modify_llama.py:89).  Computed in fp32 on the host CPU exactly like the reference module
+    (inv_freq, outer product, cos/sin, ``.to(dtype)``) and uploaded once."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, d, 2).float() / d))
+    t = torch.arange(n, dtype=torch.float32)
+    freqs = torch.einsum("i,j->ij", t, inv_freq)
+    return freqs.cos().to(dtype).to(device).contiguous(), freqs.sin().to(dtype).to(device).contiguous()
+
+
+class DecodeWorkspace:
+    """Split-N partials + arrival counters (zero-filled once, re-armed by the kernel)."""
+
+    def __init__(self, batch: int, heads: int, head_dim: int, device, max_splits: int = 64):
+        lib = _lib.load()
+        self.max_splits = max_splits
+        self.key = (batch, heads, head_dim)
+        nbytes = lib.spatten_decode_workspace_bytes(batch, heads, head_dim, max_splits)
+        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+
+
+_ws_cache = {}
+
+
+def _workspace(batch, heads, head_dim, device) -> DecodeWorkspace:
+    key = (batch, heads, head_dim, str(device), torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        ws = _ws_cache[key] = DecodeWorkspace(batch, heads, head_dim, device)
+    return ws
+
+
+def attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, kv_len: int,
+                cos: torch.Tensor, sin: torch.Tensor, pos_q: int,
+                k_new: Optional[torch.Tensor] = None, v_new: Optional[torch.Tensor] = None,
+                position_ids: Optional[torch.Tensor] = None,
+                mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                scores: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,
+                n_splits: int = 0, workspace: Optional[DecodeWorkspace] = None) -> torch.Tensor:
+    """Fused decode attention (modify_llama.py:86-147 at q_len=1).
+
+    q [B,H,d]; k_cache/v_cache [B,Hkv,cap,d] un-rotated with rows [0,kv_len) live (row kv_len-1 is
+    written from k_new/v_new [B,Hkv,d] when given); cos/sin [>=kv_len, d/2]; mask [B,kv_len];
+    position_ids optional int64 [B] device tensor (overrides pos_q without a host sync);
+    scores (stash) [B,H,>=kv_len]; returns out [B, H*d]."""
+    _dev(q, k_cache, v_cache, cos, sin, k_new, v_new, mask, out, scores, lse, position_ids)
+    if position_ids is not None and position_ids.dtype != torch.int64:
+        raise TypeError("position_ids must be int64")
+    lib = _lib.load()
+    B, H, d = q.shape
+    Hkv, cap = k_cache.shape[1], k_cache.shape[2]
+    if q.stride(2) != 1 or k_cache.stride(3) != 1 or k_cache.stride(2) != d or v_cache.stride() != k_cache.stride():
+        raise ValueError("q/k_cache/v_cache need contiguous rows (pitch d) and identical K/V strides")
+    if kv_len > cap or max(kv_len, pos_q + 1) > cos.shape[0] or cos.shape[1] * 2 != d:
+        raise ValueError("kv_len exceeds cache capacity or rotary table")
+    if out is None:
+        out = torch.empty(B, H * d, dtype=q.dtype, device=q.device)
+    if (k_new is None) != (v_new is None):
+        raise ValueError("k_new and v_new come together")
+    if k_new is not None and (k_new.stride(2) != 1 or v_new.stride() != k_new.stride()):
+        raise ValueError("k_new/v_new need contiguous rows")
+    if mask is not None and mask.stride(-1) != 1:
+        raise ValueError("mask rows must be contiguous")
+    ws = workspace or _workspace(B, H, d, q.device)
+    if n_splits > ws.max_splits:
+        raise ValueError("n_splits exceeds workspace")
+    rc = lib.spatten_attn_decode(
+        _dt(q), q.data_ptr(), q.stride(0), q.stride(1),
+        k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(0), k_cache.stride(1),
+        _ptr(k_new), _ptr(v_new), 0 if k_new is None else k_new.stride(0), 0 if k_new is None else k_new.stride(1),
+        cos.data_ptr(), sin.data_ptr(), cos.shape[0],
+        _ptr(position_ids), 0 if position_ids is None else position_ids.stride(0),
+        _ptr(mask), 0 if mask is None else mask.stride(0),
+        out.data_ptr(), out.stride(0),
+        _ptr(scores), 0 if scores is None else scores.stride(0), 0 if scores is None else scores.stride(1),
+        _ptr(lse), ws.buf.data_ptr(),
+        B, H, Hkv, d, kv_len, pos_q, n_splits, _stream())
+    _lib.check(rc, "spatten_attn_decode")
+    return out
+
+
+_pf_ws = {}
+
+
+def _prefill_workspace(nbytes: int, device) -> torch.Tensor:
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    buf = _pf_ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _pf_ws[key] = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+    return buf
+
+
+def attn_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, kv_len: int,
+                 cos: torch.Tensor, sin: torch.Tensor, pos_q0: int, causal: bool = True,
+                 position_ids: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None, scores: Optional[torch.Tensor] = None,
+                 col_importance: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Flash-style prefill (modify_llama.py:86-147 at q_len>1).  q [B,H,q,d] (any strides with d
+    contiguous); caches already hold the q new rows at [kv_len-q, kv_len); mask additive [B,q,kv_len];
+    position_ids int64 [B,q].  Returns out [B, q, H*d]."""
+    _dev(q, k_cache, v_cache, cos, sin, out, scores, col_importance, position_ids, mask)
+    lib = _lib.load()
+    B, H, ql, d = q.shape
+    Hkv = k_cache.shape[1]
+    if q.stride(3) != 1 or k_cache.stride(3) != 1 or k_cache.stride(2) != d or v_cache.stride() != k_cache.stride():
+        raise ValueError("q needs contiguous d; k_cache/v_cache need contiguous rows (pitch d)")
+    if max(kv_len, pos_q0 + ql) > cos.shape[0] and position_ids is None:
+        raise ValueError("rotary table too short")
+    if position_ids is not None and (position_ids.dtype != torch.int64 or position_ids.stride(-1) != 1):
+        raise TypeError("position_ids must be int64 with contiguous rows")
+    if mask is not None and (mask.stride(-1) != 1 or mask.dtype != q.dtype):
+        raise ValueError("mask must be in the model dtype with contiguous rows")
+    if out is None:
+        out = torch.empty(B, ql, H * d, dtype=q.dtype, device=q.device)
+    ws = _prefill_workspace(lib.spatten_prefill_workspace_bytes(_dt(q), B, H, Hkv, d, ql, kv_len), q.device)
+    rc = lib.spatten_attn_prefill(
+        _dt(q), q.data_ptr(), q.stride(0), q.stride(1), q.stride(2),
+        k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(0), k_cache.stride(1),
+        cos.data_ptr(), sin.data_ptr(), cos.shape[0],
+        _ptr(position_ids), 0 if position_ids is None else (position_ids.stride(0) if position_ids.shape[0] > 1 else 0),
+        _ptr(mask), *((0, 0) if mask is None else (mask.stride(0), mask.stride(1))),
+        out.data_ptr(), out.stride(0), out.stride(1),
+        _ptr(scores), *((0, 0, 0) if scores is None else (scores.stride(0), scores.stride(1), scores.stride(2))),
+        _ptr(col_importance), ws.data_ptr(),
+        B, H, Hkv, d, ql, kv_len, pos_q0, int(causal), _stream())
+    _lib.check(rc, "spatten_attn_prefill")
+    return out
+
+
+def rope_single(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                position_ids: Optional[torch.Tensor] = None, pos0: int = 0) -> torch.Tensor:
+    """apply_rotary_pos_emb_single (modify_llama.py:21-28); x [B,H,n,d] (d contiguous, any other
+    strides); cos/sin are the [rows, d/2] half tables; position_ids int64 [B,n] or [1,n] or None."""
+    _dev(x, cos, sin, position_ids)
+    lib = _lib.load()
+    B, H, n, d = x.shape
+    if x.stride(3) != 1:
+        x = x.contiguous()
+    y = torch.empty(B, H, n, d, dtype=x.dtype, device=x.device)
+    pos_sb = 0
+    if position_ids is not None:
+        if position_ids.dim() == 1:
+            position_ids = position_ids[None]
+        position_ids = position_ids.to(torch.int64)
+        if position_ids.stride(-1) != 1:
+            position_ids = position_ids.contiguous()
+        pos_sb = position_ids.stride(0) if position_ids.shape[0] > 1 else 0
+    rc = lib.spatten_rope_single(_dt(x), x.data_ptr(), x.stride(0), x.stride(1), x.stride(2),
+                                 y.data_ptr(), y.stride(0), y.stride(1), y.stride(2),
+                                 cos.data_ptr(), sin.data_ptr(), cos.shape[0],
+                                 _ptr(position_ids), pos_sb, pos0, B, H, n, d, _stream())
+    _lib.check(rc, "spatten_rope_single")
+    return y
+
+
+def importance(stash: torch.Tensor) -> torch.Tensor:
+    """stash [B,H,q,L] -> [H,L] = stash.sum(0).sum(1) (kv_cache_token_pruning.py:51)."""
+    _dev(stash)
+    B, H, Q, L = stash.shape
+    if B == 1 and Q == 1:
+        return stash[0, :, 0, :]          # the two sums are identities; a view, like the values torch returns
+    lib = _lib.load()
+    if stash.stride(3) != 1:
+        stash = stash.contiguous()
+    out = torch.empty(H, L, dtype=stash.dtype, device=stash.device)
+    rc = lib.spatten_importance(_dt(stash), stash.data_ptr(), stash.stride(0), stash.stride(1), stash.stride(2),
+                                out.data_ptr(), out.stride(0), B, H, Q, L, _stream())
+    _lib.check(rc, "spatten_importance")
+    return out
+
+
+def topk_select(score: torch.Tensor, lo: int, hi: int, k: int) -> torch.Tensor:
+    """score [H, L] -> int32 [H, k]: ascending absolute positions of the k largest of score[:, lo:hi]
+    (kv_cache_token_pruning.py:59-63; ties at the k-th value: lowest index first)."""
+    _dev(score)
+    lib = _lib.load()
+    H, L = score.shape
+    hi = min(hi, L)
+    if score.stride(1) != 1:
+        score = score.contiguous()
+    idx = torch.empty(H, max(k, 0), dtype=torch.int32, device=score.device)
+    rc = lib.spatten_topk_select(_dt(score), score.data_ptr(), score.stride(0), H, lo, hi, k,
+                                 idx.data_ptr(), idx.stride(0), _stream())
+    _lib.check(rc, "spatten_topk_select")
+    return idx
+
+
+def kv_compact(K: torch.Tensor, V: Optional[torch.Tensor], idx: torch.Tensor, start: int, tail_lo: int,
+               L: Optional[int] = None, capacity: Optional[int] = None):
+    """Fused gather + concat (kv_cache_token_pruning.py:64-96).  K,V [B,H,>=L,d]; idx int32 [H,k].
+    Returns (K', V') [B,H,L',d] views of freshly allocated [B,H,capacity,d] slabs."""
+    _dev(K, V, idx)
+    lib = _lib.load()
+    B, H, Lk, d = K.shape
+    L = Lk if L is None else L
+    k = idx.shape[1]
+    tail_lo = min(max(tail_lo, 0), L)
+    tail_len = L - tail_lo
+    Lp = start + k + tail_len
+    cap = max(capacity or Lp, Lp)
+    if K.stride(3) != 1 or K.stride(2) != d or (V is not None and V.stride() != K.stride()):
+        raise ValueError("K/V need contiguous rows and identical strides")
+    Kd = torch.empty(B, H, cap, d, dtype=K.dtype, device=K.device)
+    Vd = torch.empty_like(Kd) if V is not None else None
+    rc = lib.spatten_kv_compact(_dt(K), K.data_ptr(), _ptr(V), K.stride(0), K.stride(1),
+                                Kd.data_ptr(), _ptr(Vd), Kd.stride(0), Kd.stride(1),
+                                idx.data_ptr(), idx.stride(0), B, H, d, start, k, tail_lo, tail_len, _stream())
+    _lib.check(rc, "spatten_kv_compact")
+    return Kd[:, :, :Lp], (None if Vd is None else Vd[:, :, :Lp])
+
+
+class PrunePlan:
+    """Device pointer tables for the batched all-layer prune (spatten_prune_layers)."""
+
+    def __init__(self, scores: Sequence[torch.Tensor], Ks, Vs, Kd, Vd):
+        dev = Ks[0].device
+        mk = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64).to(dev)
+        self.score_ptrs, self.ks, self.vs, self.kd, self.vd = mk(scores), mk(Ks), mk(Vs), mk(Kd), mk(Vd)
+        self.keep = (list(scores), list(Ks), list(Vs), list(Kd), list(Vd))
+
+
+def prune_layers(scores: Sequence[torch.Tensor], Ks: Sequence[torch.Tensor], Vs: Sequence[torch.Tensor],
+                 L: int, lo: int, hi: int, k: int, capacity: Optional[int] = None,
+                 dst: Optional[Tuple[List[torch.Tensor], List[torch.Tensor]]] = None,
+                 plan: Optional[PrunePlan] = None, idx: Optional[torch.Tensor] = None):
+    """All layers of apply_token_pruning's loop (kv_cache_token_pruning.py:55-96) in two launches.
+    scores[l] [H, >=hi]; Ks[l]/Vs[l] [B,H,>=L,d].  Returns (K' list, V' list, idx [layers,H,k])."""
+    _dev(*scores, *Ks, *Vs)
+    lib = _lib.load()
+    nl = len(Ks)
+    B, H, _, d = Ks[0].shape
+    hi = min(hi, L)
+    tail_lo = hi
+    tail_len = L - tail_lo
+    Lp = lo + k + tail_len
+    cap = max(capacity or Lp, Lp)
+    if dst is None:
+        Kd = [torch.empty(B, H, cap, d, dtype=Ks[0].dtype, device=Ks[0].device) for _ in range(nl)]
+        Vd = [torch.empty_like(x) for x in Kd]
+    else:
+        Kd, Vd = dst
+    for t in list(Ks) + list(Vs) + Kd + Vd:
+        if t.stride(3) != 1 or t.stride(2) != d:
+            raise ValueError("K/V need contiguous rows (pitch d)")
+    if any(t.stride() != Ks[0].stride() for t in list(Ks) + list(Vs)) or any(t.stride() != Kd[0].stride() for t in Kd + Vd):
+        raise ValueError("all layers must share strides")
+    if any(s.stride(1) != 1 or s.stride(0) != scores[0].stride(0) for s in scores):
+        raise ValueError("scores need contiguous rows and a common head stride")
+    if plan is None:
+        plan = PrunePlan(scores, Ks, Vs, Kd, Vd)
+    if idx is None:
+        idx = torch.empty(nl, H, k, dtype=torch.int32, device=Ks[0].device)
+    rc = lib.spatten_prune_layers(_dt(Ks[0]), nl, plan.score_ptrs.data_ptr(), scores[0].stride(0),
+                                  plan.ks.data_ptr(), plan.vs.data_ptr(), Ks[0].stride(0), Ks[0].stride(1),
+                                  plan.kd.data_ptr(), plan.vd.data_ptr(), Kd[0].stride(0), Kd[0].stride(1),
+                                  idx.data_ptr(), B, H, d, lo, hi, k, tail_lo, tail_len, _stream())
+    _lib.check(rc, "spatten_prune_layers")
+    return [x[:, :, :Lp] for x in Kd], [x[:, :, :Lp] for x in Vd], idx
