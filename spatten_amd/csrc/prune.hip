@@ -65,7 +65,8 @@ __global__ __launch_bounds__(kSelThreads) void topk_select_kernel(const SelectPa
   const int W = p.hi - p.lo;
 
   // ---- radix select: the key of the k-th largest element ----------------------------------------
-  constexpr int kPasses = DT<T>::k16 ? 2 : 4;   // 16-bit dtypes only populate the top 16 key bits
+  // fp32 keys of bf16 values populate the top 16 bits, of f16 values the top 19 (1+8+10), fp32 all 32
+  constexpr int kPasses = sizeof(T) == 4 ? 4 : (DT<T>::kId == SPATTEN_BF16 ? 2 : 3);
   unsigned prefix = 0, pmask = 0;
   unsigned k_rem = (unsigned)p.k;
 #pragma unroll 1
