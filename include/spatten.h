@@ -65,12 +65,17 @@ int spatten_decode_auto_splits(int batch, int heads, int head_dim, int kv_len);
  * Decode attention (q_len == 1), fused:  modify_llama.py:86-147.
  *
  *   q        [B, H, d]            un-rotated query of the new token      (strides q_sb, q_sh; d contiguous)
- *   k_cache  [B, Hkv, cap, d]     UN-rotated keys (modify_llama.py:100)  (strides kv_sb, kv_sh; rows contiguous, pitch d)
+ *   k_cache  [B, Hkv, cap, d]     UN-rotated keys (modify_llama.py:100)  (strides kv_sb, kv_sh; rows contiguous,
+ *                                 pitch d).  Only WRITTEN (append of the new row); may be NULL when k_new is NULL
+ *   kr_cache [B, Hkv, cap, d]     rotated shadow: row j = apply_rotary_pos_emb_single(k_cache row j, position j)
+ *                                 (modify_llama.py:103-104), valid for rows [0, kv_len - (k_new ? 1 : 0)); built with
+ *                                 spatten_rope_single, kept current by this call's append.  Same strides
  *   v_cache  [B, Hkv, cap, d]     values, same strides
- *   k_new, v_new [B, Hkv, d]      optional (may be NULL): the new token's K/V rows; when given they are
- *                                 appended IN PLACE at slot kv_len-1 (replaces torch.cat, :95-98) and used
- *                                 for that slot; strides new_sb, new_sh
- *   cos, sin [>= max(kv_len, pos_q+1), d/2]  rotary table in the model dtype (transformers 4.33
+ *   k_new, v_new [B, Hkv, d]      optional (may be NULL): the new token's un-rotated K/V rows; when given they
+ *                                 are appended IN PLACE at slot kv_len-1 of k_cache / v_cache (replaces torch.cat,
+ *                                 :95-98), the rotated row goes to kr_cache, and they are used for that slot;
+ *                                 strides new_sb, new_sh
+ *   cos, sin [table_rows >= max(kv_len, pos_q+1), d/2]  rotary table in the model dtype (transformers 4.33
  *                                 LlamaRotaryEmbedding rounds it with .to(x.dtype)); only the first half of
  *                                 the d columns is stored because emb = cat(freqs, freqs)
  *   table_rows  number of rows of cos/sin (positions are clamped to it for memory safety)
@@ -85,7 +90,7 @@ int spatten_decode_auto_splits(int batch, int heads, int head_dim, int kv_len);
  * ---------------------------------------------------------------------------------------------- */
 int spatten_attn_decode(int dtype,
                         const void* q, int64_t q_sb, int64_t q_sh,
-                        void* k_cache, void* v_cache, int64_t kv_sb, int64_t kv_sh,
+                        void* k_cache, void* kr_cache, void* v_cache, int64_t kv_sb, int64_t kv_sh,
                         const void* k_new, const void* v_new, int64_t new_sb, int64_t new_sh,
                         const void* cos, const void* sin, int table_rows,
                         const int64_t* position_ids, int64_t pos_sb,

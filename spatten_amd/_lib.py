@@ -31,7 +31,7 @@ def _declare(lib):
     lib.spatten_decode_auto_splits.argtypes = [i, i, i, i]
     lib.spatten_attn_decode.restype = c_int
     lib.spatten_attn_decode.argtypes = [
-        i, p, i64, i64, p, p, i64, i64, p, p, i64, i64, p, p, i, p, i64, p, i64, p, i64, p, i64, i64, p, p,
+        i, p, i64, i64, p, p, p, i64, i64, p, p, i64, i64, p, p, i, p, i64, p, i64, p, i64, p, i64, i64, p, p,
         i, i, i, i, i, i, i, p]
     lib.spatten_prefill_workspace_bytes.restype = c_size_t
     lib.spatten_prefill_workspace_bytes.argtypes = [i, i, i, i, i, i, i]

@@ -125,20 +125,95 @@ template <> struct Vec8<f16_t> {
 };
 
 // ------------------------------------------------------------------------------------------------
-// wave64 reductions
+// wave64 cross-lane helpers.  DPP / permlane-swap forms run at VALU rate (a ds_bpermute shuffle is an
+// LDS round trip of ~100+ cycles, which is what a latency-bound decode kernel cannot afford).
 // ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ inline float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+constexpr int kDppXor1 = 0xB1;         // quad_perm:[1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm:[2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // lane i <-> 7-i within 8
+constexpr int kDppMirror = 0x140;      // lane i <-> 15-i within 16
+constexpr int kDppRor4 = 0x124;        // rotate right by 4 within 16
+constexpr int kDppRor8 = 0x128;        // rotate right by 8 within 16 (== xor 8)
+
+// sum over aligned groups of WIDTH lanes (4, 8 or 16); every lane of the group gets the total
 template <int WIDTH>
-__device__ inline float group_sum(float v) {  // sum over aligned groups of WIDTH lanes (power of 2)
-#pragma unroll
-  for (int off = WIDTH / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+__device__ inline float group_sum(float v) {
+  static_assert(WIDTH == 4 || WIDTH == 8 || WIDTH == 16, "group width");
+  v += dpp_mov<kDppXor1>(v);
+  v += dpp_mov<kDppXor2>(v);
+  if (WIDTH >= 8) v += dpp_mov<kDppHalfMirror>(v);
+  if (WIDTH >= 16) v += dpp_mov<kDppMirror>(v);
   return v;
+}
+// x[i] + x[i^16] and x[i] + x[i^32] in every lane (gfx950 v_permlane16_swap / v_permlane32_swap)
+__device__ inline float xor16_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ inline float xor32_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ inline float xor16_max(float x) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ inline float xor32_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ inline float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
-  return v;
+  v = fmaxf(v, dpp_mov<kDppXor1>(v));
+  v = fmaxf(v, dpp_mov<kDppXor2>(v));
+  v = fmaxf(v, dpp_mov<kDppHalfMirror>(v));
+  v = fmaxf(v, dpp_mov<kDppMirror>(v));
+  return xor32_max(xor16_max(v));
 }
-__device__ inline float wave_sum(float v) { return group_sum<64>(v); }
+__device__ inline float wave_sum(float v) { return xor32_sum(xor16_sum(group_sum<16>(v))); }
+
+// dot product of 8 packed model-dtype pairs with fp32 accumulation (v_dot2c_f32_bf16 / v_dot2_f32_f16)
+template <typename T> struct Dot8;
+template <> struct Dot8<float> {
+  using packed = Vec8<float>::raw;
+  __device__ static inline packed pack(const float (&v)[8]) { return Vec8<float>::pack(v); }
+  __device__ static inline float dot(const packed& a, const packed& b, float acc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc = fmaf(a.a[i], b.a[i], acc); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc = fmaf(a.b[i], b.b[i], acc); }
+    return acc;
+  }
+};
+template <> struct Dot8<bf16_t> {
+  using packed = u32x4;
+  typedef bf16_t bf2 __attribute__((ext_vector_type(2)));
+  __device__ static inline packed pack(const float (&v)[8]) { return Vec8<bf16_t>::pack(v); }
+  __device__ static inline float dot(const packed& a, const packed& b, float acc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t x = a[i], y = b[i];
+      acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<bf2*>(&x), *reinterpret_cast<bf2*>(&y), acc, false);
+    }
+    return acc;
+  }
+};
+template <> struct Dot8<f16_t> {
+  using packed = u32x4;
+  typedef f16_t h2 __attribute__((ext_vector_type(2)));
+  __device__ static inline packed pack(const float (&v)[8]) { return Vec8<f16_t>::pack(v); }
+  __device__ static inline float dot(const packed& a, const packed& b, float acc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t x = a[i], y = b[i];
+      acc = __builtin_amdgcn_fdot2(*reinterpret_cast<h2*>(&x), *reinterpret_cast<h2*>(&y), acc, false);
+    }
+    return acc;
+  }
+};
 
 // Monotone fp32 -> uint32 key: larger value => larger key, NaN largest, -0 == +0.
 // This is the total order torch.topk(largest=True) ranks by.

@@ -1,55 +1,62 @@
-// decode_attn.hip — fused single-token attention over an un-rotated, per-head-pruned KV cache.
+// decode_attn.hip — fused single-token (or few-token) attention over a per-head-pruned KV cache.
 //
-// Replaces modify_llama.py:86-147 at q_len == 1 (reference = ~25 eager torch ops per layer):
+// Replaces modify_llama.py:86-147 at small q_len (reference = ~25 eager torch ops per layer):
 //   RoPE(Q @ pos_q) · RoPE(K_j @ j)^T / sqrt(d)  -> stash (pre-mask)  -> +mask -> fp32 softmax -> P·V
 // with the new token's K/V row appended in place (replaces torch.cat, :95-98).
 //
-// Shape of the problem (C2: B=1, H=32, d=128, n=2048 kept rows, bf16): 32 MiB of K+V per layer, 67 MFLOP
+// Rotated shadow.  The reference re-rotates the WHOLE un-rotated K cache on every step because key
+// positions are cache-relative (:100-104).  Between two prune events the position of a cached key (its
+// slot) never changes, so its rotated row is constant: the cache keeps, next to the un-rotated K the
+// reference's API hands around, a rotated shadow Kr (same layout, model dtype, rounded exactly like the
+// reference's three RoPE ops).  Decode streams Kr and V once and touches K only to append the new row;
+// the shadow is rebuilt (rope kernel / fused into the compaction) after a prune, when slots move.
+// This trades HBM capacity (3 instead of 2 planes; 288 GB per MI355X) for ~4x less VALU work and no
+// rotary-table traffic in the per-token kernel.
+//
+// Shape of the problem (C2: B=1, H=32, d=128, n=2048 kept rows, bf16): 32 MiB of Kr+V per layer, 67 MFLOP
 // -> HBM-bound (1 FLOP/B).  No MFMA: a 1xd by dxn product has no reuse to feed a matrix core with.
 //
 // Mapping (wave64, 256-thread workgroups):
-//   grid = B*H*S workgroups; workgroup (b,h,s) owns `chunk` consecutive keys of head h (split-N so that
-//   32 heads still fill 256 CUs).  A row of d elements is covered by LPR = d/16 lanes; lane c of a row
-//   holds elements [8c,8c+8) and [d/2+8c, d/2+8c+8) — the two halves RoPE pairs up — so the rotation
-//   needs no cross-lane traffic, and every global access is a 16-byte load of a fully used 128-byte
-//   line (K/V rows are contiguous, pitch d).
-//   A tile = UNR row-groups; all K, V, cos, sin loads of a tile are issued before the first use so one
-//   workgroup keeps ~64 KiB of HBM reads in flight; 2-3 workgroups per CU overlap compute with loads.
-//   Softmax is online across tiles (running max / sum), partial (o, m, l) per split goes to a small fp32
-//   workspace; the LAST split to arrive for a (b,h) merges the partials (ticket counter, write-through
-//   stores + agent-scope loads, no second launch).
+//   grid = (B*H*S, n_q) workgroups; workgroup (b,h,s) owns `chunk` consecutive keys of head h (split-N so
+//   that 32 heads still fill 256 CUs).  A row of d elements is covered by LPR = d/16 lanes; lane c holds
+//   elements [8c,8c+8) and [d/2+8c, d/2+8c+8) — the two halves RoPE pairs up — so rotating the query and
+//   the appended key needs no cross-lane traffic, and every global access is a 16-byte load of a fully
+//   used 128-byte line (rows are contiguous, pitch d).
+//   A tile = UNR row-groups; all loads of a tile are issued before the first use.  Softmax is online
+//   across tiles; per-split partials (o, m, l) go to a small fp32 workspace and the LAST split to arrive
+//   for a (b,h) merges them (ticket counter; write-through stores + agent-scope loads, one round trip).
 //
-// Rounding: in the 16-bit dtypes the reference rounds after every torch op; the kernel reproduces those
-// roundings for everything that feeds the stash (x*cos, rot*sin, their sum, matmul result, /sqrt(d)) so
-// stash values — the input of the top-k — match the reference except where fp32 accumulation ORDER
-// moves a value across a rounding boundary.  P is NOT rounded to the model dtype before P·V (it would
-// need the global softmax denominator before the first V row); documented tolerance in tests.
+// Rounding: in the 16-bit dtypes the reference rounds after every torch op; everything that feeds the
+// stash is reproduced (rotations, matmul result -> dtype, /sqrt(d) -> dtype) so stash values — the input
+// of the top-k — match the reference except where fp32 accumulation ORDER moves a value across a
+// rounding boundary.  P is NOT rounded to the model dtype before P·V (it would need the global softmax
+// denominator before the first V row); tolerance stated in tests/util.py.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace spatten {
 
 template <typename T>
 struct DecodeParams {
-  const T* q; int64_t q_sb, q_sh;
-  T* kc; T* vc; int64_t kv_sb, kv_sh;
+  const T* q; int64_t q_sb, q_sh, q_sq;
+  T* kc; T* krc; T* vc; int64_t kv_sb, kv_sh;
   const T* k_new; const T* v_new; int64_t new_sb, new_sh;
   const T* cos; const T* sin; int table_rows;
   const int64_t* pos_ids; int64_t pos_sb;
-  const T* mask; int64_t mask_sb;
-  T* out; int64_t out_sb;
-  T* scores; int64_t sc_sb, sc_sh;
+  const T* mask; int64_t mask_sb, mask_sq;
+  T* out; int64_t out_sb, out_sq;
+  T* scores; int64_t sc_sb, sc_sh, sc_sq;
   float* lse;
-  float* ws_part;       // [B*H, S, D+2]
-  unsigned* ws_cnt;     // [B*H]
-  int B, H, Hkv, N, pos_q, S, chunk;
+  unsigned long long* ws_part;   // [B*H*n_q, S, D+2] {value, tag} granules
+  unsigned* ws_cnt;     // [B*H*n_q]
+  int B, H, Hkv, N, pos_q, S, chunk, n_q, causal;
   float sqrt_d;
 };
 
 constexpr int kDecodeThreads = 256;
-// row-groups per tile: 4 for the 16-bit dtypes (6 x 16 B in flight per row-group and lane), 2 for fp32
-template <typename T> constexpr int decode_unr() { return sizeof(T) == 4 ? 2 : 4; }
 
-template <typename T, int D>
+template <typename T>
 __device__ inline void rope_pair(const float (&xlo)[8], const float (&xhi)[8], const float (&c)[8],
                                  const float (&s)[8], float (&ylo)[8], float (&yhi)[8]) {
   // y = x*cos + rotate_half(x)*sin with rotate_half(x) = cat(-x[d/2:], x[:d/2])   (modify_llama.py:21-28)
@@ -66,19 +73,25 @@ __device__ inline void rope_pair(const float (&xlo)[8], const float (&xhi)[8], c
   }
 }
 
-template <typename T, int D>
+// one 8-byte {value, tag} granule of a published partial (tag != 0 <=> the value has landed)
+__device__ inline void store_granule(unsigned long long* g, float v) {
+  __hip_atomic_store(g, ((unsigned long long)1u << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T, int D, int UNR>
 __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const DecodeParams<T> p) {
   constexpr int LPR = D / 16;                    // lanes per row
   constexpr int RPI = kDecodeThreads / LPR;      // rows per iteration of the workgroup
-  constexpr int UNR = decode_unr<T>();
   constexpr int TILE = RPI * UNR;
   constexpr int HALF = D / 2;
+  constexpr int G = (kDecodeThreads / D) > 0 ? (kDecodeThreads / D) : 1;   // merge thread groups
   using V8 = Vec8<T>;
   using raw_t = typename V8::raw;
+  using D8 = Dot8<T>;
 
-  __shared__ float s_stash[TILE];
   __shared__ float s_red[4];
-  __shared__ float s_o[4][D + 1];
+  __shared__ float s_o[4][D + 2];
   __shared__ unsigned s_ticket;
 
   const int tid = threadIdx.x;
@@ -87,122 +100,131 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
   const int wave = tid / kWave;
   const int lane = tid % kWave;
 
-  const int split = blockIdx.x % p.S;
-  const int bh = blockIdx.x / p.S;
-  const int h = bh % p.H;
-  const int b = bh / p.H;
-  const int hkv = h / (p.H / p.Hkv);
+  // grid = (S, H, B * n_q): no integer divisions on the way to the first load
+  const int split = blockIdx.x;
+  const int h = blockIdx.y;
+  const int b = p.n_q == 1 ? (int)blockIdx.z : (int)blockIdx.z / p.n_q;
+  const int qi = p.n_q == 1 ? 0 : (int)blockIdx.z - b * p.n_q;
+  const int hkv = p.Hkv == p.H ? h : h / (p.H / p.Hkv);
+  const int unit = (b * p.H + h) * p.n_q + qi;   // one softmax row
 
+  // keys this query may attend to (HF causal: j <= P + i with P = N - n_q); the stash covers all N
+  const int n_vis = p.causal ? min(p.N, p.N - p.n_q + qi + 1) : p.N;
   const int lo = split * p.chunk;
-  const int hi = min(lo + p.chunk, p.N);
+  const int hi = min(lo + p.chunk, (p.scores != nullptr) ? p.N : n_vis);
 
-  // ---- rotated query (registers): elements [8c,8c+8) and [HALF+8c, HALF+8c+8) --------------------
-  float qlo[8], qhi[8];
-  {
-    const T* qp = p.q + b * p.q_sb + h * p.q_sh;
-    float xlo[8], xhi[8], cc[8], ss[8];
-    V8::unpack(V8::ldg(qp + 8 * c), xlo);
-    V8::unpack(V8::ldg(qp + HALF + 8 * c), xhi);
-    int pq = p.pos_ids ? (int)p.pos_ids[b * p.pos_sb] : p.pos_q;
-    pq = min(max(pq, 0), p.table_rows - 1);
-    V8::unpack(V8::ldg(p.cos + (int64_t)pq * HALF + 8 * c), cc);
-    V8::unpack(V8::ldg(p.sin + (int64_t)pq * HALF + 8 * c), ss);
-    rope_pair<T, D>(xlo, xhi, cc, ss, qlo, qhi);
-  }
-
-  T* kbase = p.kc + b * p.kv_sb + hkv * p.kv_sh;
+  T* krbase = p.krc + b * p.kv_sb + hkv * p.kv_sh;
   T* vbase = p.vc + b * p.kv_sb + hkv * p.kv_sh;
-  const bool has_new = (p.k_new != nullptr);
+  const bool owns_new = (p.k_new != nullptr) && lo < p.N && hi == p.N;   // this workgroup appends row N-1
 
+  // ---- loads of the first tile go out before anything else --------------------------------------
+  raw_t k_lo[UNR], k_hi[UNR], v_lo[UNR], v_hi[UNR];
+  auto issue_tile = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      int j = t0 + u * RPI + r;
+      j = j < hi ? j : hi - 1;
+      const T* kp = krbase + (int64_t)j * D;
+      const T* vp = vbase + (int64_t)j * D;
+      if (owns_new && j == p.N - 1) {   // the token being appended: source = k_new / v_new (un-rotated)
+        kp = p.k_new + b * p.new_sb + hkv * p.new_sh;
+        vp = p.v_new + b * p.new_sb + hkv * p.new_sh;
+      }
+      k_lo[u] = V8::ldg(kp + 8 * c);
+      k_hi[u] = V8::ldg(kp + HALF + 8 * c);
+      v_lo[u] = V8::ldg(vp + 8 * c);
+      v_hi[u] = V8::ldg(vp + HALF + 8 * c);
+    }
+  };
+  if (lo < hi) issue_tile(lo);
+
+  // ---- un-rotated query + its table row ----------------------------------------------------------
+  typename D8::packed q_lo, q_hi;                // rotated query, packed in the model dtype (exact: it IS rounded)
+  raw_t n_raw[2];
+  {
+    const T* qp = p.q + b * p.q_sb + h * p.q_sh + qi * p.q_sq;
+    int pq = p.pos_ids ? (int)p.pos_ids[b * p.pos_sb + qi] : p.pos_q + qi;
+    pq = min(max(pq, 0), p.table_rows - 1);
+    const raw_t q0 = V8::ldg(qp + 8 * c);
+    const raw_t q1 = V8::ldg(qp + HALF + 8 * c);
+    const raw_t q2 = V8::ldg(p.cos + (int64_t)pq * HALF + 8 * c);
+    const raw_t q3 = V8::ldg(p.sin + (int64_t)pq * HALF + 8 * c);
+    if (owns_new) {   // the appended key is rotated at its slot index N-1 (modify_llama.py:103-104)
+      n_raw[0] = V8::ldg(p.cos + (int64_t)(p.N - 1) * HALF + 8 * c);
+      n_raw[1] = V8::ldg(p.sin + (int64_t)(p.N - 1) * HALF + 8 * c);
+    }
+    float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8];
+    V8::unpack(q0, xlo);
+    V8::unpack(q1, xhi);
+    V8::unpack(q2, cc);
+    V8::unpack(q3, ss);
+    rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
+    q_lo = D8::pack(ylo);
+    q_hi = D8::pack(yhi);
+  }
+  const T* maskp = p.mask ? p.mask + b * p.mask_sb + qi * p.mask_sq : nullptr;
+  T* stashp = p.scores ? p.scores + b * p.sc_sb + h * p.sc_sh + qi * p.sc_sq : nullptr;
+  T* kbase = p.kc ? p.kc + b * p.kv_sb + hkv * p.kv_sh : nullptr;
+
+  // per-THREAD online softmax (the LPR lanes of a row share its score, so they agree): no barrier and
+  // no cross-lane maximum inside the loop; the row groups are reconciled once, after the loop.
   float m_run = -INFINITY, l_run = 0.f;
   float olo[8], ohi[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { olo[i] = 0.f; ohi[i] = 0.f; }
 
   for (int t0 = lo; t0 < hi; t0 += TILE) {
-    // ---- issue every load of the tile -----------------------------------------------------------
-    raw_t k_lo[UNR], k_hi[UNR], v_lo[UNR], v_hi[UNR], cs[UNR], sn[UNR];
-    bool valid[UNR];
+    if (t0 != lo) issue_tile(t0);
+    float mk[UNR];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      int j = t0 + u * RPI + r;
-      valid[u] = j < hi;
-      j = valid[u] ? j : hi - 1;
-      const T* kp = kbase + (int64_t)j * D;
-      const T* vp = vbase + (int64_t)j * D;
-      if (has_new && j == p.N - 1) {   // the token being appended: source = k_new / v_new
-        kp = p.k_new + b * p.new_sb + hkv * p.new_sh;
-        vp = p.v_new + b * p.new_sb + hkv * p.new_sh;
-      }
-      k_lo[u] = V8::ldg(kp + 8 * c);
-      k_hi[u] = V8::ldg(kp + HALF + 8 * c);
-      cs[u] = V8::ldg(p.cos + (int64_t)j * HALF + 8 * c);
-      sn[u] = V8::ldg(p.sin + (int64_t)j * HALF + 8 * c);
-      v_lo[u] = V8::ldg(vp + 8 * c);
-      v_hi[u] = V8::ldg(vp + HALF + 8 * c);
-    }
-    if (has_new && t0 + TILE >= p.N && hi == p.N) {
-      // append in place (modify_llama.py:95-100; K stays un-rotated)
+    for (int u = 0; u < UNR; ++u) mk[u] = maskp ? DT<T>::to_f32(maskp[min(t0 + u * RPI + r, n_vis - 1)]) : 0.f;
+
+    if (owns_new && t0 + TILE >= p.N) {
+      // append in place: K un-rotated (modify_llama.py:95-100), its rotation into the shadow, V
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int j = t0 + u * RPI + r;
         if (j == p.N - 1) {
-          V8::stg(kbase + (int64_t)j * D + 8 * c, k_lo[u]);
-          V8::stg(kbase + (int64_t)j * D + HALF + 8 * c, k_hi[u]);
+          float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8];
+          V8::unpack(k_lo[u], xlo);
+          V8::unpack(k_hi[u], xhi);
+          V8::unpack(n_raw[0], cc);
+          V8::unpack(n_raw[1], ss);
+          rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
+          if (kbase) {
+            V8::stg(kbase + (int64_t)j * D + 8 * c, k_lo[u]);
+            V8::stg(kbase + (int64_t)j * D + HALF + 8 * c, k_hi[u]);
+          }
+          k_lo[u] = V8::pack(ylo);
+          k_hi[u] = V8::pack(yhi);
+          V8::stg(krbase + (int64_t)j * D + 8 * c, k_lo[u]);
+          V8::stg(krbase + (int64_t)j * D + HALF + 8 * c, k_hi[u]);
           V8::stg(vbase + (int64_t)j * D + 8 * c, v_lo[u]);
           V8::stg(vbase + (int64_t)j * D + HALF + 8 * c, v_hi[u]);
         }
       }
     }
 
-    // ---- scores ---------------------------------------------------------------------------------
-    float sc[UNR];
-    float m_loc = -INFINITY;
+    // ---- row group by row group, in load order: score -> softmax update -> P·V ------------------
+    // (the loads of group u+1.. are still in flight while group u is consumed)
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8];
-      V8::unpack(k_lo[u], xlo);
-      V8::unpack(k_hi[u], xhi);
-      V8::unpack(cs[u], cc);
-      V8::unpack(sn[u], ss);
-      rope_pair<T, D>(xlo, xhi, cc, ss, ylo, yhi);
-      float acc = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc = fmaf(qlo[i], ylo[i], acc);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc = fmaf(qhi[i], yhi[i], acc);
-      acc = group_sum<LPR>(acc);
-      // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
-      float s = DT<T>::round(DT<T>::round(acc) / p.sqrt_d);
       const int j = t0 + u * RPI + r;
-      if (c == 0) s_stash[u * RPI + r] = s;
-      if (p.mask != nullptr && valid[u]) s = DT<T>::round(s + DT<T>::to_f32(p.mask[b * p.mask_sb + j]));
-      sc[u] = valid[u] ? s : -INFINITY;
-      m_loc = fmaxf(m_loc, sc[u]);
-    }
-    m_loc = wave_max(m_loc);
-    if (lane == 0) s_red[wave] = m_loc;
-    __syncthreads();
-    // stash (raw scaled logits, pre-mask), coalesced
-    if (p.scores != nullptr) {
-      for (int i = tid; i < TILE; i += kDecodeThreads) {
-        const int j = t0 + i;
-        if (j < hi) p.scores[b * p.sc_sb + h * p.sc_sh + j] = DT<T>::from_f32(s_stash[i]);
+      const bool valid = j < hi;
+      float s = group_sum<LPR>(D8::dot(q_hi, k_hi[u], D8::dot(q_lo, k_lo[u], 0.f)));
+      // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
+      s = DT<T>::round(DT<T>::round(s) / p.sqrt_d);
+      if (stashp != nullptr && c == 0 && valid) stashp[j] = DT<T>::from_f32(s);       // pre-mask (:116-119)
+      if (maskp != nullptr) s = DT<T>::round(s + mk[u]);                               // :132
+      s = (valid && j < n_vis) ? s : -INFINITY;
+      if (s > m_run) {                             // rare after the first rows
+        const float alpha = __expf(m_run - s);     // m_run = -inf -> 0
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { olo[i] *= alpha; ohi[i] *= alpha; }
+        m_run = s;
       }
-    }
-    const float m_tile = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    const float m_new = fmaxf(m_run, m_tile);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __expf(m_run - m_use);     // m_run = -inf -> 0
-    l_run *= alpha;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { olo[i] *= alpha; ohi[i] *= alpha; }
-    m_run = m_new;
-
-    // ---- P·V ------------------------------------------------------------------------------------
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const float pj = __expf(sc[u] - m_use);      // invalid rows: exp(-inf) = 0
+      const float pj = (s == -INFINITY) ? 0.f : __expf(s - m_run);
       l_run += pj;
       float vlo[8], vhi[8];
       V8::unpack(v_lo[u], vlo);
@@ -210,19 +232,37 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
 #pragma unroll
       for (int i = 0; i < 8; ++i) { olo[i] = fmaf(pj, vlo[i], olo[i]); ohi[i] = fmaf(pj, vhi[i], ohi[i]); }
     }
-    __syncthreads();   // s_stash / s_red reused by the next tile
   }
 
-  // ---- reduce over the row groups of the workgroup ----------------------------------------------
+  // ---- reconcile the row groups: workgroup max, rescale, sum ------------------------------------
+  {
+    const float mw = wave_max(m_run);
+    if (lane == 0) s_red[wave] = mw;
+    __syncthreads();
+    const float m_wg = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_wg);
+    l_run *= alpha;
 #pragma unroll
-  for (int off = LPR; off < kWave; off <<= 1) {
-    l_run += __shfl_xor(l_run, off, kWave);
+    for (int i = 0; i < 8; ++i) { olo[i] *= alpha; ohi[i] *= alpha; }
+    m_run = m_wg;
+  }
+  // lanes with equal c across the wave's row groups: in-row rotations (DPP), then rows (permlane swaps)
+  if (LPR == 4) {
+    l_run += dpp_mov<kDppRor8>(l_run);
+    l_run += dpp_mov<kDppRor4>(l_run);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      olo[i] += __shfl_xor(olo[i], off, kWave);
-      ohi[i] += __shfl_xor(ohi[i], off, kWave);
+      olo[i] += dpp_mov<kDppRor8>(olo[i]); olo[i] += dpp_mov<kDppRor4>(olo[i]);
+      ohi[i] += dpp_mov<kDppRor8>(ohi[i]); ohi[i] += dpp_mov<kDppRor4>(ohi[i]);
     }
+  } else if (LPR == 8) {
+    l_run += dpp_mov<kDppRor8>(l_run);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { olo[i] += dpp_mov<kDppRor8>(olo[i]); ohi[i] += dpp_mov<kDppRor8>(ohi[i]); }
   }
+  l_run = xor32_sum(xor16_sum(l_run));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { olo[i] = xor32_sum(xor16_sum(olo[i])); ohi[i] = xor32_sum(xor16_sum(ohi[i])); }
   if (lane < LPR) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -232,63 +272,138 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
     if (lane == 0) s_o[wave][D] = l_run;
   }
   __syncthreads();
-  float o_tot = 0.f, l_tot = 0.f;
+  float o_tot = 0.f;
   if (tid < D) o_tot = s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid];
-  l_tot = s_o[0][D] + s_o[1][D] + s_o[2][D] + s_o[3][D];
+  const float l_tot = s_o[0][D] + s_o[1][D] + s_o[2][D] + s_o[3][D];
 
+  T* outp = p.out + b * p.out_sb + qi * p.out_sq + h * D;
   if (p.S == 1) {
-    if (tid < D) p.out[b * p.out_sb + h * D + tid] = DT<T>::from_f32(o_tot / l_tot);
-    if (p.lse != nullptr && tid == 0) { p.lse[bh * 2] = m_run; p.lse[bh * 2 + 1] = l_tot; }
+    if (tid < D) outp[tid] = DT<T>::from_f32(o_tot / l_tot);
+    if (p.lse != nullptr && tid == 0) { p.lse[unit * 2] = m_run; p.lse[unit * 2 + 1] = l_tot; }
     return;
   }
 
   // ---- publish the partial; the last split to arrive merges ------------------------------------
-  // Write-through (agent-scope relaxed atomic = sc1) stores + drained counter; the merger reads with
-  // agent-scope loads: placement independent across the 8 XCD L2s, no fences needed.
-  float* part = p.ws_part + ((int64_t)bh * p.S + split) * (D + 2);
-  if (tid < D) __hip_atomic_store(part + tid, o_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (tid == 0) {
-    __hip_atomic_store(part + D, m_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(part + D + 1, l_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) s_ticket = __hip_atomic_fetch_add(p.ws_cnt + bh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // Every value goes out as ONE 8-byte write-through {value, tag} granule (agent-scope relaxed atomic
+  // store = sc1): the data is its own flag, so nobody waits for store acknowledgements.  The ticket
+  // tells the last arriver that every other split has ISSUED its granules; it then reads them with
+  // agent-scope loads (placement independent across the 8 XCD L2s) and re-reads the rare granule whose
+  // tag has not landed yet.  It finally clears the tags and the counter for the next launch.
+  unsigned long long* ws = p.ws_part + ((int64_t)unit * p.S) * (D + 2);
+  unsigned long long* part = ws + (int64_t)split * (D + 2);
+  if (tid < D) store_granule(part + tid, o_tot);
+  if (tid == 0) { store_granule(part + D, m_run); store_granule(part + D + 1, l_tot); }
+  if (tid == 0) s_ticket = __hip_atomic_fetch_add(p.ws_cnt + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (s_ticket != (unsigned)(p.S - 1)) return;
 
-  const float* base = p.ws_part + (int64_t)bh * p.S * (D + 2);
-  float m_g = -INFINITY;
-  for (int s = 0; s < p.S; ++s)
-    m_g = fmaxf(m_g, __hip_atomic_load(base + s * (D + 2) + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  const float m_gu = (m_g == -INFINITY) ? 0.f : m_g;
-  float l_g = 0.f, o_g = 0.f;
-  for (int s = 0; s < p.S; ++s) {
-    const float ms = __hip_atomic_load(base + s * (D + 2) + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const float ls = __hip_atomic_load(base + s * (D + 2) + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const float w = __expf(ms - m_gu);
-    l_g = fmaf(ls, w, l_g);
-    if (tid < D) o_g = fmaf(__hip_atomic_load(base + s * (D + 2) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), w, o_g);
+  // merge in ONE round trip: thread (g, e) takes splits s = g, g+G, ...; every load below — its partial-o
+  // elements and the (m, l) of the same splits — is independent.  Each group folds its splits relative to
+  // its own running max; the groups are then folded through LDS.
+  constexpr int KB = 8;                          // splits per thread per round trip
+  const int e = tid % D, g = tid / D;
+  float mg = -INFINITY, lg = 0.f, og = 0.f;
+  if (g < G) {
+    for (int s0 = g; s0 < p.S; s0 += KB * G) {
+      unsigned long long ga[KB], gm[KB], gl[KB];
+      bool ok;
+      int spins = 0;
+      do {
+        ok = true;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+          const int sc_ = (s0 + k * G) < p.S ? (s0 + k * G) : g;
+          const unsigned long long* q = ws + (int64_t)sc_ * (D + 2);
+          ga[k] = __hip_atomic_load(q + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          gm[k] = __hip_atomic_load(q + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          gl[k] = __hip_atomic_load(q + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && (ga[k] >> 32) && (gm[k] >> 32) && (gl[k] >> 32);
+        }
+      } while (!ok && ++spins < (1 << 20));      // bounded: a granule that was issued always lands
+      float a[KB], ms[KB], ls[KB];
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        const bool live = (s0 + k * G) < p.S;
+        a[k] = live ? __uint_as_float((unsigned)ga[k]) : 0.f;
+        ms[k] = live ? __uint_as_float((unsigned)gm[k]) : -INFINITY;
+        ls[k] = live ? __uint_as_float((unsigned)gl[k]) : 0.f;
+      }
+      // every granule this thread read has landed: clear its tag for the next launch (re-arm)
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        if ((s0 + k * G) < p.S) {
+          unsigned long long* q = ws + (int64_t)(s0 + k * G) * (D + 2);
+          q[e] = 0ull;                           // only this thread reads q[e]; (m, l) are shared: cleared below
+        }
+      }
+      float mn = mg;
+#pragma unroll
+      for (int k = 0; k < KB; ++k) mn = fmaxf(mn, ms[k]);
+      const float mu = (mn == -INFINITY) ? 0.f : mn;
+      const float w0 = __expf(mg - mu);
+      og *= w0; lg *= w0;
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        const float w = __expf(ms[k] - mu);
+        og = fmaf(a[k], w, og);
+        lg = fmaf(ls[k], w, lg);
+      }
+      mg = mn;
+    }
   }
-  if (tid < D) p.out[b * p.out_sb + h * D + tid] = DT<T>::from_f32(o_g / l_g);
+  __syncthreads();                               // every thread is done with the shared (m, l) granules
+  if (tid < p.S) { ws[(int64_t)tid * (D + 2) + D] = 0ull; ws[(int64_t)tid * (D + 2) + D + 1] = 0ull; }
+  if (G > 1) {                                   // fold the thread groups through LDS
+    if (g < G) { s_o[g][e] = og; if (e == 0) { s_o[g][D] = mg; s_o[g][D + 1] = lg; } }
+    __syncthreads();
+    if (g == 0) {
+      float mn = mg;
+#pragma unroll
+      for (int gg = 1; gg < G; ++gg) mn = fmaxf(mn, s_o[gg][D]);
+      const float mu = (mn == -INFINITY) ? 0.f : mn;
+      const float w0 = __expf(mg - mu);
+      og *= w0; lg *= w0;
+#pragma unroll
+      for (int gg = 1; gg < G; ++gg) {
+        const float w = __expf(s_o[gg][D] - mu);
+        og = fmaf(s_o[gg][e], w, og);
+        lg = fmaf(s_o[gg][D + 1], w, lg);
+      }
+      mg = mn;
+    }
+  }
+  if (g == 0) outp[e] = DT<T>::from_f32(og / lg);
   if (tid == 0) {
-    if (p.lse != nullptr) { p.lse[bh * 2] = m_g; p.lse[bh * 2 + 1] = l_g; }
-    __hip_atomic_store(p.ws_cnt + bh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    if (p.lse != nullptr) { p.lse[unit * 2] = mg; p.lse[unit * 2 + 1] = lg; }
+    __hip_atomic_store(p.ws_cnt + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static inline int decode_tile_rows(int d, int dtype) {
-  return (kDecodeThreads / (d / 16)) * (dtype == SPATTEN_F32 ? 2 : 4);
+// row-groups per tile (UNR): tuning knob, overridable with SPATTEN_DECODE_UNR (1|2|4) for experiments
+static int decode_unr_for(int dtype) {
+  static int env = -1;
+  if (env < 0) {
+    const char* e = getenv("SPATTEN_DECODE_UNR");
+    env = e ? atoi(e) : 0;
+  }
+  int u = env > 0 ? env : (dtype == SPATTEN_F32 ? 2 : 4);
+  if (dtype == SPATTEN_F32 && u > 2) u = 2;
+  return (u == 1 || u == 2 || u == 4) ? u : 4;
 }
+static inline int decode_tile_rows(int d, int dtype) { return (kDecodeThreads / (d / 16)) * decode_unr_for(dtype); }
 
-static int auto_splits(int batch, int heads, int d, int kv_len, int dtype = SPATTEN_BF16) {
+static int auto_splits(int units, int d, int kv_len, int dtype) {
   const int tile = decode_tile_rows(d, dtype);
   const int max_by_len = ceil_div(kv_len, tile);
-  // aim for >= 4 workgroups per CU-slot pair: 256 CUs x 2
-  int s = ceil_div(512, batch * heads);
+  // one workgroup per CU (256 CUs): measured best at Llama-2-7B decode sizes — more splits shorten each
+  // workgroup's stream but lengthen the merge (a memory round trip per batch of partials)
+  int s = 256 / (units > 0 ? units : 1);
+  static int env_s = -1;
+  if (env_s < 0) { const char* e = getenv("SPATTEN_DECODE_SPLITS"); env_s = e ? atoi(e) : 0; }
+  if (env_s > 0) s = env_s;
   if (s > max_by_len) s = max_by_len;
   if (s < 1) s = 1;
   if (s > 64) s = 64;
@@ -297,8 +412,14 @@ static int auto_splits(int batch, int heads, int d, int kv_len, int dtype = SPAT
 
 template <typename T, int D>
 static int launch_decode(const DecodeParams<T>& p, hipStream_t stream) {
-  const dim3 grid((unsigned)(p.B * p.H * p.S));
-  hipLaunchKernelGGL((decode_attn_kernel<T, D>), grid, dim3(kDecodeThreads), 0, stream, p);
+  const dim3 grid((unsigned)p.S, (unsigned)p.H, (unsigned)(p.B * p.n_q));
+  switch (decode_unr_for(DT<T>::kId)) {
+    case 1: hipLaunchKernelGGL((decode_attn_kernel<T, D, 1>), grid, dim3(kDecodeThreads), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((decode_attn_kernel<T, D, 2>), grid, dim3(kDecodeThreads), 0, stream, p); break;
+    default:
+      if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((decode_attn_kernel<T, D, 2>), grid, dim3(kDecodeThreads), 0, stream, p);
+      else hipLaunchKernelGGL((decode_attn_kernel<T, D, 4>), grid, dim3(kDecodeThreads), 0, stream, p);
+  }
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }
 
@@ -312,66 +433,86 @@ static int dispatch_decode(DecodeParams<T>& p, int d, hipStream_t stream) {
   }
 }
 
+static size_t decode_cnt_bytes(size_t units) { return (units * sizeof(unsigned) + 255) / 256 * 256; }
+
+// shared by spatten_attn_decode and the small-q / fp32 leg of spatten_attn_prefill
+int decode_rows(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sq, void* k_cache, void* kr_cache,
+                void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* k_new, const void* v_new, int64_t new_sb,
+                int64_t new_sh, const void* cos, const void* sin, int table_rows, const int64_t* position_ids,
+                int64_t pos_sb, const void* mask, int64_t mask_sb, int64_t mask_sq, void* out, int64_t out_sb,
+                int64_t out_sq, void* scores, int64_t sc_sb, int64_t sc_sh, int64_t sc_sq, float* lse, void* workspace,
+                size_t workspace_units, int batch, int heads, int kv_heads, int head_dim, int kv_len, int pos_q,
+                int n_q, int causal, int n_splits, hipStream_t stream) {
+  if (!q || !kr_cache || !v_cache || !cos || !sin || !out) return SPATTEN_ERR_INVALID;
+  if (batch <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads != 0 || kv_len <= 0 || pos_q < 0 || n_q <= 0)
+    return SPATTEN_ERR_INVALID;
+  if ((k_new == nullptr) != (v_new == nullptr)) return SPATTEN_ERR_INVALID;
+  if (k_new && n_q != 1) return SPATTEN_ERR_INVALID;
+  if (table_rows < kv_len || (!position_ids && pos_q + n_q > table_rows)) return SPATTEN_ERR_INVALID;
+  if (head_dim != 64 && head_dim != 128 && head_dim != 256) return SPATTEN_ERR_UNSUPPORTED;
+  if (dtype != SPATTEN_F32 && dtype != SPATTEN_F16 && dtype != SPATTEN_BF16) return SPATTEN_ERR_INVALID;
+  const int units = batch * heads * n_q;
+  const int tile = decode_tile_rows(head_dim, dtype);
+  int S = n_splits > 0 ? n_splits : auto_splits(units, head_dim, kv_len, dtype);
+  if (S > ceil_div(kv_len, tile)) S = ceil_div(kv_len, tile);
+  if (S > 64) S = 64;
+  // chunk = rows per split, a multiple of the tile so every split starts tile-aligned
+  const int chunk = ceil_div(ceil_div(kv_len, S), tile) * tile;
+  S = ceil_div(kv_len, chunk);
+  if (S > 1 && (!workspace || (size_t)units > workspace_units)) return SPATTEN_ERR_INVALID;
+  const size_t cnt_bytes = decode_cnt_bytes(workspace_units);
+
+#define SPATTEN_FILL(T)                                                                                  \
+  DecodeParams<T> p;                                                                                     \
+  p.q = (const T*)q; p.q_sb = q_sb; p.q_sh = q_sh; p.q_sq = q_sq;                                        \
+  p.kc = (T*)k_cache; p.krc = (T*)kr_cache; p.vc = (T*)v_cache; p.kv_sb = kv_sb; p.kv_sh = kv_sh;        \
+  p.k_new = (const T*)k_new; p.v_new = (const T*)v_new; p.new_sb = new_sb; p.new_sh = new_sh;            \
+  p.cos = (const T*)cos; p.sin = (const T*)sin; p.table_rows = table_rows;                               \
+  p.pos_ids = position_ids; p.pos_sb = pos_sb;                                                           \
+  p.mask = (const T*)mask; p.mask_sb = mask_sb; p.mask_sq = mask_sq;                                     \
+  p.out = (T*)out; p.out_sb = out_sb; p.out_sq = out_sq;                                                 \
+  p.scores = (T*)scores; p.sc_sb = sc_sb; p.sc_sh = sc_sh; p.sc_sq = sc_sq;                              \
+  p.lse = lse;                                                                                           \
+  p.ws_cnt = (unsigned*)workspace;                                                                       \
+  p.ws_part = workspace ? (unsigned long long*)((char*)workspace + cnt_bytes) : nullptr;                              \
+  p.B = batch; p.H = heads; p.Hkv = kv_heads; p.N = kv_len; p.pos_q = pos_q; p.S = S; p.chunk = chunk;   \
+  p.n_q = n_q; p.causal = causal;                                                                        \
+  p.sqrt_d = sqrtf((float)head_dim);                                                                     \
+  return dispatch_decode<T>(p, head_dim, stream);
+
+  switch (dtype) {
+    case SPATTEN_F32: { SPATTEN_FILL(float) }
+    case SPATTEN_F16: { SPATTEN_FILL(f16_t) }
+    default: { SPATTEN_FILL(bf16_t) }
+  }
+#undef SPATTEN_FILL
+}
+
 }  // namespace spatten
 
 using namespace spatten;
 
 extern "C" size_t spatten_decode_workspace_bytes(int batch, int heads, int head_dim, int max_splits) {
   if (batch <= 0 || heads <= 0 || head_dim <= 0 || max_splits <= 0) return 0;
-  const size_t cnt = ((size_t)batch * heads * sizeof(unsigned) + 255) / 256 * 256;
-  return cnt + (size_t)batch * heads * max_splits * (head_dim + 2) * sizeof(float);
+  const size_t units = (size_t)batch * heads;
+  return decode_cnt_bytes(units) + units * max_splits * (head_dim + 2) * sizeof(unsigned long long);
 }
 
 extern "C" int spatten_decode_auto_splits(int batch, int heads, int head_dim, int kv_len) {
   if (batch <= 0 || heads <= 0 || kv_len <= 0 || (head_dim != 64 && head_dim != 128 && head_dim != 256)) return 1;
-  return auto_splits(batch, heads, head_dim, kv_len);
+  return auto_splits(batch * heads, head_dim, kv_len, SPATTEN_BF16);
 }
 
 extern "C" int spatten_attn_decode(int dtype, const void* q, int64_t q_sb, int64_t q_sh, void* k_cache,
-                                   void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* k_new,
+                                   void* kr_cache, void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* k_new,
                                    const void* v_new, int64_t new_sb, int64_t new_sh, const void* cos,
                                    const void* sin, int table_rows, const int64_t* position_ids,
                                    int64_t pos_sb, const void* mask, int64_t mask_sb, void* out,
                                    int64_t out_sb, void* scores, int64_t sc_sb, int64_t sc_sh, float* lse,
                                    void* workspace, int batch, int heads, int kv_heads, int head_dim,
                                    int kv_len, int pos_q, int n_splits, void* stream) {
-  if (!q || !k_cache || !v_cache || !cos || !sin || !out) return SPATTEN_ERR_INVALID;
-  if (batch <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads != 0 || kv_len <= 0 || pos_q < 0)
-    return SPATTEN_ERR_INVALID;
-  if (table_rows < kv_len || (!position_ids && pos_q >= table_rows)) return SPATTEN_ERR_INVALID;
-  if ((k_new == nullptr) != (v_new == nullptr)) return SPATTEN_ERR_INVALID;
-  if (head_dim != 64 && head_dim != 128 && head_dim != 256) return SPATTEN_ERR_UNSUPPORTED;
-  const int tile = decode_tile_rows(head_dim, dtype);
-  int S = n_splits > 0 ? n_splits : auto_splits(batch, heads, head_dim, kv_len, dtype);
-  if (S > ceil_div(kv_len, tile)) S = ceil_div(kv_len, tile);
-  if (S > 1 && !workspace) return SPATTEN_ERR_INVALID;
-  // chunk = rows per split, a multiple of the tile so every split starts tile-aligned
-  int chunk = ceil_div(ceil_div(kv_len, S), tile) * tile;
-  S = ceil_div(kv_len, chunk);
-  const size_t cnt_bytes = ((size_t)batch * heads * sizeof(unsigned) + 255) / 256 * 256;
-
-#define SPATTEN_FILL(T)                                                                                  \
-  DecodeParams<T> p;                                                                                     \
-  p.q = (const T*)q; p.q_sb = q_sb; p.q_sh = q_sh;                                                       \
-  p.kc = (T*)k_cache; p.vc = (T*)v_cache; p.kv_sb = kv_sb; p.kv_sh = kv_sh;                              \
-  p.k_new = (const T*)k_new; p.v_new = (const T*)v_new; p.new_sb = new_sb; p.new_sh = new_sh;            \
-  p.cos = (const T*)cos; p.sin = (const T*)sin; p.table_rows = table_rows;                               \
-  p.pos_ids = position_ids; p.pos_sb = pos_sb;                                                           \
-  p.mask = (const T*)mask; p.mask_sb = mask_sb;                                                          \
-  p.out = (T*)out; p.out_sb = out_sb;                                                                    \
-  p.scores = (T*)scores; p.sc_sb = sc_sb; p.sc_sh = sc_sh;                                               \
-  p.lse = lse;                                                                                           \
-  p.ws_cnt = (unsigned*)workspace;                                                                       \
-  p.ws_part = workspace ? (float*)((char*)workspace + cnt_bytes) : nullptr;                              \
-  p.B = batch; p.H = heads; p.Hkv = kv_heads; p.N = kv_len; p.pos_q = pos_q; p.S = S; p.chunk = chunk;   \
-  p.sqrt_d = sqrtf((float)head_dim);                                                                     \
-  return dispatch_decode<T>(p, head_dim, (hipStream_t)stream);
-
-  switch (dtype) {
-    case SPATTEN_F32: { SPATTEN_FILL(float) }
-    case SPATTEN_F16: { SPATTEN_FILL(f16_t) }
-    case SPATTEN_BF16: { SPATTEN_FILL(bf16_t) }
-    default: return SPATTEN_ERR_INVALID;
-  }
-#undef SPATTEN_FILL
+  return decode_rows(dtype, q, q_sb, q_sh, 0, k_cache, kr_cache, v_cache, kv_sb, kv_sh, k_new, v_new, new_sb, new_sh,
+                     cos, sin, table_rows, position_ids, pos_sb, mask, mask_sb, 0, out, out_sb, 0, scores, sc_sb,
+                     sc_sh, 0, lse, workspace, (size_t)batch * heads, batch, heads, kv_heads, head_dim, kv_len, pos_q,
+                     1, 0, n_splits, (hipStream_t)stream);
 }

@@ -70,7 +70,7 @@ def _workspace(batch, heads, head_dim, device) -> DecodeWorkspace:
     return ws
 
 
-def attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, kv_len: int,
+def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: torch.Tensor, v_cache: torch.Tensor, kv_len: int,
                 cos: torch.Tensor, sin: torch.Tensor, pos_q: int,
                 k_new: Optional[torch.Tensor] = None, v_new: Optional[torch.Tensor] = None,
                 position_ids: Optional[torch.Tensor] = None,
@@ -79,18 +79,22 @@ def attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, k
                 n_splits: int = 0, workspace: Optional[DecodeWorkspace] = None) -> torch.Tensor:
     """Fused decode attention (modify_llama.py:86-147 at q_len=1).
 
-    q [B,H,d]; k_cache/v_cache [B,Hkv,cap,d] un-rotated with rows [0,kv_len) live (row kv_len-1 is
-    written from k_new/v_new [B,Hkv,d] when given); cos/sin [>=kv_len, d/2]; mask [B,kv_len];
+    q [B,H,d]; k_cache (un-rotated, only appended to) / kr_cache (rotated shadow, see build_shadow) /
+    v_cache [B,Hkv,cap,d] with rows [0,kv_len) live (row kv_len-1 is written from k_new/v_new [B,Hkv,d]
+    when given); cos/sin [>=kv_len, d/2]; mask [B,kv_len];
     position_ids optional int64 [B] device tensor (overrides pos_q without a host sync);
     scores (stash) [B,H,>=kv_len]; returns out [B, H*d]."""
-    _dev(q, k_cache, v_cache, cos, sin, k_new, v_new, mask, out, scores, lse, position_ids)
+    _dev(q, k_cache, kr_cache, v_cache, cos, sin, k_new, v_new, mask, out, scores, lse, position_ids)
     if position_ids is not None and position_ids.dtype != torch.int64:
         raise TypeError("position_ids must be int64")
     lib = _lib.load()
     B, H, d = q.shape
-    Hkv, cap = k_cache.shape[1], k_cache.shape[2]
-    if q.stride(2) != 1 or k_cache.stride(3) != 1 or k_cache.stride(2) != d or v_cache.stride() != k_cache.stride():
-        raise ValueError("q/k_cache/v_cache need contiguous rows (pitch d) and identical K/V strides")
+    Hkv, cap = kr_cache.shape[1], kr_cache.shape[2]
+    if q.stride(2) != 1 or kr_cache.stride(3) != 1 or kr_cache.stride(2) != d or v_cache.stride() != kr_cache.stride() \
+            or (k_cache is not None and k_cache.stride() != kr_cache.stride()):
+        raise ValueError("q/k_cache/kr_cache/v_cache need contiguous rows (pitch d) and identical strides")
+    if k_new is not None and k_cache is None:
+        raise ValueError("appending needs the un-rotated k_cache")
     if kv_len > cap or max(kv_len, pos_q + 1) > cos.shape[0] or cos.shape[1] * 2 != d:
         raise ValueError("kv_len exceeds cache capacity or rotary table")
     if out is None:
@@ -106,7 +110,7 @@ def attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, k
         raise ValueError("n_splits exceeds workspace")
     rc = lib.spatten_attn_decode(
         _dt(q), q.data_ptr(), q.stride(0), q.stride(1),
-        k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(0), k_cache.stride(1),
+        _ptr(k_cache), kr_cache.data_ptr(), v_cache.data_ptr(), kr_cache.stride(0), kr_cache.stride(1),
         _ptr(k_new), _ptr(v_new), 0 if k_new is None else k_new.stride(0), 0 if k_new is None else k_new.stride(1),
         cos.data_ptr(), sin.data_ptr(), cos.shape[0],
         _ptr(position_ids), 0 if position_ids is None else position_ids.stride(0),
@@ -167,8 +171,15 @@ def attn_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, 
     return out
 
 
+def build_shadow(k_cache: torch.Tensor, kr_cache: torch.Tensor, lo: int, hi: int, cos: torch.Tensor, sin: torch.Tensor):
+    """Rotate rows [lo,hi) of the un-rotated cache at their slot index into the shadow (modify_llama.py:103-104)."""
+    if hi > lo:
+        rope_single(k_cache[:, :, lo:hi], cos, sin, pos0=lo, out=kr_cache[:, :, lo:hi])
+
+
 def rope_single(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
-                position_ids: Optional[torch.Tensor] = None, pos0: int = 0) -> torch.Tensor:
+                position_ids: Optional[torch.Tensor] = None, pos0: int = 0,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """apply_rotary_pos_emb_single (modify_llama.py:21-28); x [B,H,n,d] (d contiguous, any other
     strides); cos/sin are the [rows, d/2] half tables; position_ids int64 [B,n] or [1,n] or None."""
     _dev(x, cos, sin, position_ids)
@@ -176,7 +187,9 @@ def rope_single(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
     B, H, n, d = x.shape
     if x.stride(3) != 1:
         x = x.contiguous()
-    y = torch.empty(B, H, n, d, dtype=x.dtype, device=x.device)
+    y = torch.empty(B, H, n, d, dtype=x.dtype, device=x.device) if out is None else out
+    if y.stride(3) != 1 or y.shape != x.shape:
+        raise ValueError("rope_single output must match x and have contiguous d")
     pos_sb = 0
     if position_ids is not None:
         if position_ids.dim() == 1:

@@ -27,6 +27,7 @@ def run_decode(q, k, v, past, dt, mask=None, n_splits=0, pos_q=None, use_pos_ten
     N = P + 1
     cap = N + extra_cap
     kc = torch.full((B, Hkv, cap, d), float("nan"), dtype=TORCH_DT[dt], device="cuda")
+    krc = torch.full((B, Hkv, cap, d), float("nan"), dtype=TORCH_DT[dt], device="cuda")
     vc = torch.full((B, Hkv, cap, d), float("nan"), dtype=TORCH_DT[dt], device="cuda")
     if P:
         kc[:, :, :P] = dev(past[0], dt)
@@ -36,15 +37,20 @@ def run_decode(q, k, v, past, dt, mask=None, n_splits=0, pos_q=None, use_pos_ten
         cos, sin = ops.rope_table(max(N, pos_q + 1) + 5, d, TORCH_DT[dt], "cuda")
     else:
         cos, sin = oracle_table(max(N, pos_q + 1) + 5, d, dt)
+    ops.build_shadow(kc, krc, 0, P, cos, sin)          # rotated shadow of the past rows
     scores = torch.full((B, H, N + 2), float("nan"), dtype=TORCH_DT[dt], device="cuda")
     lse = torch.zeros(B, H, 2, dtype=torch.float32, device="cuda")
     pos_t = torch.full((B,), pos_q, dtype=torch.int64, device="cuda") if use_pos_tensor else None
-    out = ops.attn_decode(dev(q[:, :, 0], dt), kc, vc, N, cos, sin, 0 if use_pos_tensor else pos_q,
+    out = ops.attn_decode(dev(q[:, :, 0], dt), kc, krc, vc, N, cos, sin, 0 if use_pos_tensor else pos_q,
                           k_new=dev(k[:, :, 0], dt), v_new=dev(v[:, :, 0], dt), position_ids=pos_t,
                           mask=None if mask is None else dev(mask, dt), scores=scores, lse=lse, n_splits=n_splits)
     torch.cuda.synchronize()
     assert torch.isnan(scores[:, :, N:].float()).all(), "stash written past kv_len"
     assert torch.isnan(kc[:, :, N:].float()).all() and torch.isnan(vc[:, :, N:].float()).all(), "cache written past kv_len"
+    assert torch.isnan(krc[:, :, N:].float()).all()
+    # the shadow row appended by the kernel == the rope kernel's rotation of the appended K row
+    want = ops.rope_single(kc[:, :, N - 1:N], cos, sin, pos0=N - 1)
+    assert torch.equal(krc[:, :, N - 1:N], want), "shadow append"
     return host(out)[:, None, :], host(scores[:, :, :N])[:, :, None, :], host(kc[:, :, :N]), host(vc[:, :, :N]), host(lse)
 
 
@@ -134,8 +140,9 @@ def test_decode_workspace_rearms_across_launches():
     kc = dev(np.concatenate([past[0], k], 2), dt)
     vc = dev(np.concatenate([past[1], v], 2), dt)
     cos, sin = ops.rope_table(N, d, TORCH_DT[dt], "cuda")
+    krc = ops.rope_single(kc, cos, sin)
     qd = dev(q[:, :, 0], dt)
-    outs = [ops.attn_decode(qd, kc, vc, N, cos, sin, N - 1) for _ in range(50)]
+    outs = [ops.attn_decode(qd, None, krc, vc, N, cos, sin, N - 1) for _ in range(50)]
     torch.cuda.synchronize()
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
@@ -148,6 +155,26 @@ def test_decode_errors():
     kc = torch.zeros(1, 4, 8, 96, dtype=dt, device="cuda")
     cos, sin = ops.rope_table(8, 96, dt, "cuda")
     with pytest.raises(RuntimeError, match="unsupported"):
-        ops.attn_decode(q, kc, kc.clone(), 8, cos, sin, 7)
+        ops.attn_decode(q, kc, kc.clone(), kc.clone(), 8, cos, sin, 7)
     with pytest.raises(RuntimeError, match="device"):
-        ops.attn_decode(q.cpu(), kc, kc, 8, cos, sin, 7)
+        ops.attn_decode(q.cpu(), kc, kc, kc, 8, cos, sin, 7)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+def test_rope_single_matches_reference_golden(dt):
+    """apply_rotary_pos_emb_single (modify_llama.py:21-28): bit exact vs the reference on its own table."""
+    from spatten_amd import ops
+    g = golden("g4_rope.npz")
+    x = orc.synth_normal(40, 0, (2, 4, 33, 64), dt)
+    cos, sin = dev(g[f"rope_{dt}_cos"][:, :32], dt), dev(g[f"rope_{dt}_sin"][:, :32], dt)
+    pos = torch.from_numpy(g[f"rope_{dt}_pos"]).cuda()
+    y = ops.rope_single(dev(x, dt), cos, sin, position_ids=pos)
+    assert np.array_equal(host(y), g[f"rope_{dt}_y"])
+    # strided input view ([B,n,H,d] projection layout viewed as [B,H,n,d]) and consecutive positions
+    xt = dev(x, dt).transpose(1, 2).contiguous().transpose(1, 2)
+    y2 = ops.rope_single(xt, cos, sin, pos0=7)
+    want = orc.apply_rotary_pos_emb_single(x, g[f"rope_{dt}_cos"], g[f"rope_{dt}_sin"], (np.arange(33) + 7)[None], dt)
+    assert np.array_equal(host(y2), want)
+    # the torch-built table of ops.rope_table is the reference module's table
+    c2, s2 = ops.rope_table(200, 64, TORCH_DT[dt], "cuda")
+    assert np.array_equal(host(c2), g[f"rope_{dt}_cos"][:, :32]) and np.array_equal(host(s2), g[f"rope_{dt}_sin"][:, :32])
