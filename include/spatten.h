@@ -105,12 +105,14 @@ int spatten_attn_decode(int dtype,
 
 /* ------------------------------------------------------------------------------------------------
  * Prefill attention (q_len >= 1), flash-style, same semantics as above for a block of queries.
- * Two stages on `stream`: (1) rotate Q and the whole K cache into the workspace and lay V out
- * key-contiguous for the matrix cores, (2) MFMA flash attention with online softmax.
+ * bf16/f16 with head_dim 64/128: rotate Q into the workspace, lay V out key-contiguous for the matrix cores,
+ * then MFMA flash attention with online softmax.  fp32, q_len <= 8 or head_dim 256: the decode kernel, one
+ * softmax row per workgroup column (exact fp32).
  *
  *   q            [B, H, q_len, d]   un-rotated (strides q_sb, q_sh, q_sq; d contiguous) — the [B,q,H*d]
  *                                   projection output viewed as [B,H,q,d] is accepted without a copy
- *   k_cache/v_cache [B,Hkv,cap,d]   must ALREADY hold the q_len new rows at slots [kv_len-q_len, kv_len)
+ *   kr_cache     [B,Hkv,cap,d]      rotated shadow of the key cache (see spatten_attn_decode), rows [0, kv_len)
+ *   v_cache      [B,Hkv,cap,d]      values; both must ALREADY hold the q_len new rows at [kv_len-q_len, kv_len)
  *   pos_q0       rotary position of query row 0 (row i uses pos_q0 + i) unless
  *   position_ids optional int64 [B, q_len] DEVICE pointer (stride pos_sb, rows contiguous)
  *   causal       1: HF causal mask (key j visible to row i iff j <= kv_len - q_len + i); 0: none
@@ -120,13 +122,14 @@ int spatten_attn_decode(int dtype,
  *   scores       optional [B,H,q_len,kv_len] stash (strides sc_sb, sc_sh, sc_sq) — pre-mask, like the reference
  *   col_importance optional [B,H,kv_len] fp32, ZERO-FILLED by the caller: += sum over query rows of the
  *                stash column = the reference importance (kv_cache_token_pruning.py:51) without the stash
+ *                (MFMA leg only; fp32 atomics, so the summation order is not reproducible run to run)
  *   workspace    spatten_prefill_workspace_bytes(...) bytes of device scratch
  * ---------------------------------------------------------------------------------------------- */
 size_t spatten_prefill_workspace_bytes(int dtype, int batch, int heads, int kv_heads, int head_dim,
                                        int q_len, int kv_len);
 int spatten_attn_prefill(int dtype,
                          const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sq,
-                         const void* k_cache, const void* v_cache, int64_t kv_sb, int64_t kv_sh,
+                         const void* kr_cache, const void* v_cache, int64_t kv_sb, int64_t kv_sh,
                          const void* cos, const void* sin, int table_rows,
                          const int64_t* position_ids, int64_t pos_sb,
                          const void* mask, int64_t mask_sb, int64_t mask_sq,
@@ -166,9 +169,12 @@ int spatten_topk_select(int dtype, const void* score, int64_t score_sh, int head
  *   dst[b,h,start:start+k]        = src[b,h,idx[h,:]]
  *   dst[b,h,start+k:start+k+tail] = src[b,h,tail_lo:tail_lo+tail_len]
  * src [B,H,L,d] (strides src_sb, src_sh), dst [B,H,cap',d] (strides dst_sb, dst_sh), rows contiguous (pitch d).
- * v_src/v_dst may be NULL to move K only. */
+ * v_src/v_dst may be NULL to move K only.  kr_dst (optional, same strides as k_dst) receives the rotated shadow
+ * of the NEW cache, row r rotated at position r (modify_llama.py:103-104) with the half tables cos/sin
+ * [table_rows >= new length, d/2] — the slots moved, so the shadow is rebuilt by the pass that moves them. */
 int spatten_kv_compact(int dtype, const void* k_src, const void* v_src, int64_t src_sb, int64_t src_sh,
-                       void* k_dst, void* v_dst, int64_t dst_sb, int64_t dst_sh,
+                       void* k_dst, void* v_dst, void* kr_dst, int64_t dst_sb, int64_t dst_sh,
+                       const void* cos, const void* sin, int table_rows,
                        const int32_t* idx, int64_t idx_sh,
                        int batch, int heads, int head_dim,
                        int start, int k, int tail_lo, int tail_len, void* stream);
@@ -181,7 +187,9 @@ int spatten_kv_compact(int dtype, const void* k_src, const void* v_src, int64_t 
 int spatten_prune_layers(int dtype, int layers,
                          const void* const* score_ptrs, int64_t score_sh,
                          const void* const* k_src_ptrs, const void* const* v_src_ptrs, int64_t src_sb, int64_t src_sh,
-                         void* const* k_dst_ptrs, void* const* v_dst_ptrs, int64_t dst_sb, int64_t dst_sh,
+                         void* const* k_dst_ptrs, void* const* v_dst_ptrs, void* const* kr_dst_ptrs /* optional */,
+                         int64_t dst_sb, int64_t dst_sh,
+                         const void* cos, const void* sin, int table_rows /* for kr_dst_ptrs */,
                          int32_t* idx,
                          int batch, int heads, int head_dim,
                          int lo, int hi, int k, int tail_lo, int tail_len, void* stream);

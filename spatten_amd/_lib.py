@@ -47,9 +47,9 @@ def _declare(lib):
     lib.spatten_topk_select.restype = c_int
     lib.spatten_topk_select.argtypes = [i, p, i64, i, i, i, i, p, i64, p]
     lib.spatten_kv_compact.restype = c_int
-    lib.spatten_kv_compact.argtypes = [i, p, p, i64, i64, p, p, i64, i64, p, i64, i, i, i, i, i, i, i, p]
+    lib.spatten_kv_compact.argtypes = [i, p, p, i64, i64, p, p, p, i64, i64, p, p, i, p, i64, i, i, i, i, i, i, i, p]
     lib.spatten_prune_layers.restype = c_int
-    lib.spatten_prune_layers.argtypes = [i, i, p, i64, p, p, i64, i64, p, p, i64, i64, p,
+    lib.spatten_prune_layers.argtypes = [i, i, p, i64, p, p, i64, i64, p, p, p, i64, i64, p, p, i, p,
                                          i, i, i, i, i, i, i, i, p]
 
 

@@ -1,9 +1,360 @@
-// prefill_attn.hip — placeholder until the MFMA flash kernel lands (next commit).
+// prefill_attn.hip — attention for a block of queries (modify_llama.py:86-147 at q_len > 1).
+//
+// Three legs behind one entry point (spatten_attn_prefill):
+//   * rows leg  (fp32, very short q, head_dim 256): the decode kernel, one softmax row per workgroup column
+//     (decode_rows in decode_attn.hip) — exact fp32, no matrix cores needed for a handful of rows.
+//   * flash leg (bf16/f16, head_dim 64/128): compute-bound -> MFMA.  Two preparation kernels and the flash
+//     kernel on the same stream:
+//       (1) rope kernel: Q rows -> Qrot scratch (reference rounding, modify_llama.py:92);  K is NOT rotated
+//           here: the cache already carries the rotated shadow Kr (see decode_attn.hip),
+//       (2) vt kernel: V [keys][d] -> Vt [d][keys] scratch so that the P·V matrix product finds its
+//           contraction index (keys) contiguous per lane; inside every 32-key block the keys are permuted
+//           into the order in which a lane holds them after the Q·K^T product (no shuffles between the two
+//           products),
+//       (3) flash kernel: workgroup = 128 queries (4 waves x 32), key tiles of 64 staged in LDS
+//           (XOR-swizzled 16-byte slots, conflict-free ds_read_b128), S^T = Kr·Qrot^T and O^T = Vt·P^T on
+//           v_mfma_f32_32x32x16_{bf16,f16}: a lane owns ONE query column, so the online softmax needs a
+//           single cross-lane exchange (lane <-> lane+32) per tile.
+//     The stash (pre-mask logits, modify_llama.py:116-119) and the column importance (kv_cache_token_pruning.py:51
+//     includes the acausal logits) are optional by-products; when requested, key tiles above the causal
+//     diagonal are still scored (but skip softmax / P·V).
 #include "common.h"
-extern "C" size_t spatten_prefill_workspace_bytes(int, int, int, int, int, int, int) { return 256; }
-extern "C" int spatten_attn_prefill(int, const void*, int64_t, int64_t, int64_t, const void*, const void*, int64_t,
-                                    int64_t, const void*, const void*, int, const int64_t*, int64_t, const void*,
-                                    int64_t, int64_t, void*, int64_t, int64_t, void*, int64_t, int64_t, int64_t,
-                                    float*, void*, int, int, int, int, int, int, int, int, void*) {
-  return SPATTEN_ERR_UNSUPPORTED;
+
+namespace spatten {
+
+int decode_rows(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sq, void* k_cache, void* kr_cache,
+                void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* k_new, const void* v_new, int64_t new_sb,
+                int64_t new_sh, const void* cos, const void* sin, int table_rows, const int64_t* position_ids,
+                int64_t pos_sb, const void* mask, int64_t mask_sb, int64_t mask_sq, void* out, int64_t out_sb,
+                int64_t out_sq, void* scores, int64_t sc_sb, int64_t sc_sh, int64_t sc_sq, float* lse, void* workspace,
+                size_t workspace_units, int batch, int heads, int kv_heads, int head_dim, int kv_len, int pos_q,
+                int n_q, int causal, int n_splits, hipStream_t stream);
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename T> struct Mfma;
+template <> struct Mfma<bf16_t> {
+  typedef bf16_t frag __attribute__((ext_vector_type(8)));
+  __device__ static inline f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma<f16_t> {
+  typedef f16_t frag __attribute__((ext_vector_type(8)));
+  __device__ static inline f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+// position of key (0..31, within its 32-key block) in a Vt row: the order in which the Q·K^T accumulator
+// registers of a lane enumerate keys:  key = (r&3) + 8*(r>>2) + 4*hi  for register r (0..15), half hi.
+__host__ __device__ inline int vt_key_of_pos(int pos) {
+  const int t = pos >> 4, hi = (pos >> 3) & 1, e = pos & 7, r = t * 8 + e;
+  return (r & 3) + 8 * (r >> 2) + 4 * hi;
+}
+
+// ------------------------------------------------------------------------------------------------
+// (2) V [B,Hkv,N,d] -> Vt [B,Hkv,d,Npad]  (16-bit dtypes; zero beyond N)
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void vt_kernel(const uint16_t* __restrict__ v, int64_t kv_sb, int64_t kv_sh,
+                                                 uint16_t* __restrict__ vt, int N, int Npad, int Hkv) {
+  constexpr int PITCH = D + 8;
+  __shared__ __attribute__((aligned(16))) uint16_t tile[64 * PITCH];
+  const int tid = threadIdx.x, tile_i = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
+  const uint16_t* src = v + b * kv_sb + hkv * kv_sh;
+  for (int id = tid; id < 64 * (D / 8); id += 256) {
+    const int key = id / (D / 8), c8 = id % (D / 8);
+    const int j = tile_i * 64 + key;
+    u32x4 x = {0u, 0u, 0u, 0u};
+    if (j < N) x = *reinterpret_cast<const u32x4*>(src + (int64_t)j * D + c8 * 8);
+    *reinterpret_cast<u32x4*>(&tile[key * PITCH + c8 * 8]) = x;
+  }
+  __syncthreads();
+  uint16_t* dst = vt + ((int64_t)(b * Hkv + hkv) * D) * Npad + (int64_t)tile_i * 64;
+  for (int id = tid; id < D * 8; id += 256) {
+    const int dv = id >> 3, pc = id & 7;
+    uint32_t w[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      const int p0 = pc * 8 + 2 * e2, p1 = p0 + 1;
+      const int k0 = (p0 & 32) + vt_key_of_pos(p0 & 31), k1 = (p1 & 32) + vt_key_of_pos(p1 & 31);
+      w[e2] = (uint32_t)tile[k0 * PITCH + dv] | ((uint32_t)tile[k1 * PITCH + dv] << 16);
+    }
+    u32x4 o = {w[0], w[1], w[2], w[3]};
+    *reinterpret_cast<u32x4*>(dst + (int64_t)dv * Npad + pc * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (3) flash kernel
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct FlashParams {
+  const T* qrot;      // [B,H,q_len,D] contiguous
+  const T* kr;        // rotated shadow [B,Hkv,cap,D]
+  int64_t kv_sb, kv_sh;
+  const T* vt;        // [B,Hkv,D,Npad]
+  const T* mask; int64_t mask_sb, mask_sq;
+  T* out; int64_t out_sb, out_sq;
+  T* scores; int64_t sc_sb, sc_sh, sc_sq;
+  float* col_imp;     // [B,H,N]
+  int B, H, Hkv, q_len, N, Npad, causal;
+  float sqrt_d;
+};
+
+template <int ROWB> __device__ inline int lds_off(int row, int slot) {
+  // 16-byte slots, XOR-swizzled so the 16 lanes of a ds_read_b128 group land on distinct bank quads
+  if (ROWB == 256) return row * 256 + ((slot ^ (row & 15)) << 4);
+  return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void prefill_flash_kernel(const FlashParams<T> p) {
+  constexpr int KK = D / 16;       // MFMA k-steps of the Q·K^T product
+  constexpr int DB = D / 32;       // 32-row blocks of O^T
+  constexpr int KROWB = D * 2;     // bytes per K row in LDS (256 / 128)
+  using frag = typename Mfma<T>::frag;
+  __shared__ __attribute__((aligned(16))) char lds[64 * KROWB + D * 128];
+  char* ldsK = lds;
+  char* ldsV = lds + 64 * KROWB;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, qi = lane & 31, hi = lane >> 5;
+  const int qblk = gridDim.x - 1 - blockIdx.x;          // longest (latest) query blocks first
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int hkv = p.Hkv == p.H ? h : h / (p.H / p.Hkv);
+  const int q0 = qblk * 128 + wave * 32;
+  const int myq = q0 + qi;
+  const bool qvalid = myq < p.q_len;
+  const int P = p.N - p.q_len;
+
+  frag qf[KK];
+  {
+    const T* qrow = p.qrot + ((int64_t)(b * p.H + h) * p.q_len + min(myq, p.q_len - 1)) * D;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) qf[kk] = *reinterpret_cast<const frag*>(qrow + 16 * kk + 8 * hi);
+  }
+  f32x16 o[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int wg_q_end = min(p.q_len, qblk * 128 + 128);
+  const int att_keys = p.causal ? min(p.N, P + wg_q_end) : p.N;          // keys any query of this workgroup sees
+  const int n_att_tiles = (att_keys + 63) / 64;
+  const bool byproducts = (p.scores != nullptr) || (p.col_imp != nullptr);
+  const int n_tiles = byproducts ? (p.N + 63) / 64 : n_att_tiles;
+  const int my_vis = p.causal ? min(p.N, P + myq + 1) : p.N;             // keys [0, my_vis) are visible to my query
+
+  const T* krb = p.kr + b * p.kv_sb + hkv * p.kv_sh;
+  const T* vtb = p.vt + ((int64_t)(b * p.Hkv + hkv) * D) * p.Npad;
+  const T* maskrow = p.mask ? p.mask + b * p.mask_sb + (int64_t)min(myq, p.q_len - 1) * p.mask_sq : nullptr;
+  T* stashrow = p.scores ? p.scores + b * p.sc_sb + h * p.sc_sh + (int64_t)min(myq, p.q_len - 1) * p.sc_sq : nullptr;
+  float* colrow = p.col_imp ? p.col_imp + (int64_t)(b * p.H + h) * p.N : nullptr;
+
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    const bool attend = tile < n_att_tiles;
+    __syncthreads();                                   // previous tile's LDS reads are done
+    for (int id = tid; id < 64 * (D / 8); id += 256) {
+      const int row = id / (D / 8), slot = id % (D / 8);
+      const int j = min(tile * 64 + row, p.N - 1);     // rows past N are masked; stay inside the allocation
+      const u32x4 x = *reinterpret_cast<const u32x4*>(krb + (int64_t)j * D + slot * 8);
+      *reinterpret_cast<u32x4*>(ldsK + lds_off<KROWB>(row, slot)) = x;
+    }
+    if (attend) {
+      for (int id = tid; id < D * 8; id += 256) {
+        const int dv = id >> 3, slot = id & 7;
+        const u32x4 x = *reinterpret_cast<const u32x4*>(vtb + (int64_t)dv * p.Npad + tile * 64 + slot * 8);
+        *reinterpret_cast<u32x4*>(ldsV + lds_off<128>(dv, slot)) = x;
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T (64 keys x 32 queries per wave) -----------------------------------------------------
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const frag a = *reinterpret_cast<const frag*>(ldsK + lds_off<KROWB>(kb * 32 + qi, 2 * kk + hi));
+        s[kb] = Mfma<T>::mma(a, qf[kk], s[kb]);
+      }
+    }
+    float m_tile = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = tile * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
+        float v = DT<T>::round(DT<T>::round(s[kb][r]) / p.sqrt_d);
+        const bool inb = key < p.N;
+        if (stashrow != nullptr && inb && qvalid) stashrow[key] = DT<T>::from_f32(v);        // pre-mask (:116-119)
+        if (colrow != nullptr) {
+          float cv = (inb && qvalid) ? v : 0.f;       // sum over this wave's 32 queries, then one atomic per key
+          cv = xor16_sum(group_sum<16>(cv));
+          if (qi == 0 && inb) atomicAdd(colrow + key, cv);
+        }
+        if (maskrow != nullptr && inb) v = DT<T>::round(v + DT<T>::to_f32(maskrow[key]));      // :132
+        v = (key < my_vis) ? v : -INFINITY;
+        s[kb][r] = v;
+        m_tile = fmaxf(m_tile, v);
+      }
+    }
+    if (!attend) continue;
+
+    // ---- online softmax: a lane and its partner (lane ^ 32) share one query ----------------------
+    m_tile = xor32_max(m_tile);
+    const float m_new = fmaxf(m_run, m_tile);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __expf(m_run - m_use);
+    float lsum = 0.f;
+    frag pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pv = __expf(s[kb][t * 8 + e] - m_use);     // exp(-inf) = 0 for masked keys
+          lsum += pv;
+          pf[kb][t][e] = DT<T>::from_f32(pv);
+        }
+      }
+    }
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+    // ---- O^T (D dv x 32 queries) += Vt · P^T -----------------------------------------------------
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const frag a = *reinterpret_cast<const frag*>(ldsV + lds_off<128>(db * 32 + qi, kb * 4 + t * 2 + hi));
+          o[db] = Mfma<T>::mma(a, pf[kb][t], o[db]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: O = O^T / l, 4 consecutive dv per 8-byte store ---------------------------------
+  const float l_tot = xor32_sum(l_run);
+  const float inv = 1.f / l_tot;
+  if (qvalid) {
+    T* orow = p.out + b * p.out_sb + (int64_t)myq * p.out_sq + h * D;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dv = db * 32 + 8 * g + 4 * hi;
+        T v4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = DT<T>::from_f32(o[db][4 * g + e] * inv);
+        *reinterpret_cast<u32x2*>(orow + dv) = *reinterpret_cast<u32x2*>(v4);
+      }
+    }
+  }
+}
+
+static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+static inline int rows_leg(int dtype, int head_dim, int q_len) {
+  return dtype == SPATTEN_F32 || q_len <= 8 || (head_dim != 64 && head_dim != 128);
+}
+static inline int rows_splits(int units) { int s = 256 / (units > 0 ? units : 1); return s < 1 ? 1 : (s > 64 ? 64 : s); }
+
+template <typename T, int D>
+static int launch_flash(const FlashParams<T>& p, hipStream_t st) {
+  const dim3 grid((unsigned)ceil_div(p.q_len, 128), (unsigned)p.H, (unsigned)p.B);
+  hipLaunchKernelGGL((prefill_flash_kernel<T, D>), grid, dim3(256), 0, st, p);
+  return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+}
+
+}  // namespace spatten
+
+using namespace spatten;
+
+extern "C" int spatten_rope_single(int dtype, const void* x, int64_t x_sb, int64_t x_sh, int64_t x_sn, void* y,
+                                   int64_t y_sb, int64_t y_sh, int64_t y_sn, const void* cos, const void* sin,
+                                   int table_rows, const int64_t* position_ids, int64_t pos_sb, int pos0,
+                                   int batch, int heads, int n, int head_dim, void* stream);
+
+extern "C" size_t spatten_prefill_workspace_bytes(int dtype, int batch, int heads, int kv_heads, int head_dim,
+                                                  int q_len, int kv_len) {
+  if (batch <= 0 || heads <= 0 || kv_heads <= 0 || head_dim <= 0 || q_len <= 0 || kv_len <= 0) return 0;
+  if (rows_leg(dtype, head_dim, q_len)) {
+    const size_t units = (size_t)batch * heads * q_len;
+    const int S = rows_splits((int)(units > (1u << 30) ? (1u << 30) : units));
+    return 256 + align256(units * sizeof(unsigned)) + (S > 1 ? units * S * (head_dim + 2) * sizeof(unsigned long long) : 0);
+  }
+  const size_t es = 2, npad = (size_t)ceil_div(kv_len, 64) * 64;
+  return 256 + align256((size_t)batch * heads * q_len * head_dim * es) + align256((size_t)batch * kv_heads * head_dim * npad * es);
+}
+
+extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sq,
+                                    const void* kr_cache, const void* v_cache, int64_t kv_sb, int64_t kv_sh,
+                                    const void* cos, const void* sin, int table_rows, const int64_t* position_ids,
+                                    int64_t pos_sb, const void* mask, int64_t mask_sb, int64_t mask_sq, void* out,
+                                    int64_t out_sb, int64_t out_sq, void* scores, int64_t sc_sb, int64_t sc_sh,
+                                    int64_t sc_sq, float* col_importance, void* workspace, int batch, int heads,
+                                    int kv_heads, int head_dim, int q_len, int kv_len, int pos_q0, int causal,
+                                    void* stream) {
+  if (!q || !kr_cache || !v_cache || !cos || !sin || !out || !workspace) return SPATTEN_ERR_INVALID;
+  if (batch <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads != 0 || q_len <= 0 || kv_len < q_len || pos_q0 < 0)
+    return SPATTEN_ERR_INVALID;
+  if (dtype != SPATTEN_F32 && dtype != SPATTEN_F16 && dtype != SPATTEN_BF16) return SPATTEN_ERR_INVALID;
+  if (table_rows < kv_len || (!position_ids && pos_q0 + q_len > table_rows)) return SPATTEN_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)(((uintptr_t)workspace + 255) / 256 * 256);
+
+  if (rows_leg(dtype, head_dim, q_len)) {
+    if (col_importance) return SPATTEN_ERR_UNSUPPORTED;   // by-product of the flash leg only (use the stash here)
+    const size_t units = (size_t)batch * heads * q_len;
+    const int S = rows_splits((int)units);
+    if (S > 1 && hipMemsetAsync(ws, 0, align256(units * sizeof(unsigned)), st) != hipSuccess) return SPATTEN_ERR_LAUNCH;
+    // granule tags must start cleared too; the merger re-arms them, so only a fresh workspace needs this
+    if (S > 1 && hipMemsetAsync(ws + align256(units * sizeof(unsigned)), 0,
+                                units * S * (head_dim + 2) * sizeof(unsigned long long), st) != hipSuccess)
+      return SPATTEN_ERR_LAUNCH;
+    return decode_rows(dtype, q, q_sb, q_sh, q_sq, nullptr, const_cast<void*>(kr_cache), const_cast<void*>(v_cache),
+                       kv_sb, kv_sh, nullptr, nullptr, 0, 0, cos, sin, table_rows, position_ids, pos_sb, mask, mask_sb,
+                       mask_sq, out, out_sb, out_sq, scores, sc_sb, sc_sh, sc_sq, nullptr, ws, units, batch, heads,
+                       kv_heads, head_dim, kv_len, pos_q0, q_len, causal, S, st);
+  }
+
+  const int npad = ceil_div(kv_len, 64) * 64;
+  void* qrot = ws;
+  void* vt = ws + align256((size_t)batch * heads * q_len * head_dim * 2);
+  // (1) rotated queries, contiguous [B,H,q,d]
+  int rc = spatten_rope_single(dtype, q, q_sb, q_sh, q_sq, qrot, (int64_t)heads * q_len * head_dim,
+                               (int64_t)q_len * head_dim, head_dim, cos, sin, table_rows, position_ids, pos_sb, pos_q0,
+                               batch, heads, q_len, head_dim, stream);
+  if (rc != SPATTEN_OK) return rc;
+  // (2) key-contiguous V
+  {
+    const dim3 grid((unsigned)(npad / 64), (unsigned)kv_heads, (unsigned)batch);
+    if (head_dim == 128)
+      hipLaunchKernelGGL((vt_kernel<128>), grid, dim3(256), 0, st, (const uint16_t*)v_cache, kv_sb, kv_sh, (uint16_t*)vt, kv_len, npad, kv_heads);
+    else
+      hipLaunchKernelGGL((vt_kernel<64>), grid, dim3(256), 0, st, (const uint16_t*)v_cache, kv_sb, kv_sh, (uint16_t*)vt, kv_len, npad, kv_heads);
+    if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
+  }
+  // (3) flash
+#define SPATTEN_FLASH(T, DD)                                                                           \
+  {                                                                                                    \
+    FlashParams<T> p;                                                                                  \
+    p.qrot = (const T*)qrot; p.kr = (const T*)kr_cache; p.kv_sb = kv_sb; p.kv_sh = kv_sh;              \
+    p.vt = (const T*)vt; p.mask = (const T*)mask; p.mask_sb = mask_sb; p.mask_sq = mask_sq;            \
+    p.out = (T*)out; p.out_sb = out_sb; p.out_sq = out_sq;                                             \
+    p.scores = (T*)scores; p.sc_sb = sc_sb; p.sc_sh = sc_sh; p.sc_sq = sc_sq;                          \
+    p.col_imp = col_importance;                                                                        \
+    p.B = batch; p.H = heads; p.Hkv = kv_heads; p.q_len = q_len; p.N = kv_len; p.Npad = npad;          \
+    p.causal = causal; p.sqrt_d = sqrtf((float)head_dim);                                              \
+    return launch_flash<T, DD>(p, st);                                                                 \
+  }
+  if (dtype == SPATTEN_BF16) { if (head_dim == 128) SPATTEN_FLASH(bf16_t, 128) else SPATTEN_FLASH(bf16_t, 64) }
+  else { if (head_dim == 128) SPATTEN_FLASH(f16_t, 128) else SPATTEN_FLASH(f16_t, 64) }
+#undef SPATTEN_FLASH
 }

@@ -149,9 +149,10 @@ constexpr int kCompThreads = 256;
 constexpr int kCompUnroll = 4;
 
 struct CompactParams {
-  const void* k_src; const void* v_src; void* k_dst; void* v_dst;       // single layer, or
-  const void* const* k_src_ptrs; const void* const* v_src_ptrs;          // per-layer pointers (device memory)
-  void* const* k_dst_ptrs; void* const* v_dst_ptrs;
+  const void* k_src; const void* v_src; void* k_dst; void* v_dst; void* kr_dst;   // single layer, or
+  const void* const* k_src_ptrs; const void* const* v_src_ptrs;                    // per-layer pointers (device memory)
+  void* const* k_dst_ptrs; void* const* v_dst_ptrs; void* const* kr_dst_ptrs;
+  const void* cos; const void* sin; int table_rows;   // rotary half tables, only for the shadow (kr) output
   int64_t src_sb, src_sh, dst_sb, dst_sh;   // in BYTES
   const int32_t* idx; int64_t idx_sl, idx_sh;
   int B, H, layers, n_tensors;              // n_tensors: 2 = K and V, 1 = K only
@@ -162,14 +163,23 @@ struct CompactParams {
   long long total;                          // pieces_per_tensor * n_tensors * layers
 };
 
+// T only matters for the optional rotated-shadow output: the lane that moves piece `pc` of a K row in the
+// first half also fetches the partner piece of the second half (an L1/L2 hit: a neighbouring lane streams
+// it anyway), rotates the pair at the row's NEW slot index (modify_llama.py:103-104) and writes both
+// shadow pieces — the shadow is rebuilt by the same pass that moves the rows.
+template <typename T>
 __global__ __launch_bounds__(kCompThreads) void kv_compact_kernel(const CompactParams p) {
   const long long g0 = (long long)blockIdx.x * (kCompThreads * kCompUnroll) + threadIdx.x;
-  u32x4 val[kCompUnroll];
+  u32x4 val[kCompUnroll], val2[kCompUnroll], cs[kCompUnroll], sn[kCompUnroll];
   char* dptr[kCompUnroll];
+  char* rptr[kCompUnroll];
+  const bool want_kr = (p.kr_dst != nullptr) || (p.kr_dst_ptrs != nullptr);
+  const int half_ppr = p.ppr / 2;
 #pragma unroll
   for (int u = 0; u < kCompUnroll; ++u) {
     const long long g = g0 + (long long)u * kCompThreads;
     dptr[u] = nullptr;
+    rptr[u] = nullptr;
     if (g < p.total) {
       const int tl = (int)(g / p.pieces_per_tensor);
       const unsigned rem = (unsigned)(g - (long long)tl * p.pieces_per_tensor);   // < 2^32 (checked on host)
@@ -196,13 +206,46 @@ __global__ __launch_bounds__(kCompThreads) void kv_compact_kernel(const CompactP
         dbase = (char*)(t == 0 ? p.k_dst : p.v_dst);
       }
       const char* sp = sbase + b * p.src_sb + h * p.src_sh + (int64_t)src_row * p.row_bytes + piece * 16;
-      dptr[u] = dbase + b * p.dst_sb + h * p.dst_sh + (int64_t)r * p.row_bytes + piece * 16;
+      const int64_t doff = b * p.dst_sb + h * p.dst_sh + (int64_t)r * p.row_bytes + piece * 16;
+      dptr[u] = dbase + doff;
       val[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp));
+      if (want_kr && t == 0 && (int)piece < half_ppr) {
+        char* rbase = (char*)(p.kr_dst_ptrs ? p.kr_dst_ptrs[layer] : p.kr_dst);
+        rptr[u] = rbase + doff;
+        val2[u] = *reinterpret_cast<const u32x4*>(sp + p.row_bytes / 2);
+        const int pos = min((int)r, p.table_rows - 1);
+        const int64_t toff = (int64_t)pos * (p.row_bytes / 2) + piece * 16;
+        cs[u] = *reinterpret_cast<const u32x4*>((const char*)p.cos + toff);
+        sn[u] = *reinterpret_cast<const u32x4*>((const char*)p.sin + toff);
+      }
     }
   }
 #pragma unroll
-  for (int u = 0; u < kCompUnroll; ++u)
+  for (int u = 0; u < kCompUnroll; ++u) {
     if (dptr[u]) __builtin_nontemporal_store(val[u], reinterpret_cast<u32x4*>(dptr[u]));
+    if (rptr[u]) {
+      constexpr int E = 16 / sizeof(T);              // elements per 16-byte piece (8, or 4 for fp32)
+      const T* xl = reinterpret_cast<const T*>(&val[u]);
+      const T* xh = reinterpret_cast<const T*>(&val2[u]);
+      const T* cc = reinterpret_cast<const T*>(&cs[u]);
+      const T* ss = reinterpret_cast<const T*>(&sn[u]);
+      u32x4 olo, ohi;
+      T* yl = reinterpret_cast<T*>(&olo);
+      T* yh = reinterpret_cast<T*>(&ohi);
+      {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const float a = DT<T>::to_f32(xl[e]), bb = DT<T>::to_f32(xh[e]);
+          const float c = DT<T>::to_f32(cc[e]), s_ = DT<T>::to_f32(ss[e]);
+          yl[e] = DT<T>::from_f32(DT<T>::round(a * c) + DT<T>::round(-bb * s_));
+          yh[e] = DT<T>::from_f32(DT<T>::round(bb * c) + DT<T>::round(a * s_));
+        }
+      }
+      *reinterpret_cast<u32x4*>(rptr[u]) = olo;
+      *reinterpret_cast<u32x4*>(rptr[u] + p.row_bytes / 2) = ohi;
+    }
+  }
 }
 
 // ================================================================================================
@@ -293,7 +336,13 @@ static int compact_any(int dtype, CompactParams& p, int head_dim, int tail_len, 
   const long long per_block = kCompThreads * kCompUnroll;
   const long long blocks = (p.total + per_block - 1) / per_block;
   if (blocks >= (1ll << 31)) return SPATTEN_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(kv_compact_kernel, dim3((unsigned)blocks), dim3(kCompThreads), 0, st, p);
+  const bool want_kr = p.kr_dst || p.kr_dst_ptrs;
+  if (want_kr && (!p.cos || !p.sin || p.table_rows < p.Lp || p.ppr % 2 != 0)) return SPATTEN_ERR_INVALID;
+  switch (dtype) {
+    case SPATTEN_F32: hipLaunchKernelGGL((kv_compact_kernel<float>), dim3((unsigned)blocks), dim3(kCompThreads), 0, st, p); break;
+    case SPATTEN_F16: hipLaunchKernelGGL((kv_compact_kernel<f16_t>), dim3((unsigned)blocks), dim3(kCompThreads), 0, st, p); break;
+    default: hipLaunchKernelGGL((kv_compact_kernel<bf16_t>), dim3((unsigned)blocks), dim3(kCompThreads), 0, st, p);
+  }
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }
 
@@ -329,12 +378,14 @@ extern "C" int spatten_topk_select(int dtype, const void* score, int64_t score_s
 }
 
 extern "C" int spatten_kv_compact(int dtype, const void* k_src, const void* v_src, int64_t src_sb, int64_t src_sh,
-                                  void* k_dst, void* v_dst, int64_t dst_sb, int64_t dst_sh, const int32_t* idx,
+                                  void* k_dst, void* v_dst, void* kr_dst, int64_t dst_sb, int64_t dst_sh,
+                                  const void* cos, const void* sin, int table_rows, const int32_t* idx,
                                   int64_t idx_sh, int batch, int heads, int head_dim, int start, int k,
                                   int tail_lo, int tail_len, void* stream) {
   if (!k_src || !k_dst || ((v_src == nullptr) != (v_dst == nullptr))) return SPATTEN_ERR_INVALID;
   CompactParams p{};
-  p.k_src = k_src; p.v_src = v_src; p.k_dst = k_dst; p.v_dst = v_dst;
+  p.k_src = k_src; p.v_src = v_src; p.k_dst = k_dst; p.v_dst = v_dst; p.kr_dst = kr_dst;
+  p.cos = cos; p.sin = sin; p.table_rows = table_rows;
   p.src_sb = src_sb; p.src_sh = src_sh; p.dst_sb = dst_sb; p.dst_sh = dst_sh;
   p.idx = idx; p.idx_sl = 0; p.idx_sh = idx_sh;
   p.B = batch; p.H = heads; p.layers = 1; p.n_tensors = v_src ? 2 : 1;
@@ -345,7 +396,8 @@ extern "C" int spatten_kv_compact(int dtype, const void* k_src, const void* v_sr
 extern "C" int spatten_prune_layers(int dtype, int layers, const void* const* score_ptrs, int64_t score_sh,
                                     const void* const* k_src_ptrs, const void* const* v_src_ptrs, int64_t src_sb,
                                     int64_t src_sh, void* const* k_dst_ptrs, void* const* v_dst_ptrs,
-                                    int64_t dst_sb, int64_t dst_sh, int32_t* idx, int batch, int heads,
+                                    void* const* kr_dst_ptrs, int64_t dst_sb, int64_t dst_sh, const void* cos,
+                                    const void* sin, int table_rows, int32_t* idx, int batch, int heads,
                                     int head_dim, int lo, int hi, int k, int tail_lo, int tail_len, void* stream) {
   if (!score_ptrs || !k_src_ptrs || !v_src_ptrs || !k_dst_ptrs || !v_dst_ptrs || !idx) return SPATTEN_ERR_INVALID;
   const int rc = select_any(dtype, nullptr, score_ptrs, score_sh, layers, heads, lo, hi, k, idx,
@@ -353,6 +405,7 @@ extern "C" int spatten_prune_layers(int dtype, int layers, const void* const* sc
   if (rc != SPATTEN_OK) return rc;
   CompactParams p{};
   p.k_src_ptrs = k_src_ptrs; p.v_src_ptrs = v_src_ptrs; p.k_dst_ptrs = k_dst_ptrs; p.v_dst_ptrs = v_dst_ptrs;
+  p.kr_dst_ptrs = kr_dst_ptrs; p.cos = cos; p.sin = sin; p.table_rows = table_rows;
   p.src_sb = src_sb; p.src_sh = src_sh; p.dst_sb = dst_sb; p.dst_sh = dst_sh;
   p.idx = idx; p.idx_sl = (int64_t)heads * k; p.idx_sh = k;
   p.B = batch; p.H = heads; p.layers = layers; p.n_tensors = 2;

@@ -20,7 +20,7 @@ from typing import List, Optional, Sequence
 
 import torch
 
-from . import ops
+from . import kv_slab, ops
 
 
 def slice2d(x, start, end):
@@ -95,12 +95,20 @@ class SpAttenKVCache:
         Ks = [_rows(kv[0]) for kv in past_key_values]
         Vs = [_rows(kv[1]) for kv in past_key_values]
         Ks, Vs = _common_strides(Ks, Vs)
-        Kn, Vn, idx = ops.prune_layers(scores, Ks, Vs, seq_len, lo, hi, self.important_size,
-                                       capacity=new_len + max(int(num_coming), 0))
+        B, H, _, d = Ks[0].shape
+        cap = kv_slab.round_capacity(new_len + max(int(num_coming), 0))
+        rope = kv_slab.rope_tables(cap, d, Ks[0].dtype, Ks[0].device)
+        Kn, Vn, Krn, idx = ops.prune_layers(scores, Ks, Vs, seq_len, lo, hi, self.important_size,
+                                            capacity=cap, rope=rope)
         self.keep_indices = idx
         self.n_pruned_last = seq_len - new_len
         self.n_pruned_total += self.n_pruned_last
-        return [[k, v] for k, v in zip(Kn, Vn)]                               # list of lists (:72-96)
+        out = []
+        for k, v, kr in zip(Kn, Vn, Krn):
+            # remember the slab (spare capacity + rotated shadow) on the tensor HF will hand back to the forward
+            kv_slab.attach(k, v, kr, new_len)
+            out.append([k, v])
+        return out                                                            # list of lists (:72-96)
 
 
 def _rows(t: torch.Tensor) -> torch.Tensor:

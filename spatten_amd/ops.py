@@ -134,20 +134,21 @@ def _prefill_workspace(nbytes: int, device) -> torch.Tensor:
     return buf
 
 
-def attn_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, kv_len: int,
+def attn_prefill(q: torch.Tensor, kr_cache: torch.Tensor, v_cache: torch.Tensor, kv_len: int,
                  cos: torch.Tensor, sin: torch.Tensor, pos_q0: int, causal: bool = True,
                  position_ids: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
                  out: Optional[torch.Tensor] = None, scores: Optional[torch.Tensor] = None,
                  col_importance: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Flash-style prefill (modify_llama.py:86-147 at q_len>1).  q [B,H,q,d] (any strides with d
-    contiguous); caches already hold the q new rows at [kv_len-q, kv_len); mask additive [B,q,kv_len];
-    position_ids int64 [B,q].  Returns out [B, q, H*d]."""
-    _dev(q, k_cache, v_cache, cos, sin, out, scores, col_importance, position_ids, mask)
+    """Flash-style prefill (modify_llama.py:86-147 at q_len>1).  q [B,H,q,d] un-rotated (any strides with d
+    contiguous); kr_cache = ROTATED shadow of the keys, v_cache values, both already holding the q new rows
+    at [kv_len-q, kv_len); mask additive [B,q,kv_len]; position_ids int64 [B,q].  Returns out [B, q, H*d]."""
+    _dev(q, kr_cache, v_cache, cos, sin, out, scores, col_importance, position_ids, mask)
     lib = _lib.load()
     B, H, ql, d = q.shape
-    Hkv = k_cache.shape[1]
+    Hkv = kr_cache.shape[1]
+    k_cache = kr_cache
     if q.stride(3) != 1 or k_cache.stride(3) != 1 or k_cache.stride(2) != d or v_cache.stride() != k_cache.stride():
-        raise ValueError("q needs contiguous d; k_cache/v_cache need contiguous rows (pitch d)")
+        raise ValueError("q needs contiguous d; kr_cache/v_cache need contiguous rows (pitch d)")
     if max(kv_len, pos_q0 + ql) > cos.shape[0] and position_ids is None:
         raise ValueError("rotary table too short")
     if position_ids is not None and (position_ids.dtype != torch.int64 or position_ids.stride(-1) != 1):
@@ -239,9 +240,11 @@ def topk_select(score: torch.Tensor, lo: int, hi: int, k: int) -> torch.Tensor:
 
 
 def kv_compact(K: torch.Tensor, V: Optional[torch.Tensor], idx: torch.Tensor, start: int, tail_lo: int,
-               L: Optional[int] = None, capacity: Optional[int] = None):
+               L: Optional[int] = None, capacity: Optional[int] = None,
+               rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
     """Fused gather + concat (kv_cache_token_pruning.py:64-96).  K,V [B,H,>=L,d]; idx int32 [H,k].
-    Returns (K', V') [B,H,L',d] views of freshly allocated [B,H,capacity,d] slabs."""
+    Returns (K', V', Kr') [B,H,L',d] views of freshly allocated [B,H,capacity,d] slabs; Kr' (the rotated
+    shadow of K' at its new slot positions) only when ``rope=(cos, sin)`` half tables are given."""
     _dev(K, V, idx)
     lib = _lib.load()
     B, H, Lk, d = K.shape
@@ -255,29 +258,35 @@ def kv_compact(K: torch.Tensor, V: Optional[torch.Tensor], idx: torch.Tensor, st
         raise ValueError("K/V need contiguous rows and identical strides")
     Kd = torch.empty(B, H, cap, d, dtype=K.dtype, device=K.device)
     Vd = torch.empty_like(Kd) if V is not None else None
+    Krd = torch.empty_like(Kd) if rope is not None else None
+    cos, sin = rope if rope is not None else (None, None)
     rc = lib.spatten_kv_compact(_dt(K), K.data_ptr(), _ptr(V), K.stride(0), K.stride(1),
-                                Kd.data_ptr(), _ptr(Vd), Kd.stride(0), Kd.stride(1),
+                                Kd.data_ptr(), _ptr(Vd), _ptr(Krd), Kd.stride(0), Kd.stride(1),
+                                _ptr(cos), _ptr(sin), 0 if cos is None else cos.shape[0],
                                 idx.data_ptr(), idx.stride(0), B, H, d, start, k, tail_lo, tail_len, _stream())
     _lib.check(rc, "spatten_kv_compact")
-    return Kd[:, :, :Lp], (None if Vd is None else Vd[:, :, :Lp])
+    return Kd[:, :, :Lp], (None if Vd is None else Vd[:, :, :Lp]), (None if Krd is None else Krd[:, :, :Lp])
 
 
 class PrunePlan:
     """Device pointer tables for the batched all-layer prune (spatten_prune_layers)."""
 
-    def __init__(self, scores: Sequence[torch.Tensor], Ks, Vs, Kd, Vd):
+    def __init__(self, scores: Sequence[torch.Tensor], Ks, Vs, Kd, Vd, Krd=None):
         dev = Ks[0].device
         mk = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64).to(dev)
         self.score_ptrs, self.ks, self.vs, self.kd, self.vd = mk(scores), mk(Ks), mk(Vs), mk(Kd), mk(Vd)
-        self.keep = (list(scores), list(Ks), list(Vs), list(Kd), list(Vd))
+        self.krd = mk(Krd) if Krd is not None else None
+        self.keep = (list(scores), list(Ks), list(Vs), list(Kd), list(Vd), None if Krd is None else list(Krd))
 
 
 def prune_layers(scores: Sequence[torch.Tensor], Ks: Sequence[torch.Tensor], Vs: Sequence[torch.Tensor],
                  L: int, lo: int, hi: int, k: int, capacity: Optional[int] = None,
-                 dst: Optional[Tuple[List[torch.Tensor], List[torch.Tensor]]] = None,
-                 plan: Optional[PrunePlan] = None, idx: Optional[torch.Tensor] = None):
+                 dst: Optional[Tuple[List[torch.Tensor], List[torch.Tensor], Optional[List[torch.Tensor]]]] = None,
+                 plan: Optional[PrunePlan] = None, idx: Optional[torch.Tensor] = None,
+                 rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
     """All layers of apply_token_pruning's loop (kv_cache_token_pruning.py:55-96) in two launches.
-    scores[l] [H, >=hi]; Ks[l]/Vs[l] [B,H,>=L,d].  Returns (K' list, V' list, idx [layers,H,k])."""
+    scores[l] [H, >=hi]; Ks[l]/Vs[l] [B,H,>=L,d].  With ``rope=(cos, sin)`` the rotated shadow of every new
+    cache is produced by the same pass.  Returns (K' list, V' list, Kr' list or None, idx [layers,H,k])."""
     _dev(*scores, *Ks, *Vs)
     lib = _lib.load()
     nl = len(Ks)
@@ -290,22 +299,29 @@ def prune_layers(scores: Sequence[torch.Tensor], Ks: Sequence[torch.Tensor], Vs:
     if dst is None:
         Kd = [torch.empty(B, H, cap, d, dtype=Ks[0].dtype, device=Ks[0].device) for _ in range(nl)]
         Vd = [torch.empty_like(x) for x in Kd]
+        Krd = [torch.empty_like(x) for x in Kd] if rope is not None else None
     else:
-        Kd, Vd = dst
-    for t in list(Ks) + list(Vs) + Kd + Vd:
+        Kd, Vd, Krd = dst
+    for t in list(Ks) + list(Vs) + Kd + Vd + (Krd or []):
         if t.stride(3) != 1 or t.stride(2) != d:
             raise ValueError("K/V need contiguous rows (pitch d)")
-    if any(t.stride() != Ks[0].stride() for t in list(Ks) + list(Vs)) or any(t.stride() != Kd[0].stride() for t in Kd + Vd):
+    if any(t.stride() != Ks[0].stride() for t in list(Ks) + list(Vs)) \
+            or any(t.stride() != Kd[0].stride() for t in Kd + Vd + (Krd or [])):
         raise ValueError("all layers must share strides")
     if any(s.stride(1) != 1 or s.stride(0) != scores[0].stride(0) for s in scores):
         raise ValueError("scores need contiguous rows and a common head stride")
+    if Krd is not None and rope is None:
+        raise ValueError("a shadow destination needs the rotary tables")
     if plan is None:
-        plan = PrunePlan(scores, Ks, Vs, Kd, Vd)
+        plan = PrunePlan(scores, Ks, Vs, Kd, Vd, Krd)
     if idx is None:
         idx = torch.empty(nl, H, k, dtype=torch.int32, device=Ks[0].device)
+    cos, sin = rope if rope is not None else (None, None)
     rc = lib.spatten_prune_layers(_dt(Ks[0]), nl, plan.score_ptrs.data_ptr(), scores[0].stride(0),
                                   plan.ks.data_ptr(), plan.vs.data_ptr(), Ks[0].stride(0), Ks[0].stride(1),
-                                  plan.kd.data_ptr(), plan.vd.data_ptr(), Kd[0].stride(0), Kd[0].stride(1),
+                                  plan.kd.data_ptr(), plan.vd.data_ptr(), _ptr(plan.krd), Kd[0].stride(0), Kd[0].stride(1),
+                                  _ptr(cos), _ptr(sin), 0 if cos is None else cos.shape[0],
                                   idx.data_ptr(), B, H, d, lo, hi, k, tail_lo, tail_len, _stream())
     _lib.check(rc, "spatten_prune_layers")
-    return [x[:, :, :Lp] for x in Kd], [x[:, :, :Lp] for x in Vd], idx
+    return ([x[:, :, :Lp] for x in Kd], [x[:, :, :Lp] for x in Vd],
+            None if Krd is None else [x[:, :, :Lp] for x in Krd], idx)

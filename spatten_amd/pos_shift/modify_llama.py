@@ -1,0 +1,175 @@
+"""Cache-relative-RoPE ("pos_shift") attention forward for HF LlamaAttention on the HIP kernels.
+
+Mirror of the reference's spatten_llm/pos_shift/modify_llama.py: same public names
+(``apply_rotary_pos_emb_single``, ``llama_pos_shift_attention_forward``,
+``enable_llama_pos_shift_attention``), same forward signature / return triple / side effect
+(``self.attn_scores`` = raw scaled logits before mask and softmax, :116-119), same ValueErrors.
+
+What changed underneath (reference lines in parentheses):
+  * q_len == 1: ONE fused launch (ops.attn_decode) replaces RoPE(Q) (:92), torch.cat of the cache (:95-98),
+    RoPE of the whole K cache (:103-104), repeat_kv (:108-109), QK^T/sqrt(d) (:111-113), the stash clone
+    (:116-119), +mask (:132), fp32 softmax (:135-137), PV (:138) and the head merge (:146-147).
+  * q_len  > 1: rope kernel for the new rows + MFMA flash prefill (ops.attn_prefill).
+  * the KV cache lives in capacity slabs with a rotated shadow (kv_slab.py); the returned
+    ``past_key_value`` is still ``(K_unrotated[B,Hkv,N,d], V[B,Hkv,N,d])`` — views, appended in place.
+The q/k/v/o projections stay torch (hipBLASLt) GEMMs, as in the reference (:43-74, :149-163).
+"""
+from __future__ import annotations
+
+import types
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .. import kv_slab, ops
+
+__all__ = ["enable_llama_pos_shift_attention"]
+
+
+def apply_rotary_pos_emb_single(x, cos, sin, position_ids):
+    """modify_llama.py:21-28.  ``cos``/``sin`` are the 4.33-style tables [1,1,S,d] (or [S,d]); only their
+    first d/2 columns are read (the table is ``cat(freqs, freqs)``)."""
+    cos = cos.reshape(-1, cos.shape[-1])
+    sin = sin.reshape(-1, sin.shape[-1])
+    h = x.shape[-1] // 2
+    return ops.rope_single(x, cos[:, :h].contiguous(), sin[:, :h].contiguous(), position_ids=position_ids)
+
+
+def _cfg(self, name, *fallbacks, default=None):
+    v = getattr(self, name, None)
+    if v is not None:
+        return v
+    cfg = getattr(self, "config", None)
+    for fb in fallbacks:
+        v = getattr(cfg, fb, None)
+        if v is not None:
+            return v
+    return default
+
+
+def _rope_base(self) -> float:
+    rot = getattr(self, "rotary_emb", None)
+    base = getattr(rot, "base", None)
+    if base is None:
+        base = getattr(getattr(self, "config", None), "rope_theta", None)
+    return float(base) if base is not None else 10000.0
+
+
+def llama_pos_shift_attention_forward(
+    self,
+    hidden_states: torch.Tensor,
+    attention_mask: Optional[torch.Tensor] = None,
+    position_ids: Optional[torch.LongTensor] = None,
+    past_key_value: Optional[Tuple[torch.Tensor]] = None,
+    output_attentions: bool = False,
+    use_cache: bool = False,
+    padding_mask: Optional[torch.Tensor] = None,
+) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[Tuple[torch.Tensor]]]:
+    bsz, q_len, _ = hidden_states.size()
+    num_heads = _cfg(self, "num_heads", "num_attention_heads")
+    num_kv_heads = _cfg(self, "num_key_value_heads", "num_key_value_heads", default=num_heads)
+    head_dim = _cfg(self, "head_dim", "head_dim") or (_cfg(self, "hidden_size", "hidden_size") // num_heads)
+    hidden_size = _cfg(self, "hidden_size", "hidden_size", default=num_heads * head_dim)
+    tp = getattr(getattr(self, "config", None), "pretraining_tp", 1) or 1
+
+    if tp > 1:                                                                    # :43-69
+        kv_slicing = (num_kv_heads * head_dim) // tp
+        q_slices = self.q_proj.weight.split((num_heads * head_dim) // tp, dim=0)
+        k_slices = self.k_proj.weight.split(kv_slicing, dim=0)
+        v_slices = self.v_proj.weight.split(kv_slicing, dim=0)
+        query_states = torch.cat([F.linear(hidden_states, q_slices[i]) for i in range(tp)], dim=-1)
+        key_states = torch.cat([F.linear(hidden_states, k_slices[i]) for i in range(tp)], dim=-1)
+        value_states = torch.cat([F.linear(hidden_states, v_slices[i]) for i in range(tp)], dim=-1)
+    else:                                                                         # :72-74
+        query_states = self.q_proj(hidden_states)
+        key_states = self.k_proj(hidden_states)
+        value_states = self.v_proj(hidden_states)
+
+    dtype, device = query_states.dtype, query_states.device
+    past_len = 0 if past_key_value is None else past_key_value[0].shape[-2]       # :86-88
+    kv_seq_len = past_len + q_len
+    if attention_mask is not None and attention_mask.size() != (bsz, 1, q_len, kv_seq_len):   # :127-131
+        raise ValueError(
+            f"Attention mask should be of size {(bsz, 1, q_len, kv_seq_len)}, but is {attention_mask.size()}")
+
+    base = _rope_base(self)
+    pk, pv = (None, None) if past_key_value is None else (past_key_value[0], past_key_value[1])
+    slab = kv_slab.slab_for(pk, pv, kv_seq_len, bsz, num_kv_heads, head_dim, dtype, device, base)
+    cos, sin = kv_slab.rope_tables(max(slab.capacity, kv_seq_len), head_dim, dtype, device, base)
+    if position_ids is not None:
+        position_ids = position_ids.to(device=device, dtype=torch.int64)
+        if position_ids.dim() == 1:
+            position_ids = position_ids[None]
+        if position_ids.shape[0] not in (1, bsz) or position_ids.shape[-1] != q_len:
+            raise ValueError(f"position_ids should be of size {(bsz, q_len)}, but is {tuple(position_ids.shape)}")
+        if position_ids.shape[0] == 1 and bsz > 1:
+            position_ids = position_ids.expand(bsz, q_len)
+        position_ids = position_ids.contiguous()
+
+    stash = torch.empty(bsz, num_heads, q_len, kv_seq_len, dtype=dtype, device=device)
+    if attention_mask is not None:
+        attention_mask = attention_mask.to(dtype)
+    if q_len == 1:
+        slab.ensure_shadow(past_len)
+        attn_output = ops.attn_decode(
+            query_states.view(bsz, num_heads, head_dim), slab.k, slab.kr, slab.v, kv_seq_len, cos, sin, past_len,
+            k_new=key_states.view(bsz, num_kv_heads, head_dim), v_new=value_states.view(bsz, num_kv_heads, head_dim),
+            position_ids=None if position_ids is None else position_ids[:, 0],
+            mask=None if attention_mask is None else attention_mask[:, 0, 0, :],
+            scores=stash.view(bsz, num_heads, kv_seq_len))
+        slab.length = slab.rot_len = kv_seq_len
+        attn_output = attn_output.view(bsz, 1, num_heads * head_dim)
+    else:
+        slab.k[:, :, past_len:kv_seq_len].copy_(key_states.view(bsz, q_len, num_kv_heads, head_dim).transpose(1, 2))
+        slab.v[:, :, past_len:kv_seq_len].copy_(value_states.view(bsz, q_len, num_kv_heads, head_dim).transpose(1, 2))
+        slab.length = kv_seq_len
+        slab.ensure_shadow(kv_seq_len)
+        assume_causal = bool(getattr(self, "spatten_assume_causal", False)) and attention_mask is not None
+        attn_output = ops.attn_prefill(
+            query_states.view(bsz, q_len, num_heads, head_dim).transpose(1, 2), slab.kr, slab.v, kv_seq_len,
+            cos, sin, past_len, causal=assume_causal, position_ids=position_ids,
+            mask=None if (attention_mask is None or assume_causal) else attention_mask[:, 0],
+            scores=stash)
+
+    # store attention scores for deciding which token to prune (:116-119) — raw scaled logits, pre-mask
+    self.attn_scores = stash
+
+    if attn_output.size() != (bsz, q_len, hidden_size):                           # :140-147
+        raise ValueError(
+            f"`attn_output` should be of size {(bsz, q_len, hidden_size)}, but is {attn_output.size()}")
+
+    if tp > 1:                                                                    # :149-161
+        attn_output = attn_output.split(hidden_size // tp, dim=2)
+        o_slices = self.o_proj.weight.split(hidden_size // tp, dim=1)
+        attn_output = sum(F.linear(attn_output[i], o_slices[i]) for i in range(tp))
+    else:
+        attn_output = self.o_proj(attn_output)                                    # :163
+
+    attn_weights = None
+    if output_attentions:                                                         # :135-137 on request only
+        logits = stash if attention_mask is None else stash + attention_mask
+        attn_weights = torch.softmax(logits, dim=-1, dtype=torch.float32).to(dtype)
+
+    new_past = slab.views() if use_cache else None                                # :100
+    return attn_output, attn_weights, new_past
+
+
+def _is_llama_attention(module) -> bool:
+    if getattr(module, "_spatten_llama_attention", False) or type(module).__name__ == "LlamaAttention":
+        return True
+    try:
+        from transformers.models.llama.modeling_llama import LlamaAttention
+    except Exception:  # transformers absent: duck typing above is all there is
+        return False
+    return isinstance(module, LlamaAttention)
+
+
+def enable_llama_pos_shift_attention(model):
+    """modify_llama.py:171-181: depth-first over ``model._modules`` (reversed), rebinding ``forward`` on
+    every LlamaAttention instance."""
+    for name, module in reversed(model._modules.items()):
+        if len(list(module.children())) > 0:
+            enable_llama_pos_shift_attention(module)
+        if _is_llama_attention(module):
+            model._modules[name].forward = types.MethodType(llama_pos_shift_attention_forward, model._modules[name])

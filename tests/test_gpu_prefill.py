@@ -1,0 +1,232 @@
+"""Prefill attention (rows leg + MFMA flash leg) and the patched forward vs reference goldens / oracle.  Needs an MI355X."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from oracle import spatten_oracle as orc
+from tests.util import OUT_TOL, TORCH_DT, attn_inputs, check_stash, dev, golden, host
+
+pytestmark = pytest.mark.gpu
+
+
+def run_prefill(q, k, v, past, dt, mask=None, causal=False, stash=True, colimp=False, table="oracle", pos_t=None):
+    from spatten_amd import ops
+    B, H, ql, d = q.shape
+    Hkv = k.shape[1]
+    P = 0 if past is None else past[0].shape[2]
+    N = P + ql
+    kc = k if past is None else np.concatenate([past[0], k], 2)
+    vc = v if past is None else np.concatenate([past[1], v], 2)
+    cap = N + 7
+    kd = torch.full((B, Hkv, cap, d), float("nan"), dtype=TORCH_DT[dt], device="cuda")
+    vd = torch.full((B, Hkv, cap, d), float("nan"), dtype=TORCH_DT[dt], device="cuda")
+    kd[:, :, :N] = dev(kc, dt)
+    vd[:, :, :N] = dev(vc, dt)
+    if table == "torch":
+        cos, sin = ops.rope_table(N + 3, d, TORCH_DT[dt], "cuda")
+    else:
+        c, s = orc.rope_table(N + 3, d, dt)
+        cos, sin = dev(c[:, : d // 2], dt), dev(s[:, : d // 2], dt)
+    krd = torch.full_like(kd, float("nan"))
+    ops.build_shadow(kd, krd, 0, N, cos, sin)
+    scores = torch.full((B, H, ql, N), float("nan"), dtype=TORCH_DT[dt], device="cuda") if stash else None
+    ci = torch.zeros(B, H, N, dtype=torch.float32, device="cuda") if colimp else None
+    # q in the projection layout [B,q,H*d] viewed as [B,H,q,d] (no copy), like the forward passes it
+    qd = dev(np.swapaxes(q, 1, 2).reshape(B, ql, H * d), dt).view(B, ql, H, d).transpose(1, 2)
+    out = ops.attn_prefill(qd, krd, vd, N, cos, sin, P, causal=causal, position_ids=pos_t,
+                           mask=None if mask is None else dev(mask, dt), scores=scores, col_importance=ci)
+    torch.cuda.synchronize()
+    return host(out), (None if scores is None else host(scores)), (None if ci is None else host(ci))
+
+
+def test_prefill_matches_reference_goldens():
+    g = golden("g3_attention.npz")
+    n = 0
+    for m in g["meta"]:
+        name, B, H, Hkv, d, P, ql, mask_kind, dt, seed = m.split("|")
+        B, H, Hkv, d, P, ql, seed = map(int, (B, H, Hkv, d, P, ql, seed))
+        if ql == 1:
+            continue
+        q, k, v, past = attn_inputs(B, H, Hkv, d, P, ql, dt, seed)
+        N = P + ql
+        mask = orc.causal_mask(B, ql, N, dt)[:, 0] if mask_kind == "causal" else None
+        out, stash, _ = run_prefill(q, k, v, past, dt, mask=mask, table="torch")          # explicit HF mask
+        np.testing.assert_allclose(out, g[f"{name}_out"], err_msg=name, **OUT_TOL[dt])
+        check_stash(stash, g[f"{name}_stash"], dt, name)
+        if mask_kind == "causal":                                                          # causal flag, no mask read
+            out2, stash2, _ = run_prefill(q, k, v, past, dt, causal=True, table="torch")
+            np.testing.assert_allclose(out2, g[f"{name}_out"], err_msg=name, **OUT_TOL[dt])
+            check_stash(stash2, g[f"{name}_stash"], dt, name)
+            out3, _, _ = run_prefill(q, k, v, past, dt, causal=True, stash=False, table="torch")   # tile skipping
+            np.testing.assert_allclose(out3, g[f"{name}_out"], err_msg=name, **OUT_TOL[dt])
+        n += 1
+    assert n >= 7
+
+
+@pytest.mark.parametrize("dt,d", [("bf16", 128), ("f16", 64), ("bf16", 64), ("f32", 128)])
+@pytest.mark.parametrize("P,ql", [(0, 130), (300, 200), (77, 9), (513, 64)])
+def test_prefill_vs_oracle(dt, d, P, ql):
+    B, H, Hkv = 2, 4, 2
+    q, k, v, past = attn_inputs(B, H, Hkv, d, P, ql, dt, seed=300 + P + ql)
+    N = P + ql
+    pos = np.tile(np.arange(P, N)[None], (B, 1))
+    mask = orc.causal_mask(B, ql, N, dt)
+    o, stash, _ = orc.attention_core(q, k, v, None if past is None else past[0], None if past is None else past[1], pos, mask, dt)
+    out, st, ci = run_prefill(q, k, v, past, dt, causal=True, colimp=(dt != "f32" and ql > 8))
+    np.testing.assert_allclose(out, o, **OUT_TOL[dt])
+    check_stash(st, stash, dt)
+    if ci is not None:       # reference-mode importance without the stash: sum over query rows, acausal logits included
+        np.testing.assert_allclose(ci, st.sum(axis=2, dtype=np.float32), rtol=1e-4, atol=1e-3)
+    # explicit arbitrary mask + explicit position ids (shifted), no causal flag
+    rng = np.random.default_rng(1)
+    am = np.where(rng.random((B, 1, ql, N)) < 0.2, np.float32(orc.finfo_min(dt)), np.float32(0)).astype(np.float32)
+    am[..., 0] = 0
+    pos2 = pos + 3
+    cos, sin = orc.rope_table(N + 3, d, dt)
+    qr = orc.apply_rotary_pos_emb_single(q, cos, sin, pos2, dt)
+    kc = k if past is None else np.concatenate([past[0], k], 2)
+    vc = v if past is None else np.concatenate([past[1], v], 2)
+    kr = orc.repeat_kv(orc.apply_rotary_pos_emb_single(kc, cos, sin, np.arange(N)[None], dt), H // Hkv)
+    s = orc.round_dt(orc.round_dt(np.matmul(qr, np.swapaxes(kr, 2, 3)), dt) / np.float32(np.sqrt(d)), dt)
+    pm = orc.softmax_probs(orc.round_dt(s + am, dt))
+    o2 = np.swapaxes(np.matmul(pm, orc.repeat_kv(vc, H // Hkv)), 1, 2).reshape(B, ql, H * d)
+    out2, st2, _ = run_prefill(q, k, v, past, dt, mask=am[:, 0], pos_t=torch.from_numpy(pos2).cuda())
+    np.testing.assert_allclose(out2, orc.round_dt(o2, dt), **OUT_TOL[dt])
+    check_stash(st2, s, dt)
+
+
+# ---- the patched forward through a stub module with the transformers-4.33 attribute surface ---------
+class Fixed(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.t = None
+
+    def forward(self, x):
+        return self.t
+
+
+class StubAttn(nn.Module):
+    _spatten_llama_attention = True
+
+    def __init__(self, H, Hkv, d):
+        super().__init__()
+        self.config = SimpleNamespace(pretraining_tp=1, model_type="llama")
+        self.num_heads, self.num_key_value_heads, self.head_dim = H, Hkv, d
+        self.num_key_value_groups = H // Hkv
+        self.hidden_size = H * d
+        self.q_proj, self.k_proj, self.v_proj = Fixed(), Fixed(), Fixed()
+        self.o_proj = nn.Identity()
+
+
+def fwd(m, q, k, v, past, pos, mask, dt):
+    from spatten_amd.pos_shift.modify_llama import llama_pos_shift_attention_forward
+    B, H, ql, d = q.shape
+    Hkv = k.shape[1]
+    m.q_proj.t = dev(np.swapaxes(q, 1, 2).reshape(B, ql, H * d), dt)
+    m.k_proj.t = dev(np.swapaxes(k, 1, 2).reshape(B, ql, Hkv * d), dt)
+    m.v_proj.t = dev(np.swapaxes(v, 1, 2).reshape(B, ql, Hkv * d), dt)
+    hidden = torch.zeros(B, ql, H * d, dtype=TORCH_DT[dt], device="cuda")
+    return llama_pos_shift_attention_forward(m, hidden, attention_mask=mask, position_ids=pos, past_key_value=past,
+                                             use_cache=True)
+
+
+def test_forward_matches_reference_goldens():
+    g = golden("g3_attention.npz")
+    for mline in g["meta"]:
+        name, B, H, Hkv, d, P, ql, mask_kind, dt, seed = mline.split("|")
+        B, H, Hkv, d, P, ql, seed = map(int, (B, H, Hkv, d, P, ql, seed))
+        q, k, v, past = attn_inputs(B, H, Hkv, d, P, ql, dt, seed)
+        N = P + ql
+        m = StubAttn(H, Hkv, d)
+        pos = torch.arange(P, N, device="cuda")[None].expand(B, ql)
+        mask = None
+        if mask_kind == "zeros":
+            mask = torch.zeros(B, 1, ql, N, dtype=TORCH_DT[dt], device="cuda")
+        elif mask_kind == "causal":
+            mask = dev(orc.causal_mask(B, ql, N, dt), dt)
+        pkv = None if past is None else (dev(past[0], dt), dev(past[1], dt))
+        out, w, new_past = fwd(m, q, k, v, pkv, pos, mask, dt)
+        torch.cuda.synchronize()
+        assert w is None and out.shape == (B, ql, H * d)
+        np.testing.assert_allclose(host(out), g[f"{name}_out"], err_msg=name, **OUT_TOL[dt])
+        check_stash(host(m.attn_scores), g[f"{name}_stash"], dt, name)
+        assert m.attn_scores.shape == (B, H, ql, N)
+        # returned cache: un-rotated concat, bit exact, HF layout
+        want_k = k if past is None else np.concatenate([past[0], k], 2)
+        assert new_past[0].shape == (B, Hkv, N, d) and np.array_equal(host(new_past[0]), want_k), name
+        if pkv is not None:
+            assert np.array_equal(host(pkv[0]), past[0])       # inputs never mutated
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_forward_multi_step_decode_and_prune_roundtrip(dt):
+    """prefill -> 5 decode steps (in-place appends into the slab) -> prune -> decode again: every step vs the oracle
+    run on the reference's semantics (cat + re-rotate everything each step)."""
+    from spatten_amd import SpAttenKVCache
+    B, H, d = 1, 4, 128
+    m = StubAttn(H, H, d)
+    rng_seed = 77
+    past_np, past_dev = None, None
+    L = 0
+    for step, ql in enumerate([150, 1, 1, 1, 1, 1]):
+        q = orc.synth_normal(rng_seed, 10 * step, (B, H, ql, d), dt)
+        k = orc.synth_normal(rng_seed, 10 * step + 1, (B, H, ql, d), dt)
+        v = orc.synth_normal(rng_seed, 10 * step + 2, (B, H, ql, d), dt)
+        N = L + ql
+        pos = np.tile(np.arange(L, N)[None], (B, 1))
+        mask_np = orc.causal_mask(B, ql, N, dt)
+        o, stash, (kc, vc) = orc.attention_core(q, k, v, None if past_np is None else past_np[0],
+                                                None if past_np is None else past_np[1], pos, mask_np, dt)
+        out, _, past_dev = fwd(m, q, k, v, past_dev, torch.from_numpy(pos).cuda(), dev(mask_np, dt), dt)
+        # the oracle's table is numpy's; the forward's is torch's: same values except rare 1-ulp table entries,
+        # so compare with the output tolerance only
+        np.testing.assert_allclose(host(out), o, err_msg=f"step {step}", **OUT_TOL[dt])
+        assert np.array_equal(host(past_dev[0]), kc) and np.array_equal(host(past_dev[1]), vc)
+        past_np, L = (kc, vc), N
+    slab = past_dev[0]._spatten_slab
+    assert slab.length == L and slab.rot_len == L and slab.capacity >= L
+    # prune with the last stash, then one more decode step on the pruned cache
+    cache = SpAttenKVCache(start_size=4, recent_size=40, important_size=60)
+    stash_dev = m.attn_scores
+    pruned = cache.apply_token_pruning([past_dev], 10, [stash_dev])
+    want, idx = orc.apply_token_pruning([past_np], 10, [host(stash_dev)], 4, 40, 60, dt)
+    assert np.array_equal(host(pruned[0][0]), want[0][0]) and np.array_equal(host(pruned[0][1]), want[0][1])
+    Lp = want[0][0].shape[2]
+    q = orc.synth_normal(rng_seed, 100, (B, H, 1, d), dt)
+    k = orc.synth_normal(rng_seed, 101, (B, H, 1, d), dt)
+    v = orc.synth_normal(rng_seed, 102, (B, H, 1, d), dt)
+    pos = np.full((B, 1), Lp)
+    o, _, (kc, vc) = orc.attention_core(q, k, v, want[0][0], want[0][1], pos, None, dt)
+    out, _, past2 = fwd(m, q, k, v, tuple(pruned[0]), torch.from_numpy(pos).cuda(), None, dt)
+    np.testing.assert_allclose(host(out), o, **OUT_TOL[dt])
+    assert np.array_equal(host(past2[0]), kc)
+    # the pruned slab came with its rotated shadow and spare room: the append was in place
+    assert past2[0].data_ptr() == pruned[0][0].data_ptr()
+
+
+def test_enable_patches_every_llama_attention_and_rejects_others():
+    from spatten_amd import enable_spatten_llm
+    from spatten_amd.pos_shift.modify_llama import llama_pos_shift_attention_forward
+
+    class Layer(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.self_attn = StubAttn(4, 4, 64)
+            self.mlp = nn.Linear(4, 4)
+
+    class Model(nn.Module):
+        def __init__(self, mt):
+            super().__init__()
+            self.config = SimpleNamespace(model_type=mt)
+            self.layers = nn.ModuleList([Layer(), Layer(), Layer()])
+
+    model = Model("llama")
+    cache = enable_spatten_llm(model, start_size=4, important_size=10, recent_size=12)
+    assert cache.cache_size == 26
+    for layer in model.layers:
+        assert layer.self_attn.forward.__func__ is llama_pos_shift_attention_forward
+    with pytest.raises(ValueError, match="got gpt2"):
+        enable_spatten_llm(Model("gpt2"), 4, 10, 12)

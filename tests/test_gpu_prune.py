@@ -103,9 +103,17 @@ def test_kv_compact_batch_heads_vs_oracle(dt, d):
     for start, tail_lo, k in ((4, 500, 300), (0, 700, 128), (7, 650, 1), (4, 100, 96)):
         idx = orc.topk_window(s, start, tail_lo, k)
         wk, wv = orc.kv_compact(K, V, idx, start, tail_lo)
-        gk, gv = ops.kv_compact(dev(K, dt), dev(V, dt), torch.from_numpy(idx).cuda(), start, tail_lo, capacity=900)
+        rope = None
+        if d % 16 == 0:      # also rebuild the rotated shadow of the new cache in the same pass
+            c, sn = orc.rope_table(900, d, dt)
+            rope = (dev(c[:, : d // 2], dt), dev(sn[:, : d // 2], dt))
+        gk, gv, gkr = ops.kv_compact(dev(K, dt), dev(V, dt), torch.from_numpy(idx).cuda(), start, tail_lo,
+                                     capacity=900, rope=rope)
         assert gk.shape == wk.shape
         assert np.array_equal(host(gk), wk) and np.array_equal(host(gv), wv)
+        if rope is not None:   # shadow row r = RoPE(new K row r, position r)  (modify_llama.py:103-104), bit exact
+            want = orc.apply_rotary_pos_emb_single(wk, c, sn, np.arange(wk.shape[2])[None], dt)
+            assert np.array_equal(host(gkr), want)
 
 
 def test_h1_and_batch2_supported():

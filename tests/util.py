@@ -15,9 +15,11 @@ TORCH_DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
 #    keeps P in fp32 -> a few output ulps: bf16 atol 1e-2 rtol 2e-2; f16 atol 2e-3 rtol 4e-3
 #  * 16-bit stash: every reference rounding step is reproduced; a value may still land one ulp away
 #    where fp32 accumulation order crosses the matmul->dtype rounding boundary; the following
-#    /sqrt(d) -> dtype step stretches that to <= 2 ulp of the (smaller) quotient -> <2% of entries, <= 2 ulp
+#    /sqrt(d) -> dtype step stretches that to <= 2 ulp of the (smaller) quotient -> <2% of entries, <= 2 ulp.
+#    f16 only: torch's CPU half GEMM does not accumulate purely in fp32 (observed 4e-4 absolute deviation on a
+#    cancelling dot product of O(1) terms, reproduced by neither numpy, C nor the GPU) -> atol 6e-5 after /sqrt(d)
 OUT_TOL = {"f32": dict(atol=2e-5, rtol=1e-5), "bf16": dict(atol=1e-2, rtol=2e-2), "f16": dict(atol=2e-3, rtol=4e-3)}
-STASH_TOL = {"f32": dict(atol=2e-5, rtol=1e-5), "bf16": dict(atol=1e-30, rtol=2 ** -6), "f16": dict(atol=1e-6, rtol=2 ** -9)}
+STASH_TOL = {"f32": dict(atol=2e-5, rtol=1e-5), "bf16": dict(atol=2e-6, rtol=2 ** -6), "f16": dict(atol=6e-5, rtol=2 ** -9)}
 
 
 def dev(a, dt):
