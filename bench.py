@@ -1,0 +1,346 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline workload on MI355X: attention-path decode throughput of Llama-2-7B
+geometry at N=4096 with 50% cascade token pruning (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One STEP = one decode token through the attention path of all 32 layers (fused RoPE / KV append / Q·K /
+stash / softmax / P·V kernel per layer) over the pruned cache; every 64th step (a "turn", the reference's
+max_gen_len, run_spatten_llama.py:61) starts with the prune event of all layers (per-head top-k over the
+stashed scores of the 4096-token cache + fused gather/compaction + rotated-shadow rebuild) that takes the
+cache from 4096 to 2048 rows.  Inputs are synthetic, resident in HBM before the timed region.
+
+N > 1: head-parallel (spatten_amd/parallel.py).  Weak scaling: the batch grows with N (B = N sequences), every
+rank owns H/N heads of every sequence — the same KV bytes per rank as the single-GPU run — and each layer
+all-gathers its [B, H/N*d] output slice over RCCL.
+
+Prints ONE JSON line (rank 0).  `value` = whole-job tokens/s.  `roofline` describes the dominant kernel
+(decode attention, HBM-bound); `cpu_baseline` times the C port of the reference (oracle/oracle.c — it re-rotates
+the whole K cache every step, as the reference does) on the host cores, on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LAYERS, HEADS, HEAD_DIM, CTX = 32, 32, 128, 4096
+START, IMPORTANT, RECENT, TURN = 4, 1020, 1024, 64
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the dense / eager comparison legs")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
+    return ap.parse_args()
+
+
+def eager_pos_shift_layer(q, k_new, v_new, past_k, past_v, inv_freq):
+    """torch-eager replica of the reference's dense pos-shift attention core (modify_llama.py:86-147) — the
+    'dense HF attention' the >=4x target is measured against.  q [B,H,1,d]; past [B,H,P,d] un-rotated."""
+    d = q.shape[-1]
+    N = past_k.shape[2] + 1
+    t = torch.arange(N, device=q.device, dtype=torch.float32)
+    freqs = torch.einsum("i,j->ij", t, inv_freq)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    cos, sin = emb.cos().to(q.dtype), emb.sin().to(q.dtype)
+
+    def rot(x, pos):
+        c, s = cos[pos][None, None], sin[pos][None, None]
+        h = x.shape[-1] // 2
+        return x * c + torch.cat((-x[..., h:], x[..., :h]), dim=-1) * s
+
+    qr = rot(q, torch.arange(N - 1, N, device=q.device))
+    k = torch.cat([past_k, k_new], dim=2)
+    v = torch.cat([past_v, v_new], dim=2)
+    kr = rot(k, torch.arange(N, device=q.device))
+    w = torch.matmul(qr, kr.transpose(2, 3)) / (d ** 0.5)
+    stash = w.detach().clone()
+    w = w + torch.zeros(q.shape[0], 1, 1, N, dtype=q.dtype, device=q.device)
+    w = torch.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+    o = torch.matmul(w, v).transpose(1, 2).contiguous().reshape(q.shape[0], 1, -1)
+    return o, stash, (k, v)
+
+
+def time_region(fn, steps, dist_on):
+    import torch.distributed as dist
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn(steps)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from spatten_amd import kv_slab, ops
+    from spatten_amd.parallel import HeadParallel
+
+    dt = torch.bfloat16
+    hp = HeadParallel(HEADS)
+    B, Hl, d, L = world, hp.local_heads, HEAD_DIM, LAYERS
+    new_len = START + IMPORTANT + RECENT                     # 2048
+    cap = kv_slab.round_capacity(new_len + TURN)             # 2176
+    lo, hi = START, CTX - RECENT                             # window [4, 3072), num_coming = 0
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    rnd = lambda *shape: torch.randn(*shape, device=dev, dtype=torch.float32, generator=gen).to(dt)
+
+    cos, sin = ops.rope_table(CTX + TURN, d, dt, dev)
+    # ---- the 4096-token cache of every layer (this rank's heads) and the stash of its last decode step ----
+    Kp = [rnd(B, Hl, CTX, d) for _ in range(L)]
+    Vp = [rnd(B, Hl, CTX, d) for _ in range(L)]
+    q = [rnd(B, Hl, d) for _ in range(L)]
+    kn = [rnd(B, Hl, d) for _ in range(L)]
+    vn = [rnd(B, Hl, d) for _ in range(L)]
+    ws = ops.DecodeWorkspace(B, Hl, d, dev)
+    stash_full = [torch.empty(B, Hl, 1, CTX, dtype=dt, device=dev) for _ in range(L)]
+    Krp = []
+    for l in range(L):
+        kr = ops.rope_single(Kp[l], cos, sin)
+        ops.attn_decode(q[l], None, kr, Vp[l], CTX, cos, sin, CTX - 1, scores=stash_full[l].view(B, Hl, CTX), workspace=ws)
+        Krp.append(kr)
+    importance = [ops.importance(s).contiguous() for s in stash_full]         # [Hl, CTX] (sum over batch, :51)
+    torch.cuda.synchronize()
+
+    # ---- pruned slabs (K, rotated shadow, V) with room for one turn ------------------------------------
+    Kd = [torch.zeros(B, Hl, cap, d, dtype=dt, device=dev) for _ in range(L)]
+    Krd = [torch.zeros_like(x) for x in Kd]
+    Vd = [torch.zeros_like(x) for x in Kd]
+    plan = ops.PrunePlan(importance, Kp, Vp, Kd, Vd, Krd)
+    idx = torch.empty(L, Hl, IMPORTANT, dtype=torch.int32, device=dev)
+    stash = [torch.empty(B, Hl, cap, dtype=dt, device=dev) for _ in range(L)]
+    outs = [torch.empty(B, Hl * d, dtype=dt, device=dev) for _ in range(L)]
+    staging = [hp.gather_staging(B, 1, d, dt, dev) for _ in range(L)] if dist_on else None
+
+    def prune():
+        ops.prune_layers(importance, Kp, Vp, CTX, lo, hi, IMPORTANT, dst=(Kd, Vd, Krd), plan=plan, idx=idx,
+                         rope=(cos, sin))
+
+    def decode_token(n):                       # n = cache length AFTER the append
+        works = []
+        for l in range(L):
+            ops.attn_decode(q[l], Kd[l], Krd[l], Vd[l], n, cos, sin, n - 1, k_new=kn[l], v_new=vn[l],
+                            scores=stash[l], out=outs[l], workspace=ws)
+            if dist_on:
+                _, w = hp.gather_heads(outs[l].view(B, 1, Hl * d), staging[l], async_op=True)
+                works.append(w)
+        for w in works:
+            w.wait()
+
+    def run_slot(slot):
+        if slot == 0:
+            prune()
+        decode_token(new_len + slot + 1)
+
+    # ---- HIP graphs: one per position in the turn (kv_len is a launch parameter) -------------------------
+    graphs = None
+    use_graph = not args.no_graph
+    if use_graph:
+        try:
+            for s in range(2):
+                run_slot(s)
+            torch.cuda.synchronize()
+            graphs = []
+            for slot in range(TURN):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    run_slot(slot)
+                graphs.append(g)
+        except Exception as e:  # e.g. a collective that cannot be captured: fall back to eager launches
+            if rank == 0:
+                print(f"graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graphs = None
+            torch.cuda.synchronize()
+
+    def run_steps(n, first=0):
+        for i in range(first, first + n):
+            if graphs is not None:
+                graphs[i % TURN].replay()
+            else:
+                run_slot(i % TURN)
+
+    run_steps(args.warmup)
+    elapsed = time_region(lambda n: run_steps(n, args.warmup), args.steps, dist_on)
+    tokens_per_s = B * args.steps / elapsed
+
+    result = {
+        "metric": "decode tokens/sec (attention path), Llama-2-7B N=4k, 50% token prune",
+        "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "llama2-7b attention path: 4096-token KV cache -> per-head top-k prune to 2048 "
+                               "(start 4 / important 1020 / recent 1024) -> decode, 64-token turns",
+                   "layers": L, "heads": HEADS, "head_dim": d, "batch": B, "kv_len_before_prune": CTX,
+                   "kv_len_after_prune": new_len, "turn_tokens": TURN,
+                   "parallelism": f"head-parallel x{world} (H/{world} heads per rank, all-gather of outputs)" if dist_on else "single GPU",
+                   "launch": "hip-graph" if graphs is not None else "eager"},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (decode attention, HBM-bound) -------------------------------
+        # average launch duration, live: HIP events on the launch stream around replays of the 63 decode-only
+        # slots; 32 launches per slot.  The figure includes the ~1 us gap between dependent launches, so it
+        # under-states the kernel (rocprofv3 --kernel-trace gives the bare duration: profiles/).
+        if graphs is not None and not dist_on:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 3
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                for slot in range(1, TURN):
+                    graphs[slot].replay()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / (reps * (TURN - 1) * L)
+            n_avg = new_len + 1 + (TURN) / 2.0
+            algo_bytes = 2 * B * Hl * n_avg * d * 2 + 2 * B * Hl * d * 2 + B * Hl * n_avg * 2
+            gbs = algo_bytes / us / 1e3
+            result["roofline"] = {"kernel": "decode_attn_kernel<bf16,128>", "bound": "hbm", "achieved": round(gbs, 1),
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                  "traffic": None, "avg_launch_us": round(us, 3),
+                                  "algorithmic_bytes_per_launch": int(algo_bytes)}
+            # the prune event (select + fused gather): separate, informative
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                prune()
+            e1.record()
+            torch.cuda.synchronize()
+            pus = e0.elapsed_time(e1) * 1e3 / 5
+            gather_bytes = 2 * 2 * L * B * Hl * new_len * d * 2            # K,V x read+write
+            moved = gather_bytes * 5 // 4                                   # + the rotated shadow written by the same pass
+            # the reference's gather+concat alone (no shadow output): the "pruned KV gather" of the north star
+            plan2 = ops.PrunePlan(importance, Kp, Vp, Kd, Vd, None)
+            ops.prune_layers(importance, Kp, Vp, CTX, lo, hi, IMPORTANT, dst=(Kd, Vd, None), plan=plan2, idx=idx)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                ops.prune_layers(importance, Kp, Vp, CTX, lo, hi, IMPORTANT, dst=(Kd, Vd, None), plan=plan2, idx=idx)
+            e1.record()
+            torch.cuda.synchronize()
+            gus = e0.elapsed_time(e1) * 1e3 / 5
+            result["prune_event"] = {
+                "us_all_layers": round(pus, 1), "bytes_moved": int(moved),
+                "GBs_moved_incl_select": round(moved / pus / 1e3, 1), "frac_of_hbm_peak": round(moved / pus / 1e3 / HBM_PEAK_GBS, 4),
+                "gather_only_us": round(gus, 1), "gather_only_GBs_incl_select": round(gather_bytes / gus / 1e3, 1),
+                "gather_only_frac_of_hbm_peak": round(gather_bytes / gus / 1e3 / HBM_PEAK_GBS, 4)}
+            prune()   # restore the shadow planes for whatever runs next
+
+        # ---- dense comparison legs ---------------------------------------------------------------------
+        if not args.no_extras and not dist_on:
+            extras = {}
+            gd = torch.cuda.CUDAGraph()
+            so = torch.empty(B, Hl, CTX, dtype=dt, device=dev)
+
+            def dense_token():
+                for l in range(L):
+                    ops.attn_decode(q[l], None, Krp[l], Vp[l], CTX, cos, sin, CTX - 1, scores=so, out=outs[l], workspace=ws)
+            dense_token()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(gd):
+                dense_token()
+            for _ in range(3):
+                gd.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                gd.replay()
+            torch.cuda.synchronize()
+            extras["dense_fused_tokens_per_s"] = round(50 / (time.perf_counter() - t0), 2)
+            inv_freq = 1.0 / (10000.0 ** (torch.arange(0, d, 2, device=dev).float() / d))
+            pk = [k[:, :, :CTX - 1] for k in Kp]
+            pv = [v[:, :, :CTX - 1] for v in Vp]
+
+            def eager_token():
+                for l in range(L):
+                    eager_pos_shift_layer(q[l][:, :, None], kn[l][:, :, None], vn[l][:, :, None], pk[l], pv[l], inv_freq)
+            for _ in range(2):
+                eager_token()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                eager_token()
+            torch.cuda.synchronize()
+            extras["dense_eager_posshift_tokens_per_s"] = round(5 / (time.perf_counter() - t0), 2)
+            extras["speedup_vs_dense_eager"] = round(tokens_per_s / extras["dense_eager_posshift_tokens_per_s"], 2)
+            extras["speedup_vs_dense_fused"] = round(tokens_per_s / extras["dense_fused_tokens_per_s"], 2)
+            result["extras"] = extras
+
+        # ---- CPU baseline: the C port of the reference on the host cores, bounded sample ------------------
+        if not args.no_cpu_baseline and not dist_on:
+            import numpy as np
+            from oracle import c_oracle as co              # checker / baseline only
+            threads = min(os.cpu_count() or 1, 32)
+            co.set_threads(threads)
+            n = new_len + TURN // 2
+            rs = np.random.default_rng(0)
+            mk = lambda *s: (rs.standard_normal(s).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+            qh, kc, vc = mk(1, HEADS, d), mk(1, HEADS, n, d), mk(1, HEADS, n, d)
+            cs, sn = mk(n, d // 2), mk(n, d // 2)
+            oh = np.empty((1, HEADS * d), np.uint16)
+            sh = np.empty((1, HEADS, n), np.uint16)
+            co.attn_decode_raw("bf16", qh, kc, vc, cs, sn, None, oh, sh, 1, HEADS, HEADS, d, n, n - 1)   # warm
+            reps, t0 = 0, time.perf_counter()
+            while reps < 3 or (time.perf_counter() - t0 < 8.0 and reps < 64):
+                co.attn_decode_raw("bf16", qh, kc, vc, cs, sn, None, oh, sh, 1, HEADS, HEADS, d, n, n - 1)
+                reps += 1
+            t_dec = (time.perf_counter() - t0) / reps
+            score = rs.standard_normal((HEADS, CTX)).astype(np.float32)
+            kfull = mk(1, HEADS, CTX, d)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ix = co.topk_window(score, lo, hi, IMPORTANT, "f32")
+                co.kv_compact_raw("bf16", kfull, ix, START, hi)
+                co.kv_compact_raw("bf16", kfull, ix, START, hi)
+            t_prune = (time.perf_counter() - t0) / 3
+            cpu_tps = 1.0 / (L * t_dec + L * t_prune / TURN)
+            result["cpu_baseline"] = {"value": round(cpu_tps, 4), "unit": "tokens/s", "cores": threads, "kind": "port",
+                                      "sample": f"{reps} decode-attention layer steps at kv_len {n} + 3 one-layer prune events "
+                                                f"(C port of the reference, OpenMP over heads), extrapolated to {L} layers per token "
+                                                f"and one prune per {TURN} tokens",
+                                      "ms_per_layer_decode": round(t_dec * 1e3, 3), "ms_per_layer_prune": round(t_prune * 1e3, 3),
+                                      "host_cpus": os.cpu_count()}
+        print(json.dumps(result))
+
+    if dist_on:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

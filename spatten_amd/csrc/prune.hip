@@ -146,7 +146,10 @@ __global__ __launch_bounds__(kSelThreads) void topk_select_kernel(const SelectPa
 // fused gather + concat of K and V, all layers
 // ================================================================================================
 constexpr int kCompThreads = 256;
-constexpr int kCompUnroll = 4;
+#ifndef SPATTEN_COMP_UNROLL
+#define SPATTEN_COMP_UNROLL 4
+#endif
+constexpr int kCompUnroll = SPATTEN_COMP_UNROLL;
 
 struct CompactParams {
   const void* k_src; const void* v_src; void* k_dst; void* v_dst; void* kr_dst;   // single layer, or
@@ -159,22 +162,23 @@ struct CompactParams {
   int start, k, tail_lo, Lp;                // Lp = start + k + tail_len
   int ppr;                                  // 16-byte pieces per row
   int row_bytes;
-  long long pieces_per_tensor;              // B*H*Lp*ppr
+  long long pieces_per_tensor;              // work items per plane: B*H*Lp*(ppr/2) piece pairs
   long long total;                          // pieces_per_tensor * n_tensors * layers
 };
 
-// T only matters for the optional rotated-shadow output: the lane that moves piece `pc` of a K row in the
-// first half also fetches the partner piece of the second half (an L1/L2 hit: a neighbouring lane streams
-// it anyway), rotates the pair at the row's NEW slot index (modify_llama.py:103-104) and writes both
-// shadow pieces — the shadow is rebuilt by the same pass that moves the rows.
+// One work item = the PAIR of 16-byte pieces (pc, pc + ppr/2) of one destination row — the two halves RoPE
+// pairs up — so the optional rotated-shadow output (row r of the new cache rotated at its NEW slot index r,
+// modify_llama.py:103-104) is produced in registers by the lane that moves the row: the shadow is rebuilt by
+// the same pass that moves the rows, and every lane of a wave does the same amount of work.
 template <typename T>
 __global__ __launch_bounds__(kCompThreads) void kv_compact_kernel(const CompactParams p) {
   const long long g0 = (long long)blockIdx.x * (kCompThreads * kCompUnroll) + threadIdx.x;
-  u32x4 val[kCompUnroll], val2[kCompUnroll], cs[kCompUnroll], sn[kCompUnroll];
+  const int half_ppr = p.ppr / 2;
+  const int half_bytes = p.row_bytes / 2;
+  const bool want_kr = (p.kr_dst != nullptr) || (p.kr_dst_ptrs != nullptr);
+  u32x4 lo_v[kCompUnroll], hi_v[kCompUnroll], cs[kCompUnroll], sn[kCompUnroll];
   char* dptr[kCompUnroll];
   char* rptr[kCompUnroll];
-  const bool want_kr = (p.kr_dst != nullptr) || (p.kr_dst_ptrs != nullptr);
-  const int half_ppr = p.ppr / 2;
 #pragma unroll
   for (int u = 0; u < kCompUnroll; ++u) {
     const long long g = g0 + (long long)u * kCompThreads;
@@ -185,11 +189,11 @@ __global__ __launch_bounds__(kCompThreads) void kv_compact_kernel(const CompactP
       const unsigned rem = (unsigned)(g - (long long)tl * p.pieces_per_tensor);   // < 2^32 (checked on host)
       const int layer = tl / p.n_tensors;
       const int t = tl - layer * p.n_tensors;
-      const unsigned per_bh = (unsigned)p.Lp * (unsigned)p.ppr;
+      const unsigned per_bh = (unsigned)p.Lp * (unsigned)half_ppr;
       const unsigned bh = rem / per_bh;
       const unsigned rr = rem - bh * per_bh;
-      const unsigned r = rr / (unsigned)p.ppr;
-      const unsigned piece = rr - r * (unsigned)p.ppr;
+      const unsigned r = rr / (unsigned)half_ppr;
+      const unsigned piece = rr - r * (unsigned)half_ppr;
       const int b = bh / p.H;
       const int h = bh - b * p.H;
       int src_row;
@@ -208,13 +212,13 @@ __global__ __launch_bounds__(kCompThreads) void kv_compact_kernel(const CompactP
       const char* sp = sbase + b * p.src_sb + h * p.src_sh + (int64_t)src_row * p.row_bytes + piece * 16;
       const int64_t doff = b * p.dst_sb + h * p.dst_sh + (int64_t)r * p.row_bytes + piece * 16;
       dptr[u] = dbase + doff;
-      val[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp));
-      if (want_kr && t == 0 && (int)piece < half_ppr) {
+      lo_v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp));
+      hi_v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp + half_bytes));
+      if (want_kr && t == 0) {
         char* rbase = (char*)(p.kr_dst_ptrs ? p.kr_dst_ptrs[layer] : p.kr_dst);
         rptr[u] = rbase + doff;
-        val2[u] = *reinterpret_cast<const u32x4*>(sp + p.row_bytes / 2);
         const int pos = min((int)r, p.table_rows - 1);
-        const int64_t toff = (int64_t)pos * (p.row_bytes / 2) + piece * 16;
+        const int64_t toff = (int64_t)pos * half_bytes + piece * 16;
         cs[u] = *reinterpret_cast<const u32x4*>((const char*)p.cos + toff);
         sn[u] = *reinterpret_cast<const u32x4*>((const char*)p.sin + toff);
       }
@@ -222,11 +226,14 @@ __global__ __launch_bounds__(kCompThreads) void kv_compact_kernel(const CompactP
   }
 #pragma unroll
   for (int u = 0; u < kCompUnroll; ++u) {
-    if (dptr[u]) __builtin_nontemporal_store(val[u], reinterpret_cast<u32x4*>(dptr[u]));
+    if (dptr[u]) {
+      __builtin_nontemporal_store(lo_v[u], reinterpret_cast<u32x4*>(dptr[u]));
+      __builtin_nontemporal_store(hi_v[u], reinterpret_cast<u32x4*>(dptr[u] + half_bytes));
+    }
     if (rptr[u]) {
       constexpr int E = 16 / sizeof(T);              // elements per 16-byte piece (8, or 4 for fp32)
-      const T* xl = reinterpret_cast<const T*>(&val[u]);
-      const T* xh = reinterpret_cast<const T*>(&val2[u]);
+      const T* xl = reinterpret_cast<const T*>(&lo_v[u]);
+      const T* xh = reinterpret_cast<const T*>(&hi_v[u]);
       const T* cc = reinterpret_cast<const T*>(&cs[u]);
       const T* ss = reinterpret_cast<const T*>(&sn[u]);
       u32x4 olo, ohi;
@@ -242,8 +249,8 @@ __global__ __launch_bounds__(kCompThreads) void kv_compact_kernel(const CompactP
           yh[e] = DT<T>::from_f32(DT<T>::round(bb * c) + DT<T>::round(a * s_));
         }
       }
-      *reinterpret_cast<u32x4*>(rptr[u]) = olo;
-      *reinterpret_cast<u32x4*>(rptr[u] + p.row_bytes / 2) = ohi;
+      __builtin_nontemporal_store(olo, reinterpret_cast<u32x4*>(rptr[u]));
+      __builtin_nontemporal_store(ohi, reinterpret_cast<u32x4*>(rptr[u] + half_bytes));
     }
   }
 }
@@ -329,7 +336,8 @@ static int compact_any(int dtype, CompactParams& p, int head_dim, int tail_len, 
   p.ppr = p.row_bytes / 16;
   p.Lp = p.start + p.k + tail_len;
   p.src_sb *= es; p.src_sh *= es; p.dst_sb *= es; p.dst_sh *= es;
-  p.pieces_per_tensor = (long long)p.B * p.H * p.Lp * p.ppr;
+  if (p.ppr % 2 != 0) return SPATTEN_ERR_UNSUPPORTED;      // rows are moved as (first half, second half) piece pairs
+  p.pieces_per_tensor = (long long)p.B * p.H * p.Lp * (p.ppr / 2);   // work items (piece pairs) per plane
   if (p.pieces_per_tensor >= (1ll << 32)) return SPATTEN_ERR_UNSUPPORTED;
   p.total = p.pieces_per_tensor * p.n_tensors * p.layers;
   if (p.total == 0) return SPATTEN_OK;
@@ -337,7 +345,7 @@ static int compact_any(int dtype, CompactParams& p, int head_dim, int tail_len, 
   const long long blocks = (p.total + per_block - 1) / per_block;
   if (blocks >= (1ll << 31)) return SPATTEN_ERR_UNSUPPORTED;
   const bool want_kr = p.kr_dst || p.kr_dst_ptrs;
-  if (want_kr && (!p.cos || !p.sin || p.table_rows < p.Lp || p.ppr % 2 != 0)) return SPATTEN_ERR_INVALID;
+  if (want_kr && (!p.cos || !p.sin || p.table_rows < p.Lp)) return SPATTEN_ERR_INVALID;
   switch (dtype) {
     case SPATTEN_F32: hipLaunchKernelGGL((kv_compact_kernel<float>), dim3((unsigned)blocks), dim3(kCompThreads), 0, st, p); break;
     case SPATTEN_F16: hipLaunchKernelGGL((kv_compact_kernel<f16_t>), dim3((unsigned)blocks), dim3(kCompThreads), 0, st, p); break;

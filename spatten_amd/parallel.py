@@ -1,0 +1,66 @@
+"""Head-parallel partitioning of the hot path across the GPUs of one node (one process per GPU).
+
+Every op on the path is independent per (batch, head): rotation, Q·K, softmax, P·V, the importance row,
+the per-head top-k and the KV gather (kv_cache_token_pruning.py:59-69 work row-wise on [H, .]).  Rank r owns
+heads [r*H/G, (r+1)*H/G) and the KV planes of those heads; KV never moves.  The only exchange on the path
+is the all-gather of the per-rank attention outputs [B, q, H/G*d] -> [B, q, H*d] in front of o_proj (RCCL
+``all_gather_into_tensor`` over xGMI; backend "nccl" on ROCm IS RCCL), plus — for head pruning — an
+all-gather of H/G fp32 head scores followed by an identical, deterministic top-k on every rank.
+Token pruning needs no communication at all.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class HeadParallel:
+    def __init__(self, num_heads: int, num_kv_heads: Optional[int] = None, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        num_kv_heads = num_kv_heads or num_heads
+        if num_heads % self.world or num_kv_heads % self.world:
+            raise ValueError(f"heads ({num_heads}/{num_kv_heads}) must divide evenly over {self.world} ranks")
+        self.num_heads, self.num_kv_heads = num_heads, num_kv_heads
+        self.local_heads = num_heads // self.world
+        self.local_kv_heads = num_kv_heads // self.world
+
+    def head_range(self, rank: Optional[int] = None) -> Tuple[int, int]:
+        r = self.rank if rank is None else rank
+        return r * self.local_heads, (r + 1) * self.local_heads
+
+    def kv_head_range(self, rank: Optional[int] = None) -> Tuple[int, int]:
+        r = self.rank if rank is None else rank
+        return r * self.local_kv_heads, (r + 1) * self.local_kv_heads
+
+    def shard_heads(self, x: torch.Tensor, dim: int = 1, kv: bool = False) -> torch.Tensor:
+        lo, hi = self.kv_head_range() if kv else self.head_range()
+        return x.narrow(dim, lo, hi - lo)
+
+    def gather_staging(self, batch: int, q_len: int, head_dim: int, dtype, device) -> torch.Tensor:
+        """[world, B, q, H/G*d] receive buffer for ``gather_heads``."""
+        return torch.empty(self.world, batch, q_len, self.local_heads * head_dim, dtype=dtype, device=device)
+
+    def gather_heads(self, out_local: torch.Tensor, staging: Optional[torch.Tensor] = None,
+                     async_op: bool = False):
+        """all-gather of [B, q, H/G*d] -> view [B, q, H*d] (rank-major = head-major, the reference's
+        ``transpose(1,2).reshape`` layout, modify_llama.py:146-147).  Returns (full_view, work)."""
+        B, ql, hd = out_local.shape
+        if self.world == 1:
+            return out_local, None
+        if staging is None:
+            staging = torch.empty(self.world, B, ql, hd, dtype=out_local.dtype, device=out_local.device)
+        work = dist.all_gather_into_tensor(staging, out_local.contiguous(), group=self.group, async_op=async_op)
+        full = staging.permute(1, 2, 0, 3).reshape(B, ql, self.world * hd)
+        return full, work
+
+    def gather_head_scores(self, local_scores: torch.Tensor) -> torch.Tensor:
+        """[H/G] fp32 -> [H] on every rank (head pruning: every rank then runs the same top-k)."""
+        if self.world == 1:
+            return local_scores
+        full = torch.empty(self.world * local_scores.numel(), dtype=local_scores.dtype, device=local_scores.device)
+        dist.all_gather_into_tensor(full, local_scores.contiguous(), group=self.group)
+        return full

@@ -93,7 +93,7 @@ def test_topk_large_window_and_bf16_threshold_ties():
         ops.topk_select(dev(s, "f32"), 5, 10, 6)
 
 
-@pytest.mark.parametrize("dt,d", [("bf16", 128), ("f32", 64), ("f16", 72)])
+@pytest.mark.parametrize("dt,d", [("bf16", 128), ("f32", 64), ("f16", 80), ("f32", 8)])
 def test_kv_compact_batch_heads_vs_oracle(dt, d):
     from spatten_amd import ops
     B, H, L = 2, 5, 700
