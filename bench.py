@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the dense / eager comparison legs")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
+    ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL path even with one rank (testing)")
+    ap.add_argument("--gather", choices=["grouped", "per-layer"], default="grouped",
+                    help="N>1: issue the 32 per-layer all-gathers of a token as ONE RCCL group after the token's "
+                         "attention graph (default), or one eager collective per layer")
     return ap.parse_args()
 
 
@@ -96,10 +100,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    dist_on = world > 1 or args.force_dist
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -114,6 +121,7 @@ def main():
     dt = torch.bfloat16
     hp = HeadParallel(HEADS)
     B, Hl, d, L = world, hp.local_heads, HEAD_DIM, LAYERS
+    world_eff = hp.world
     new_len = START + IMPORTANT + RECENT                     # 2048
     cap = kv_slab.round_capacity(new_len + TURN)             # 2176
     lo, hi = START, CTX - RECENT                             # window [4, 3072), num_coming = 0
@@ -152,15 +160,26 @@ def main():
                          rope=(cos, sin))
 
     def decode_token(n):                       # n = cache length AFTER the append
-        works = []
         for l in range(L):
             ops.attn_decode(q[l], Kd[l], Krd[l], Vd[l], n, cos, sin, n - 1, k_new=kn[l], v_new=vn[l],
                             scores=stash[l], out=outs[l], workspace=ws)
-            if dist_on:
-                _, w = hp.gather_heads(outs[l].view(B, 1, Hl * d), staging[l], async_op=True)
-                works.append(w)
-        for w in works:
-            w.wait()
+
+    def gather_token():
+        """The exchange step of the head-parallel path: every layer's [B, H/N*d] slice -> [B, H*d] on all ranks.
+        Collectives are NOT captured into HIP graphs (torch's RCCL watchdog aborts on captured work on this
+        stack), so they are issued eagerly after the token's attention graph: as one RCCL group of 32
+        all-gathers (one launch), or one by one with --gather per-layer."""
+        import torch.distributed as dist
+        if args.gather == "grouped" and hasattr(dist, "_coalescing_manager"):
+            with dist._coalescing_manager(device=dev, async_ops=True) as cm:
+                for l in range(L):
+                    dist.all_gather_into_tensor(staging[l].view(world_eff * B, 1, Hl * d), outs[l].view(B, 1, Hl * d))
+            cm.wait()
+        else:
+            works = [dist.all_gather_into_tensor(staging[l].view(world_eff * B, 1, Hl * d), outs[l].view(B, 1, Hl * d),
+                                                 async_op=True) for l in range(L)]
+            for w in works:
+                w.wait()
 
     def run_slot(slot):
         if slot == 0:
@@ -181,6 +200,9 @@ def main():
                 with torch.cuda.graph(g):
                     run_slot(slot)
                 graphs.append(g)
+            for g in graphs[:2]:               # a captured collective must also replay
+                g.replay()
+            torch.cuda.synchronize()
         except Exception as e:  # e.g. a collective that cannot be captured: fall back to eager launches
             if rank == 0:
                 print(f"graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
@@ -193,6 +215,8 @@ def main():
                 graphs[i % TURN].replay()
             else:
                 run_slot(i % TURN)
+            if dist_on:
+                gather_token()
 
     run_steps(args.warmup)
     elapsed = time_region(lambda n: run_steps(n, args.warmup), args.steps, dist_on)
@@ -207,7 +231,8 @@ def main():
                                "(start 4 / important 1020 / recent 1024) -> decode, 64-token turns",
                    "layers": L, "heads": HEADS, "head_dim": d, "batch": B, "kv_len_before_prune": CTX,
                    "kv_len_after_prune": new_len, "turn_tokens": TURN,
-                   "parallelism": f"head-parallel x{world} (H/{world} heads per rank, all-gather of outputs)" if dist_on else "single GPU",
+                   "parallelism": (f"head-parallel x{world} (H/{world} heads per rank; RCCL all-gather of every layer's output, "
+                                   f"{args.gather})") if dist_on else "single GPU",
                    "launch": "hip-graph" if graphs is not None else "eager"},
     }
 
@@ -335,11 +360,18 @@ def main():
                                                 f"and one prune per {TURN} tokens",
                                       "ms_per_layer_decode": round(t_dec * 1e3, 3), "ms_per_layer_prune": round(t_prune * 1e3, 3),
                                       "host_cpus": os.cpu_count()}
-        print(json.dumps(result))
-
     if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its banner through C stdio: flush it first so the JSON line is the LAST line of stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

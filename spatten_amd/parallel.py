@@ -16,6 +16,25 @@ import torch
 import torch.distributed as dist
 
 
+class _Done:
+    work = None
+
+    def __init__(self, t):
+        self.t = t
+
+    def wait(self):
+        return self.t
+
+
+class _Pending:
+    def __init__(self, work, merge):
+        self.work, self.merge = work, merge
+
+    def wait(self):
+        self.work.wait()
+        return self.merge()
+
+
 class HeadParallel:
     def __init__(self, num_heads: int, num_kv_heads: Optional[int] = None, group=None):
         self.group = group
@@ -46,16 +65,22 @@ class HeadParallel:
 
     def gather_heads(self, out_local: torch.Tensor, staging: Optional[torch.Tensor] = None,
                      async_op: bool = False):
-        """all-gather of [B, q, H/G*d] -> view [B, q, H*d] (rank-major = head-major, the reference's
-        ``transpose(1,2).reshape`` layout, modify_llama.py:146-147).  Returns (full_view, work)."""
+        """all-gather of [B, q, H/G*d] -> [B, q, H*d] (rank-major = head-major, the reference's
+        ``transpose(1,2).reshape`` layout, modify_llama.py:146-147).  Synchronous: returns (full, None).
+        ``async_op=True``: returns (None, handle); ``handle.wait()`` yields the merged tensor (the
+        head-major merge reads the staging buffer, so it must not run before the collective finished)."""
         B, ql, hd = out_local.shape
-        if self.world == 1:
-            return out_local, None
+        if self.world == 1 and not (dist.is_initialized() and staging is not None):
+            return (None, _Done(out_local)) if async_op else (out_local, None)
         if staging is None:
             staging = torch.empty(self.world, B, ql, hd, dtype=out_local.dtype, device=out_local.device)
-        work = dist.all_gather_into_tensor(staging, out_local.contiguous(), group=self.group, async_op=async_op)
-        full = staging.permute(1, 2, 0, 3).reshape(B, ql, self.world * hd)
-        return full, work
+        # concatenation form (output = inputs stacked along dim 0): accepted by RCCL and by gloo alike
+        work = dist.all_gather_into_tensor(staging.view(self.world * B, ql, hd), out_local.contiguous(),
+                                           group=self.group, async_op=async_op)
+        merge = lambda: staging.permute(1, 2, 0, 3).reshape(B, ql, self.world * hd)
+        if async_op:
+            return None, _Pending(work, merge)
+        return merge(), None
 
     def gather_head_scores(self, local_scores: torch.Tensor) -> torch.Tensor:
         """[H/G] fp32 -> [H] on every rank (head pruning: every rank then runs the same top-k)."""

@@ -1,0 +1,62 @@
+"""The C-ABI library loads on a GPU-less box and exports every symbol include/spatten.h declares (no compute)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "spatten.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(spatten_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_hot_path():
+    names = declared_functions()
+    for must in ("spatten_attn_decode", "spatten_attn_prefill", "spatten_topk_select", "spatten_kv_compact",
+                 "spatten_prune_layers", "spatten_importance", "spatten_rope_single", "spatten_abi_version"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    lib_path = os.path.join(ROOT, "spatten_amd", "lib", "libspatten_hip.so")
+    if not os.path.exists(lib_path):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(lib_path)
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, f"declared in include/spatten.h but not exported: {missing}"
+    lib.spatten_abi_version.restype = ctypes.c_int
+    assert lib.spatten_abi_version() == 1
+    lib.spatten_status_string.restype = ctypes.c_char_p
+    assert lib.spatten_status_string(-3).decode().startswith("top-k window")
+    lib.spatten_decode_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.spatten_decode_workspace_bytes(1, 32, 128, 64) > 32 * 64 * 130 * 8
+
+
+def test_ctypes_layer_declares_every_symbol():
+    from spatten_amd import _lib
+    lib = _lib.load()
+    for n in declared_functions():
+        fn = getattr(lib, n)
+        assert fn.argtypes is not None or n in ("spatten_abi_version",), n
+
+
+def test_product_fails_loudly_without_library_or_gpu(monkeypatch):
+    import torch
+    from spatten_amd import _lib, ops
+    # CPU tensors: no CPU path in the product
+    q = torch.zeros(1, 4, 64)
+    kc = torch.zeros(1, 4, 8, 64)
+    with pytest.raises(RuntimeError, match="ROCm device tensors"):
+        ops.attn_decode(q, kc, kc, kc, 8, torch.zeros(8, 32), torch.zeros(8, 32), 7)
+    with pytest.raises(RuntimeError, match="ROCm device tensors"):
+        ops.topk_select(torch.zeros(2, 16), 0, 16, 4)
+    # missing .so: loud error naming the build command
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libspatten_hip.so")
+    with pytest.raises(_lib.SpattenLibraryError, match="make lib"):
+        _lib.load()
