@@ -255,9 +255,18 @@ def main():
             n_avg = new_len + 1 + (TURN) / 2.0
             algo_bytes = 2 * B * Hl * n_avg * d * 2 + 2 * B * Hl * d * 2 + B * Hl * n_avg * 2
             gbs = algo_bytes / us / 1e3
+            # HBM traffic per launch: PMC counters collected in separate rocprofv3 --pmc passes (tools/pmc_decode.sh,
+            # FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md), committed under profiles/
+            traffic = None
+            try:
+                pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_decode.json"))
+                if pm:
+                    traffic = int(json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["traffic_bytes_per_launch"])
+            except Exception:
+                traffic = None
             result["roofline"] = {"kernel": "decode_attn_kernel<bf16,128>", "bound": "hbm", "achieved": round(gbs, 1),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                  "traffic": None, "avg_launch_us": round(us, 3),
+                                  "traffic": traffic, "avg_launch_us": round(us, 3),
                                   "algorithmic_bytes_per_launch": int(algo_bytes)}
             # the prune event (select + fused gather): separate, informative
             torch.cuda.synchronize()
