@@ -103,6 +103,28 @@ int spatten_attn_decode(int dtype,
                         int kv_len, int pos_q, int n_splits,
                         void* stream);
 
+/* spatten_attn_decode with the SpAtten extras:
+ *   head_ids / n_active_heads  head pruning: only the listed query heads are launched (ascending int32 list in
+ *                              DEVICE memory, NULL = all); rows of pruned heads in out / scores / lse are left untouched
+ *   flags                      SPATTEN_DECODE_SCORES_ONLY: write the stash and lse only (no V traffic, no output) —
+ *                              pass 1 of local V pruning (scores, lse required; k_new must be NULL) */
+#define SPATTEN_DECODE_SCORES_ONLY 1
+int spatten_attn_decode_ex(int dtype,
+                           const void* q, int64_t q_sb, int64_t q_sh,
+                           void* k_cache, void* kr_cache, void* v_cache, int64_t kv_sb, int64_t kv_sh,
+                           const void* k_new, const void* v_new, int64_t new_sb, int64_t new_sh,
+                           const void* cos, const void* sin, int table_rows,
+                           const int64_t* position_ids, int64_t pos_sb,
+                           const void* mask, int64_t mask_sb,
+                           void* out, int64_t out_sb,
+                           void* scores, int64_t sc_sb, int64_t sc_sh,
+                           float* lse,
+                           void* workspace,
+                           int batch, int heads, int kv_heads, int head_dim,
+                           int kv_len, int pos_q, int n_splits,
+                           const int32_t* head_ids, int n_active_heads, int flags,
+                           void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Prefill attention (q_len >= 1), flash-style, same semantics as above for a block of queries.
  * bf16/f16 with head_dim 64/128: rotate Q into the workspace, lay V out key-contiguous for the matrix cores,
@@ -193,6 +215,37 @@ int spatten_prune_layers(int dtype, int layers,
                          int32_t* idx,
                          int batch, int heads, int head_dim,
                          int lo, int hi, int k, int tail_lo, int tail_len, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SpAtten semantics with no numeric implementation in the reference ("parity unpinned": restated from the RTL
+ * control flow / README, checked against oracle/spatten_oracle.py only).
+ * ---------------------------------------------------------------------------------------------- */
+/* Cascade (cumulative) importance, README.md:11 / trace flag if_accumulate_importance (workloads/small.csv:1):
+ *   acc[h, j] += sum over batch b and query rows i of softmax(stash[b,h,i,:] + mask[b,i,:])[j]
+ * stash [B,H,q,L] (strides sb, sh, sq; L contiguous), lse [B,H,q,2] fp32 = (row max, sum exp) of the masked logits as
+ * produced by spatten_attn_decode or spatten_row_lse, mask optional [B,q,L] (strides mask_sb, mask_sq),
+ * acc [H, L] fp32 (stride acc_sh).  causal != 0: row i only sees keys j <= L - q + i. */
+int spatten_importance_accumulate(int dtype, const void* stash, int64_t sb, int64_t sh, int64_t sq,
+                                  const float* lse, const void* mask, int64_t mask_sb, int64_t mask_sq,
+                                  float* acc, int64_t acc_sh, int batch, int heads, int q_len, int kv_len,
+                                  int causal, void* stream);
+/* (row max, sum exp) of every masked logit row: lse [B,H,q,2] fp32 — for stashes that did not come with one. */
+int spatten_row_lse(int dtype, const void* stash, int64_t sb, int64_t sh, int64_t sq, const void* mask,
+                    int64_t mask_sb, int64_t mask_sq, float* lse, int batch, int heads, int q_len, int kv_len,
+                    int causal, void* stream);
+/* The accumulator follows the cache through a prune: dst[h, :] = cat(src[h, :start], src[h, idx[h, :]], src[h, tail_lo:tail_lo+tail_len]) */
+int spatten_importance_compact(const float* src, int64_t src_sh, float* dst, int64_t dst_sh, const int32_t* idx,
+                               int64_t idx_sh, int heads, int start, int k, int tail_lo, int tail_len, void* stream);
+/* Head importance (head pruning, README.md:21): scores[h] += sum over b, i, d of |out[b, i, h*d : (h+1)*d]|; out [B,q,H*d]. */
+int spatten_head_scores(int dtype, const void* out, int64_t out_sb, int64_t out_sq, float* scores,
+                        int batch, int q_len, int heads, int head_dim, void* stream);
+/* Local V pruning, pass 2 (SpAttenController.scala:546-558,591-612): out[b, h*d:(h+1)*d] = sum over the kept keys
+ * j = idx[b*H+h, i] of exp(stash[b,h,j] (+mask[b,j]) - lse_max) / lse_sum * V[b, hkv, j, :]   (no renormalisation).
+ * idx int32 [B*H, k] (stride idx_sr) from spatten_topk_select over the stash rows. */
+int spatten_pv_gather(int dtype, const void* stash, int64_t sc_sb, int64_t sc_sh, const float* lse,
+                      const void* mask, int64_t mask_sb, const void* v_cache, int64_t kv_sb, int64_t kv_sh,
+                      const int32_t* idx, int64_t idx_sr, int k, void* out, int64_t out_sb,
+                      int batch, int heads, int kv_heads, int head_dim, void* stream);
 
 #ifdef __cplusplus
 }

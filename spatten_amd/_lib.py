@@ -33,6 +33,18 @@ def _declare(lib):
     lib.spatten_attn_decode.argtypes = [
         i, p, i64, i64, p, p, p, i64, i64, p, p, i64, i64, p, p, i, p, i64, p, i64, p, i64, p, i64, i64, p, p,
         i, i, i, i, i, i, i, p]
+    lib.spatten_attn_decode_ex.restype = c_int
+    lib.spatten_attn_decode_ex.argtypes = lib.spatten_attn_decode.argtypes[:-1] + [p, i, i, p]
+    lib.spatten_importance_accumulate.restype = c_int
+    lib.spatten_importance_accumulate.argtypes = [i, p, i64, i64, i64, p, p, i64, i64, p, i64, i, i, i, i, i, p]
+    lib.spatten_row_lse.restype = c_int
+    lib.spatten_row_lse.argtypes = [i, p, i64, i64, i64, p, i64, i64, p, i, i, i, i, i, p]
+    lib.spatten_importance_compact.restype = c_int
+    lib.spatten_importance_compact.argtypes = [p, i64, p, i64, p, i64, i, i, i, i, i, p]
+    lib.spatten_head_scores.restype = c_int
+    lib.spatten_head_scores.argtypes = [i, p, i64, i64, p, i, i, i, i, p]
+    lib.spatten_pv_gather.restype = c_int
+    lib.spatten_pv_gather.argtypes = [i, p, i64, i64, p, p, i64, p, i64, i64, p, i64, i, p, i64, i, i, i, i, p]
     lib.spatten_prefill_workspace_bytes.restype = c_size_t
     lib.spatten_prefill_workspace_bytes.argtypes = [i, i, i, i, i, i, i]
     lib.spatten_attn_prefill.restype = c_int

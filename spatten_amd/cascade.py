@@ -1,0 +1,70 @@
+"""SpAtten's cascade semantics on top of the drop-in path — PARITY UNPINNED: the reference's
+Python implements none of this (its importance is the last step's raw logits, kv_cache_token_pruning.py:51); the
+rules below restate the paper / RTL control flow and are checked against oracle/spatten_oracle.py.
+
+* ``CascadeImportance``  cumulative importance = running sum of softmax probabilities per (head, key)
+  (README.md:11; trace flag ``if_accumulate_importance``), carried through prunes with the cache.
+* ``local_v_decode``     local V pruning (SpAttenController.scala:546-558, 591-612): per head keep the ``keep``
+  largest probabilities, fetch only those V rows, no renormalisation.
+* ``HeadPruner``         head pruning (README.md:21): cumulative sum |attn_out_h|, keep the top heads; the decode
+  kernel then launches only the kept heads.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import ops
+
+
+class CascadeImportance:
+    def __init__(self, layers: int, heads: int, capacity: int, device):
+        self.acc: List[torch.Tensor] = [torch.zeros(heads, capacity, dtype=torch.float32, device=device) for _ in range(layers)]
+
+    def accumulate(self, layer: int, stash: torch.Tensor, lse: Optional[torch.Tensor] = None,
+                   mask: Optional[torch.Tensor] = None, causal: bool = False):
+        """stash [B,H,q,L] of this layer's last forward; lse [B,H,q,2] when the kernel already produced it."""
+        L = stash.shape[-1]
+        if self.acc[layer].shape[1] < L:
+            grown = torch.zeros(self.acc[layer].shape[0], 2 * L, dtype=torch.float32, device=stash.device)
+            grown[:, :self.acc[layer].shape[1]] = self.acc[layer]
+            self.acc[layer] = grown
+        ops.importance_accumulate(self.acc[layer], stash, lse, mask, causal)
+
+    def select(self, layer: int, L: int, lo: int, hi: int, k: int) -> torch.Tensor:
+        """Kept positions of the window [lo, hi): top-k of the ACCUMULATED importance (fp32), ascending."""
+        return ops.topk_select(self.acc[layer][:, :L], lo, hi, k)
+
+    def compact(self, layer: int, idx: torch.Tensor, start: int, tail_lo: int, L: int, capacity: Optional[int] = None):
+        self.acc[layer] = ops.importance_compact(self.acc[layer], idx, start, tail_lo, L, capacity or self.acc[layer].shape[1])
+
+
+def local_v_decode(q, kr_cache, v_cache, kv_len, cos, sin, pos_q, keep, mask=None, workspace=None):
+    """Decode step with local V pruning: (1) scores + (max, sum) without touching V, (2) per-(b,h) top-``keep`` of the
+    masked logits (same order as the probabilities), (3) P·V over the kept rows only.  Returns (out [B,H*d], stash)."""
+    B, H, d = q.shape
+    stash = torch.empty(B, H, kv_len, dtype=q.dtype, device=q.device)
+    lse = torch.empty(B, H, 2, dtype=torch.float32, device=q.device)
+    ops.attn_decode(q, None, kr_cache, v_cache, kv_len, cos, sin, pos_q, mask=mask, scores=stash, lse=lse,
+                    scores_only=True, workspace=workspace)
+    keep = min(keep, kv_len)
+    logits = stash if mask is None else (stash + mask[:, None, :])
+    idx = ops.topk_select(logits.reshape(B * H, kv_len), 0, kv_len, keep)
+    out = ops.pv_gather(stash, lse, v_cache, idx, mask=mask)
+    return out, stash
+
+
+class HeadPruner:
+    def __init__(self, heads: int, device):
+        self.heads = heads
+        self.scores = torch.zeros(heads, dtype=torch.float32, device=device)
+
+    def observe(self, attn_out: torch.Tensor):
+        """attn_out [B,q,H*d] (before o_proj) of one layer-step."""
+        ops.head_scores(attn_out, self.heads, self.scores)
+
+    def select(self, keep: int) -> torch.Tensor:
+        """int32 ascending ids of the ``keep`` highest-scoring heads (ties: lowest id) — identical on every rank
+        once the scores have been all-gathered (parallel.HeadParallel.gather_head_scores)."""
+        return ops.topk_select(self.scores[None, :], 0, self.heads, keep)[0].contiguous()

@@ -48,6 +48,7 @@ struct DecodeParams {
   T* out; int64_t out_sb, out_sq;
   T* scores; int64_t sc_sb, sc_sh, sc_sq;
   float* lse;
+  const int32_t* head_ids;   // optional: blockIdx.y -> query head (head pruning: only the kept heads are launched)
   unsigned long long* ws_part;   // [B*H*n_q, S, D+2] {value, tag} granules
   unsigned* ws_cnt;     // [B*H*n_q]
   int B, H, Hkv, N, pos_q, S, chunk, n_q, causal;
@@ -79,7 +80,8 @@ __device__ inline void store_granule(unsigned long long* g, float v) {
                      __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename T, int D, int UNR>
+// SCORES_ONLY: stash + (max, sum) only — no V traffic, no output (first pass of local V pruning)
+template <typename T, int D, int UNR, bool SCORES_ONLY = false>
 __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const DecodeParams<T> p) {
   constexpr int LPR = D / 16;                    // lanes per row
   constexpr int RPI = kDecodeThreads / LPR;      // rows per iteration of the workgroup
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
 
   // grid = (S, H, B * n_q): no integer divisions on the way to the first load
   const int split = blockIdx.x;
-  const int h = blockIdx.y;
+  const int h = p.head_ids ? p.head_ids[blockIdx.y] : (int)blockIdx.y;
   const int b = p.n_q == 1 ? (int)blockIdx.z : (int)blockIdx.z / p.n_q;
   const int qi = p.n_q == 1 ? 0 : (int)blockIdx.z - b * p.n_q;
   const int hkv = p.Hkv == p.H ? h : h / (p.H / p.Hkv);
@@ -132,8 +134,10 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
       }
       k_lo[u] = V8::ldg(kp + 8 * c);
       k_hi[u] = V8::ldg(kp + HALF + 8 * c);
-      v_lo[u] = V8::ldg(vp + 8 * c);
-      v_hi[u] = V8::ldg(vp + HALF + 8 * c);
+      if (!SCORES_ONLY || owns_new) {
+        v_lo[u] = V8::ldg(vp + 8 * c);
+        v_hi[u] = V8::ldg(vp + HALF + 8 * c);
+      }
     }
   };
   if (lo < hi) issue_tile(lo);
@@ -226,11 +230,13 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
       }
       const float pj = (s == -INFINITY) ? 0.f : __expf(s - m_run);
       l_run += pj;
-      float vlo[8], vhi[8];
-      V8::unpack(v_lo[u], vlo);
-      V8::unpack(v_hi[u], vhi);
+      if (!SCORES_ONLY) {
+        float vlo[8], vhi[8];
+        V8::unpack(v_lo[u], vlo);
+        V8::unpack(v_hi[u], vhi);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { olo[i] = fmaf(pj, vlo[i], olo[i]); ohi[i] = fmaf(pj, vhi[i], ohi[i]); }
+        for (int i = 0; i < 8; ++i) { olo[i] = fmaf(pj, vlo[i], olo[i]); ohi[i] = fmaf(pj, vhi[i], ohi[i]); }
+      }
     }
   }
 
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
 
   T* outp = p.out + b * p.out_sb + qi * p.out_sq + h * D;
   if (p.S == 1) {
-    if (tid < D) outp[tid] = DT<T>::from_f32(o_tot / l_tot);
+    if (!SCORES_ONLY && tid < D) outp[tid] = DT<T>::from_f32(o_tot / l_tot);
     if (p.lse != nullptr && tid == 0) { p.lse[unit * 2] = m_run; p.lse[unit * 2 + 1] = l_tot; }
     return;
   }
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
       mg = mn;
     }
   }
-  if (g == 0) outp[e] = DT<T>::from_f32(og / lg);
+  if (!SCORES_ONLY && g == 0) outp[e] = DT<T>::from_f32(og / lg);
   if (tid == 0) {
     if (p.lse != nullptr) { p.lse[unit * 2] = mg; p.lse[unit * 2 + 1] = lg; }
     __hip_atomic_store(p.ws_cnt + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
@@ -411,8 +417,13 @@ static int auto_splits(int units, int d, int kv_len, int dtype) {
 }
 
 template <typename T, int D>
-static int launch_decode(const DecodeParams<T>& p, hipStream_t stream) {
-  const dim3 grid((unsigned)p.S, (unsigned)p.H, (unsigned)(p.B * p.n_q));
+static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_only, hipStream_t stream) {
+  const dim3 grid((unsigned)p.S, (unsigned)n_active, (unsigned)(p.B * p.n_q));
+  if (scores_only) {
+    if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((decode_attn_kernel<T, D, 2, true>), grid, dim3(kDecodeThreads), 0, stream, p);
+    else hipLaunchKernelGGL((decode_attn_kernel<T, D, 4, true>), grid, dim3(kDecodeThreads), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+  }
   switch (decode_unr_for(DT<T>::kId)) {
     case 1: hipLaunchKernelGGL((decode_attn_kernel<T, D, 1>), grid, dim3(kDecodeThreads), 0, stream, p); break;
     case 2: hipLaunchKernelGGL((decode_attn_kernel<T, D, 2>), grid, dim3(kDecodeThreads), 0, stream, p); break;
@@ -424,11 +435,11 @@ static int launch_decode(const DecodeParams<T>& p, hipStream_t stream) {
 }
 
 template <typename T>
-static int dispatch_decode(DecodeParams<T>& p, int d, hipStream_t stream) {
+static int dispatch_decode(DecodeParams<T>& p, int d, int n_active, bool scores_only, hipStream_t stream) {
   switch (d) {
-    case 64: return launch_decode<T, 64>(p, stream);
-    case 128: return launch_decode<T, 128>(p, stream);
-    case 256: return launch_decode<T, 256>(p, stream);
+    case 64: return launch_decode<T, 64>(p, n_active, scores_only, stream);
+    case 128: return launch_decode<T, 128>(p, n_active, scores_only, stream);
+    case 256: return launch_decode<T, 256>(p, n_active, scores_only, stream);
     default: return SPATTEN_ERR_UNSUPPORTED;
   }
 }
@@ -442,8 +453,13 @@ int decode_rows(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
                 int64_t pos_sb, const void* mask, int64_t mask_sb, int64_t mask_sq, void* out, int64_t out_sb,
                 int64_t out_sq, void* scores, int64_t sc_sb, int64_t sc_sh, int64_t sc_sq, float* lse, void* workspace,
                 size_t workspace_units, int batch, int heads, int kv_heads, int head_dim, int kv_len, int pos_q,
-                int n_q, int causal, int n_splits, hipStream_t stream) {
-  if (!q || !kr_cache || !v_cache || !cos || !sin || !out) return SPATTEN_ERR_INVALID;
+                int n_q, int causal, int n_splits, hipStream_t stream, const int32_t* head_ids, int n_active,
+                int flags) {
+  const bool scores_only = (flags & SPATTEN_DECODE_SCORES_ONLY) != 0;
+  if (!q || !kr_cache || !cos || !sin || (!scores_only && (!out || !v_cache))) return SPATTEN_ERR_INVALID;
+  if (scores_only && (!scores || !lse || k_new)) return SPATTEN_ERR_INVALID;
+  if (!head_ids) n_active = heads;
+  if (n_active <= 0 || n_active > heads) return SPATTEN_ERR_INVALID;
   if (batch <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads != 0 || kv_len <= 0 || pos_q < 0 || n_q <= 0)
     return SPATTEN_ERR_INVALID;
   if ((k_new == nullptr) != (v_new == nullptr)) return SPATTEN_ERR_INVALID;
@@ -451,9 +467,9 @@ int decode_rows(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
   if (table_rows < kv_len || (!position_ids && pos_q + n_q > table_rows)) return SPATTEN_ERR_INVALID;
   if (head_dim != 64 && head_dim != 128 && head_dim != 256) return SPATTEN_ERR_UNSUPPORTED;
   if (dtype != SPATTEN_F32 && dtype != SPATTEN_F16 && dtype != SPATTEN_BF16) return SPATTEN_ERR_INVALID;
-  const int units = batch * heads * n_q;
+  const int units = batch * heads * n_q;          // workspace is indexed by the FULL head id
   const int tile = decode_tile_rows(head_dim, dtype);
-  int S = n_splits > 0 ? n_splits : auto_splits(units, head_dim, kv_len, dtype);
+  int S = n_splits > 0 ? n_splits : auto_splits(batch * n_active * n_q, head_dim, kv_len, dtype);
   if (S > ceil_div(kv_len, tile)) S = ceil_div(kv_len, tile);
   if (S > 64) S = 64;
   // chunk = rows per split, a multiple of the tile so every split starts tile-aligned
@@ -472,13 +488,13 @@ int decode_rows(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
   p.mask = (const T*)mask; p.mask_sb = mask_sb; p.mask_sq = mask_sq;                                     \
   p.out = (T*)out; p.out_sb = out_sb; p.out_sq = out_sq;                                                 \
   p.scores = (T*)scores; p.sc_sb = sc_sb; p.sc_sh = sc_sh; p.sc_sq = sc_sq;                              \
-  p.lse = lse;                                                                                           \
+  p.lse = lse; p.head_ids = head_ids;                                                                    \
   p.ws_cnt = (unsigned*)workspace;                                                                       \
   p.ws_part = workspace ? (unsigned long long*)((char*)workspace + cnt_bytes) : nullptr;                              \
   p.B = batch; p.H = heads; p.Hkv = kv_heads; p.N = kv_len; p.pos_q = pos_q; p.S = S; p.chunk = chunk;   \
   p.n_q = n_q; p.causal = causal;                                                                        \
   p.sqrt_d = sqrtf((float)head_dim);                                                                     \
-  return dispatch_decode<T>(p, head_dim, stream);
+  return dispatch_decode<T>(p, head_dim, n_active, scores_only, stream);
 
   switch (dtype) {
     case SPATTEN_F32: { SPATTEN_FILL(float) }
@@ -503,6 +519,21 @@ extern "C" int spatten_decode_auto_splits(int batch, int heads, int head_dim, in
   return auto_splits(batch * heads, head_dim, kv_len, SPATTEN_BF16);
 }
 
+extern "C" int spatten_attn_decode_ex(int dtype, const void* q, int64_t q_sb, int64_t q_sh, void* k_cache,
+                                      void* kr_cache, void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* k_new,
+                                      const void* v_new, int64_t new_sb, int64_t new_sh, const void* cos,
+                                      const void* sin, int table_rows, const int64_t* position_ids,
+                                      int64_t pos_sb, const void* mask, int64_t mask_sb, void* out,
+                                      int64_t out_sb, void* scores, int64_t sc_sb, int64_t sc_sh, float* lse,
+                                      void* workspace, int batch, int heads, int kv_heads, int head_dim,
+                                      int kv_len, int pos_q, int n_splits, const int32_t* head_ids,
+                                      int n_active_heads, int flags, void* stream) {
+  return decode_rows(dtype, q, q_sb, q_sh, 0, k_cache, kr_cache, v_cache, kv_sb, kv_sh, k_new, v_new, new_sb, new_sh,
+                     cos, sin, table_rows, position_ids, pos_sb, mask, mask_sb, 0, out, out_sb, 0, scores, sc_sb,
+                     sc_sh, 0, lse, workspace, (size_t)batch * heads, batch, heads, kv_heads, head_dim, kv_len, pos_q,
+                     1, 0, n_splits, (hipStream_t)stream, head_ids, n_active_heads, flags);
+}
+
 extern "C" int spatten_attn_decode(int dtype, const void* q, int64_t q_sb, int64_t q_sh, void* k_cache,
                                    void* kr_cache, void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* k_new,
                                    const void* v_new, int64_t new_sb, int64_t new_sh, const void* cos,
@@ -511,8 +542,8 @@ extern "C" int spatten_attn_decode(int dtype, const void* q, int64_t q_sb, int64
                                    int64_t out_sb, void* scores, int64_t sc_sb, int64_t sc_sh, float* lse,
                                    void* workspace, int batch, int heads, int kv_heads, int head_dim,
                                    int kv_len, int pos_q, int n_splits, void* stream) {
-  return decode_rows(dtype, q, q_sb, q_sh, 0, k_cache, kr_cache, v_cache, kv_sb, kv_sh, k_new, v_new, new_sb, new_sh,
-                     cos, sin, table_rows, position_ids, pos_sb, mask, mask_sb, 0, out, out_sb, 0, scores, sc_sb,
-                     sc_sh, 0, lse, workspace, (size_t)batch * heads, batch, heads, kv_heads, head_dim, kv_len, pos_q,
-                     1, 0, n_splits, (hipStream_t)stream);
+  return spatten_attn_decode_ex(dtype, q, q_sb, q_sh, k_cache, kr_cache, v_cache, kv_sb, kv_sh, k_new, v_new, new_sb,
+                                new_sh, cos, sin, table_rows, position_ids, pos_sb, mask, mask_sb, out, out_sb, scores,
+                                sc_sb, sc_sh, lse, workspace, batch, heads, kv_heads, head_dim, kv_len, pos_q, n_splits,
+                                nullptr, 0, 0, stream);
 }

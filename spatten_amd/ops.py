@@ -76,14 +76,17 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: torc
                 position_ids: Optional[torch.Tensor] = None,
                 mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                 scores: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,
-                n_splits: int = 0, workspace: Optional[DecodeWorkspace] = None) -> torch.Tensor:
+                n_splits: int = 0, workspace: Optional[DecodeWorkspace] = None,
+                head_ids: Optional[torch.Tensor] = None, scores_only: bool = False) -> torch.Tensor:
     """Fused decode attention (modify_llama.py:86-147 at q_len=1).
 
     q [B,H,d]; k_cache (un-rotated, only appended to) / kr_cache (rotated shadow, see build_shadow) /
     v_cache [B,Hkv,cap,d] with rows [0,kv_len) live (row kv_len-1 is written from k_new/v_new [B,Hkv,d]
     when given); cos/sin [>=kv_len, d/2]; mask [B,kv_len];
     position_ids optional int64 [B] device tensor (overrides pos_q without a host sync);
-    scores (stash) [B,H,>=kv_len]; returns out [B, H*d]."""
+    scores (stash) [B,H,>=kv_len]; lse [B,H,2] fp32 (row max, sum exp); head_ids int32 ascending list of the
+    heads to run (head pruning; rows of the others are left untouched); scores_only: stash + lse only, no V
+    traffic (pass 1 of local V pruning).  Returns out [B, H*d]."""
     _dev(q, k_cache, kr_cache, v_cache, cos, sin, k_new, v_new, mask, out, scores, lse, position_ids)
     if position_ids is not None and position_ids.dtype != torch.int64:
         raise TypeError("position_ids must be int64")
@@ -108,7 +111,9 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: torc
     ws = workspace or _workspace(B, H, d, q.device)
     if n_splits > ws.max_splits:
         raise ValueError("n_splits exceeds workspace")
-    rc = lib.spatten_attn_decode(
+    if head_ids is not None and (head_ids.dtype != torch.int32 or not head_ids.is_cuda or head_ids.dim() != 1):
+        raise TypeError("head_ids must be a 1-D int32 device tensor")
+    rc = lib.spatten_attn_decode_ex(
         _dt(q), q.data_ptr(), q.stride(0), q.stride(1),
         _ptr(k_cache), kr_cache.data_ptr(), v_cache.data_ptr(), kr_cache.stride(0), kr_cache.stride(1),
         _ptr(k_new), _ptr(v_new), 0 if k_new is None else k_new.stride(0), 0 if k_new is None else k_new.stride(1),
@@ -118,7 +123,8 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: torc
         out.data_ptr(), out.stride(0),
         _ptr(scores), 0 if scores is None else scores.stride(0), 0 if scores is None else scores.stride(1),
         _ptr(lse), ws.buf.data_ptr(),
-        B, H, Hkv, d, kv_len, pos_q, n_splits, _stream())
+        B, H, Hkv, d, kv_len, pos_q, n_splits,
+        _ptr(head_ids), 0 if head_ids is None else head_ids.numel(), 1 if scores_only else 0, _stream())
     _lib.check(rc, "spatten_attn_decode")
     return out
 
@@ -325,3 +331,89 @@ def prune_layers(scores: Sequence[torch.Tensor], Ks: Sequence[torch.Tensor], Vs:
     _lib.check(rc, "spatten_prune_layers")
     return ([x[:, :, :Lp] for x in Kd], [x[:, :, :Lp] for x in Vd],
             None if Krd is None else [x[:, :, :Lp] for x in Krd], idx)
+
+
+# ------------------------------------------------------------------------------------------------
+# SpAtten semantics beyond the reference's Python (parity unpinned; oracle/spatten_oracle.py restates them)
+# ------------------------------------------------------------------------------------------------
+def row_lse(stash: torch.Tensor, mask: Optional[torch.Tensor] = None, causal: bool = False) -> torch.Tensor:
+    """stash [B,H,q,L] (+ additive mask [B,q,L]) -> lse [B,H,q,2] fp32 = (row max, sum exp)."""
+    _dev(stash, mask)
+    B, H, Q, L = stash.shape
+    if stash.stride(3) != 1:
+        stash = stash.contiguous()
+    lse = torch.empty(B, H, Q, 2, dtype=torch.float32, device=stash.device)
+    rc = _lib.load().spatten_row_lse(_dt(stash), stash.data_ptr(), stash.stride(0), stash.stride(1), stash.stride(2),
+                                     _ptr(mask), *((0, 0) if mask is None else (mask.stride(0), mask.stride(1))),
+                                     lse.data_ptr(), B, H, Q, L, int(causal), _stream())
+    _lib.check(rc, "spatten_row_lse")
+    return lse
+
+
+def importance_accumulate(acc: torch.Tensor, stash: torch.Tensor, lse: Optional[torch.Tensor] = None,
+                          mask: Optional[torch.Tensor] = None, causal: bool = False) -> torch.Tensor:
+    """Cascade importance: acc[h, j] += sum_{b,i} softmax(stash[b,h,i,:] + mask[b,i,:])[j]  (in place).
+    acc [H, >=L] fp32; stash [B,H,q,L]; lse [B,H,q,2] from attn_decode / row_lse (computed when None)."""
+    _dev(acc, stash, lse, mask)
+    B, H, Q, L = stash.shape
+    if stash.stride(3) != 1:
+        stash = stash.contiguous()
+    if acc.dtype != torch.float32 or acc.stride(1) != 1 or acc.shape[0] != H or acc.shape[1] < L:
+        raise ValueError("acc must be fp32 [H, >=L] with contiguous rows")
+    if lse is None:
+        lse = row_lse(stash, mask, causal)
+    rc = _lib.load().spatten_importance_accumulate(
+        _dt(stash), stash.data_ptr(), stash.stride(0), stash.stride(1), stash.stride(2), lse.data_ptr(),
+        _ptr(mask), *((0, 0) if mask is None else (mask.stride(0), mask.stride(1))),
+        acc.data_ptr(), acc.stride(0), B, H, Q, L, int(causal), _stream())
+    _lib.check(rc, "spatten_importance_accumulate")
+    return acc
+
+
+def importance_compact(acc: torch.Tensor, idx: torch.Tensor, start: int, tail_lo: int, L: int,
+                       capacity: Optional[int] = None) -> torch.Tensor:
+    """The accumulator follows the cache through a prune (same row map as kv_compact)."""
+    _dev(acc, idx)
+    H = acc.shape[0]
+    k = idx.shape[1]
+    tail_lo = min(max(tail_lo, 0), L)
+    tail_len = L - tail_lo
+    Lp = start + k + tail_len
+    dst = torch.zeros(H, max(capacity or Lp, Lp), dtype=torch.float32, device=acc.device)
+    rc = _lib.load().spatten_importance_compact(acc.data_ptr(), acc.stride(0), dst.data_ptr(), dst.stride(0),
+                                                idx.data_ptr(), idx.stride(0), H, start, k, tail_lo, tail_len, _stream())
+    _lib.check(rc, "spatten_importance_compact")
+    return dst
+
+
+def head_scores(out: torch.Tensor, heads: int, scores: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """scores[h] += sum |out[b, i, h*d:(h+1)*d]|; out [B,q,H*d] (or [B,H*d]); scores fp32 [H] (zeros when None)."""
+    _dev(out, scores)
+    if out.dim() == 2:
+        out = out[:, None, :]
+    B, Q, HD = out.shape
+    if out.stride(2) != 1:
+        out = out.contiguous()
+    if scores is None:
+        scores = torch.zeros(heads, dtype=torch.float32, device=out.device)
+    rc = _lib.load().spatten_head_scores(_dt(out), out.data_ptr(), out.stride(0), out.stride(1), scores.data_ptr(),
+                                         B, Q, heads, HD // heads, _stream())
+    _lib.check(rc, "spatten_head_scores")
+    return scores
+
+
+def pv_gather(stash: torch.Tensor, lse: torch.Tensor, v_cache: torch.Tensor, idx: torch.Tensor,
+              mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Local V pruning, pass 2: out[b,h] = sum_{j in idx[b*H+h]} softmax_full(stash[b,h] + mask[b])[j] * V[b,hkv,j].
+    stash [B,H,>=L]; lse [B,H,2]; v_cache [B,Hkv,cap,d]; idx int32 [B*H, k]."""
+    _dev(stash, lse, v_cache, idx, mask, out)
+    B, H = stash.shape[0], stash.shape[1]
+    Hkv, d = v_cache.shape[1], v_cache.shape[3]
+    if out is None:
+        out = torch.empty(B, H * d, dtype=v_cache.dtype, device=v_cache.device)
+    rc = _lib.load().spatten_pv_gather(_dt(v_cache), stash.data_ptr(), stash.stride(0), stash.stride(1), lse.data_ptr(),
+                                       _ptr(mask), 0 if mask is None else mask.stride(0), v_cache.data_ptr(),
+                                       v_cache.stride(0), v_cache.stride(1), idx.data_ptr(), idx.stride(0), idx.shape[1],
+                                       out.data_ptr(), out.stride(0), B, H, Hkv, d, _stream())
+    _lib.check(rc, "spatten_pv_gather")
+    return out

@@ -1,0 +1,99 @@
+"""Cascade importance, local V pruning, head pruning (PARITY UNPINNED: vs the oracle's restatement only)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import spatten_oracle as orc
+from tests.util import OUT_TOL, TORCH_DT, attn_inputs, dev, host
+
+pytestmark = pytest.mark.gpu
+
+
+def setup_decode(B, H, Hkv, d, P, dt, seed):
+    from spatten_amd import ops
+    q, k, v, past = attn_inputs(B, H, Hkv, d, P + 1, 1, dt, seed)   # treat all P+1 rows as cached
+    kc, vc = past
+    N = P + 1
+    c, s = orc.rope_table(N, d, dt)
+    cos, sin = dev(c[:, : d // 2], dt), dev(s[:, : d // 2], dt)
+    kd, vd = dev(kc, dt), dev(vc, dt)
+    krd = ops.rope_single(kd, cos, sin)
+    pos = np.full((B, 1), N - 1)
+    qr = orc.apply_rotary_pos_emb_single(q, c, s, pos, dt)
+    kr = orc.repeat_kv(orc.apply_rotary_pos_emb_single(kc, c, s, np.arange(N)[None], dt), H // Hkv)
+    stash = orc.round_dt(orc.round_dt(np.matmul(qr, np.swapaxes(kr, 2, 3)), dt) / np.float32(np.sqrt(d)), dt)
+    return q, kc, vc, stash, (dev(q[:, :, 0], dt), krd, vd, cos, sin, N)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_cascade_importance_accumulate_and_compact(dt):
+    from spatten_amd import ops
+    from spatten_amd.cascade import CascadeImportance
+    B, H, d, P = 2, 4, 64, 300
+    q, kc, vc, stash, (qd, krd, vd, cos, sin, N) = setup_decode(B, H, H, d, P, dt, 11)
+    ci = CascadeImportance(1, H, 512, "cuda")
+    st = torch.empty(B, H, N, dtype=TORCH_DT[dt], device="cuda")
+    lse = torch.empty(B, H, 2, dtype=torch.float32, device="cuda")
+    ops.attn_decode(qd, None, krd, vd, N, cos, sin, N - 1, scores=st, lse=lse)
+    acc_want = np.zeros((H, N), np.float32)
+    for rep in range(3):       # three steps accumulate
+        ci.accumulate(0, st[:, :, None, :], lse[:, :, None, :])
+        acc_want = orc.cascade_importance_accumulate(acc_want, host(st)[:, :, None, :])
+    np.testing.assert_allclose(host(ci.acc[0])[:, :N], acc_want, rtol=2e-3, atol=1e-5)
+    # lse recomputed from the stash (prefill-style stash with q > 1 rows and a causal mask)
+    ql = 5
+    st2 = dev(orc.synth_normal(3, 0, (B, H, ql, N), dt), dt)
+    acc2 = torch.zeros(H, N, dtype=torch.float32, device="cuda")
+    ops.importance_accumulate(acc2, st2, causal=True)
+    mask = orc.causal_mask(B, ql, N, "f32")
+    mask = np.where(mask < 0, -np.inf, 0).astype(np.float32)
+    want2 = orc.cascade_importance_accumulate(np.zeros((H, N), np.float32), host(st2), mask)
+    np.testing.assert_allclose(host(acc2), want2, rtol=2e-3, atol=1e-5)
+    # selection on the accumulated importance + compaction of the accumulator (bit exact moves)
+    idx = ci.select(0, N, 4, N - 50, 100)
+    assert np.array_equal(idx.cpu().numpy(), orc.topk_window(host(ci.acc[0])[:, :N], 4, N - 50, 100))
+    before = host(ci.acc[0])[:, :N]
+    ci.compact(0, idx, 4, N - 50, N)
+    ii = idx.cpu().numpy()
+    want = np.concatenate([before[:, :4], np.take_along_axis(before, ii, 1), before[:, N - 50:]], axis=1)
+    assert np.array_equal(host(ci.acc[0])[:, :want.shape[1]], want)
+
+
+@pytest.mark.parametrize("dt,Hkv", [("bf16", 8), ("f16", 2), ("f32", 8)])
+def test_local_value_pruning_vs_oracle(dt, Hkv):
+    from spatten_amd.cascade import local_v_decode
+    B, H, d, P = 2, 8, 128, 700
+    q, kc, vc, stash, (qd, krd, vd, cos, sin, N) = setup_decode(B, H, Hkv, d, P, dt, 21)
+    for keep in (N // 5, 64, N):
+        out, st = local_v_decode(qd, krd, vd, N, cos, sin, N - 1, keep)
+        probs = orc.softmax_probs(host(st))                       # probabilities of the kernel's own stash
+        want = orc.local_value_prune(probs, orc.repeat_kv(vc, H // Hkv), keep).reshape(B, H * d)
+        np.testing.assert_allclose(host(out), orc.round_dt(want, dt), **OUT_TOL[dt])
+        np.testing.assert_allclose(host(st), stash[:, :, 0] if stash.ndim == 4 else stash, rtol=2 ** -6, atol=1e-4)
+
+
+def test_head_scores_and_pruned_decode():
+    from spatten_amd import ops
+    from spatten_amd.cascade import HeadPruner
+    dt, B, H, d, P = "bf16", 2, 8, 128, 400
+    q, kc, vc, stash, (qd, krd, vd, cos, sin, N) = setup_decode(B, H, H, d, P, dt, 31)
+    full = ops.attn_decode(qd, None, krd, vd, N, cos, sin, N - 1)
+    hp = HeadPruner(H, "cuda")
+    hp.observe(full[:, None, :])
+    hp.observe(full[:, None, :])
+    want = 2 * orc.head_scores(host(full)[:, None, :], H)
+    np.testing.assert_allclose(host(hp.scores), want, rtol=1e-5)
+    keep = hp.select(6)
+    assert np.array_equal(keep.cpu().numpy(), orc.head_prune_select(want, 6))
+    # pruned decode: only the kept heads run; their outputs are identical, the others stay untouched
+    out = torch.full_like(full, float("nan"))
+    st = torch.full((B, H, N), float("nan"), dtype=TORCH_DT[dt], device="cuda")
+    ops.attn_decode(qd, None, krd, vd, N, cos, sin, N - 1, out=out, scores=st, head_ids=keep)
+    torch.cuda.synchronize()
+    o3, f3 = out.view(B, H, d), full.view(B, H, d)
+    kept = keep.cpu().numpy().tolist()
+    for h in range(H):
+        if h in kept:
+            assert torch.equal(o3[:, h], f3[:, h])
+        else:
+            assert torch.isnan(o3[:, h].float()).all() and torch.isnan(st[:, h].float()).all()
