@@ -247,6 +247,30 @@ int spatten_pv_gather(int dtype, const void* stash, int64_t sc_sb, int64_t sc_sh
                       const int32_t* idx, int64_t idx_sr, int k, void* out, int64_t out_sb,
                       int batch, int heads, int kv_heads, int head_dim, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Progressive quantisation of the (rotated) key cache — MSB-first fetch with LSB refetch on low confidence
+ * (MatrixFetcher.scala:48-51,341-348; RequantDecision.scala:44-72; SpAttenController.scala:35-39,402).  Parity unpinned.
+ *   msb, lsb  [B,Hkv,cap,d/2] bytes: two 4-bit fields per byte (element 2i low nibble), msb signed, lsb unsigned,
+ *             q8 = msb*16 + lsb;  scale [B,Hkv,cap] fp32 per row;  x ~ q8 * scale   (plane strides pl_sb, pl_sh in
+ *             bytes; scale strides sc_sb, sc_sh in elements)
+ * ---------------------------------------------------------------------------------------------- */
+/* quantise rows [row_lo, row_hi) of the rotated shadow kr_cache into the planes */
+int spatten_pq_pack(int dtype, const void* kr_cache, int64_t kv_sb, int64_t kv_sh, void* msb, void* lsb, float* scale,
+                    int64_t pl_sb, int64_t pl_sh, int64_t sc_sb, int64_t sc_sh, int batch, int kv_heads, int head_dim,
+                    int row_lo, int row_hi, void* stream);
+size_t spatten_pq_scratch_bytes(int batch, int heads, int head_dim, int kv_len);
+/* decode step over the planes: pass 1 scores from the MSB plane; heads with max_j prob_j < threshold refetch the LSB
+ * plane and are recomputed once; softmax + P.V with the un-quantised V.  q [B,H,d] un-rotated (rotated at pos_q);
+ * need_lsb optional int32 [B*H] (which heads refetched); scratch = spatten_pq_scratch_bytes; workspace = the decode
+ * workspace (spatten_decode_workspace_bytes). */
+int spatten_attn_decode_pq(int dtype, const void* q, int64_t q_sb, int64_t q_sh,
+                           const void* msb, const void* lsb, const float* scale,
+                           int64_t pl_sb, int64_t pl_sh, int64_t sc_sb, int64_t sc_sh,
+                           const void* v_cache, int64_t kv_sb, int64_t kv_sh,
+                           const void* cos, const void* sin, int table_rows, int pos_q, float threshold,
+                           void* out, int64_t out_sb, int32_t* need_lsb, void* scratch, void* workspace,
+                           int batch, int heads, int kv_heads, int head_dim, int kv_len, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,13 @@ def _declare(lib):
     lib.spatten_head_scores.argtypes = [i, p, i64, i64, p, i, i, i, i, p]
     lib.spatten_pv_gather.restype = c_int
     lib.spatten_pv_gather.argtypes = [i, p, i64, i64, p, p, i64, p, i64, i64, p, i64, i, p, i64, i, i, i, i, p]
+    lib.spatten_pq_pack.restype = c_int
+    lib.spatten_pq_pack.argtypes = [i, p, i64, i64, p, p, p, i64, i64, i64, i64, i, i, i, i, i, p]
+    lib.spatten_pq_scratch_bytes.restype = c_size_t
+    lib.spatten_pq_scratch_bytes.argtypes = [i, i, i, i]
+    lib.spatten_attn_decode_pq.restype = c_int
+    lib.spatten_attn_decode_pq.argtypes = [i, p, i64, i64, p, p, p, i64, i64, i64, i64, p, i64, i64, p, p, i, i, c_float,
+                                           p, i64, p, p, p, i, i, i, i, i, p]
     lib.spatten_prefill_workspace_bytes.restype = c_size_t
     lib.spatten_prefill_workspace_bytes.argtypes = [i, i, i, i, i, i, i]
     lib.spatten_attn_prefill.restype = c_int

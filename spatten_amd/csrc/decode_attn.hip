@@ -49,6 +49,7 @@ struct DecodeParams {
   T* scores; int64_t sc_sb, sc_sh, sc_sq;
   float* lse;
   const int32_t* head_ids;   // optional: blockIdx.y -> query head (head pruning: only the kept heads are launched)
+  const float* scores_in; int64_t si_sb, si_sh;   // optional: final fp32 logits given (progressive-quant path): no K traffic
   unsigned long long* ws_part;   // [B*H*n_q, S, D+2] {value, tag} granules
   unsigned* ws_cnt;     // [B*H*n_q]
   int B, H, Hkv, N, pos_q, S, chunk, n_q, causal;
@@ -132,8 +133,10 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
         kp = p.k_new + b * p.new_sb + hkv * p.new_sh;
         vp = p.v_new + b * p.new_sb + hkv * p.new_sh;
       }
-      k_lo[u] = V8::ldg(kp + 8 * c);
-      k_hi[u] = V8::ldg(kp + HALF + 8 * c);
+      if (p.scores_in == nullptr) {
+        k_lo[u] = V8::ldg(kp + 8 * c);
+        k_hi[u] = V8::ldg(kp + HALF + 8 * c);
+      }
       if (!SCORES_ONLY || owns_new) {
         v_lo[u] = V8::ldg(vp + 8 * c);
         v_hi[u] = V8::ldg(vp + HALF + 8 * c);
@@ -215,9 +218,14 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
     for (int u = 0; u < UNR; ++u) {
       const int j = t0 + u * RPI + r;
       const bool valid = j < hi;
-      float s = group_sum<LPR>(D8::dot(q_hi, k_hi[u], D8::dot(q_lo, k_lo[u], 0.f)));
-      // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
-      s = DT<T>::round(DT<T>::round(s) / p.sqrt_d);
+      float s;
+      if (p.scores_in != nullptr) {
+        s = p.scores_in[b * p.si_sb + h * p.si_sh + min(j, hi - 1)];
+      } else {
+        s = group_sum<LPR>(D8::dot(q_hi, k_hi[u], D8::dot(q_lo, k_lo[u], 0.f)));
+        // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
+        s = DT<T>::round(DT<T>::round(s) / p.sqrt_d);
+      }
       if (stashp != nullptr && c == 0 && valid) stashp[j] = DT<T>::from_f32(s);       // pre-mask (:116-119)
       if (maskp != nullptr) s = DT<T>::round(s + mk[u]);                               // :132
       s = (valid && j < n_vis) ? s : -INFINITY;
@@ -454,9 +462,9 @@ int decode_rows(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
                 int64_t out_sq, void* scores, int64_t sc_sb, int64_t sc_sh, int64_t sc_sq, float* lse, void* workspace,
                 size_t workspace_units, int batch, int heads, int kv_heads, int head_dim, int kv_len, int pos_q,
                 int n_q, int causal, int n_splits, hipStream_t stream, const int32_t* head_ids, int n_active,
-                int flags) {
+                int flags, const float* scores_in, int64_t si_sb, int64_t si_sh) {
   const bool scores_only = (flags & SPATTEN_DECODE_SCORES_ONLY) != 0;
-  if (!q || !kr_cache || !cos || !sin || (!scores_only && (!out || !v_cache))) return SPATTEN_ERR_INVALID;
+  if (!q || (!kr_cache && !scores_in) || !cos || !sin || (!scores_only && (!out || !v_cache))) return SPATTEN_ERR_INVALID;
   if (scores_only && (!scores || !lse || k_new)) return SPATTEN_ERR_INVALID;
   if (!head_ids) n_active = heads;
   if (n_active <= 0 || n_active > heads) return SPATTEN_ERR_INVALID;
@@ -489,6 +497,7 @@ int decode_rows(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
   p.out = (T*)out; p.out_sb = out_sb; p.out_sq = out_sq;                                                 \
   p.scores = (T*)scores; p.sc_sb = sc_sb; p.sc_sh = sc_sh; p.sc_sq = sc_sq;                              \
   p.lse = lse; p.head_ids = head_ids;                                                                    \
+  p.scores_in = scores_in; p.si_sb = si_sb; p.si_sh = si_sh;                                             \
   p.ws_cnt = (unsigned*)workspace;                                                                       \
   p.ws_part = workspace ? (unsigned long long*)((char*)workspace + cnt_bytes) : nullptr;                              \
   p.B = batch; p.H = heads; p.Hkv = kv_heads; p.N = kv_len; p.pos_q = pos_q; p.S = S; p.chunk = chunk;   \
@@ -531,7 +540,7 @@ extern "C" int spatten_attn_decode_ex(int dtype, const void* q, int64_t q_sb, in
   return decode_rows(dtype, q, q_sb, q_sh, 0, k_cache, kr_cache, v_cache, kv_sb, kv_sh, k_new, v_new, new_sb, new_sh,
                      cos, sin, table_rows, position_ids, pos_sb, mask, mask_sb, 0, out, out_sb, 0, scores, sc_sb,
                      sc_sh, 0, lse, workspace, (size_t)batch * heads, batch, heads, kv_heads, head_dim, kv_len, pos_q,
-                     1, 0, n_splits, (hipStream_t)stream, head_ids, n_active_heads, flags);
+                     1, 0, n_splits, (hipStream_t)stream, head_ids, n_active_heads, flags, nullptr, 0, 0);
 }
 
 extern "C" int spatten_attn_decode(int dtype, const void* q, int64_t q_sb, int64_t q_sh, void* k_cache,

@@ -417,3 +417,63 @@ def pv_gather(stash: torch.Tensor, lse: torch.Tensor, v_cache: torch.Tensor, idx
                                        out.data_ptr(), out.stride(0), B, H, Hkv, d, _stream())
     _lib.check(rc, "spatten_pv_gather")
     return out
+
+
+class PQPlanes:
+    """Progressive-quantisation planes of a rotated key cache: msb / lsb [B,Hkv,cap,d/2] uint8 (two 4-bit fields
+    per byte), scale [B,Hkv,cap] fp32;  q8 = msb*16 + lsb,  x ~ q8 * scale."""
+
+    def __init__(self, batch, kv_heads, cap, d, device):
+        self.msb = torch.zeros(batch, kv_heads, cap, d // 2, dtype=torch.uint8, device=device)
+        self.lsb = torch.zeros_like(self.msb)
+        self.scale = torch.ones(batch, kv_heads, cap, dtype=torch.float32, device=device)
+
+    def unpack(self, n: int):
+        """(msb int8 [B,H,n,d], lsb uint8 [B,H,n,d], scale [B,H,n,1]) on the host — for tests."""
+        m, l = self.msb[:, :, :n].cpu().numpy(), self.lsb[:, :, :n].cpu().numpy()
+        import numpy as np
+        mm = np.stack([m & 15, m >> 4], axis=-1).reshape(*m.shape[:-1], -1).astype(np.int8)
+        mm = np.where(mm > 7, mm - 16, mm).astype(np.int8)
+        ll = np.stack([l & 15, l >> 4], axis=-1).reshape(*l.shape[:-1], -1).astype(np.uint8)
+        return mm, ll, self.scale[:, :, :n, None].cpu().numpy()
+
+
+def pq_pack(kr_cache: torch.Tensor, planes: PQPlanes, lo: int, hi: int):
+    """Quantise rows [lo, hi) of the rotated shadow into the MSB / LSB planes."""
+    _dev(kr_cache, planes.msb)
+    B, Hkv, cap, d = kr_cache.shape
+    rc = _lib.load().spatten_pq_pack(_dt(kr_cache), kr_cache.data_ptr(), kr_cache.stride(0), kr_cache.stride(1),
+                                     planes.msb.data_ptr(), planes.lsb.data_ptr(), planes.scale.data_ptr(),
+                                     planes.msb.stride(0), planes.msb.stride(1), planes.scale.stride(0), planes.scale.stride(1),
+                                     B, Hkv, d, lo, hi, _stream())
+    _lib.check(rc, "spatten_pq_pack")
+
+
+_pq_scratch = {}
+
+
+def attn_decode_pq(q: torch.Tensor, planes: PQPlanes, v_cache: torch.Tensor, kv_len: int, cos: torch.Tensor,
+                   sin: torch.Tensor, pos_q: int, threshold: float, out: Optional[torch.Tensor] = None,
+                   need_lsb: Optional[torch.Tensor] = None, workspace: Optional[DecodeWorkspace] = None) -> torch.Tensor:
+    """Decode over progressively quantised keys: MSB-plane pass, LSB refetch for heads whose max probability is
+    below ``threshold``, softmax + P·V with the un-quantised V.  q [B,H,d]; need_lsb optional int32 [B*H]."""
+    _dev(q, planes.msb, v_cache, cos, sin, out, need_lsb)
+    lib = _lib.load()
+    B, H, d = q.shape
+    Hkv = v_cache.shape[1]
+    if out is None:
+        out = torch.empty(B, H * d, dtype=q.dtype, device=q.device)
+    ws = workspace or _workspace(B, H, d, q.device)
+    nbytes = lib.spatten_pq_scratch_bytes(B, H, d, kv_len)
+    key = (str(q.device), torch.cuda.current_stream().cuda_stream)
+    scratch = _pq_scratch.get(key)
+    if scratch is None or scratch.numel() < nbytes:
+        scratch = _pq_scratch[key] = torch.empty(int(nbytes * 1.5), dtype=torch.uint8, device=q.device)
+    rc = lib.spatten_attn_decode_pq(_dt(q), q.data_ptr(), q.stride(0), q.stride(1), planes.msb.data_ptr(),
+                                    planes.lsb.data_ptr(), planes.scale.data_ptr(), planes.msb.stride(0), planes.msb.stride(1),
+                                    planes.scale.stride(0), planes.scale.stride(1), v_cache.data_ptr(), v_cache.stride(0),
+                                    v_cache.stride(1), cos.data_ptr(), sin.data_ptr(), cos.shape[0], pos_q, float(threshold),
+                                    out.data_ptr(), out.stride(0), _ptr(need_lsb), scratch.data_ptr(), ws.buf.data_ptr(),
+                                    B, H, Hkv, d, kv_len, _stream())
+    _lib.check(rc, "spatten_attn_decode_pq")
+    return out

@@ -97,3 +97,34 @@ def test_head_scores_and_pruned_decode():
             assert torch.equal(o3[:, h], f3[:, h])
         else:
             assert torch.isnan(o3[:, h].float()).all() and torch.isnan(st[:, h].float()).all()
+
+
+@pytest.mark.parametrize("dt,d,Hkv", [("bf16", 128, 8), ("f16", 64, 8), ("f32", 128, 4)])
+def test_progressive_quant_planes_and_decode_vs_oracle(dt, d, Hkv):
+    """MSB/LSB planes bit exact vs the oracle's quantiser; decode = MSB pass, LSB refetch below the threshold, P·V."""
+    from spatten_amd import ops
+    B, H, P = 2, 8, 500
+    q, kc, vc, stash, (qd, krd, vd, cos, sin, N) = setup_decode(B, H, Hkv, d, P, dt, 41)
+    planes = ops.PQPlanes(B, Hkv, N + 9, d, "cuda")
+    ops.pq_pack(krd, planes, 0, N)
+    kr_host = host(krd)
+    msb, lsb, scale = orc.pq_quantize(kr_host)
+    gm, gl, gs = planes.unpack(N)
+    assert np.array_equal(gm, msb) and np.array_equal(gl, lsb) and np.array_equal(gs, scale)
+    c, s = orc.rope_table(N, d, dt)
+    qr = orc.apply_rotary_pos_emb_single(q, c, s, np.full((B, 1), N - 1), dt)[:, :, 0]
+    rep = lambda a: orc.repeat_kv(a, H // Hkv)
+    # thresholds: never refetch, always refetch, and a mix (median of the pass-1 max probabilities)
+    k1 = orc.pq_dequant(rep(msb), None, rep(scale))
+    p1max = orc.softmax_probs(np.einsum("bhd,bhld->bhl", qr, k1) / np.float32(np.sqrt(d))).max(-1)
+    for thr in (0.0, 2.0, float(np.median(p1max))):
+        want, need = orc.pq_decode_attention(qr, rep(msb), rep(lsb), rep(scale), rep(vc), thr)
+        need_dev = torch.full((B * H,), -1, dtype=torch.int32, device="cuda")
+        out = ops.attn_decode_pq(qd, planes, vd, N, cos, sin, N - 1, thr, need_lsb=need_dev)
+        torch.cuda.synchronize()
+        assert np.array_equal(need_dev.cpu().numpy().reshape(B, H).astype(bool), need), thr
+        np.testing.assert_allclose(host(out).reshape(B, H, d), orc.round_dt(want, dt), **OUT_TOL[dt])
+    # 8-bit keys are close to, but not the same as, the un-quantised attention: sanity bound
+    full = ops.attn_decode(qd, None, krd, vd, N, cos, sin, N - 1)
+    out8 = ops.attn_decode_pq(qd, planes, vd, N, cos, sin, N - 1, 2.0)
+    assert float((full.float() - out8.float()).abs().max()) < 0.05
