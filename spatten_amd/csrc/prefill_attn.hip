@@ -106,15 +106,26 @@ template <int ROWB> __device__ inline int lds_off(int row, int slot) {
   return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
 }
 
-template <typename T, int D>
-__global__ __launch_bounds__(256) void prefill_flash_kernel(const FlashParams<T> p) {
+// exact-enough x / c for the logit scale: one Newton correction on the reciprocal product (3 VALU ops instead of
+// the ~15 of the IEEE divide sequence).  x is a model-dtype value (<= 11 significant bits), the result is rounded
+// to the model dtype right after, so the rare last-bit difference of the fp32 quotient cannot survive unless it
+// sits exactly on a rounding boundary of the 16-bit type.  For d = 64 / 256 (sqrt = 8 / 16) it is exact.
+__device__ inline float div_by_const(float x, float c, float rc) {
+  const float y = x * rc;
+  const float e = fmaf(-y, c, x);
+  return fmaf(e, rc, y);
+}
+
+// STASH / COLIMP / MASK: compile the optional by-products out of the hot instantiation
+template <typename T, int D, bool STASH, bool COLIMP, bool MASK>
+__global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams<T> p) {
   constexpr int KK = D / 16;       // MFMA k-steps of the Q·K^T product
   constexpr int DB = D / 32;       // 32-row blocks of O^T
   constexpr int KROWB = D * 2;     // bytes per K row in LDS (256 / 128)
+  constexpr int KBYTES = 64 * KROWB, VBYTES = D * 128, BUF = KBYTES + VBYTES;
+  constexpr int KPC = 64 * (D / 8) / 256, VPC = D * 8 / 256;   // 16-byte pieces per thread per tile (K, Vt)
   using frag = typename Mfma<T>::frag;
-  __shared__ __attribute__((aligned(16))) char lds[64 * KROWB + D * 128];
-  char* ldsK = lds;
-  char* ldsV = lds + 64 * KROWB;
+  __shared__ __attribute__((aligned(16))) char lds[2 * BUF];   // double buffered: [K tile | Vt tile] x 2
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, qi = lane & 31, hi = lane >> 5;
   const int qblk = gridDim.x - 1 - blockIdx.x;          // longest (latest) query blocks first
@@ -124,6 +135,7 @@ __global__ __launch_bounds__(256) void prefill_flash_kernel(const FlashParams<T>
   const int myq = q0 + qi;
   const bool qvalid = myq < p.q_len;
   const int P = p.N - p.q_len;
+  const float rsqrt_d = 1.0f / p.sqrt_d;
 
   frag qf[KK];
   {
@@ -141,33 +153,58 @@ __global__ __launch_bounds__(256) void prefill_flash_kernel(const FlashParams<T>
   const int wg_q_end = min(p.q_len, qblk * 128 + 128);
   const int att_keys = p.causal ? min(p.N, P + wg_q_end) : p.N;          // keys any query of this workgroup sees
   const int n_att_tiles = (att_keys + 63) / 64;
-  const bool byproducts = (p.scores != nullptr) || (p.col_imp != nullptr);
-  const int n_tiles = byproducts ? (p.N + 63) / 64 : n_att_tiles;
+  const int n_tiles = (STASH || COLIMP) ? (p.N + 63) / 64 : n_att_tiles;
   const int my_vis = p.causal ? min(p.N, P + myq + 1) : p.N;             // keys [0, my_vis) are visible to my query
+  // a tile needs no per-element visibility test when even this wave's FIRST query sees its last key
+  const int wave_full_keys = p.causal ? min(p.N, P + q0 + 1) : p.N;
 
   const T* krb = p.kr + b * p.kv_sb + hkv * p.kv_sh;
   const T* vtb = p.vt + ((int64_t)(b * p.Hkv + hkv) * D) * p.Npad;
-  const T* maskrow = p.mask ? p.mask + b * p.mask_sb + (int64_t)min(myq, p.q_len - 1) * p.mask_sq : nullptr;
-  T* stashrow = p.scores ? p.scores + b * p.sc_sb + h * p.sc_sh + (int64_t)min(myq, p.q_len - 1) * p.sc_sq : nullptr;
-  float* colrow = p.col_imp ? p.col_imp + (int64_t)(b * p.H + h) * p.N : nullptr;
+  const T* maskrow = MASK ? p.mask + b * p.mask_sb + (int64_t)min(myq, p.q_len - 1) * p.mask_sq : nullptr;
+  T* stashrow = STASH ? p.scores + b * p.sc_sb + h * p.sc_sh + (int64_t)min(myq, p.q_len - 1) * p.sc_sq : nullptr;
+  float* colrow = COLIMP ? p.col_imp + (int64_t)(b * p.H + h) * p.N : nullptr;
+
+  // ---- staging: global -> registers (issued early) -> LDS (written late, into the other buffer) --------------
+  u32x4 kreg[KPC], vreg[VPC];
+  auto stage_load = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < KPC; ++i) {
+      const int id = tid + 256 * i, row = id / (D / 8), slot = id % (D / 8);
+      const int j = min(tile * 64 + row, p.N - 1);     // rows past N are masked; stay inside the allocation
+      kreg[i] = *reinterpret_cast<const u32x4*>(krb + (int64_t)j * D + slot * 8);
+    }
+    if (tile < n_att_tiles) {
+#pragma unroll
+      for (int i = 0; i < VPC; ++i) {
+        const int id = tid + 256 * i, dv = id >> 3, slot = id & 7;
+        vreg[i] = *reinterpret_cast<const u32x4*>(vtb + (int64_t)dv * p.Npad + tile * 64 + slot * 8);
+      }
+    }
+  };
+  auto stage_write = [&](int tile, char* buf) {
+#pragma unroll
+    for (int i = 0; i < KPC; ++i) {
+      const int id = tid + 256 * i, row = id / (D / 8), slot = id % (D / 8);
+      *reinterpret_cast<u32x4*>(buf + lds_off<KROWB>(row, slot)) = kreg[i];
+    }
+    if (tile < n_att_tiles) {
+#pragma unroll
+      for (int i = 0; i < VPC; ++i) {
+        const int id = tid + 256 * i, dv = id >> 3, slot = id & 7;
+        *reinterpret_cast<u32x4*>(buf + KBYTES + lds_off<128>(dv, slot)) = vreg[i];
+      }
+    }
+  };
+
+  stage_load(0);
+  stage_write(0, lds);
+  __syncthreads();
 
   for (int tile = 0; tile < n_tiles; ++tile) {
     const bool attend = tile < n_att_tiles;
-    __syncthreads();                                   // previous tile's LDS reads are done
-    for (int id = tid; id < 64 * (D / 8); id += 256) {
-      const int row = id / (D / 8), slot = id % (D / 8);
-      const int j = min(tile * 64 + row, p.N - 1);     // rows past N are masked; stay inside the allocation
-      const u32x4 x = *reinterpret_cast<const u32x4*>(krb + (int64_t)j * D + slot * 8);
-      *reinterpret_cast<u32x4*>(ldsK + lds_off<KROWB>(row, slot)) = x;
-    }
-    if (attend) {
-      for (int id = tid; id < D * 8; id += 256) {
-        const int dv = id >> 3, slot = id & 7;
-        const u32x4 x = *reinterpret_cast<const u32x4*>(vtb + (int64_t)dv * p.Npad + tile * 64 + slot * 8);
-        *reinterpret_cast<u32x4*>(ldsV + lds_off<128>(dv, slot)) = x;
-      }
-    }
-    __syncthreads();
+    char* ldsK = lds + (tile & 1) * BUF;
+    char* ldsV = ldsK + KBYTES;
+    if (tile + 1 < n_tiles) stage_load(tile + 1);       // in flight during this tile's MFMAs
 
     // ---- S^T (64 keys x 32 queries per wave) -----------------------------------------------------
     f32x16 s[2];
@@ -181,64 +218,74 @@ __global__ __launch_bounds__(256) void prefill_flash_kernel(const FlashParams<T>
         s[kb] = Mfma<T>::mma(a, qf[kk], s[kb]);
       }
     }
+    const bool edge = tile * 64 + 64 > wave_full_keys;  // wave-uniform: some element needs the visibility test
     float m_tile = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = tile * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
-        float v = DT<T>::round(DT<T>::round(s[kb][r]) / p.sqrt_d);
-        const bool inb = key < p.N;
-        if (stashrow != nullptr && inb && qvalid) stashrow[key] = DT<T>::from_f32(v);        // pre-mask (:116-119)
-        if (colrow != nullptr) {
-          float cv = (inb && qvalid) ? v : 0.f;       // sum over this wave's 32 queries, then one atomic per key
-          cv = xor16_sum(group_sum<16>(cv));
-          if (qi == 0 && inb) atomicAdd(colrow + key, cv);
+        float v = DT<T>::round(div_by_const(DT<T>::round(s[kb][r]), p.sqrt_d, rsqrt_d));
+        if (STASH || COLIMP || MASK || edge) {
+          const int key = tile * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const bool inb = key < p.N;
+          if (STASH) { if (inb && qvalid) stashrow[key] = DT<T>::from_f32(v); }               // pre-mask (:116-119)
+          if (COLIMP) {
+            float cv = (inb && qvalid) ? v : 0.f;     // sum over this wave's 32 queries, then one atomic per key
+            cv = xor16_sum(group_sum<16>(cv));
+            if (qi == 0 && inb) atomicAdd(colrow + key, cv);
+          }
+          if (MASK) { if (inb) v = DT<T>::round(v + DT<T>::to_f32(maskrow[key])); }            // :132
+          v = (key < my_vis) ? v : -INFINITY;
         }
-        if (maskrow != nullptr && inb) v = DT<T>::round(v + DT<T>::to_f32(maskrow[key]));      // :132
-        v = (key < my_vis) ? v : -INFINITY;
         s[kb][r] = v;
         m_tile = fmaxf(m_tile, v);
       }
     }
-    if (!attend) continue;
-
-    // ---- online softmax: a lane and its partner (lane ^ 32) share one query ----------------------
-    m_tile = xor32_max(m_tile);
-    const float m_new = fmaxf(m_run, m_tile);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __expf(m_run - m_use);
-    float lsum = 0.f;
-    frag pf[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float pv = __expf(s[kb][t * 8 + e] - m_use);     // exp(-inf) = 0 for masked keys
-          lsum += pv;
-          pf[kb][t][e] = DT<T>::from_f32(pv);
-        }
-      }
-    }
-    l_run = l_run * alpha + lsum;
-    m_run = m_new;
-    // ---- O^T (D dv x 32 queries) += Vt · P^T -----------------------------------------------------
-#pragma unroll
-    for (int db = 0; db < DB; ++db) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    if (attend) {
+      // ---- online softmax: a lane and its partner (lane ^ 32) share one query --------------------
+      m_tile = xor32_max(m_tile);
+      const float m_new = fmaxf(m_run, m_tile);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      float lsum = 0.f;
+      frag pf[2][2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const frag a = *reinterpret_cast<const frag*>(ldsV + lds_off<128>(db * 32 + qi, kb * 4 + t * 2 + hi));
-          o[db] = Mfma<T>::mma(a, pf[kb][t], o[db]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float pv = __expf(s[kb][t * 8 + e] - m_use);     // exp(-inf) = 0 for masked keys
+            lsum += pv;
+            pf[kb][t][e] = DT<T>::from_f32(pv);
+          }
+        }
+      }
+      if (m_new != m_run) {                          // wave-divergent only in the first tiles of a row
+        const float alpha = __expf(m_run - m_use);
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        m_run = m_new;
+      }
+      l_run += lsum;
+      // ---- O^T (D dv x 32 queries) += Vt · P^T ---------------------------------------------------
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const frag a = *reinterpret_cast<const frag*>(ldsV + lds_off<128>(db * 32 + qi, kb * 4 + t * 2 + hi));
+            o[db] = Mfma<T>::mma(a, pf[kb][t], o[db]);
+          }
         }
       }
     }
+    if (tile + 1 < n_tiles) stage_write(tile + 1, lds + ((tile + 1) & 1) * BUF);
+    __syncthreads();                                    // next buffer complete; this buffer free for tile+2
   }
 
   // ---- epilogue: O = O^T / l, 4 consecutive dv per 8-byte store ---------------------------------
@@ -266,10 +313,20 @@ static inline int rows_leg(int dtype, int head_dim, int q_len) {
 }
 static inline int rows_splits(int units) { int s = 256 / (units > 0 ? units : 1); return s < 1 ? 1 : (s > 64 ? 64 : s); }
 
+template <typename T, int D, bool ST, bool CI>
+static void launch_flash_m(const FlashParams<T>& p, dim3 grid, hipStream_t st) {
+  if (p.mask) hipLaunchKernelGGL((prefill_flash_kernel<T, D, ST, CI, true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((prefill_flash_kernel<T, D, ST, CI, false>), grid, dim3(256), 0, st, p);
+}
+
 template <typename T, int D>
 static int launch_flash(const FlashParams<T>& p, hipStream_t st) {
   const dim3 grid((unsigned)ceil_div(p.q_len, 128), (unsigned)p.H, (unsigned)p.B);
-  hipLaunchKernelGGL((prefill_flash_kernel<T, D>), grid, dim3(256), 0, st, p);
+  const bool st_ = p.scores != nullptr, ci = p.col_imp != nullptr;
+  if (st_ && ci) launch_flash_m<T, D, true, true>(p, grid, st);
+  else if (st_) launch_flash_m<T, D, true, false>(p, grid, st);
+  else if (ci) launch_flash_m<T, D, false, true>(p, grid, st);
+  else launch_flash_m<T, D, false, false>(p, grid, st);
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }
 
