@@ -81,9 +81,13 @@ __device__ inline void store_granule(unsigned long long* g, float v) {
                      __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// SCORES_ONLY: stash + (max, sum) only — no V traffic, no output (first pass of local V pruning)
-template <typename T, int D, int UNR, bool SCORES_ONLY = false>
+// MODE 0: the fused decode step.  MODE 1 (scores only): stash + (max, sum), no V traffic, no output — first pass of
+// local V pruning.  MODE 2 (scores in): the final fp32 logits are given, no K traffic — last pass of the
+// progressive-quantisation path.  Compile-time so the hot instantiation carries no extra branches.
+template <typename T, int D, int UNR, int MODE = 0>
 __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const DecodeParams<T> p) {
+  constexpr bool SCORES_ONLY = (MODE == 1);
+  constexpr bool SCORES_IN = (MODE == 2);
   constexpr int LPR = D / 16;                    // lanes per row
   constexpr int RPI = kDecodeThreads / LPR;      // rows per iteration of the workgroup
   constexpr int TILE = RPI * UNR;
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
         kp = p.k_new + b * p.new_sb + hkv * p.new_sh;
         vp = p.v_new + b * p.new_sb + hkv * p.new_sh;
       }
-      if (p.scores_in == nullptr) {
+      if (!SCORES_IN) {
         k_lo[u] = V8::ldg(kp + 8 * c);
         k_hi[u] = V8::ldg(kp + HALF + 8 * c);
       }
@@ -169,6 +173,7 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
     q_lo = D8::pack(ylo);
     q_hi = D8::pack(yhi);
   }
+  const float rsqrt_d = 1.0f / p.sqrt_d;
   const T* maskp = p.mask ? p.mask + b * p.mask_sb + qi * p.mask_sq : nullptr;
   T* stashp = p.scores ? p.scores + b * p.sc_sb + h * p.sc_sh + qi * p.sc_sq : nullptr;
   T* kbase = p.kc ? p.kc + b * p.kv_sb + hkv * p.kv_sh : nullptr;
@@ -219,12 +224,12 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
       const int j = t0 + u * RPI + r;
       const bool valid = j < hi;
       float s;
-      if (p.scores_in != nullptr) {
+      if (SCORES_IN) {
         s = p.scores_in[b * p.si_sb + h * p.si_sh + min(j, hi - 1)];
       } else {
         s = group_sum<LPR>(D8::dot(q_hi, k_hi[u], D8::dot(q_lo, k_lo[u], 0.f)));
         // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
-        s = DT<T>::round(DT<T>::round(s) / p.sqrt_d);
+        s = DT<T>::round(div_by_const(DT<T>::round(s), p.sqrt_d, rsqrt_d));
       }
       if (stashp != nullptr && c == 0 && valid) stashp[j] = DT<T>::from_f32(s);       // pre-mask (:116-119)
       if (maskp != nullptr) s = DT<T>::round(s + mk[u]);                               // :132
@@ -428,8 +433,13 @@ template <typename T, int D>
 static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_only, hipStream_t stream) {
   const dim3 grid((unsigned)p.S, (unsigned)n_active, (unsigned)(p.B * p.n_q));
   if (scores_only) {
-    if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((decode_attn_kernel<T, D, 2, true>), grid, dim3(kDecodeThreads), 0, stream, p);
-    else hipLaunchKernelGGL((decode_attn_kernel<T, D, 4, true>), grid, dim3(kDecodeThreads), 0, stream, p);
+    if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((decode_attn_kernel<T, D, 2, 1>), grid, dim3(kDecodeThreads), 0, stream, p);
+    else hipLaunchKernelGGL((decode_attn_kernel<T, D, 4, 1>), grid, dim3(kDecodeThreads), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+  }
+  if (p.scores_in != nullptr) {
+    if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((decode_attn_kernel<T, D, 2, 2>), grid, dim3(kDecodeThreads), 0, stream, p);
+    else hipLaunchKernelGGL((decode_attn_kernel<T, D, 4, 2>), grid, dim3(kDecodeThreads), 0, stream, p);
     return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
   }
   switch (decode_unr_for(DT<T>::kId)) {

@@ -106,16 +106,6 @@ template <int ROWB> __device__ inline int lds_off(int row, int slot) {
   return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
 }
 
-// exact-enough x / c for the logit scale: one Newton correction on the reciprocal product (3 VALU ops instead of
-// the ~15 of the IEEE divide sequence).  x is a model-dtype value (<= 11 significant bits), the result is rounded
-// to the model dtype right after, so the rare last-bit difference of the fp32 quotient cannot survive unless it
-// sits exactly on a rounding boundary of the 16-bit type.  For d = 64 / 256 (sqrt = 8 / 16) it is exact.
-__device__ inline float div_by_const(float x, float c, float rc) {
-  const float y = x * rc;
-  const float e = fmaf(-y, c, x);
-  return fmaf(e, rc, y);
-}
-
 // STASH / COLIMP / MASK: compile the optional by-products out of the hot instantiation
 template <typename T, int D, bool STASH, bool COLIMP, bool MASK>
 __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams<T> p) {

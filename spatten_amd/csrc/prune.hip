@@ -65,8 +65,11 @@ __global__ __launch_bounds__(kSelThreads) void topk_select_kernel(const SelectPa
   const int W = p.hi - p.lo;
 
   // ---- radix select: the key of the k-th largest element ----------------------------------------
-  // fp32 keys of bf16 values populate the top 16 bits, of f16 values the top 19 (1+8+10), fp32 all 32
+  // fp32 keys of bf16 values populate the top 16 bits, of f16 values the top 19 (1+8+10), fp32 all 32.
+  // The radix passes only look at those bits, so the key is masked to them everywhere (the all-ones NaN key
+  // would otherwise compare GREATER than the threshold assembled from the passes and over-fill the output).
   constexpr int kPasses = sizeof(T) == 4 ? 4 : (DT<T>::kId == SPATTEN_BF16 ? 2 : 3);
+  constexpr unsigned kKeyMask = kPasses == 4 ? 0xFFFFFFFFu : (kPasses == 3 ? 0xFFFFFF00u : 0xFFFF0000u);
   unsigned prefix = 0, pmask = 0;
   unsigned k_rem = (unsigned)p.k;
 #pragma unroll 1
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(kSelThreads) void topk_select_kernel(const SelectPa
     s_hist[tid] = 0;
     __syncthreads();
     for (int i = tid; i < W; i += kSelThreads) {
-      const unsigned key = ordered_key(DT<T>::to_f32(row[i]));
+      const unsigned key = ordered_key(DT<T>::to_f32(row[i])) & kKeyMask;
       if ((key & pmask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
     }
     __syncthreads();
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(kSelThreads) void topk_select_kernel(const SelectPa
     const int i = base + tid;
     unsigned key = 0;
     const bool in = i < W;
-    if (in) key = ordered_key(DT<T>::to_f32(row[i]));
+    if (in) key = ordered_key(DT<T>::to_f32(row[i])) & kKeyMask;
     const bool gt = in && key > thr;
     const bool eq = in && key == thr;
     const unsigned long long m_gt = __ballot(gt);
@@ -136,7 +139,8 @@ __global__ __launch_bounds__(kSelThreads) void topk_select_kernel(const SelectPa
     const unsigned my_eq_rank = eq_base + __popcll(m_eq & lt);
     const bool keep = gt || (eq && my_eq_rank < need_eq);
     const unsigned long long m_keep = __ballot(keep);
-    if (keep) out[kept_base + __popcll(m_keep & lt)] = p.lo + i;
+    const unsigned pos = kept_base + __popcll(m_keep & lt);
+    if (keep && pos < (unsigned)p.k) out[pos] = p.lo + i;      // pos < k always holds; the guard keeps a logic slip local
     run_eq = tot_eq;
     run_kept = tot_kept;
   }

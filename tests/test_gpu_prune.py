@@ -73,10 +73,18 @@ def test_topk_ties_nan_inf_vs_oracle(dt):
     s[2, 5::11] = -np.inf
     s[3, 3::13] = np.nan                           # NaN ranks largest (torch.topk)
     s[4, :] = orc.round_dt(np.where(rng.random(L) < 0.5, 0.0, -0.0).astype(np.float32), dt)   # +-0 tie
-    for lo, hi, k in ((0, L, 1), (0, L, L), (4, 900, 300), (10, 11, 1), (3, 997, 994), (100, 612, 256)):
+    for lo, hi, k in ((0, L, 1), (0, L, L), (4, 900, 300), (10, 11, 1), (3, 997, 994), (100, 612, 256), (0, L, 40)):
         want = orc.topk_window(s, lo, hi, k)
-        got = ops.topk_select(dev(s, dt), lo, hi, k).cpu().numpy()
-        assert np.array_equal(got, want), (dt, lo, hi, k)
+        # the output buffer is over-allocated and poisoned: a kernel that keeps more than k (e.g. k <= #NaN) is caught
+        from spatten_amd import _lib
+        idx = torch.full((H, k + 64), -7, dtype=torch.int32, device="cuda")
+        sd = dev(s, dt)
+        rc = _lib.load().spatten_topk_select({"f32": 0, "f16": 1, "bf16": 2}[dt], sd.data_ptr(), sd.stride(0), H, lo, hi, k,
+                                             idx.data_ptr(), idx.stride(0), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        got = idx.cpu().numpy()
+        assert np.array_equal(got[:, :k], want), (dt, lo, hi, k)
+        assert (got[:, k:] == -7).all(), (dt, lo, hi, k)
 
 
 def test_topk_large_window_and_bf16_threshold_ties():
