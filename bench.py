@@ -333,6 +333,44 @@ def main():
             extras["dense_eager_posshift_tokens_per_s"] = round(5 / (time.perf_counter() - t0), 2)
             extras["speedup_vs_dense_eager"] = round(tokens_per_s / extras["dense_eager_posshift_tokens_per_s"], 2)
             extras["speedup_vs_dense_fused"] = round(tokens_per_s / extras["dense_fused_tokens_per_s"], 2)
+            # ---- other rows of the scope table, measured on the same box (not part of `value`) -----------------
+            try:
+                Np = 8192                                                   # C4: causal prefill, q = N = 8192, one layer
+                Qp, Kp2, Vp2 = rnd(1, HEADS, Np, d), rnd(1, HEADS, Np, d), rnd(1, HEADS, Np, d)
+                cp, sp = ops.rope_table(Np, d, dt, dev)
+                Krp2 = ops.rope_single(Kp2, cp, sp)
+                op = torch.empty(1, Np, HEADS * d, dtype=dt, device=dev)
+                for _ in range(2):
+                    ops.attn_prefill(Qp, Krp2, Vp2, Np, cp, sp, 0, causal=True, out=op)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    ops.attn_prefill(Qp, Krp2, Vp2, Np, cp, sp, 0, causal=True, out=op)
+                torch.cuda.synchronize()
+                tp = (time.perf_counter() - t0) / 5
+                fl = 4 * HEADS * d * Np * (Np + 1) / 2
+                extras["prefill_8192_causal_ms_per_layer"] = round(tp * 1e3, 3)
+                extras["prefill_8192_causal_TFLOPs"] = round(fl / tp / 1e12, 1)
+                extras["prefill_frac_of_bf16_mfma_peak_2500TF"] = round(fl / tp / 2.5e15, 4)
+                # progressive-quant decode over the same 8192 keys: MSB-only vs always-refetch vs bf16 keys
+                planes = ops.PQPlanes(1, HEADS, Np, d, dev)
+                ops.pq_pack(Krp2, planes, 0, Np)
+                q1 = Qp[:, :, -1].contiguous()
+                o1 = torch.empty(1, HEADS * d, dtype=dt, device=dev)
+                def _time(fn, n=30):
+                    for _ in range(3):
+                        fn()
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t) / n * 1e6
+                extras["decode_8192_bf16_keys_us"] = round(_time(lambda: ops.attn_decode(q1, None, Krp2, Vp2, Np, cp, sp, Np - 1, out=o1, workspace=ws)), 2)
+                extras["decode_8192_pq_msb_only_us"] = round(_time(lambda: ops.attn_decode_pq(q1, planes, Vp2, Np, cp, sp, Np - 1, 0.0, out=o1, workspace=ws)), 2)
+                extras["decode_8192_pq_refetch_all_us"] = round(_time(lambda: ops.attn_decode_pq(q1, planes, Vp2, Np, cp, sp, Np - 1, 2.0, out=o1, workspace=ws)), 2)
+            except Exception as e:  # the headline number must not depend on the side measurements
+                extras["side_measurements_error"] = f"{type(e).__name__}: {e}"
             result["extras"] = extras
 
         # ---- CPU baseline: the C port of the reference on the host cores, bounded sample ------------------

@@ -197,16 +197,16 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
     if (tile + 1 < n_tiles) stage_load(tile + 1);       // in flight during this tile's MFMAs
 
     // ---- S^T (64 keys x 32 queries per wave) -----------------------------------------------------
+    // the two key blocks are independent accumulators: interleave them so no MFMA waits on its predecessor
     f32x16 s[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk) {
-        const frag a = *reinterpret_cast<const frag*>(ldsK + lds_off<KROWB>(kb * 32 + qi, 2 * kk + hi));
-        s[kb] = Mfma<T>::mma(a, qf[kk], s[kb]);
-      }
+    for (int kk = 0; kk < KK; ++kk) {
+      const frag a0 = *reinterpret_cast<const frag*>(ldsK + lds_off<KROWB>(qi, 2 * kk + hi));
+      const frag a1 = *reinterpret_cast<const frag*>(ldsK + lds_off<KROWB>(32 + qi, 2 * kk + hi));
+      s[0] = Mfma<T>::mma(a0, qf[kk], s[0]);
+      s[1] = Mfma<T>::mma(a1, qf[kk], s[1]);
     }
     const bool edge = tile * 64 + 64 > wave_full_keys;  // wave-uniform: some element needs the visibility test
     float m_tile = -INFINITY;
@@ -263,11 +263,11 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
       l_run += lsum;
       // ---- O^T (D dv x 32 queries) += Vt · P^T ---------------------------------------------------
 #pragma unroll
-      for (int db = 0; db < DB; ++db) {
+      for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
-          for (int t = 0; t < 2; ++t) {
+          for (int db = 0; db < DB; ++db) {          // DB independent accumulators back to back
             const frag a = *reinterpret_cast<const frag*>(ldsV + lds_off<128>(db * 32 + qi, kb * 4 + t * 2 + hi));
             o[db] = Mfma<T>::mma(a, pf[kb][t], o[db]);
           }
