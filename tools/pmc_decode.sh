@@ -4,6 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 N=${1:-2081}
+[ -x $R/tools/mb/decode_bench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o $R/tools/mb/decode_bench $R/tools/mb/decode_bench.cpp -L$R/spatten_amd/lib -lspatten_hip -Wl,-rpath,$R/spatten_amd/lib
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -o p -- $R/tools/mb/decode_bench 1 $N 0 1 > /dev/null 2>&1
 done
