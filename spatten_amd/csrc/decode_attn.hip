@@ -35,6 +35,18 @@
 
 #include "common.h"
 
+#ifdef SPATTEN_TRACE   // developer instrumentation: per-workgroup phase timestamps (tools/mb/decode_trace.cpp)
+__device__ unsigned long long* g_spatten_trace = nullptr;
+#define SPATTEN_TSTAMP(slot)                                                                         \
+  do {                                                                                               \
+    if (g_spatten_trace && threadIdx.x == 0)                                                         \
+      g_spatten_trace[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = \
+          __builtin_readcyclecounter();                                                              \
+  } while (0)
+#else
+#define SPATTEN_TSTAMP(slot)
+#endif
+
 namespace spatten {
 
 template <typename T>
@@ -97,7 +109,6 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
   using raw_t = typename V8::raw;
   using D8 = Dot8<T>;
 
-  __shared__ float s_red[4];
   __shared__ float s_o[4][D + 2];
   __shared__ unsigned s_ticket;
 
@@ -106,6 +117,7 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
   const int r = tid / LPR;
   const int wave = tid / kWave;
   const int lane = tid % kWave;
+  SPATTEN_TSTAMP(0);
 
   // grid = (S, H, B * n_q): no integer divisions on the way to the first load
   const int split = blockIdx.x;
@@ -217,53 +229,69 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
       }
     }
 
-    // ---- row group by row group, in load order: score -> softmax update -> P·V ------------------
-    // (the loads of group u+1.. are still in flight while group u is consumed)
+    // ---- scores of the UNR row groups as independent instruction streams (ILP: one wave per SIMD has nothing
+    // else to hide a dependent VALU chain behind), then ONE per-thread softmax update, then P·V ------------
+    float sc[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (SCORES_IN) sc[u] = p.scores_in[b * p.si_sb + h * p.si_sh + min(t0 + u * RPI + r, hi - 1)];
+      else sc[u] = D8::dot(q_hi, k_hi[u], D8::dot(q_lo, k_lo[u], 0.f));
+    }
+    if (!SCORES_IN) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) sc[u] = group_sum<LPR>(sc[u]);
+      // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) sc[u] = DT<T>::round(div_by_const(DT<T>::round(sc[u]), p.sqrt_d, rsqrt_d));
+    }
+    float m_new = m_run;
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int j = t0 + u * RPI + r;
       const bool valid = j < hi;
-      float s;
-      if (SCORES_IN) {
-        s = p.scores_in[b * p.si_sb + h * p.si_sh + min(j, hi - 1)];
-      } else {
-        s = group_sum<LPR>(D8::dot(q_hi, k_hi[u], D8::dot(q_lo, k_lo[u], 0.f)));
-        // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
-        s = DT<T>::round(div_by_const(DT<T>::round(s), p.sqrt_d, rsqrt_d));
-      }
+      float s = sc[u];
       if (stashp != nullptr && c == 0 && valid) stashp[j] = DT<T>::from_f32(s);       // pre-mask (:116-119)
       if (maskp != nullptr) s = DT<T>::round(s + mk[u]);                               // :132
       s = (valid && j < n_vis) ? s : -INFINITY;
-      if (s > m_run) {                             // rare after the first rows
-        const float alpha = __expf(m_run - s);     // m_run = -inf -> 0
-        l_run *= alpha;
+      sc[u] = s;
+      m_new = fmaxf(m_new, s);
+    }
+    if (m_new > m_run) {                           // rare after the first tile
+      const float alpha = __expf(m_run - m_new);   // m_run = -inf -> 0
+      l_run *= alpha;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { olo[i] *= alpha; ohi[i] *= alpha; }
-        m_run = s;
-      }
-      const float pj = (s == -INFINITY) ? 0.f : __expf(s - m_run);
-      l_run += pj;
-      if (!SCORES_ONLY) {
+      for (int i = 0; i < 8; ++i) { olo[i] *= alpha; ohi[i] *= alpha; }
+      m_run = m_new;
+    }
+    float pj[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      pj[u] = (sc[u] == -INFINITY) ? 0.f : __expf(sc[u] - m_run);
+      l_run += pj[u];
+    }
+    if (!SCORES_ONLY) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
         float vlo[8], vhi[8];
         V8::unpack(v_lo[u], vlo);
         V8::unpack(v_hi[u], vhi);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { olo[i] = fmaf(pj, vlo[i], olo[i]); ohi[i] = fmaf(pj, vhi[i], ohi[i]); }
+        for (int i = 0; i < 8; ++i) { olo[i] = fmaf(pj[u], vlo[i], olo[i]); ohi[i] = fmaf(pj[u], vhi[i], ohi[i]); }
       }
     }
   }
 
-  // ---- reconcile the row groups: workgroup max, rescale, sum ------------------------------------
+  SPATTEN_TSTAMP(1);
+  // ---- reconcile the row groups: per-wave max and sums (registers only), then ONE LDS hop across the waves ------
+  // (measured alternatives: an extra barrier for a workgroup-wide max first — same time; LDS over the 16 DPP rows
+  //  instead of the permlane swaps — slower: 16 exps + 48 LDS reads per thread in the last stage)
   {
     const float mw = wave_max(m_run);
-    if (lane == 0) s_red[wave] = mw;
-    __syncthreads();
-    const float m_wg = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_wg);
+    const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - mw);
     l_run *= alpha;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { olo[i] *= alpha; ohi[i] *= alpha; }
-    m_run = m_wg;
+    m_run = mw;
   }
   // lanes with equal c across the wave's row groups: in-row rotations (DPP), then rows (permlane swaps)
   if (LPR == 4) {
@@ -288,13 +316,20 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
       s_o[wave][8 * lane + i] = olo[i];
       s_o[wave][HALF + 8 * lane + i] = ohi[i];
     }
-    if (lane == 0) s_o[wave][D] = l_run;
+    if (lane == 0) { s_o[wave][D] = l_run; s_o[wave][D + 1] = m_run; }
   }
   __syncthreads();
-  float o_tot = 0.f;
-  if (tid < D) o_tot = s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid];
-  const float l_tot = s_o[0][D] + s_o[1][D] + s_o[2][D] + s_o[3][D];
-
+  float o_tot = 0.f, l_tot = 0.f;
+  {
+    const float m0 = s_o[0][D + 1], m1 = s_o[1][D + 1], m2 = s_o[2][D + 1], m3 = s_o[3][D + 1];
+    const float m_wg = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    const float mu = (m_wg == -INFINITY) ? 0.f : m_wg;
+    const float w0 = __expf(m0 - mu), w1 = __expf(m1 - mu), w2 = __expf(m2 - mu), w3 = __expf(m3 - mu);   // exp(-inf) = 0
+    if (tid < D) o_tot = (s_o[0][tid] * w0 + s_o[1][tid] * w1) + (s_o[2][tid] * w2 + s_o[3][tid] * w3);
+    l_tot = (s_o[0][D] * w0 + s_o[1][D] * w1) + (s_o[2][D] * w2 + s_o[3][D] * w3);
+    m_run = m_wg;
+  }
+  SPATTEN_TSTAMP(2);
   T* outp = p.out + b * p.out_sb + qi * p.out_sq + h * D;
   if (p.S == 1) {
     if (!SCORES_ONLY && tid < D) outp[tid] = DT<T>::from_f32(o_tot / l_tot);
@@ -310,10 +345,15 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
   // tag has not landed yet.  It finally clears the tags and the counter for the next launch.
   unsigned long long* ws = p.ws_part + ((int64_t)unit * p.S) * (D + 2);
   unsigned long long* part = ws + (int64_t)split * (D + 2);
-  if (tid < D) store_granule(part + tid, o_tot);
-  if (tid == 0) { store_granule(part + D, m_run); store_granule(part + D + 1, l_tot); }
-  if (tid == 0) s_ticket = __hip_atomic_fetch_add(p.ws_cnt + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the ticket is drawn by the LAST wave, which has no stores in flight: on CDNA4 vmcnt also counts stores, so a
+  // wave that just issued granules would wait for their write-through acknowledgements before it sees its ticket
+  if (tid == kDecodeThreads - 1)
+    s_ticket = __hip_atomic_fetch_add(p.ws_cnt + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < D && tid < kDecodeThreads - kWave) store_granule(part + tid, o_tot);
+  if (D > kDecodeThreads - kWave && tid >= kDecodeThreads - kWave && tid < D) store_granule(part + tid, o_tot);   // D = 256 only
+  if (tid == (D < kDecodeThreads - kWave ? D : 0)) { store_granule(part + D, m_run); store_granule(part + D + 1, l_tot); }
   __syncthreads();
+  SPATTEN_TSTAMP(3);
   if (s_ticket != (unsigned)(p.S - 1)) return;
 
   // merge in ONE round trip: thread (g, e) takes splits s = g, g+G, ...; every load below — its partial-o
@@ -325,10 +365,10 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
   if (g < G) {
     for (int s0 = g; s0 < p.S; s0 += KB * G) {
       unsigned long long ga[KB], gm[KB], gl[KB];
-      bool ok;
       int spins = 0;
-      do {
-        ok = true;
+      unsigned tags;
+      do {   // every load is issued before any tag is looked at: ONE round trip (a short-circuiting `&&` chain makes
+             // the compiler wait for each split's granules before it loads the next split's)
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
           const int sc_ = (s0 + k * G) < p.S ? (s0 + k * G) : g;
@@ -336,9 +376,11 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
           ga[k] = __hip_atomic_load(q + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           gm[k] = __hip_atomic_load(q + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           gl[k] = __hip_atomic_load(q + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = ok && (ga[k] >> 32) && (gm[k] >> 32) && (gl[k] >> 32);
         }
-      } while (!ok && ++spins < (1 << 20));      // bounded: a granule that was issued always lands
+        tags = 1u;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) tags &= (unsigned)(ga[k] >> 32) & (unsigned)(gm[k] >> 32) & (unsigned)(gl[k] >> 32);
+      } while (tags == 0u && ++spins < (1 << 20));   // bounded: a granule that was issued always lands
       float a[KB], ms[KB], ls[KB];
 #pragma unroll
       for (int k = 0; k < KB; ++k) {
@@ -396,6 +438,7 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
     if (p.lse != nullptr) { p.lse[unit * 2] = mg; p.lse[unit * 2 + 1] = lg; }
     __hip_atomic_store(p.ws_cnt + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
   }
+  SPATTEN_TSTAMP(4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -410,7 +453,7 @@ static int decode_unr_for(int dtype) {
   }
   int u = env > 0 ? env : (dtype == SPATTEN_F32 ? 2 : 4);
   if (dtype == SPATTEN_F32 && u > 2) u = 2;
-  return (u == 1 || u == 2 || u == 4) ? u : 4;
+  return (u == 1 || u == 2 || u == 4 || u == 8) ? u : 4;
 }
 static inline int decode_tile_rows(int d, int dtype) { return (kDecodeThreads / (d / 16)) * decode_unr_for(dtype); }
 
@@ -445,6 +488,10 @@ static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_onl
   switch (decode_unr_for(DT<T>::kId)) {
     case 1: hipLaunchKernelGGL((decode_attn_kernel<T, D, 1>), grid, dim3(kDecodeThreads), 0, stream, p); break;
     case 2: hipLaunchKernelGGL((decode_attn_kernel<T, D, 2>), grid, dim3(kDecodeThreads), 0, stream, p); break;
+    case 8:
+      if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((decode_attn_kernel<T, D, 2>), grid, dim3(kDecodeThreads), 0, stream, p);
+      else hipLaunchKernelGGL((decode_attn_kernel<T, D, 8>), grid, dim3(kDecodeThreads), 0, stream, p);
+      break;
     default:
       if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((decode_attn_kernel<T, D, 2>), grid, dim3(kDecodeThreads), 0, stream, p);
       else hipLaunchKernelGGL((decode_attn_kernel<T, D, 4>), grid, dim3(kDecodeThreads), 0, stream, p);
@@ -566,3 +613,9 @@ extern "C" int spatten_attn_decode(int dtype, const void* q, int64_t q_sb, int64
                                 sc_sb, sc_sh, lse, workspace, batch, heads, kv_heads, head_dim, kv_len, pos_q, n_splits,
                                 nullptr, 0, 0, stream);
 }
+
+#ifdef SPATTEN_TRACE
+extern "C" int spatten_debug_set_trace(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_spatten_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
