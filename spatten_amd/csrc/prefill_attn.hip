@@ -96,9 +96,11 @@ struct FlashParams {
   T* out; int64_t out_sb, out_sq;
   T* scores; int64_t sc_sb, sc_sh, sc_sq;
   float* col_imp;     // [B,H,N]
-  int B, H, Hkv, q_len, N, Npad, causal;
+  int B, H, Hkv, q_len, N, Npad, causal, nqb;
   float sqrt_d;
 };
+
+constexpr float kLog2e = 1.4426950408889634f;
 
 template <int ROWB> __device__ inline int lds_off(int row, int slot) {
   // 16-byte slots, XOR-swizzled so the 16 lanes of a ds_read_b128 group land on distinct bank quads
@@ -118,8 +120,28 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
   __shared__ __attribute__((aligned(16))) char lds[2 * BUF];   // double buffered: [K tile | Vt tile] x 2
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, qi = lane & 31, hi = lane >> 5;
-  const int qblk = gridDim.x - 1 - blockIdx.x;          // longest (latest) query blocks first
-  const int h = blockIdx.y, b = blockIdx.z;
+  // XCD-aware work order.  Workgroup i runs on XCD i % 8 (observed dispatch; used for speed only) and every query
+  // block of a head re-reads that head's K / Vt tiles, so the blocks of one head are kept on ONE XCD at a time:
+  // its private 4 MiB L2 then holds exactly the 2 x 2 MiB a head needs at N = 8192 instead of thrashing over 8 heads.
+  // Within a head: longest (latest) query blocks first.
+  const int nqb = p.nqb;
+  int h, qblk, b;
+  {
+    const int i = blockIdx.x, x = i & 7, sl = i >> 3;
+    const int per_b = p.H * nqb;                         // workgroups per batch element
+    const int hx = (p.H + 7) >> 3;                       // heads per XCD lane
+    b = i / per_b;
+    const int j = i - b * per_b;
+    if ((p.H & 7) == 0) {
+      const int xx = j & 7, ss = j >> 3;
+      h = xx + 8 * (ss / nqb);
+      qblk = nqb - 1 - (ss % nqb);
+    } else {                                             // head count not a multiple of 8: plain order
+      h = j / nqb;
+      qblk = nqb - 1 - (j % nqb);
+    }
+    (void)x; (void)sl; (void)hx;
+  }
   const int hkv = p.Hkv == p.H ? h : h / (p.H / p.Hkv);
   const int q0 = qblk * 128 + wave * 32;
   const int myq = q0 + qi;
@@ -154,61 +176,157 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
   T* stashrow = STASH ? p.scores + b * p.sc_sb + h * p.sc_sh + (int64_t)min(myq, p.q_len - 1) * p.sc_sq : nullptr;
   float* colrow = COLIMP ? p.col_imp + (int64_t)(b * p.H + h) * p.N : nullptr;
 
-  // ---- staging: global -> registers (issued early) -> LDS (written late, into the other buffer) --------------
+  // ---- staging: global -> registers (issued early) -> LDS (written late).  Two K slots and two Vt slots; K runs ONE
+  // tile ahead of Vt so that the Q·K^T MFMAs of tile t+1 are independent of — and overlap — the softmax of tile t.
+  auto k_slot = [&](int i) -> char* { return lds + (i & 1) * BUF; };
+  auto v_slot = [&](int i) -> char* { return lds + (i & 1) * BUF + KBYTES; };
   u32x4 kreg[KPC], vreg[VPC];
-  auto stage_load = [&](int tile) {
+  auto load_k = [&](int tile) {
 #pragma unroll
     for (int i = 0; i < KPC; ++i) {
       const int id = tid + 256 * i, row = id / (D / 8), slot = id % (D / 8);
       const int j = min(tile * 64 + row, p.N - 1);     // rows past N are masked; stay inside the allocation
       kreg[i] = *reinterpret_cast<const u32x4*>(krb + (int64_t)j * D + slot * 8);
     }
-    if (tile < n_att_tiles) {
+  };
+  auto load_v = [&](int tile) {
 #pragma unroll
-      for (int i = 0; i < VPC; ++i) {
-        const int id = tid + 256 * i, dv = id >> 3, slot = id & 7;
-        vreg[i] = *reinterpret_cast<const u32x4*>(vtb + (int64_t)dv * p.Npad + tile * 64 + slot * 8);
-      }
+    for (int i = 0; i < VPC; ++i) {
+      const int id = tid + 256 * i, dv = id >> 3, slot = id & 7;
+      vreg[i] = *reinterpret_cast<const u32x4*>(vtb + (int64_t)dv * p.Npad + tile * 64 + slot * 8);
     }
   };
-  auto stage_write = [&](int tile, char* buf) {
+  auto write_k = [&](char* buf) {
 #pragma unroll
     for (int i = 0; i < KPC; ++i) {
       const int id = tid + 256 * i, row = id / (D / 8), slot = id % (D / 8);
       *reinterpret_cast<u32x4*>(buf + lds_off<KROWB>(row, slot)) = kreg[i];
     }
-    if (tile < n_att_tiles) {
+  };
+  auto write_v = [&](char* buf) {
 #pragma unroll
-      for (int i = 0; i < VPC; ++i) {
-        const int id = tid + 256 * i, dv = id >> 3, slot = id & 7;
-        *reinterpret_cast<u32x4*>(buf + KBYTES + lds_off<128>(dv, slot)) = vreg[i];
-      }
+    for (int i = 0; i < VPC; ++i) {
+      const int id = tid + 256 * i, dv = id >> 3, slot = id & 7;
+      *reinterpret_cast<u32x4*>(buf + lds_off<128>(dv, slot)) = vreg[i];
+    }
+  };
+  // S^T (64 keys x 32 queries per wave): the two key blocks are independent accumulators, interleaved
+  auto qk = [&](const char* kbuf, f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const frag a0 = *reinterpret_cast<const frag*>(kbuf + lds_off<KROWB>(qi, 2 * kk + hi));
+      const frag a1 = *reinterpret_cast<const frag*>(kbuf + lds_off<KROWB>(32 + qi, 2 * kk + hi));
+      acc[0] = Mfma<T>::mma(a0, qf[kk], acc[0]);
+      acc[1] = Mfma<T>::mma(a1, qf[kk], acc[1]);
     }
   };
 
-  stage_load(0);
-  stage_write(0, lds);
+  // prologue: K(0), Vt(0) [, K(1)] resident; S(0) computed
+  load_k(0);
+  write_k(k_slot(0));
+  if (n_att_tiles > 0) { load_v(0); write_v(v_slot(0)); }
+  if (n_tiles > 1) { load_k(1); write_k(k_slot(1)); }
   __syncthreads();
+  f32x16 s[2], sn[2];
+  qk(k_slot(0), s);
 
   for (int tile = 0; tile < n_tiles; ++tile) {
     const bool attend = tile < n_att_tiles;
-    char* ldsK = lds + (tile & 1) * BUF;
-    char* ldsV = ldsK + KBYTES;
-    if (tile + 1 < n_tiles) stage_load(tile + 1);       // in flight during this tile's MFMAs
-
-    // ---- S^T (64 keys x 32 queries per wave) -----------------------------------------------------
-    // the two key blocks are independent accumulators: interleave them so no MFMA waits on its predecessor
-    f32x16 s[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-      const frag a0 = *reinterpret_cast<const frag*>(ldsK + lds_off<KROWB>(qi, 2 * kk + hi));
-      const frag a1 = *reinterpret_cast<const frag*>(ldsK + lds_off<KROWB>(32 + qi, 2 * kk + hi));
-      s[0] = Mfma<T>::mma(a0, qf[kk], s[0]);
-      s[1] = Mfma<T>::mma(a1, qf[kk], s[1]);
-    }
+    const bool more_k = tile + 2 < n_tiles, more_v = tile + 1 < n_att_tiles;
+    if (more_k) load_k(tile + 2);                        // in flight during this tile's MFMAs and softmax
+    if (more_v) load_v(tile + 1);
     const bool edge = tile * 64 + 64 > wave_full_keys;  // wave-uniform: some element needs the visibility test
+    if (!STASH && !COLIMP && !MASK && !edge && attend) {
+      // ---- hot path: fully visible tile, no by-products.  ONE basic block so that the compiler can weave the next
+      // tile's Q·K^T MFMAs (independent accumulators sn) into this tile's softmax VALU stream. -----------------
+      qk(k_slot(tile + 1), sn);                         // past the last tile this scores a stale slot; never used
+      float m_tile = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = DT<T>::round(div_by_const(DT<T>::round(s[kb][r]), p.sqrt_d, rsqrt_d));
+          s[kb][r] = v;
+          m_tile = fmaxf(m_tile, v);
+        }
+      m_tile = xor32_max(m_tile);
+      const float m_new = fmaxf(m_run, m_tile);
+      const float m2 = m_new * kLog2e;
+      float lsum = 0.f;
+      frag pf[2][2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], kLog2e, -m2));
+            lsum += pv;
+            pf[kb][t][e] = DT<T>::from_f32(pv);
+          }
+      // 16 MFMAs woven into ~500 VALU instructions: one MFMA, then a slice of the VALU stream (T19)
+#ifndef SPATTEN_PF_SCHED
+#define SPATTEN_PF_SCHED 1
+#endif
+#if SPATTEN_PF_SCHED == 1
+#pragma unroll
+      for (int i = 0; i < 2 * KK; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 DS read (the next A fragment)
+        __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);   // a slice of VALU
+      }
+#elif SPATTEN_PF_SCHED == 2
+#pragma unroll
+      for (int i = 0; i < 2 * KK; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 34, 0);
+      }
+#elif SPATTEN_PF_SCHED == 3
+#pragma unroll
+      for (int i = 0; i < 2 * KK; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+      }
+#elif SPATTEN_PF_SCHED == 4
+#pragma unroll
+      for (int i = 0; i < KK; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 56, 0);
+      }
+#endif
+      if (m_new != m_run) {
+        const float alpha = __expf(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        m_run = m_new;
+      }
+      l_run += lsum;
+      const char* ldsV = v_slot(tile);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int db = 0; db < DB; ++db) {
+            const frag a = *reinterpret_cast<const frag*>(ldsV + lds_off<128>(db * 32 + qi, kb * 4 + t * 2 + hi));
+            o[db] = Mfma<T>::mma(a, pf[kb][t], o[db]);
+          }
+      if (more_k) write_k(k_slot(tile));
+      if (more_v) write_v(v_slot(tile + 1));
+      __syncthreads();
+      s[0] = sn[0];
+      s[1] = sn[1];
+      continue;
+    }
+    if (tile + 1 < n_tiles) qk(k_slot(tile + 1), sn);   // next tile's scores
     float m_tile = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -237,6 +355,7 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
       m_tile = xor32_max(m_tile);
       const float m_new = fmaxf(m_run, m_tile);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float m2 = m_use * kLog2e;
       float lsum = 0.f;
       frag pf[2][2];
 #pragma unroll
@@ -245,7 +364,8 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float pv = __expf(s[kb][t * 8 + e] - m_use);     // exp(-inf) = 0 for masked keys
+            // exp(s - m) as one fma + v_exp_f32 (a base-2 exponential); exp2(-inf) = 0 for masked keys
+            const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], kLog2e, -m2));
             lsum += pv;
             pf[kb][t][e] = DT<T>::from_f32(pv);
           }
@@ -262,6 +382,7 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
       }
       l_run += lsum;
       // ---- O^T (D dv x 32 queries) += Vt · P^T ---------------------------------------------------
+      const char* ldsV = v_slot(tile);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -274,8 +395,11 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
         }
       }
     }
-    if (tile + 1 < n_tiles) stage_write(tile + 1, lds + ((tile + 1) & 1) * BUF);
-    __syncthreads();                                    // next buffer complete; this buffer free for tile+2
+    if (more_k) write_k(k_slot(tile));                // K(tile+2) replaces K(tile), consumed one iteration ago
+    if (more_v) write_v(v_slot(tile + 1));
+    __syncthreads();
+    s[0] = sn[0];
+    s[1] = sn[1];
   }
 
   // ---- epilogue: O = O^T / l, 4 consecutive dv per 8-byte store ---------------------------------
@@ -311,7 +435,7 @@ static void launch_flash_m(const FlashParams<T>& p, dim3 grid, hipStream_t st) {
 
 template <typename T, int D>
 static int launch_flash(const FlashParams<T>& p, hipStream_t st) {
-  const dim3 grid((unsigned)ceil_div(p.q_len, 128), (unsigned)p.H, (unsigned)p.B);
+  const dim3 grid((unsigned)(ceil_div(p.q_len, 128) * p.H * p.B));
   const bool st_ = p.scores != nullptr, ci = p.col_imp != nullptr;
   if (st_ && ci) launch_flash_m<T, D, true, true>(p, grid, st);
   else if (st_) launch_flash_m<T, D, true, false>(p, grid, st);
@@ -399,7 +523,7 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
     p.scores = (T*)scores; p.sc_sb = sc_sb; p.sc_sh = sc_sh; p.sc_sq = sc_sq;                          \
     p.col_imp = col_importance;                                                                        \
     p.B = batch; p.H = heads; p.Hkv = kv_heads; p.q_len = q_len; p.N = kv_len; p.Npad = npad;          \
-    p.causal = causal; p.sqrt_d = sqrtf((float)head_dim);                                              \
+    p.causal = causal; p.sqrt_d = sqrtf((float)head_dim); p.nqb = ceil_div(q_len, 128);                \
     return launch_flash<T, DD>(p, st);                                                                 \
   }
   if (dtype == SPATTEN_BF16) { if (head_dim == 128) SPATTEN_FLASH(bf16_t, 128) else SPATTEN_FLASH(bf16_t, 64) }
