@@ -96,7 +96,10 @@ __device__ inline void store_granule(unsigned long long* g, float v) {
 // MODE 0: the fused decode step.  MODE 1 (scores only): stash + (max, sum), no V traffic, no output — first pass of
 // local V pruning.  MODE 2 (scores in): the final fp32 logits are given, no K traffic — last pass of the
 // progressive-quantisation path.  Compile-time so the hot instantiation carries no extra branches.
-template <typename T, int D, int UNR, int MODE = 0>
+// LEAN: the plain decode step (one query row, MHA, no mask / position tensor / head list) — the common case gets an
+// instantiation that reads fewer kernel arguments (one scalar-load batch instead of three dependent ones: ~1 us of
+// launch-to-first-load latency on a 14 us kernel) and carries no integer divisions.
+template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false>
 __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const DecodeParams<T> p) {
   constexpr bool SCORES_ONLY = (MODE == 1);
   constexpr bool SCORES_IN = (MODE == 2);
@@ -121,14 +124,14 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
 
   // grid = (S, H, B * n_q): no integer divisions on the way to the first load
   const int split = blockIdx.x;
-  const int h = p.head_ids ? p.head_ids[blockIdx.y] : (int)blockIdx.y;
-  const int b = p.n_q == 1 ? (int)blockIdx.z : (int)blockIdx.z / p.n_q;
-  const int qi = p.n_q == 1 ? 0 : (int)blockIdx.z - b * p.n_q;
-  const int hkv = p.Hkv == p.H ? h : h / (p.H / p.Hkv);
-  const int unit = (b * p.H + h) * p.n_q + qi;   // one softmax row
+  const int h = (!LEAN && p.head_ids) ? p.head_ids[blockIdx.y] : (int)blockIdx.y;
+  const int b = (LEAN || p.n_q == 1) ? (int)blockIdx.z : (int)blockIdx.z / p.n_q;
+  const int qi = (LEAN || p.n_q == 1) ? 0 : (int)blockIdx.z - b * p.n_q;
+  const int hkv = (LEAN || p.Hkv == p.H) ? h : h / (p.H / p.Hkv);
+  const int unit = LEAN ? (b * p.H + h) : (b * p.H + h) * p.n_q + qi;   // one softmax row
 
   // keys this query may attend to (HF causal: j <= P + i with P = N - n_q); the stash covers all N
-  const int n_vis = p.causal ? min(p.N, p.N - p.n_q + qi + 1) : p.N;
+  const int n_vis = (!LEAN && p.causal) ? min(p.N, p.N - p.n_q + qi + 1) : p.N;
   const int lo = split * p.chunk;
   const int hi = min(lo + p.chunk, (p.scores != nullptr) ? p.N : n_vis);
 
@@ -160,13 +163,14 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
     }
   };
   if (lo < hi) issue_tile(lo);
+  SPATTEN_TSTAMP(5);
 
   // ---- un-rotated query + its table row ----------------------------------------------------------
   typename D8::packed q_lo, q_hi;                // rotated query, packed in the model dtype (exact: it IS rounded)
   raw_t n_raw[2];
   {
-    const T* qp = p.q + b * p.q_sb + h * p.q_sh + qi * p.q_sq;
-    int pq = p.pos_ids ? (int)p.pos_ids[b * p.pos_sb + qi] : p.pos_q + qi;
+    const T* qp = p.q + b * p.q_sb + h * p.q_sh + (LEAN ? 0 : qi * p.q_sq);
+    int pq = (!LEAN && p.pos_ids) ? (int)p.pos_ids[b * p.pos_sb + qi] : p.pos_q + qi;
     pq = min(max(pq, 0), p.table_rows - 1);
     const raw_t q0 = V8::ldg(qp + 8 * c);
     const raw_t q1 = V8::ldg(qp + HALF + 8 * c);
@@ -185,9 +189,10 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
     q_lo = D8::pack(ylo);
     q_hi = D8::pack(yhi);
   }
+  SPATTEN_TSTAMP(6);
   const float rsqrt_d = 1.0f / p.sqrt_d;
-  const T* maskp = p.mask ? p.mask + b * p.mask_sb + qi * p.mask_sq : nullptr;
-  T* stashp = p.scores ? p.scores + b * p.sc_sb + h * p.sc_sh + qi * p.sc_sq : nullptr;
+  const T* maskp = (!LEAN && p.mask) ? p.mask + b * p.mask_sb + qi * p.mask_sq : nullptr;
+  T* stashp = p.scores ? p.scores + b * p.sc_sb + h * p.sc_sh + (LEAN ? 0 : qi * p.sc_sq) : nullptr;
   T* kbase = p.kc ? p.kc + b * p.kv_sb + hkv * p.kv_sh : nullptr;
 
   // per-THREAD online softmax (the LPR lanes of a row share its score, so they agree): no barrier and
@@ -244,6 +249,10 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
 #pragma unroll
       for (int u = 0; u < UNR; ++u) sc[u] = DT<T>::round(div_by_const(DT<T>::round(sc[u]), p.sqrt_d, rsqrt_d));
     }
+#ifdef SPATTEN_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tracing build only: when has ALL of the tile landed?
+    SPATTEN_TSTAMP(7);
+#endif
     float m_new = m_run;
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -293,7 +302,8 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
     for (int i = 0; i < 8; ++i) { olo[i] *= alpha; ohi[i] *= alpha; }
     m_run = mw;
   }
-  // lanes with equal c across the wave's row groups: in-row rotations (DPP), then rows (permlane swaps)
+  // lanes with equal c across the wave's row groups: in-row rotations (DPP), then rows (permlane swaps).
+  // (Measured alternative: sending the 16 DPP rows through LDS instead of the swaps is SLOWER — 2.9k vs 1.9k cycles.)
   if (LPR == 4) {
     l_run += dpp_mov<kDppRor8>(l_run);
     l_run += dpp_mov<kDppRor4>(l_run);
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
     m_run = m_wg;
   }
   SPATTEN_TSTAMP(2);
-  T* outp = p.out + b * p.out_sb + qi * p.out_sq + h * D;
+  T* outp = p.out + b * p.out_sb + (LEAN ? 0 : qi * p.out_sq) + h * D;
   if (p.S == 1) {
     if (!SCORES_ONLY && tid < D) outp[tid] = DT<T>::from_f32(o_tot / l_tot);
     if (p.lse != nullptr && tid == 0) { p.lse[unit * 2] = m_run; p.lse[unit * 2 + 1] = l_tot; }
@@ -483,6 +493,12 @@ static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_onl
   if (p.scores_in != nullptr) {
     if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((decode_attn_kernel<T, D, 2, 2>), grid, dim3(kDecodeThreads), 0, stream, p);
     else hipLaunchKernelGGL((decode_attn_kernel<T, D, 4, 2>), grid, dim3(kDecodeThreads), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+  }
+  const bool lean = p.n_q == 1 && p.Hkv == p.H && !p.mask && !p.pos_ids && !p.head_ids && !p.causal;
+  if (lean && decode_unr_for(DT<T>::kId) == 4) {
+    if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((decode_attn_kernel<T, D, 2, 0, true>), grid, dim3(kDecodeThreads), 0, stream, p);
+    else hipLaunchKernelGGL((decode_attn_kernel<T, D, 4, 0, true>), grid, dim3(kDecodeThreads), 0, stream, p);
     return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
   }
   switch (decode_unr_for(DT<T>::kId)) {

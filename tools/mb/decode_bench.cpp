@@ -8,21 +8,21 @@ int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 1, N = argc > 2 ? atoi(argv[2]) : 2048, ns = argc > 3 ? atoi(argv[3]) : 0;
   const int stash = argc > 4 ? atoi(argv[4]) : 1;
   const int H = 32, d = 128, L = 32;
-  const size_t row = (size_t)d * 2, per = (size_t)B * H * (N + 64) * row;
+  const size_t row = (size_t)d * 2, per = (size_t)B * H * (N + 128) * row;
   std::vector<void*> kr(L), v(L);
   for (int l = 0; l < L; ++l) { (void)hipMalloc(&kr[l], per); (void)hipMalloc(&v[l], per); (void)hipMemset(kr[l], 0x3c, per); (void)hipMemset(v[l], 0x3c, per); }
   void *q, *cos, *sin, *out, *sc, *ws;
   (void)hipMalloc(&q, B * H * row); (void)hipMemset(q, 0x3c, B * H * row);
-  (void)hipMalloc(&cos, (N + 64) * row / 2); (void)hipMemset(cos, 0x3c, (N + 64) * row / 2);
-  (void)hipMalloc(&sin, (N + 64) * row / 2); (void)hipMemset(sin, 0x3c, (N + 64) * row / 2);
-  (void)hipMalloc(&out, B * H * row); (void)hipMalloc(&sc, (size_t)B * H * (N + 64) * 2);
+  (void)hipMalloc(&cos, (N + 128) * row / 2); (void)hipMemset(cos, 0x3c, (N + 128) * row / 2);
+  (void)hipMalloc(&sin, (N + 128) * row / 2); (void)hipMemset(sin, 0x3c, (N + 128) * row / 2);
+  (void)hipMalloc(&out, B * H * row); (void)hipMalloc(&sc, (size_t)B * H * (N + 128) * 2);
   size_t wsb = spatten_decode_workspace_bytes(B, H, d, 64);
   (void)hipMalloc(&ws, wsb); (void)hipMemset(ws, 0, wsb);
   auto go = [&]() {
     for (int l = 0; l < L; ++l) {
-      int rc = spatten_attn_decode(SPATTEN_BF16, q, (int64_t)H * d, d, nullptr, kr[l], v[l], (int64_t)H * (N + 64) * d,
-                                   (int64_t)(N + 64) * d, nullptr, nullptr, 0, 0, cos, sin, N + 64, nullptr, 0, nullptr, 0,
-                                   out, (int64_t)H * d, stash ? sc : nullptr, (int64_t)H * (N + 64), N + 64, nullptr, ws, B, H, H, d,
+      int rc = spatten_attn_decode(SPATTEN_BF16, q, (int64_t)H * d, d, nullptr, kr[l], v[l], (int64_t)H * (N + 128) * d,
+                                   (int64_t)(N + 128) * d, nullptr, nullptr, 0, 0, cos, sin, N + 64, nullptr, 0, nullptr, 0,
+                                   out, (int64_t)H * d, stash ? sc : nullptr, (int64_t)H * (N + 128), N + 64, nullptr, ws, B, H, H, d,
                                    N, N - 1, ns, nullptr);
       if (rc) { printf("rc=%d\n", rc); exit(1); }
     }

@@ -37,13 +37,15 @@ int main(int argc, char** argv) {
   // layer L-1 (steady state): times relative to the earliest workgroup start, in units of the cycle counter
   const unsigned long long* t = h.data() + (size_t)(L - 1) * WG * 8;
   // cycle counters are per-XCD: only per-workgroup DELTAS are meaningful
-  const char* names[4] = {"start->loop done", "loop->wg reduced", "reduced->ticket", "ticket->merge done"};
-  for (int s = 0; s < 4; ++s) {
+  struct { const char* name; int from, to; } ph[] = {{"start->loads issued", 0, 5}, {"issued->q rotated", 5, 6},
+      {"q rotated->scores(last tile)", 6, 7}, {"scores->loop done", 7, 1}, {"start->loop done", 0, 1},
+      {"loop->wg reduced", 1, 2}, {"reduced->ticket", 2, 3}, {"ticket->merge done", 3, 4}};
+  for (auto& q_ : ph) {
     std::vector<double> x;
-    for (int w = 0; w < WG; ++w) if (t[w * 8 + s + 1] && t[w * 8 + s]) x.push_back((double)(t[w * 8 + s + 1] - t[w * 8 + s]));
+    for (int w = 0; w < WG; ++w) if (t[w * 8 + q_.to] && t[w * 8 + q_.from]) x.push_back((double)(t[w * 8 + q_.to] - t[w * 8 + q_.from]));
     if (x.empty()) continue;
     std::sort(x.begin(), x.end());
-    printf("%-20s n=%4zu  min %7.0f  median %7.0f  p90 %7.0f  max %7.0f cycles\n", names[s], x.size(), x[0], x[x.size() / 2], x[x.size() * 9 / 10], x.back());
+    printf("%-30s n=%4zu  min %7.0f  median %7.0f  p90 %7.0f  max %7.0f cycles\n", q_.name, x.size(), x[0], x[x.size() / 2], x[x.size() * 9 / 10], x.back());
   }
   return 0;
 }
