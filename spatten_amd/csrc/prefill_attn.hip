@@ -117,7 +117,9 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
   constexpr int KBYTES = 64 * KROWB, VBYTES = D * 128, BUF = KBYTES + VBYTES;
   constexpr int KPC = 64 * (D / 8) / 256, VPC = D * 8 / 256;   // 16-byte pieces per thread per tile (K, Vt)
   using frag = typename Mfma<T>::frag;
-  __shared__ __attribute__((aligned(16))) char lds[2 * BUF];   // double buffered: [K tile | Vt tile] x 2
+  constexpr int SPITCH = 80;                                    // bytes per staged stash row (32 keys x 2 B, padded)
+  constexpr int SBYTES = STASH ? 4 * 32 * SPITCH : 0;           // per-wave 32 x 32 transpose tile for the stash
+  __shared__ __attribute__((aligned(16))) char lds[2 * BUF + SBYTES];   // double buffered [K tile | Vt tile] x 2 (+ stash)
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, qi = lane & 31, hi = lane >> 5;
   // XCD-aware work order.  Workgroup i runs on XCD i % 8 (observed dispatch; used for speed only) and every query
@@ -175,6 +177,8 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
   const T* maskrow = MASK ? p.mask + b * p.mask_sb + (int64_t)min(myq, p.q_len - 1) * p.mask_sq : nullptr;
   T* stashrow = STASH ? p.scores + b * p.sc_sb + h * p.sc_sh + (int64_t)min(myq, p.q_len - 1) * p.sc_sq : nullptr;
   float* colrow = COLIMP ? p.col_imp + (int64_t)(b * p.H + h) * p.N : nullptr;
+  // 16-byte stash stores need 16-byte aligned rows (row pitch and base offsets multiples of 8 elements)
+  const bool stash_vec = STASH && ((p.sc_sq | p.sc_sh | p.sc_sb) % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.scores) & 15) == 0);
 
   // ---- staging: global -> registers (issued early) -> LDS (written late).  Two K slots and two Vt slots; K runs ONE
   // tile ahead of Vt so that the Q·K^T MFMAs of tile t+1 are independent of — and overlap — the softmax of tile t.
@@ -337,7 +341,14 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
         if (STASH || COLIMP || MASK || edge) {
           const int key = tile * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
           const bool inb = key < p.N;
-          if (STASH) { if (inb && qvalid) stashrow[key] = DT<T>::from_f32(v); }               // pre-mask (:116-119)
+          if (STASH) {                                                                        // pre-mask (:116-119)
+            if (stash_vec) {       // stage [query][key] in LDS; written out below as 16-byte row pieces
+              char* sw = lds + 2 * BUF + wave * (32 * SPITCH);
+              *reinterpret_cast<T*>(sw + qi * SPITCH + ((r & 3) + 8 * (r >> 2) + 4 * hi) * 2) = DT<T>::from_f32(v);
+            } else if (inb && qvalid) {
+              stashrow[key] = DT<T>::from_f32(v);
+            }
+          }
           if (COLIMP) {
             float cv = (inb && qvalid) ? v : 0.f;     // sum over this wave's 32 queries, then one atomic per key
             cv = xor16_sum(group_sum<16>(cv));
@@ -348,6 +359,26 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
         }
         s[kb][r] = v;
         m_tile = fmaxf(m_tile, v);
+      }
+      if (STASH && stash_vec) {
+        // the wave's 32 queries x 32 keys of this key block, transposed through LDS: 64-byte row segments, 16 B / lane
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const char* sw = lds + 2 * BUF + wave * (32 * SPITCH);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int id = lane + 64 * i, row = id >> 2, c4 = id & 3;
+          const u32x4 piece = *reinterpret_cast<const u32x4*>(sw + row * SPITCH + c4 * 16);
+          const int qq = q0 + row, key0 = tile * 64 + kb * 32 + c4 * 8;
+          if (qq < p.q_len && key0 < p.N) {
+            T* dst = p.scores + b * p.sc_sb + h * p.sc_sh + (int64_t)qq * p.sc_sq + key0;
+            if (key0 + 8 <= p.N) *reinterpret_cast<u32x4*>(dst) = piece;
+            else {
+              const T* pe = reinterpret_cast<const T*>(&piece);
+              for (int e = 0; e < p.N - key0; ++e) dst[e] = pe[e];
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     }
     if (attend) {
