@@ -129,9 +129,8 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
   const int nqb = p.nqb;
   int h, qblk, b;
   {
-    const int i = blockIdx.x, x = i & 7, sl = i >> 3;
+    const int i = blockIdx.x;
     const int per_b = p.H * nqb;                         // workgroups per batch element
-    const int hx = (p.H + 7) >> 3;                       // heads per XCD lane
     b = i / per_b;
     const int j = i - b * per_b;
     if ((p.H & 7) == 0) {
@@ -142,7 +141,6 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
       h = j / nqb;
       qblk = nqb - 1 - (j % nqb);
     }
-    (void)x; (void)sl; (void)hx;
   }
   const int hkv = p.Hkv == p.H ? h : h / (p.H / p.Hkv);
   const int q0 = qblk * 128 + wave * 32;

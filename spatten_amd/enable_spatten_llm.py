@@ -1,16 +1,33 @@
-"""Plugin entry point — mirror of spatten_llm/enable_spatten_llm.py:5-23."""
+"""Plugin entry point of the drop-in surface.
+
+Contract (reference: spatten_llm/enable_spatten_llm.py:5-23): ``enable_spatten_llm(model, start_size,
+important_size, recent_size)`` patches the model's attention modules for cache-relative RoPE + score stashing and
+returns the ``SpAttenKVCache`` that prunes its KV cache; model families the path does not cover raise
+``ValueError("got <model_type>")``.
+"""
+from typing import Callable, Dict, Tuple
+
 from .kv_cache_token_pruning import SpAttenKVCache
 
 __all__ = ["enable_spatten_llm"]
 
 
-def enable_spatten_llm(model, start_size, important_size, recent_size):
-    if "llama" in model.config.model_type:                                   # :6
-        k_seq_dim = v_seq_dim = 2
-        from .pos_shift.modify_llama import enable_llama_pos_shift_attention
+def _patch_llama(model) -> Tuple[int, int]:
+    from .pos_shift.modify_llama import enable_llama_pos_shift_attention
 
-        enable_llama_pos_shift_attention(model)
-    else:
-        raise ValueError(f"got {model.config.model_type}")                    # :13-14
-    return SpAttenKVCache(start_size=start_size, important_size=important_size, recent_size=recent_size,
-                          k_seq_dim=k_seq_dim, v_seq_dim=v_seq_dim)
+    enable_llama_pos_shift_attention(model)
+    return 2, 2            # K and V are [B, H, L, d]: the sequence axis is dim 2
+
+
+# model_type substring -> (patcher returning the (k_seq_dim, v_seq_dim) of that family's cache layout)
+_FAMILIES: Dict[str, Callable] = {"llama": _patch_llama}
+
+
+def enable_spatten_llm(model, start_size, important_size, recent_size):
+    model_type = model.config.model_type
+    patch = next((fn for key, fn in _FAMILIES.items() if key in model_type), None)
+    if patch is None:
+        raise ValueError(f"got {model_type}")
+    k_dim, v_dim = patch(model)
+    return SpAttenKVCache(start_size=start_size, recent_size=recent_size, important_size=important_size,
+                          k_seq_dim=k_dim, v_seq_dim=v_dim)

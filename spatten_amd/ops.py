@@ -152,8 +152,7 @@ def attn_prefill(q: torch.Tensor, kr_cache: torch.Tensor, v_cache: torch.Tensor,
     lib = _lib.load()
     B, H, ql, d = q.shape
     Hkv = kr_cache.shape[1]
-    k_cache = kr_cache
-    if q.stride(3) != 1 or k_cache.stride(3) != 1 or k_cache.stride(2) != d or v_cache.stride() != k_cache.stride():
+    if q.stride(3) != 1 or kr_cache.stride(3) != 1 or kr_cache.stride(2) != d or v_cache.stride() != kr_cache.stride():
         raise ValueError("q needs contiguous d; kr_cache/v_cache need contiguous rows (pitch d)")
     if max(kv_len, pos_q0 + ql) > cos.shape[0] and position_ids is None:
         raise ValueError("rotary table too short")
