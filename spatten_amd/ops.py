@@ -165,7 +165,7 @@ def attn_prefill(q: torch.Tensor, kr_cache: torch.Tensor, v_cache: torch.Tensor,
     ws = _prefill_workspace(lib.spatten_prefill_workspace_bytes(_dt(q), B, H, Hkv, d, ql, kv_len), q.device)
     rc = lib.spatten_attn_prefill(
         _dt(q), q.data_ptr(), q.stride(0), q.stride(1), q.stride(2),
-        k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(0), k_cache.stride(1),
+        kr_cache.data_ptr(), v_cache.data_ptr(), kr_cache.stride(0), kr_cache.stride(1),
         cos.data_ptr(), sin.data_ptr(), cos.shape[0],
         _ptr(position_ids), 0 if position_ids is None else (position_ids.stride(0) if position_ids.shape[0] > 1 else 0),
         _ptr(mask), *((0, 0) if mask is None else (mask.stride(0), mask.stride(1))),
