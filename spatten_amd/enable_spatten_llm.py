@@ -23,11 +23,21 @@ def _patch_llama(model) -> Tuple[int, int]:
 _FAMILIES: Dict[str, Callable] = {"llama": _patch_llama}
 
 
-def enable_spatten_llm(model, start_size, important_size, recent_size):
+def enable_spatten_llm(model, start_size, important_size, recent_size, importance_mode="reference"):
+    """``importance_mode="cascade"`` (extension, parity unpinned) makes the patched forward accumulate softmax
+    probabilities per (layer, head, key) and the returned cache prune by them instead of by the last step's logits."""
     model_type = model.config.model_type
     patch = next((fn for key, fn in _FAMILIES.items() if key in model_type), None)
     if patch is None:
         raise ValueError(f"got {model_type}")
     k_dim, v_dim = patch(model)
-    return SpAttenKVCache(start_size=start_size, recent_size=recent_size, important_size=important_size,
-                          k_seq_dim=k_dim, v_seq_dim=v_dim)
+    cache = SpAttenKVCache(start_size=start_size, recent_size=recent_size, important_size=important_size,
+                           k_seq_dim=k_dim, v_seq_dim=v_dim, importance_mode=importance_mode)
+    if importance_mode == "cascade":
+        from .pos_shift.modify_llama import attention_modules
+
+        mods = attention_modules(model)                            # model.modules() order = layer order (:74-77)
+        cache._cascade_modules = mods
+        for layer, m in enumerate(mods):
+            m._spatten_cascade = (cache, layer)
+    return cache

@@ -39,7 +39,8 @@ DIM_TO_SLICE = {1: slice1d, 2: slice2d, 3: slice3d}
 
 
 class SpAttenKVCache:
-    def __init__(self, start_size=4, recent_size=128, important_size=128, k_seq_dim=2, v_seq_dim=2):
+    def __init__(self, start_size=4, recent_size=128, important_size=128, k_seq_dim=2, v_seq_dim=2,
+                 importance_mode="reference"):
         # the reference prints this banner from its constructor (kv_cache_token_pruning.py:32)
         print(f"SpAttenKVCache: keep start: {start_size}, keep recent: {recent_size}, keep important: {important_size}")
         self.start_size = start_size
@@ -50,6 +51,13 @@ class SpAttenKVCache:
         self.v_seq_dim = v_seq_dim
         self.k_slice = DIM_TO_SLICE[k_seq_dim]
         self.v_slice = DIM_TO_SLICE[v_seq_dim]
+        if importance_mode not in ("reference", "cascade"):
+            raise ValueError("importance_mode must be 'reference' or 'cascade'")
+        # "reference": importance = the last forward's stashed raw logits (kv_cache_token_pruning.py:51).
+        # "cascade"  : importance = running sum of softmax probabilities over every forward since the key entered
+        #              the cache (SpAtten paper / README.md:11; PARITY UNPINNED), accumulated by the patched forward.
+        self.importance_mode = importance_mode
+        self.cascade = None                 # spatten_amd.cascade.CascadeImportance, created by the first forward
         self.importance_score: Optional[List[torch.Tensor]] = None
         self.keep_indices: Optional[torch.Tensor] = None      # int32 [layers, H, important] of the last prune
         self.n_pruned_last = 0
@@ -83,6 +91,8 @@ class SpAttenKVCache:
                 f"top-k window [{lo},{hi}) holds fewer than important_size={self.important_size} candidates "
                 f"(seq_len={seq_len}, num_coming={num_coming})")
         n_layers = len(past_key_values)
+        if self.importance_mode == "cascade":
+            return self._prune_cascade(past_key_values, seq_len, num_coming, lo, hi, new_len)
         if len(attn_score_all) != n_layers:
             raise ValueError("attn_score_all must hold one stash per layer")
 
@@ -109,6 +119,35 @@ class SpAttenKVCache:
             kv_slab.attach(k, v, kr, new_len)
             out.append([k, v])
         return out                                                            # list of lists (:72-96)
+
+
+    def _prune_cascade(self, past_key_values, seq_len, num_coming, lo, hi, new_len):
+        """Same window / row map as the reference prune, but ranked by the accumulated probabilities; the
+        accumulators are compacted with the cache so they keep describing the surviving keys."""
+        if self.cascade is None:
+            raise RuntimeError("cascade importance has not been accumulated: run the patched forward first "
+                               "(enable_spatten_llm(..., importance_mode='cascade'))")
+        out, idxs = [], []
+        self.importance_score = []
+        for layer, (K, V) in enumerate(past_key_values):
+            K, V = _rows(K), _rows(V)
+            if V.stride() != K.stride():
+                K, V = K.contiguous(), V.contiguous()
+            d = K.shape[3]
+            acc = self.cascade.acc[layer]
+            self.importance_score.append(acc[:, :seq_len])
+            idx = ops.topk_select(acc[:, :seq_len], lo, hi, self.important_size)
+            cap = kv_slab.round_capacity(new_len + max(int(num_coming), 0))
+            rope = kv_slab.rope_tables(cap, d, K.dtype, K.device)
+            k, v, kr = ops.kv_compact(K, V, idx, self.start_size, hi, L=seq_len, capacity=cap, rope=rope)
+            self.cascade.compact(layer, idx, self.start_size, hi, seq_len)
+            kv_slab.attach(k, v, kr, new_len)
+            out.append([k, v])
+            idxs.append(idx)
+        self.keep_indices = torch.stack(idxs)
+        self.n_pruned_last = seq_len - new_len
+        self.n_pruned_total += self.n_pruned_last
+        return out
 
 
 def _rows(t: torch.Tensor) -> torch.Tensor:

@@ -110,6 +110,8 @@ def llama_pos_shift_attention_forward(
     stash = torch.empty(bsz, num_heads, q_len, kv_seq_len, dtype=dtype, device=device)
     if attention_mask is not None:
         attention_mask = attention_mask.to(dtype)
+    cascade = getattr(self, "_spatten_cascade", None)
+    lse = torch.empty(bsz, num_heads, 1, 2, dtype=torch.float32, device=device) if (cascade and q_len == 1) else None
     if q_len == 1:
         slab.ensure_shadow(past_len)
         attn_output = ops.attn_decode(
@@ -117,7 +119,7 @@ def llama_pos_shift_attention_forward(
             k_new=key_states.view(bsz, num_kv_heads, head_dim), v_new=value_states.view(bsz, num_kv_heads, head_dim),
             position_ids=None if position_ids is None else position_ids[:, 0],
             mask=None if attention_mask is None else attention_mask[:, 0, 0, :],
-            scores=stash.view(bsz, num_heads, kv_seq_len))
+            scores=stash.view(bsz, num_heads, kv_seq_len), lse=None if lse is None else lse.view(bsz, num_heads, 2))
         slab.length = slab.rot_len = kv_seq_len
         attn_output = attn_output.view(bsz, 1, num_heads * head_dim)
     else:
@@ -134,6 +136,14 @@ def llama_pos_shift_attention_forward(
 
     # store attention scores for deciding which token to prune (:116-119) — raw scaled logits, pre-mask
     self.attn_scores = stash
+    if cascade is not None:          # extension: cumulative importance = sum of softmax probabilities (parity unpinned)
+        kv_cache, layer = cascade
+        if kv_cache.cascade is None:
+            from ..cascade import CascadeImportance
+            n_layers = sum(1 for _ in attention_modules_of(kv_cache, self))
+            kv_cache.cascade = CascadeImportance(n_layers, num_heads, kv_slab.round_capacity(kv_seq_len + kv_slab.GROW), device)
+        kv_cache.cascade.accumulate(layer, stash, lse,
+                                    None if attention_mask is None else attention_mask[:, 0])
 
     if attn_output.size() != (bsz, q_len, hidden_size):                           # :140-147
         raise ValueError(
@@ -153,6 +163,17 @@ def llama_pos_shift_attention_forward(
 
     new_past = slab.views() if use_cache else None                                # :100
     return attn_output, attn_weights, new_past
+
+
+def attention_modules(model):
+    """The patched attention modules in ``model.modules()`` order (= layer order, run_spatten_llama.py:74-77)."""
+    return [m for m in model.modules() if _is_llama_attention(m)]
+
+
+def attention_modules_of(kv_cache, any_module):
+    """All modules sharing ``kv_cache``'s cascade state (registered by enable_spatten_llm)."""
+    reg = getattr(kv_cache, "_cascade_modules", None)
+    return reg if reg is not None else [any_module]
 
 
 def _is_llama_attention(module) -> bool:

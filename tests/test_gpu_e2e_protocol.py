@@ -63,11 +63,22 @@ class TinyLlama(nn.Module):
 class NumpyReplica:
     """Same weights, reference semantics restated by the oracle (cat + re-rotate all keys every step)."""
 
-    def __init__(self, model):
+    def __init__(self, model, cascade=False):
+        self.cascade = cascade
         g = lambda t: t.detach().cpu().numpy().astype(np.float32)
         self.emb, self.lm = g(model.embed.weight), g(model.lm_head.weight)
         self.w = [{n: g(getattr(l.self_attn, n).weight) for n in ("q_proj", "k_proj", "v_proj", "o_proj")} for l in model.layers]
         self.stash = [None] * L
+        self.acc = None          # cascade mode: [L][H, len] accumulated probabilities
+
+    def accumulate(self, i, stash, mask):
+        if self.acc is None:
+            self.acc = [np.zeros((H, 0), np.float32) for _ in range(L)]
+        n = stash.shape[-1]
+        if self.acc[i].shape[1] < n:
+            self.acc[i] = np.concatenate([self.acc[i], np.zeros((H, n - self.acc[i].shape[1]), np.float32)], 1)
+        m = np.where(mask < 0, -np.inf, 0).astype(np.float32)
+        self.acc[i] = orc.cascade_importance_accumulate(self.acc[i], stash, m)
 
     def forward(self, ids, past):
         B, q = ids.shape
@@ -83,6 +94,8 @@ class NumpyReplica:
                                               None if past is None else past[i][0], None if past is None else past[i][1],
                                               pos, mask, "f32")
             self.stash[i] = stash
+            if self.cascade:
+                self.accumulate(i, stash, mask)
             x = x + o @ w["o_proj"].T
             new_past.append(kv)
         return x @ self.lm.T, new_past
@@ -136,3 +149,42 @@ def test_multi_turn_protocol_matches_reference_semantics(capsys):
             np.testing.assert_allclose(lg[0].cpu().numpy(), lr[0], atol=1e-5, rtol=1e-5)
     assert pruned_g == pruned_r > 0 and kv_cache.n_pruned_total == pruned_g
     assert "SpAttenKVCache: keep start: 4" in capsys.readouterr().out
+
+
+def test_multi_turn_protocol_cascade_importance_mode():
+    """Extension (parity unpinned): importance = accumulated softmax probabilities; the patched forward accumulates,
+    the cache prunes by them and carries the accumulators through the prune.  GPU vs the oracle's restatement."""
+    from spatten_amd import enable_spatten_llm
+    torch.manual_seed(1)
+    model = TinyLlama().cuda().float()
+    for p in model.parameters():
+        p.data.mul_(0.6)
+    ref = NumpyReplica(model, cascade=True)
+    kv_cache = enable_spatten_llm(model, START, IMPORTANT, RECENT, importance_mode="cascade")
+    rng = np.random.default_rng(2)
+    prompts = [rng.integers(0, VOCAB, size=n)[None] for n in (36, 30, 22)]
+    past_g = past_r = None
+    for turn, prompt in enumerate(prompts):
+        if turn > 0:
+            space_needed = prompt.shape[1] + MAX_GEN
+            Lc = past_r[0][0].shape[2]
+            for i in range(L):        # accumulators agree before the prune
+                np.testing.assert_allclose(kv_cache.cascade.acc[i][:, :Lc].cpu().numpy(), ref.acc[i][:, :Lc], rtol=2e-3, atol=2e-5)
+            past_g = kv_cache.apply_token_pruning(past_g, space_needed, None)
+            if Lc + space_needed > START + IMPORTANT + RECENT:
+                lo, hi = START, min(Lc - RECENT + space_needed, Lc)
+                new_r = []
+                for i in range(L):
+                    idx = orc.topk_window(ref.acc[i][:, :Lc], lo, hi, IMPORTANT)
+                    assert np.array_equal(kv_cache.keep_indices[i].cpu().numpy(), idx), f"turn {turn} layer {i}"
+                    Kn, Vn = orc.kv_compact(past_r[i][0], past_r[i][1], idx, START, hi)
+                    a = ref.acc[i][:, :Lc]
+                    ref.acc[i] = np.concatenate([a[:, :START], np.take_along_axis(a, idx, 1), a[:, hi:]], 1)
+                    new_r.append((Kn, Vn))
+                past_r = new_r
+        tg, past_g, _ = greedy(lambda i, p: model(i, p), torch.from_numpy(prompt).cuda(), past_g,
+                               lambda a: torch.tensor(a, device="cuda"))
+        tr, past_r, _ = greedy(ref.forward, prompt, past_r, lambda a: np.asarray(a))
+        assert tg == tr, f"turn {turn}"
+        assert past_g[0][0].shape[2] == past_r[0][0].shape[2]
+    assert kv_cache.n_pruned_total > 0
