@@ -152,39 +152,47 @@ def main():
     plan = ops.PrunePlan(importance, Kp, Vp, Kd, Vd, Krd)
     idx = torch.empty(L, Hl, IMPORTANT, dtype=torch.int32, device=dev)
     stash = [torch.empty(B, Hl, cap, dtype=dt, device=dev) for _ in range(L)]
-    outs = [torch.empty(B, Hl * d, dtype=dt, device=dev) for _ in range(L)]
-    staging = [hp.gather_staging(B, 1, d, dt, dev) for _ in range(L)] if dist_on else None
+    # attention outputs (and all-gather receive buffers) are double-buffered by the parity of the position in the
+    # turn: the RCCL gather of token t then overlaps the attention graph of token t+1 without sharing a buffer
+    outs2 = [[torch.empty(B, Hl * d, dtype=dt, device=dev) for _ in range(L)] for _ in range(2)]
+    outs = outs2[0]
+    staging2 = [[hp.gather_staging(B, 1, d, dt, dev) for _ in range(L)] for _ in range(2)] if dist_on else None
 
     def prune():
         ops.prune_layers(importance, Kp, Vp, CTX, lo, hi, IMPORTANT, dst=(Kd, Vd, Krd), plan=plan, idx=idx,
                          rope=(cos, sin))
 
-    def decode_token(n):                       # n = cache length AFTER the append
+    def decode_token(n, par=0):                # n = cache length AFTER the append
         for l in range(L):
             ops.attn_decode(q[l], Kd[l], Krd[l], Vd[l], n, cos, sin, n - 1, k_new=kn[l], v_new=vn[l],
-                            scores=stash[l], out=outs[l], workspace=ws)
+                            scores=stash[l], out=outs2[par][l], workspace=ws)
 
-    def gather_token():
+    def gather_token(par):
         """The exchange step of the head-parallel path: every layer's [B, H/N*d] slice -> [B, H*d] on all ranks.
         Collectives are NOT captured into HIP graphs (torch's RCCL watchdog aborts on captured work on this
         stack), so they are issued eagerly after the token's attention graph: as one RCCL group of 32
-        all-gathers (one launch), or one by one with --gather per-layer."""
+        all-gathers (one launch), or one by one with --gather per-layer.  Returns an object whose ``wait()``
+        orders the current stream after the collectives (no host block)."""
         import torch.distributed as dist
+        oo, ss = outs2[par], staging2[par]
         if args.gather == "grouped" and hasattr(dist, "_coalescing_manager"):
             with dist._coalescing_manager(device=dev, async_ops=True) as cm:
                 for l in range(L):
-                    dist.all_gather_into_tensor(staging[l].view(world_eff * B, 1, Hl * d), outs[l].view(B, 1, Hl * d))
-            cm.wait()
-        else:
-            works = [dist.all_gather_into_tensor(staging[l].view(world_eff * B, 1, Hl * d), outs[l].view(B, 1, Hl * d),
-                                                 async_op=True) for l in range(L)]
-            for w in works:
-                w.wait()
+                    dist.all_gather_into_tensor(ss[l].view(world_eff * B, 1, Hl * d), oo[l].view(B, 1, Hl * d))
+            return cm
+        works = [dist.all_gather_into_tensor(ss[l].view(world_eff * B, 1, Hl * d), oo[l].view(B, 1, Hl * d),
+                                             async_op=True) for l in range(L)]
+
+        class _All:
+            def wait(self_inner):
+                for w in works:
+                    w.wait()
+        return _All()
 
     def run_slot(slot):
         if slot == 0:
             prune()
-        decode_token(new_len + slot + 1)
+        decode_token(new_len + slot + 1, slot & 1)
 
     # ---- HIP graphs: one per position in the turn (kv_len is a launch parameter) -------------------------
     graphs = None
@@ -209,14 +217,25 @@ def main():
             graphs = None
             torch.cuda.synchronize()
 
+    pending = [None, None]                    # in-flight gather per output buffer parity
+
     def run_steps(n, first=0):
         for i in range(first, first + n):
+            slot = i % TURN
+            par = slot & 1
+            if dist_on and pending[par] is not None:
+                pending[par].wait()            # the gather that still reads this parity's outputs (token i-2)
+                pending[par] = None
             if graphs is not None:
-                graphs[i % TURN].replay()
+                graphs[slot].replay()
             else:
-                run_slot(i % TURN)
+                run_slot(slot)
             if dist_on:
-                gather_token()
+                pending[par] = gather_token(par)    # overlaps the next token's attention graph
+        for par in (0, 1):                     # the timed region ends with every exchange complete
+            if pending[par] is not None:
+                pending[par].wait()
+                pending[par] = None
 
     run_steps(args.warmup)
     elapsed = time_region(lambda n: run_steps(n, args.warmup), args.steps, dist_on)
@@ -331,6 +350,23 @@ def main():
                 eager_token()
             torch.cuda.synchronize()
             extras["dense_eager_posshift_tokens_per_s"] = round(5 / (time.perf_counter() - t0), 2)
+            # "fair dense" line: torch SDPA over PRE-rotated K (no cat, no re-rotation, no stash)
+            try:
+                qs = [x[:, :, None].contiguous() for x in q]
+
+                def sdpa_token():
+                    for l in range(L):
+                        torch.nn.functional.scaled_dot_product_attention(qs[l], Krp[l], Vp[l])
+                for _ in range(3):
+                    sdpa_token()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    sdpa_token()
+                torch.cuda.synchronize()
+                extras["dense_torch_sdpa_prerotated_tokens_per_s"] = round(20 / (time.perf_counter() - t0), 2)
+            except Exception as e:
+                extras["dense_torch_sdpa_error"] = f"{type(e).__name__}: {e}"
             extras["speedup_vs_dense_eager"] = round(tokens_per_s / extras["dense_eager_posshift_tokens_per_s"], 2)
             extras["speedup_vs_dense_fused"] = round(tokens_per_s / extras["dense_fused_tokens_per_s"], 2)
             # ---- other rows of the scope table, measured on the same box (not part of `value`) -----------------
