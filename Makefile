@@ -23,7 +23,7 @@ $(LIB): $(OBJS)
 oracle: oracle/liboracle.so
 
 oracle/liboracle.so: oracle/oracle.c
-	gcc -O3 -march=native -fopenmp -fPIC -shared -o $@ $< -lm
+	gcc -O3 -march=x86-64-v3 -fopenmp -fPIC -shared -o $@ $< -lm
 
 clean:
 	rm -rf build $(LIB) oracle/liboracle.so

@@ -259,10 +259,11 @@ int spatten_pq_pack(int dtype, const void* kr_cache, int64_t kv_sb, int64_t kv_s
                     int64_t pl_sb, int64_t pl_sh, int64_t sc_sb, int64_t sc_sh, int batch, int kv_heads, int head_dim,
                     int row_lo, int row_hi, void* stream);
 size_t spatten_pq_scratch_bytes(int batch, int heads, int head_dim, int kv_len);
-/* decode step over the planes: pass 1 scores from the MSB plane; heads with max_j prob_j < threshold refetch the LSB
- * plane and are recomputed once; softmax + P.V with the un-quantised V.  q [B,H,d] un-rotated (rotated at pos_q);
- * need_lsb optional int32 [B*H] (which heads refetched); scratch = spatten_pq_scratch_bytes; workspace = the decode
- * workspace (spatten_decode_workspace_bytes). */
+/* decode step over the planes (two launches of the decode kernel): pass 1 = logits from the MSB plane, softmax, P.V
+ * with the un-quantised V, and need_lsb = (max_j prob_j < threshold) per head; pass 2 = flagged heads refetch the LSB
+ * plane and are recomputed once (confident heads return at once).  q [B,H,d] un-rotated (rotated at pos_q);
+ * need_lsb optional int32 [B*H] (which heads refetched; when NULL the flags live in scratch); scratch =
+ * spatten_pq_scratch_bytes; workspace = the decode workspace (spatten_decode_workspace_bytes). */
 int spatten_attn_decode_pq(int dtype, const void* q, int64_t q_sb, int64_t q_sh,
                            const void* msb, const void* lsb, const float* scale,
                            int64_t pl_sb, int64_t pl_sh, int64_t sc_sb, int64_t sc_sh,

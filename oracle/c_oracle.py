@@ -16,18 +16,38 @@ DT = {"f32": 0, "f16": 1, "bf16": 2}
 _lib = None
 
 
+_FLAGS = ["-O3", "-fopenmp", "-fPIC", "-shared"]
+
+
 def build():
+    """The shipped library targets x86-64-v3 (AVX2/FMA) so that one build runs on any host it travels to."""
     src = os.path.join(_HERE, "oracle.c")
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-o", LIB, src, "-lm"])
+        subprocess.check_call(["gcc", *_FLAGS, "-march=x86-64-v3", "-o", LIB, src, "-lm"])
 
 
-def load():
+def _build_native():
+    """bench.py's cpu_baseline leg: give the host CPU its best code (-march=native, built on the box it runs on,
+    outside the tree).  Returns the path or None when there is no compiler."""
+    import tempfile
+    try:
+        out = os.path.join(tempfile.mkdtemp(prefix="spatten_oracle_"), "liboracle_native.so")
+        subprocess.check_call(["gcc", *_FLAGS, "-march=native", "-o", out, os.path.join(_HERE, "oracle.c"), "-lm"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return out
+    except Exception:
+        return None
+
+
+def load(native=False):
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
-            build()
-        _lib = ctypes.CDLL(LIB)
+        path = _build_native() if native else None
+        if path is None:
+            if not os.path.exists(LIB):
+                build()
+            path = LIB
+        _lib = ctypes.CDLL(path)
         _lib.orc_max_threads.restype = ctypes.c_int
         _lib.orc_topk_window.restype = ctypes.c_int
     return _lib

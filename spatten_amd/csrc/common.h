@@ -215,6 +215,53 @@ template <> struct Dot8<f16_t> {
   }
 };
 
+// dot product of 8 query elements with the 8 unsigned nibbles of one dword of a 4-bit plane (progressive-quant keys).
+// 16-bit types: OR a nibble pair into the mantissas of two constants (bf16 128.0 / f16 1024.0 -> exactly 128+n /
+// 1024+n), feed the pair to the packed dot instruction against the query pair, and take the constant out again
+// through the precomputed query sum: 3 VALU ops per 2 elements instead of ~5 per element for extract/convert/fma.
+// Signed (MSB) nibbles are XOR-ed with 8 first (n ^ 8 = sext(n) + 8), which only changes the constant.
+// Returns sum_e q[e] * n_e with n_e = nibble e of w, minus `bias` * sum(q) (bias = 8 turns n ^ 8 back into sext(n)).
+template <typename T> struct NibbleDot;
+template <> struct NibbleDot<float> {
+  struct packed { float q[8]; float qsum; };
+  __device__ static inline packed prep(const float (&v)[8]) {
+    packed r;
+    r.qsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { r.q[i] = v[i]; r.qsum += v[i]; }
+    return r;
+  }
+  __device__ static inline float dot(const packed& a, uint32_t w, float bias) {
+    float acc = -bias * a.qsum;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc = fmaf(a.q[e], (float)((w >> (4 * e)) & 15u), acc);
+    return acc;
+  }
+};
+template <typename T, uint32_t MAGIC, int BASE>
+struct NibbleDot16 {
+  struct packed { uint32_t q[4]; float qsum; };   // q[k] = {element k, element k + 4}
+  __device__ static inline packed prep(const float (&v)[8]) {
+    packed r;
+    const float w[8] = {v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7]};
+    const u32x4 pk = Vec8<T>::pack(w);
+    r.qsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.q[i] = pk[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.qsum += v[i];   // v is already rounded to T: the packed values are exact
+    return r;
+  }
+  __device__ static inline float dot(const packed& a, uint32_t w, float bias) {
+    u32x4 x, y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { x[k] = a.q[k]; y[k] = ((w >> (4 * k)) & 0x000F000Fu) | MAGIC; }
+    return Dot8<T>::dot(x, y, -((float)BASE + bias) * a.qsum);
+  }
+};
+template <> struct NibbleDot<bf16_t> : NibbleDot16<bf16_t, 0x43004300u, 128> {};
+template <> struct NibbleDot<f16_t> : NibbleDot16<f16_t, 0x64006400u, 1024> {};
+
 // Monotone fp32 -> uint32 key: larger value => larger key, NaN largest, -0 == +0.
 // This is the total order torch.topk(largest=True) ranks by.
 __device__ inline uint32_t ordered_key(float x) {
@@ -235,5 +282,12 @@ __device__ inline float div_by_const(float x, float c, float rc) {
 }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// progressive-quant key planes handed to decode_rows (decode_attn.hip); see pq.hip for the storage format
+struct PQKeys {
+  const uint8_t* msb; const uint8_t* lsb; const float* scale;
+  int64_t pl_sb, pl_sh, sc_sb, sc_sh;
+  float threshold; int32_t* need;
+};
 
 }  // namespace spatten

@@ -61,7 +61,10 @@ struct DecodeParams {
   T* scores; int64_t sc_sb, sc_sh, sc_sq;
   float* lse;
   const int32_t* head_ids;   // optional: blockIdx.y -> query head (head pruning: only the kept heads are launched)
-  const float* scores_in; int64_t si_sb, si_sh;   // optional: final fp32 logits given (progressive-quant path): no K traffic
+  const float* scores_in; int64_t si_sb, si_sh;   // optional: final fp32 logits given: no K traffic
+  // progressive-quant key planes (KSRC != 0, pq.hip): 4-bit MSB / LSB planes [B,Hkv,cap,D/2] + per-row scale
+  const uint8_t* pq_msb; const uint8_t* pq_lsb; const float* pq_scale; int64_t pl_sb, pl_sh, ps_sb, ps_sh;
+  float pq_thr; int32_t* pq_need;   // [B*H]: written by the MSB pass (max prob < thr), read by the refetch pass
   unsigned long long* ws_part;   // [B*H*n_q, S, D+2] {value, tag} granules
   unsigned* ws_cnt;     // [B*H*n_q]
   int B, H, Hkv, N, pos_q, S, chunk, n_q, causal;
@@ -99,10 +102,18 @@ __device__ inline void store_granule(unsigned long long* g, float v) {
 // LEAN: the plain decode step (one query row, MHA, no mask / position tensor / head list) — the common case gets an
 // instantiation that reads fewer kernel arguments (one scalar-load batch instead of three dependent ones: ~1 us of
 // launch-to-first-load latency on a 14 us kernel) and carries no integer divisions.
-template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false>
+// KSRC: where keys come from.  0 = the rotated shadow (model dtype).  1 = progressive-quant MSB plane only (pass 1:
+// 4 bits / element + a per-row scale; softmax + P·V run speculatively on these logits and the merge step records
+// need_lsb = max prob < threshold, RequantDecision.scala:44-72).  2 = MSB | LSB planes (the refetch pass: only the
+// heads pass 1 flagged do any work; they recompute the row ONCE at 8 bits, SpAttenController.scala:402).
+// (Measured and dropped: a software pipeline over the tiles — loads of tile t+1 issued before the arithmetic of tile t
+//  from a second register set — changes nothing at N = 4096 / 8192: the streaming phase already runs at the HBM rate,
+//  the rest of the kernel time is launch + first-byte latency + the merge tail.)
+template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0>
 __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const DecodeParams<T> p) {
   constexpr bool SCORES_ONLY = (MODE == 1);
   constexpr bool SCORES_IN = (MODE == 2);
+  constexpr bool PQ = (KSRC != 0);
   constexpr int LPR = D / 16;                    // lanes per row
   constexpr int RPI = kDecodeThreads / LPR;      // rows per iteration of the workgroup
   constexpr int TILE = RPI * UNR;
@@ -129,6 +140,7 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
   const int qi = (LEAN || p.n_q == 1) ? 0 : (int)blockIdx.z - b * p.n_q;
   const int hkv = (LEAN || p.Hkv == p.H) ? h : h / (p.H / p.Hkv);
   const int unit = LEAN ? (b * p.H + h) : (b * p.H + h) * p.n_q + qi;   // one softmax row
+  if (KSRC == 2 && p.pq_need[unit] == 0) return;   // confident head: the MSB pass already produced its output
 
   // keys this query may attend to (HF causal: j <= P + i with P = N - n_q); the stash covers all N
   const int n_vis = (!LEAN && p.causal) ? min(p.N, p.N - p.n_q + qi + 1) : p.N;
@@ -140,33 +152,52 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
   const bool owns_new = (p.k_new != nullptr) && lo < p.N && hi == p.N;   // this workgroup appends row N-1
 
   // ---- loads of the first tile go out before anything else --------------------------------------
-  raw_t k_lo[UNR], k_hi[UNR], v_lo[UNR], v_hi[UNR];
-  auto issue_tile = [&](int t0) {
+  struct Tile {
+    raw_t k_lo[UNR], k_hi[UNR], v_lo[UNR], v_hi[UNR];
+    uint32_t pm_lo[UNR], pm_hi[UNR], pl_lo[UNR], pl_hi[UNR];   // PQ: 8 nibbles each (elements [8c,8c+8) / [d/2+8c, ..))
+    float pscale[UNR];
+  };
+  Tile tile_a;
+  const uint8_t* pq_m = PQ ? p.pq_msb + b * p.pl_sb + hkv * p.pl_sh : nullptr;
+  const uint8_t* pq_l = KSRC == 2 ? p.pq_lsb + b * p.pl_sb + hkv * p.pl_sh : nullptr;
+  const float* pq_s = PQ ? p.pq_scale + b * p.ps_sb + hkv * p.ps_sh : nullptr;
+  auto issue_tile = [&](Tile& tl, int t0) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       int j = t0 + u * RPI + r;
       j = j < hi ? j : hi - 1;
+      if (PQ) {
+        const int64_t po = (int64_t)j * HALF + 4 * c;   // a plane row is D/2 bytes
+        tl.pm_lo[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pq_m + po));
+        tl.pm_hi[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pq_m + po + HALF / 2));
+        if (KSRC == 2) {
+          tl.pl_lo[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pq_l + po));
+          tl.pl_hi[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pq_l + po + HALF / 2));
+        }
+        tl.pscale[u] = pq_s[j];
+      }
       const T* kp = krbase + (int64_t)j * D;
       const T* vp = vbase + (int64_t)j * D;
       if (owns_new && j == p.N - 1) {   // the token being appended: source = k_new / v_new (un-rotated)
         kp = p.k_new + b * p.new_sb + hkv * p.new_sh;
         vp = p.v_new + b * p.new_sb + hkv * p.new_sh;
       }
-      if (!SCORES_IN) {
-        k_lo[u] = V8::ldg(kp + 8 * c);
-        k_hi[u] = V8::ldg(kp + HALF + 8 * c);
+      if (!SCORES_IN && !PQ) {
+        tl.k_lo[u] = V8::ldg(kp + 8 * c);
+        tl.k_hi[u] = V8::ldg(kp + HALF + 8 * c);
       }
       if (!SCORES_ONLY || owns_new) {
-        v_lo[u] = V8::ldg(vp + 8 * c);
-        v_hi[u] = V8::ldg(vp + HALF + 8 * c);
+        tl.v_lo[u] = V8::ldg(vp + 8 * c);
+        tl.v_hi[u] = V8::ldg(vp + HALF + 8 * c);
       }
     }
   };
-  if (lo < hi) issue_tile(lo);
+  if (lo < hi) issue_tile(tile_a, lo);
   SPATTEN_TSTAMP(5);
 
   // ---- un-rotated query + its table row ----------------------------------------------------------
   typename D8::packed q_lo, q_hi;                // rotated query, packed in the model dtype (exact: it IS rounded)
+  typename NibbleDot<T>::packed qn_lo, qn_hi;    // PQ: the same rotated query, arranged for the nibble dot product
   raw_t n_raw[2];
   {
     const T* qp = p.q + b * p.q_sb + h * p.q_sh + (LEAN ? 0 : qi * p.q_sq);
@@ -188,6 +219,7 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
     rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
     q_lo = D8::pack(ylo);
     q_hi = D8::pack(yhi);
+    if (PQ) { qn_lo = NibbleDot<T>::prep(ylo); qn_hi = NibbleDot<T>::prep(yhi); }
   }
   SPATTEN_TSTAMP(6);
   const float rsqrt_d = 1.0f / p.sqrt_d;
@@ -202,8 +234,7 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
 #pragma unroll
   for (int i = 0; i < 8; ++i) { olo[i] = 0.f; ohi[i] = 0.f; }
 
-  for (int t0 = lo; t0 < hi; t0 += TILE) {
-    if (t0 != lo) issue_tile(t0);
+  auto process_tile = [&](Tile& tl, int t0) {
     float mk[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) mk[u] = maskp ? DT<T>::to_f32(maskp[min(t0 + u * RPI + r, n_vis - 1)]) : 0.f;
@@ -215,21 +246,21 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
         const int j = t0 + u * RPI + r;
         if (j == p.N - 1) {
           float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8];
-          V8::unpack(k_lo[u], xlo);
-          V8::unpack(k_hi[u], xhi);
+          V8::unpack(tl.k_lo[u], xlo);
+          V8::unpack(tl.k_hi[u], xhi);
           V8::unpack(n_raw[0], cc);
           V8::unpack(n_raw[1], ss);
           rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
           if (kbase) {
-            V8::stg(kbase + (int64_t)j * D + 8 * c, k_lo[u]);
-            V8::stg(kbase + (int64_t)j * D + HALF + 8 * c, k_hi[u]);
+            V8::stg(kbase + (int64_t)j * D + 8 * c, tl.k_lo[u]);
+            V8::stg(kbase + (int64_t)j * D + HALF + 8 * c, tl.k_hi[u]);
           }
-          k_lo[u] = V8::pack(ylo);
-          k_hi[u] = V8::pack(yhi);
-          V8::stg(krbase + (int64_t)j * D + 8 * c, k_lo[u]);
-          V8::stg(krbase + (int64_t)j * D + HALF + 8 * c, k_hi[u]);
-          V8::stg(vbase + (int64_t)j * D + 8 * c, v_lo[u]);
-          V8::stg(vbase + (int64_t)j * D + HALF + 8 * c, v_hi[u]);
+          tl.k_lo[u] = V8::pack(ylo);
+          tl.k_hi[u] = V8::pack(yhi);
+          V8::stg(krbase + (int64_t)j * D + 8 * c, tl.k_lo[u]);
+          V8::stg(krbase + (int64_t)j * D + HALF + 8 * c, tl.k_hi[u]);
+          V8::stg(vbase + (int64_t)j * D + 8 * c, tl.v_lo[u]);
+          V8::stg(vbase + (int64_t)j * D + HALF + 8 * c, tl.v_hi[u]);
         }
       }
     }
@@ -240,9 +271,18 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       if (SCORES_IN) sc[u] = p.scores_in[b * p.si_sb + h * p.si_sh + min(t0 + u * RPI + r, hi - 1)];
-      else sc[u] = D8::dot(q_hi, k_hi[u], D8::dot(q_lo, k_lo[u], 0.f));
+      else if (PQ) {
+        // sum_i q_i * q8_i with q8 = 16 * sext(msb nibble) + lsb nibble; the row scale is applied after the reduction
+        float a = NibbleDot<T>::dot(qn_lo, tl.pm_lo[u] ^ 0x88888888u, 8.f) + NibbleDot<T>::dot(qn_hi, tl.pm_hi[u] ^ 0x88888888u, 8.f);
+        a *= 16.f;
+        if (KSRC == 2) a += NibbleDot<T>::dot(qn_lo, tl.pl_lo[u], 0.f) + NibbleDot<T>::dot(qn_hi, tl.pl_hi[u], 0.f);
+        sc[u] = a;
+      } else sc[u] = D8::dot(q_hi, tl.k_hi[u], D8::dot(q_lo, tl.k_lo[u], 0.f));
     }
-    if (!SCORES_IN) {
+    if (PQ) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) sc[u] = group_sum<LPR>(sc[u]) * tl.pscale[u] / p.sqrt_d;   // fp32 logits
+    } else if (!SCORES_IN) {
 #pragma unroll
       for (int u = 0; u < UNR; ++u) sc[u] = group_sum<LPR>(sc[u]);
       // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
@@ -282,12 +322,16 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         float vlo[8], vhi[8];
-        V8::unpack(v_lo[u], vlo);
-        V8::unpack(v_hi[u], vhi);
+        V8::unpack(tl.v_lo[u], vlo);
+        V8::unpack(tl.v_hi[u], vhi);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { olo[i] = fmaf(pj[u], vlo[i], olo[i]); ohi[i] = fmaf(pj[u], vhi[i], ohi[i]); }
       }
     }
+  };
+  for (int t0 = lo; t0 < hi; t0 += TILE) {
+    if (t0 != lo) issue_tile(tile_a, t0);
+    process_tile(tile_a, t0);
   }
 
   SPATTEN_TSTAMP(1);
@@ -344,6 +388,7 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
   if (p.S == 1) {
     if (!SCORES_ONLY && tid < D) outp[tid] = DT<T>::from_f32(o_tot / l_tot);
     if (p.lse != nullptr && tid == 0) { p.lse[unit * 2] = m_run; p.lse[unit * 2 + 1] = l_tot; }
+    if (KSRC == 1 && tid == 0) p.pq_need[unit] = (1.0f / l_tot) < p.pq_thr ? 1 : 0;   // max prob = exp(0) / sum
     return;
   }
 
@@ -446,6 +491,7 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
   if (!SCORES_ONLY && g == 0) outp[e] = DT<T>::from_f32(og / lg);
   if (tid == 0) {
     if (p.lse != nullptr) { p.lse[unit * 2] = mg; p.lse[unit * 2 + 1] = lg; }
+    if (KSRC == 1) p.pq_need[unit] = (1.0f / lg) < p.pq_thr ? 1 : 0;
     __hip_atomic_store(p.ws_cnt + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
   }
   SPATTEN_TSTAMP(4);
@@ -490,6 +536,15 @@ static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_onl
     else hipLaunchKernelGGL((decode_attn_kernel<T, D, 4, 1>), grid, dim3(kDecodeThreads), 0, stream, p);
     return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
   }
+  if (p.pq_msb != nullptr) {   // progressive-quant keys: pass 1 on the MSB plane, then the refetch pass (same grid)
+    if constexpr (D == 256) return SPATTEN_ERR_UNSUPPORTED;
+    else {
+      constexpr int U = sizeof(T) == 4 ? 2 : 4;
+      hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, false, 1>), grid, dim3(kDecodeThreads), 0, stream, p);
+      hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, false, 2>), grid, dim3(kDecodeThreads), 0, stream, p);
+      return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+    }
+  }
   if (p.scores_in != nullptr) {
     if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((decode_attn_kernel<T, D, 2, 2>), grid, dim3(kDecodeThreads), 0, stream, p);
     else hipLaunchKernelGGL((decode_attn_kernel<T, D, 4, 2>), grid, dim3(kDecodeThreads), 0, stream, p);
@@ -497,8 +552,8 @@ static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_onl
   }
   const bool lean = p.n_q == 1 && p.Hkv == p.H && !p.mask && !p.pos_ids && !p.head_ids && !p.causal;
   if (lean && decode_unr_for(DT<T>::kId) == 4) {
-    if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((decode_attn_kernel<T, D, 2, 0, true>), grid, dim3(kDecodeThreads), 0, stream, p);
-    else hipLaunchKernelGGL((decode_attn_kernel<T, D, 4, 0, true>), grid, dim3(kDecodeThreads), 0, stream, p);
+    constexpr int U = sizeof(T) == 4 ? 2 : 4;
+    hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, true>), grid, dim3(kDecodeThreads), 0, stream, p);
     return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
   }
   switch (decode_unr_for(DT<T>::kId)) {
@@ -535,9 +590,9 @@ int decode_rows(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
                 int64_t out_sq, void* scores, int64_t sc_sb, int64_t sc_sh, int64_t sc_sq, float* lse, void* workspace,
                 size_t workspace_units, int batch, int heads, int kv_heads, int head_dim, int kv_len, int pos_q,
                 int n_q, int causal, int n_splits, hipStream_t stream, const int32_t* head_ids, int n_active,
-                int flags, const float* scores_in, int64_t si_sb, int64_t si_sh) {
+                int flags, const float* scores_in, int64_t si_sb, int64_t si_sh, const PQKeys* pq) {
   const bool scores_only = (flags & SPATTEN_DECODE_SCORES_ONLY) != 0;
-  if (!q || (!kr_cache && !scores_in) || !cos || !sin || (!scores_only && (!out || !v_cache))) return SPATTEN_ERR_INVALID;
+  if (!q || (!kr_cache && !scores_in && !pq) || !cos || !sin || (!scores_only && (!out || !v_cache))) return SPATTEN_ERR_INVALID;
   if (scores_only && (!scores || !lse || k_new)) return SPATTEN_ERR_INVALID;
   if (!head_ids) n_active = heads;
   if (n_active <= 0 || n_active > heads) return SPATTEN_ERR_INVALID;
@@ -545,6 +600,8 @@ int decode_rows(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
     return SPATTEN_ERR_INVALID;
   if ((k_new == nullptr) != (v_new == nullptr)) return SPATTEN_ERR_INVALID;
   if (k_new && n_q != 1) return SPATTEN_ERR_INVALID;
+  if (pq && (!pq->msb || !pq->lsb || !pq->scale || !pq->need || k_new || n_q != 1 || scores_in || scores_only))
+    return SPATTEN_ERR_INVALID;
   if (table_rows < kv_len || (!position_ids && pos_q + n_q > table_rows)) return SPATTEN_ERR_INVALID;
   if (head_dim != 64 && head_dim != 128 && head_dim != 256) return SPATTEN_ERR_UNSUPPORTED;
   if (dtype != SPATTEN_F32 && dtype != SPATTEN_F16 && dtype != SPATTEN_BF16) return SPATTEN_ERR_INVALID;
@@ -571,6 +628,9 @@ int decode_rows(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
   p.scores = (T*)scores; p.sc_sb = sc_sb; p.sc_sh = sc_sh; p.sc_sq = sc_sq;                              \
   p.lse = lse; p.head_ids = head_ids;                                                                    \
   p.scores_in = scores_in; p.si_sb = si_sb; p.si_sh = si_sh;                                             \
+  p.pq_msb = pq ? pq->msb : nullptr; p.pq_lsb = pq ? pq->lsb : nullptr; p.pq_scale = pq ? pq->scale : nullptr; \
+  p.pl_sb = pq ? pq->pl_sb : 0; p.pl_sh = pq ? pq->pl_sh : 0; p.ps_sb = pq ? pq->sc_sb : 0; p.ps_sh = pq ? pq->sc_sh : 0; \
+  p.pq_thr = pq ? pq->threshold : 0.f; p.pq_need = pq ? pq->need : nullptr;                              \
   p.ws_cnt = (unsigned*)workspace;                                                                       \
   p.ws_part = workspace ? (unsigned long long*)((char*)workspace + cnt_bytes) : nullptr;                              \
   p.B = batch; p.H = heads; p.Hkv = kv_heads; p.N = kv_len; p.pos_q = pos_q; p.S = S; p.chunk = chunk;   \
@@ -613,7 +673,7 @@ extern "C" int spatten_attn_decode_ex(int dtype, const void* q, int64_t q_sb, in
   return decode_rows(dtype, q, q_sb, q_sh, 0, k_cache, kr_cache, v_cache, kv_sb, kv_sh, k_new, v_new, new_sb, new_sh,
                      cos, sin, table_rows, position_ids, pos_sb, mask, mask_sb, 0, out, out_sb, 0, scores, sc_sb,
                      sc_sh, 0, lse, workspace, (size_t)batch * heads, batch, heads, kv_heads, head_dim, kv_len, pos_q,
-                     1, 0, n_splits, (hipStream_t)stream, head_ids, n_active_heads, flags, nullptr, 0, 0);
+                     1, 0, n_splits, (hipStream_t)stream, head_ids, n_active_heads, flags, nullptr, 0, 0, nullptr);
 }
 
 extern "C" int spatten_attn_decode(int dtype, const void* q, int64_t q_sb, int64_t q_sh, void* k_cache,

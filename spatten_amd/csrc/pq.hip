@@ -19,7 +19,7 @@ int decode_rows(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
                 int64_t out_sq, void* scores, int64_t sc_sb, int64_t sc_sh, int64_t sc_sq, float* lse, void* workspace,
                 size_t workspace_units, int batch, int heads, int kv_heads, int head_dim, int kv_len, int pos_q,
                 int n_q, int causal, int n_splits, hipStream_t stream, const int32_t* head_ids, int n_active,
-                int flags, const float* scores_in, int64_t si_sb, int64_t si_sh);
+                int flags, const float* scores_in, int64_t si_sb, int64_t si_sh, const PQKeys* pq);
 
 // ---- pack: rows [lo, hi) of kr [B,Hkv,cap,D] -> msb/lsb [B,Hkv,cap,D/2] bytes, scale [B,Hkv,cap] fp32 ------------
 // 16 lanes per row (8 elements each); symmetric per-row 8-bit quantiser: scale = amax/127, q = clip(rint(x/scale)).
@@ -58,62 +58,9 @@ __global__ __launch_bounds__(256) void pq_pack_kernel(const T* __restrict__ kr, 
   if (c == 0) scale[b * sc_sb + hkv * sc_sh + row] = sc;
 }
 
-// ---- scores: s[b,h,j] = (sum_i q_rot[i] * q8[j,i]) * scale[j] / sqrt(d), fp32 ----------------------------------
-// USE_LSB = false: pass 1 (MSB plane only).  USE_LSB = true: refetch pass, only for heads with 1/sum < threshold.
-template <typename T, int D, bool USE_LSB>
-__global__ __launch_bounds__(256) void pq_scores_kernel(const T* __restrict__ qrot, int64_t q_sb, int64_t q_sh,
-                                                        const uint8_t* __restrict__ msb, const uint8_t* __restrict__ lsb,
-                                                        const float* __restrict__ scale, int64_t pl_sb, int64_t pl_sh,
-                                                        int64_t sc_sb, int64_t sc_sh, const float* __restrict__ lse,
-                                                        float threshold, float* __restrict__ s_out, int64_t so_sb,
-                                                        int64_t so_sh, int32_t* __restrict__ need_out, int H, int Hkv,
-                                                        int N, float sqrt_d) {
-  constexpr int LPR = D / 8;          // 8 elements = one dword of a 4-bit plane per lane
-  constexpr int RPB = 256 / LPR;
-  constexpr int ROWS = RPB * 4;       // rows per workgroup
-  const int tid = threadIdx.x, c = tid % LPR, r = tid / LPR;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int hkv = Hkv == H ? h : h / (H / Hkv);
-  if (USE_LSB) {
-    const float l = lse[(b * H + h) * 2 + 1];
-    const bool need = (1.0f / l) < threshold;          // max prob = exp(max - max) / sum
-    if (blockIdx.x == 0 && tid == 0 && need_out) need_out[b * H + h] = need ? 1 : 0;
-    if (!need) return;
-  }
-  float qv[8];
-  Vec8<T>::unpack(Vec8<T>::ldg(qrot + b * q_sb + h * q_sh + 8 * c), qv);
-  const int64_t pb = b * pl_sb + hkv * pl_sh;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int j = blockIdx.x * ROWS + u * RPB + r;
-    const int jj = min(j, N - 1);
-    const uint32_t m4 = *reinterpret_cast<const uint32_t*>(msb + pb + (int64_t)jj * (D / 2) + 4 * c);
-    uint32_t l4 = 0;
-    if (USE_LSB) l4 = *reinterpret_cast<const uint32_t*>(lsb + pb + (int64_t)jj * (D / 2) + 4 * c);
-    const float sc = scale[b * sc_sb + hkv * sc_sh + jj];
-    float acc = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int mv = ((int)(m4 << (28 - 4 * e))) >> 28;          // sign-extended nibble
-      const int q8 = (mv << 4) | (int)((l4 >> (4 * e)) & 15u);
-      acc = fmaf(qv[e], (float)q8 * sc, acc);                     // dequantised element, like the oracle
-    }
-    acc = group_sum<LPR>(acc);
-    if (c == 0 && j < N) s_out[b * so_sb + h * so_sh + j] = acc / sqrt_d;
-  }
-}
-
 }  // namespace spatten
 
 using namespace spatten;
-
-extern "C" int spatten_rope_single(int dtype, const void* x, int64_t x_sb, int64_t x_sh, int64_t x_sn, void* y,
-                                   int64_t y_sb, int64_t y_sh, int64_t y_sn, const void* cos, const void* sin,
-                                   int table_rows, const int64_t* position_ids, int64_t pos_sb, int pos0,
-                                   int batch, int heads, int n, int head_dim, void* stream);
-extern "C" int spatten_row_lse(int dtype, const void* stash, int64_t sb, int64_t sh, int64_t sq, const void* mask,
-                               int64_t mask_sb, int64_t mask_sq, float* lse, int batch, int heads, int q_len,
-                               int kv_len, int causal, void* stream);
 
 #define SPATTEN_BY_DTYPE(dt, CALL)                        \
   switch (dt) {                                           \
@@ -145,53 +92,32 @@ static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 
 extern "C" size_t spatten_pq_scratch_bytes(int batch, int heads, int head_dim, int kv_len) {
   if (batch <= 0 || heads <= 0 || head_dim <= 0 || kv_len <= 0) return 0;
-  // rotated query (<= 4 B / element) + fp32 logits + (max, sum) per row
-  return 256 + al256((size_t)batch * heads * head_dim * 4) + al256((size_t)batch * heads * kv_len * 4) +
-         al256((size_t)batch * heads * 2 * 4);
+  return 256 + al256((size_t)batch * heads * sizeof(int32_t));      // the need_lsb flags when the caller passes none
 }
 
+// Two launches of the decode kernel (decode_attn.hip, KSRC = 1 then 2) over the same grid:
+//   pass 1  K from the MSB plane (68 B / row at d = 128) + V: logits, softmax, P·V, and need_lsb = max prob < threshold
+//           from the merged softmax sum — for a confident head this IS the result;
+//   pass 2  workgroups of confident heads return at once; flagged heads recompute the row ONCE from MSB | LSB + V.
+// A head that is never flagged costs 68 + 256 B per key row instead of 512 (bf16 K + V).
 extern "C" int spatten_attn_decode_pq(int dtype, const void* q, int64_t q_sb, int64_t q_sh, const void* msb,
                                       const void* lsb, const float* scale, int64_t pl_sb, int64_t pl_sh,
                                       int64_t sc_sb, int64_t sc_sh, const void* v_cache, int64_t kv_sb, int64_t kv_sh,
                                       const void* cos, const void* sin, int table_rows, int pos_q, float threshold,
                                       void* out, int64_t out_sb, int32_t* need_lsb, void* scratch, void* workspace,
                                       int batch, int heads, int kv_heads, int head_dim, int kv_len, void* stream) {
-  if (!q || !msb || !lsb || !scale || !v_cache || !cos || !sin || !out || !scratch) return SPATTEN_ERR_INVALID;
+  if (!q || !msb || !lsb || !scale || !v_cache || !cos || !sin || !out || (!scratch && !need_lsb)) return SPATTEN_ERR_INVALID;
   if (batch <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads || kv_len <= 0 || pos_q < 0 || pos_q >= table_rows)
     return SPATTEN_ERR_INVALID;
   if (dtype != SPATTEN_F32 && dtype != SPATTEN_F16 && dtype != SPATTEN_BF16) return SPATTEN_ERR_INVALID;
   if (head_dim != 64 && head_dim != 128) return SPATTEN_ERR_UNSUPPORTED;
-  hipStream_t st = (hipStream_t)stream;
-  char* base = (char*)(((uintptr_t)scratch + 255) / 256 * 256);
-  void* qrot = base;
-  float* s1 = (float*)(base + al256((size_t)batch * heads * head_dim * 4));
-  float* lse = (float*)((char*)s1 + al256((size_t)batch * heads * kv_len * 4));
-  // rotated query (modify_llama.py:92), model dtype
-  int rc = spatten_rope_single(dtype, q, q_sb, q_sh, head_dim, qrot, (int64_t)heads * head_dim, head_dim, head_dim, cos,
-                               sin, table_rows, nullptr, 0, pos_q, batch, heads, 1, head_dim, stream);
-  if (rc != SPATTEN_OK) return rc;
-  const int rows_per_wg = (256 / (head_dim / 8)) * 4;
-  const dim3 grid((unsigned)ceil_div(kv_len, rows_per_wg), (unsigned)heads, (unsigned)batch);
-  const float sqrt_d = sqrtf((float)head_dim);
-  const int64_t so_sb = (int64_t)heads * kv_len, so_sh = kv_len;
-#define SPATTEN_SC(DD, LSB)                                                                                          \
-  SPATTEN_BY_DTYPE(dtype, hipLaunchKernelGGL((pq_scores_kernel<T, DD, LSB>), grid, dim3(256), 0, st, (const T*)qrot,       \
-                                             (int64_t)heads * head_dim, (int64_t)head_dim, (const uint8_t*)msb,            \
-                                             (const uint8_t*)lsb, scale, pl_sb, pl_sh, sc_sb, sc_sh, lse, threshold, s1,   \
-                                             so_sb, so_sh, need_lsb, heads, kv_heads, kv_len, sqrt_d))
-  // pass 1: MSB plane only
-  if (head_dim == 128) { SPATTEN_SC(128, false); } else { SPATTEN_SC(64, false); }
-  if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
-  // softmax statistics of pass 1 -> max prob = 1 / sum
-  rc = spatten_row_lse(SPATTEN_F32, s1, so_sb, so_sh, 0, nullptr, 0, 0, lse, batch, heads, 1, kv_len, 0, stream);
-  if (rc != SPATTEN_OK) return rc;
-  // pass 2: heads whose distribution is flat refetch the LSB plane and are recomputed once
-  if (head_dim == 128) { SPATTEN_SC(128, true); } else { SPATTEN_SC(64, true); }
-  if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
-#undef SPATTEN_SC
-  // softmax + P·V over the final logits (V is not progressive): the decode kernel with the logits given
+  PQKeys keys;
+  keys.msb = (const uint8_t*)msb; keys.lsb = (const uint8_t*)lsb; keys.scale = scale;
+  keys.pl_sb = pl_sb; keys.pl_sh = pl_sh; keys.sc_sb = sc_sb; keys.sc_sh = sc_sh;
+  keys.threshold = threshold;
+  keys.need = need_lsb ? need_lsb : (int32_t*)(((uintptr_t)scratch + 255) / 256 * 256);
   return decode_rows(dtype, q, q_sb, q_sh, 0, nullptr, nullptr, const_cast<void*>(v_cache), kv_sb, kv_sh, nullptr, nullptr,
                      0, 0, cos, sin, table_rows, nullptr, 0, nullptr, 0, 0, out, out_sb, 0, nullptr, 0, 0, 0, nullptr,
-                     workspace, (size_t)batch * heads, batch, heads, kv_heads, head_dim, kv_len, pos_q, 1, 0, 0, st, nullptr,
-                     0, 0, s1, so_sb, so_sh);
+                     workspace, (size_t)batch * heads, batch, heads, kv_heads, head_dim, kv_len, pos_q, 1, 0, 0,
+                     (hipStream_t)stream, nullptr, 0, 0, nullptr, 0, 0, &keys);
 }

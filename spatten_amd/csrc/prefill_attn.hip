@@ -29,7 +29,8 @@ int decode_rows(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
                 int64_t out_sq, void* scores, int64_t sc_sb, int64_t sc_sh, int64_t sc_sq, float* lse, void* workspace,
                 size_t workspace_units, int batch, int heads, int kv_heads, int head_dim, int kv_len, int pos_q,
                 int n_q, int causal, int n_splits, hipStream_t stream, const int32_t* head_ids = nullptr,
-                int n_active = 0, int flags = 0, const float* scores_in = nullptr, int64_t si_sb = 0, int64_t si_sh = 0);
+                int n_active = 0, int flags = 0, const float* scores_in = nullptr, int64_t si_sb = 0, int64_t si_sh = 0,
+                const PQKeys* pq = nullptr);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
