@@ -47,6 +47,23 @@ template <> struct DT<bf16_t> {
   __device__ static inline float round(float x) { return (float)(bf16_t)x; }
 };
 
+// round(x) on a pair: bf16 has a packed convert (v_cvt_pk_bf16_f32), and both halves come back as fp32 with one
+// shift / one mask — 3 VALU ops per 2 values instead of 4; the other dtypes fall back to the scalar form.
+template <typename T> __device__ inline f32x2 round2(f32x2 v) { return f32x2{DT<T>::round(v[0]), DT<T>::round(v[1])}; }
+template <> __device__ inline f32x2 round2<bf16_t>(f32x2 v) {
+  typedef bf16_t bf2 __attribute__((ext_vector_type(2)));
+  bf2 b = __builtin_convertvector(v, bf2);
+  const uint32_t u = *reinterpret_cast<uint32_t*>(&b);
+  return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u)};
+}
+// div_by_const (below) on a pair: packed fp32 multiply / fma (v_pk_mul_f32, v_pk_fma_f32)
+__device__ inline f32x2 div_by_const2(f32x2 x, float c, float rc) {
+  const f32x2 c2 = {c, c}, rc2 = {rc, rc};
+  const f32x2 y = x * rc2;
+  const f32x2 e = __builtin_elementwise_fma(-y, c2, x);
+  return __builtin_elementwise_fma(e, rc2, y);
+}
+
 // 8 consecutive elements of the model dtype, kept packed ("raw") until used.  16-bit types: one
 // 16-byte access; fp32: two.  Pointers must be 16-byte aligned (head_dim % 8 == 0, rows pitch d).
 template <typename T> struct Vec8;

@@ -219,8 +219,12 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
+#if defined(SPATTEN_PF_ABL) && (SPATTEN_PF_ABL & 1)
+      const frag a0 = qf[(kk + 1) % KK], a1 = qf[(kk + 2) % KK];
+#else
       const frag a0 = *reinterpret_cast<const frag*>(kbuf + lds_off<KROWB>(qi, 2 * kk + hi));
       const frag a1 = *reinterpret_cast<const frag*>(kbuf + lds_off<KROWB>(32 + qi, 2 * kk + hi));
+#endif
       acc[0] = Mfma<T>::mma(a0, qf[kk], acc[0]);
       acc[1] = Mfma<T>::mma(a1, qf[kk], acc[1]);
     }
@@ -238,14 +242,24 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
   for (int tile = 0; tile < n_tiles; ++tile) {
     const bool attend = tile < n_att_tiles;
     const bool more_k = tile + 2 < n_tiles, more_v = tile + 1 < n_att_tiles;
+#if defined(SPATTEN_PF_ABL) && (SPATTEN_PF_ABL & 8)
+    if (tile < 0) { load_k(tile + 2); load_v(tile + 1); }
+#else
     if (more_k) load_k(tile + 2);                        // in flight during this tile's MFMAs and softmax
     if (more_v) load_v(tile + 1);
+#endif
     const bool edge = tile * 64 + 64 > wave_full_keys;  // wave-uniform: some element needs the visibility test
     if (!STASH && !COLIMP && !MASK && !edge && attend) {
       // ---- hot path: fully visible tile, no by-products.  ONE basic block so that the compiler can weave the next
       // tile's Q·K^T MFMAs (independent accumulators sn) into this tile's softmax VALU stream. -----------------
       qk(k_slot(tile + 1), sn);                         // past the last tile this scores a stale slot; never used
       float m_tile = -INFINITY;
+#ifndef SPATTEN_PF_PACK
+#define SPATTEN_PF_PACK 1
+#endif
+      float lsum = 0.f;
+      frag pf[2][2];
+#if SPATTEN_PF_PACK == 0
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -257,8 +271,6 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
       m_tile = xor32_max(m_tile);
       const float m_new = fmaxf(m_run, m_tile);
       const float m2 = m_new * kLog2e;
-      float lsum = 0.f;
-      frag pf[2][2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -269,6 +281,40 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
             lsum += pv;
             pf[kb][t][e] = DT<T>::from_f32(pv);
           }
+#else
+      // No stash is written on this path, so the logits only feed the softmax: the matmul result is rounded to the
+      // model dtype like the reference's (modify_llama.py:111) but the "/ sqrt(d) -> dtype" step (:113) is folded into
+      // the exponent's fma un-rounded — at most one 16-bit ulp of a logit away from the reference, the same size as
+      // the accumulation-order effect the stash tolerance already allows — 5.5 instead of 11 VALU issues per score.
+      // The issue port, not the MFMA pipe, is what this loop saturates (PMC: tools/pmc_prefill.sh).
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+#if SPATTEN_PF_PACK == 2
+          const f32x2 v = {s[kb][r], s[kb][r + 1]};
+#else
+          const f32x2 v = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
+#endif
+          s[kb][r] = v[0];
+          s[kb][r + 1] = v[1];
+          m_tile = fmaxf(m_tile, fmaxf(v[0], v[1]));
+        }
+      m_tile = xor32_max(m_tile) * rsqrt_d;           // rsqrt_d > 0: max commutes with the scale
+      const float m_new = fmaxf(m_run, m_tile);
+      const float m2 = m_new * kLog2e;
+      const float c2 = rsqrt_d * kLog2e;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], c2, -m2));
+            lsum += pv;
+            pf[kb][t][e] = DT<T>::from_f32(pv);
+          }
+#endif
       // 16 MFMAs woven into ~500 VALU instructions: one MFMA, then a slice of the VALU stream (T19)
 #ifndef SPATTEN_PF_SCHED
 #define SPATTEN_PF_SCHED 1
@@ -319,12 +365,22 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int db = 0; db < DB; ++db) {
+#if defined(SPATTEN_PF_ABL) && (SPATTEN_PF_ABL & 2)
+            const frag a = qf[(db + 2 * kb + t) % KK];
+#else
             const frag a = *reinterpret_cast<const frag*>(ldsV + lds_off<128>(db * 32 + qi, kb * 4 + t * 2 + hi));
+#endif
             o[db] = Mfma<T>::mma(a, pf[kb][t], o[db]);
           }
+#if defined(SPATTEN_PF_ABL) && (SPATTEN_PF_ABL & 16)
+      if (tile < 0) { write_k(k_slot(tile)); write_v(v_slot(tile + 1)); }
+#else
       if (more_k) write_k(k_slot(tile));
       if (more_v) write_v(v_slot(tile + 1));
+#endif
+#if !(defined(SPATTEN_PF_ABL) && (SPATTEN_PF_ABL & 4))
       __syncthreads();
+#endif
       s[0] = sn[0];
       s[1] = sn[1];
       continue;

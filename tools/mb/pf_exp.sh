@@ -1,7 +1,17 @@
+# A/B harness for the prefill hot path: rebuild the library with -D<macro>=<v> for each value and time causal prefill.
+#   bash tools/mb/pf_exp.sh SPATTEN_PF_PACK 0 1 2
 cd $GRAFT_REPO_ROOT
-for var in 0 1 2 3 4; do
+M=$1; shift
+cp spatten_amd/lib/libspatten_hip.so /tmp/lib_orig.so
+for var in "$@"; do
   mkdir -p /tmp/pfl; rm -f /tmp/pfl/*.o
-  for f in decode_attn prefill_attn prune cascade pq; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -DSPATTEN_PF_SCHED=$var -c spatten_amd/csrc/$f.hip -o /tmp/pfl/$f.o & done; wait
+  for f in decode_attn prefill_attn prune cascade pq; do
+    if [ $f = prefill_attn ]; then
+      /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -D$M=$var -c spatten_amd/csrc/$f.hip -o /tmp/pfl/$f.o &
+    else cp build/$f.o /tmp/pfl/$f.o 2>/dev/null || /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -c spatten_amd/csrc/$f.hip -o /tmp/pfl/$f.o &
+    fi
+  done; wait
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o spatten_amd/lib/libspatten_hip.so /tmp/pfl/*.o
-  echo "== sched $var"; python tools/probe_prefill.py 2>&1 | grep "causal:"
+  echo "== $M=$var"; python tools/probe_prefill.py 2>&1 | grep "causal:"
 done
+cp /tmp/lib_orig.so spatten_amd/lib/libspatten_hip.so
