@@ -156,6 +156,14 @@ constexpr int kDppMirror = 0x140;      // lane i <-> 15-i within 16
 constexpr int kDppRor4 = 0x124;        // rotate right by 4 within 16
 constexpr int kDppRor8 = 0x128;        // rotate right by 8 within 16 (== xor 8)
 
+// max of three without the canonicalising v_max the compiler puts in front of fmaxf on values it cannot prove quiet
+// (MFMA results, bit-built floats): one VALU issue for two new values.  NaN inputs are not expected here.
+__device__ inline float max3_raw(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // sum over aligned groups of WIDTH lanes (4, 8 or 16); every lane of the group gets the total
 template <int WIDTH>
 __device__ inline float group_sum(float v) {

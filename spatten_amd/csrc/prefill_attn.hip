@@ -18,6 +18,8 @@
 //     The stash (pre-mask logits, modify_llama.py:116-119) and the column importance (kv_cache_token_pruning.py:51
 //     includes the acausal logits) are optional by-products; when requested, key tiles above the causal
 //     diagonal are still scored (but skip softmax / P·V).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace spatten {
@@ -33,6 +35,17 @@ int decode_rows(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
                 const PQKeys* pq = nullptr);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifdef SPATTEN_PF_TRACE   // developer instrumentation (tools/probe_pf_trace.py): phase timestamps of workgroup 0
+__device__ unsigned long long* g_pf_trace = nullptr;
+#define PF_STAMP(slot)                                                                                   \
+  do {                                                                                                   \
+    if (g_pf_trace && blockIdx.x == 0 && lane == 0 && t >= 8 && t < 24)                                  \
+      g_pf_trace[((wave * 16 + (t - 8)) * 8) + (slot)] = __builtin_readcyclecounter();                   \
+  } while (0)
+#else
+#define PF_STAMP(slot)
+#endif
+
 
 template <typename T> struct Mfma;
 template <> struct Mfma<bf16_t> {
@@ -507,26 +520,412 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// (3b) ping-pong flash kernel: 8 waves = 256 queries per workgroup, one workgroup per CU, two waves per SIMD.
+// PMC of the 4-wave kernel above (tools/pmc_prefill.sh): the two waves that share a SIMD run the same code in
+// phase — both in their MFMA stretch (the matrix pipe alternates between them), then both in their softmax stretch
+// (the matrix pipe idles) — so the SIMD's time is the SUM of the two streams (MFMA pipe 33 % busy, issue port 73 %).
+// Here the two halves of the workgroup (waves 0-3 / 4-7, one of each on every SIMD) are held exactly one phase
+// apart by the workgroup barrier: while one half runs its matrix phase  { O += Vt(t)·P(t) ; S = K(t+1)·Q }
+// the other runs its vector phase  { publish staged K/V pieces to LDS, issue the next global loads, softmax(S) -> P },
+// then they swap.  Matrix beside vector on every SIMD, by construction.
+//
+// LDS ring: stage j = { K(j+1), Vt(j) } lives in slot j & 1 and is read in the matrix phase of iteration j — by
+// half 0 in global phase 2j, by half 1 in 2j+1.  Stage j+1 is written during phases 2j (half 1's pieces) and 2j+1
+// (half 0's pieces): its slot last held stage j-1, read for the last time in phase 2j-1.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D, bool STASH, bool COLIMP, bool MASK>
+__global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T> p) {
+  constexpr int KK = D / 16, DB = D / 32, KROWB = D * 2;
+  constexpr int KBYTES = 64 * KROWB, VBYTES = D * 128, BUF = KBYTES + VBYTES;
+  constexpr int KPC = 64 * (D / 8) / 512, VPC = D * 8 / 512;   // 16-byte pieces per thread per tile (K, Vt)
+  using frag = typename Mfma<T>::frag;
+  constexpr int SPITCH = 80;
+  constexpr int SBYTES = STASH ? 8 * 32 * SPITCH : 0;
+  __shared__ __attribute__((aligned(16))) char lds[2 * BUF + SBYTES];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, qi = lane & 31, hi = lane >> 5;
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);          // which half of the workgroup (wave-uniform)
+  const int nqb = p.nqb;                                             // 256-query blocks per head
+  int h, qblk, b;
+  {   // XCD-aware work order (see prefill_flash_kernel)
+    const int i = blockIdx.x;
+    const int per_b = p.H * nqb;
+    b = i / per_b;
+    const int j = i - b * per_b;
+    if ((p.H & 7) == 0) {
+      const int xx = j & 7, ss = j >> 3;
+      h = xx + 8 * (ss / nqb);
+      qblk = nqb - 1 - (ss % nqb);
+    } else {
+      h = j / nqb;
+      qblk = nqb - 1 - (j % nqb);
+    }
+  }
+  const int hkv = p.Hkv == p.H ? h : h / (p.H / p.Hkv);
+  const int q0 = qblk * 256 + wave * 32;
+  const int myq = q0 + qi;
+  const bool qvalid = myq < p.q_len;
+  const int P = p.N - p.q_len;
+  const float rsqrt_d = 1.0f / p.sqrt_d;
+
+  frag qf[KK];
+  {
+    const T* qrow = p.qrot + ((int64_t)(b * p.H + h) * p.q_len + min(myq, p.q_len - 1)) * D;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) qf[kk] = *reinterpret_cast<const frag*>(qrow + 16 * kk + 8 * hi);
+  }
+  f32x16 o[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int wg_q_end = min(p.q_len, qblk * 256 + 256);
+  const int att_keys = p.causal ? min(p.N, P + wg_q_end) : p.N;
+  const int n_att_tiles = (att_keys + 63) / 64;                          // workgroup-wide
+  const int n_tiles = (STASH || COLIMP) ? (p.N + 63) / 64 : n_att_tiles;
+  const int my_vis = p.causal ? min(p.N, P + myq + 1) : p.N;
+  const int wave_full_keys = p.causal ? min(p.N, P + q0 + 1) : p.N;
+  // tiles in which this WAVE has a visible key (its last query sees keys [0, P + q0 + 32)); later tiles only matter
+  // to it for the stash / column sums
+  const int wave_att_tiles = p.causal ? min(n_att_tiles, (max(min(p.N, P + min(q0 + 32, p.q_len)), 0) + 63) / 64) : n_att_tiles;
+  const int wave_tiles = (STASH || COLIMP) ? n_tiles : wave_att_tiles;
+
+  const T* krb = p.kr + b * p.kv_sb + hkv * p.kv_sh;
+  const T* vtb = p.vt + ((int64_t)(b * p.Hkv + hkv) * D) * p.Npad;
+  const T* maskrow = MASK ? p.mask + b * p.mask_sb + (int64_t)min(myq, p.q_len - 1) * p.mask_sq : nullptr;
+  T* stashrow = STASH ? p.scores + b * p.sc_sb + h * p.sc_sh + (int64_t)min(myq, p.q_len - 1) * p.sc_sq : nullptr;
+  float* colrow = COLIMP ? p.col_imp + (int64_t)(b * p.H + h) * p.N : nullptr;
+  const bool stash_vec = STASH && ((p.sc_sq | p.sc_sh | p.sc_sb) % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.scores) & 15) == 0);
+
+  auto k_area = [&](int stage) -> char* { return lds + (stage & 1) * BUF; };            // holds K(stage + 1)
+  auto v_area = [&](int stage) -> char* { return lds + (stage & 1) * BUF + KBYTES; };   // holds Vt(stage)
+  u32x4 kreg[KPC], vreg[VPC];
+  auto load_k = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < KPC; ++i) {
+      const int id = tid + 512 * i, row = id / (D / 8), slot = id % (D / 8);
+      const int j = min(tile * 64 + row, p.N - 1);
+      kreg[i] = *reinterpret_cast<const u32x4*>(krb + (int64_t)j * D + slot * 8);
+    }
+  };
+  auto load_v = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < VPC; ++i) {
+      const int id = tid + 512 * i, dv = id >> 3, slot = id & 7;
+      vreg[i] = *reinterpret_cast<const u32x4*>(vtb + (int64_t)dv * p.Npad + tile * 64 + slot * 8);
+    }
+  };
+  auto write_k = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < KPC; ++i) {
+      const int id = tid + 512 * i, row = id / (D / 8), slot = id % (D / 8);
+      *reinterpret_cast<u32x4*>(buf + lds_off<KROWB>(row, slot)) = kreg[i];
+    }
+  };
+  auto write_v = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < VPC; ++i) {
+      const int id = tid + 512 * i, dv = id >> 3, slot = id & 7;
+      *reinterpret_cast<u32x4*>(buf + lds_off<128>(dv, slot)) = vreg[i];
+    }
+  };
+  // stage j = { K(j+1), Vt(j) }: which of the two exist
+  auto stage_has_k = [&](int j) { return j + 1 < n_tiles; };
+  auto stage_has_v = [&](int j) { return j < n_att_tiles; };
+  auto load_stage = [&](int j) {
+    if (stage_has_k(j)) load_k(j + 1);
+    if (stage_has_v(j)) load_v(j);
+  };
+  auto write_stage = [&](int j) {
+    if (stage_has_k(j)) write_k(k_area(j));
+    if (stage_has_v(j)) write_v(v_area(j));
+  };
+
+  f32x16 s[2];
+  frag pf[2][2];
+  // S^T = K · Q^T for one 64-key tile: A fragments through a 4-deep register ring (LDS latency ~ 3 MFMAs)
+  constexpr int RING = 8;      // A fragments in flight (LDS latency under load ~ several MFMA durations)
+  auto qk = [&](const char* kbuf) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
+    frag a[RING];
+    auto kfrag = [&](int i) { return *reinterpret_cast<const frag*>(kbuf + lds_off<KROWB>((i & 1) * 32 + qi, 2 * (i >> 1) + hi)); };
+#pragma unroll
+    for (int i = 0; i < RING; ++i) a[i] = kfrag(i);
+#pragma unroll
+    for (int i = 0; i < 2 * KK; ++i) {
+      s[i & 1] = Mfma<T>::mma(a[i % RING], qf[i >> 1], s[i & 1]);
+      if (i + RING < 2 * KK) a[i % RING] = kfrag(i + RING);
+    }
+    // keep the ring as written: RING reads up front, then one read behind every MFMA (the scheduler otherwise sinks
+    // each read to just before its use and the phase becomes LDS-latency-bound)
+    __builtin_amdgcn_sched_group_barrier(0x100, RING, 0);
+#pragma unroll
+    for (int i = 0; i < 2 * KK - RING; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, RING, 0);
+  };
+  // O^T += Vt · P^T
+  auto pv = [&](const char* vbuf) {
+    frag a[RING];
+    auto vfrag = [&](int i) {   // step i: (kb, t) = i / DB, db = i % DB
+      const int db = i % DB, kt = i / DB, kb = kt >> 1, t = kt & 1;
+      return *reinterpret_cast<const frag*>(vbuf + lds_off<128>(db * 32 + qi, kb * 4 + t * 2 + hi));
+    };
+#pragma unroll
+    for (int i = 0; i < RING; ++i) a[i] = vfrag(i);
+#pragma unroll
+    for (int i = 0; i < 4 * DB; ++i) {
+      const int db = i % DB, kt = i / DB;
+      o[db] = Mfma<T>::mma(a[i % RING], pf[kt >> 1][kt & 1], o[db]);
+      if (i + RING < 4 * DB) a[i % RING] = vfrag(i + RING);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, RING, 0);
+#pragma unroll
+    for (int i = 0; i < 4 * DB - RING; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, RING, 0);
+  };
+
+  // softmax of the scores in s for `tile` -> pf (and the optional by-products); updates m_run / l_run / o
+  auto softmax_tile = [&](int tile) {
+    const bool attend = tile < wave_att_tiles;
+    const bool edge = tile * 64 + 64 > wave_full_keys;
+    if (!STASH && !COLIMP && !MASK && !edge) {
+      // fully visible tile, no by-products: one reference rounding kept, "/ sqrt(d)" folded into the exponent
+      float mt[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+#if defined(SPATTEN_SM_ABL) && (SPATTEN_SM_ABL & 2)
+          const f32x2 v = f32x2{s[kb][r], s[kb][r + 1]};
+#else
+          const f32x2 v = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
+#endif
+          s[kb][r] = v[0];
+          s[kb][r + 1] = v[1];
+#if !(defined(SPATTEN_SM_ABL) && (SPATTEN_SM_ABL & 8))
+          mt[kb] = max3_raw(mt[kb], v[0], v[1]);
+#endif
+        }
+      const float m_tile = xor32_max(fmaxf(mt[0], mt[1])) * rsqrt_d;
+      const float m_new = fmaxf(m_run, m_tile);
+      const float m2 = m_new * kLog2e;
+      const float c2 = rsqrt_d * kLog2e;
+      float ls[4] = {0.f, 0.f, 0.f, 0.f};         // independent partial sums: no 32-deep dependent add chain
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+#if defined(SPATTEN_SM_ABL) && (SPATTEN_SM_ABL & 1)
+            const float pvv = fmaf(s[kb][t * 8 + e], c2, -m2);
+#else
+            const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], c2, -m2));
+#endif
+            ls[e & 3] += pvv;
+#if defined(SPATTEN_SM_ABL) && (SPATTEN_SM_ABL & 4)
+            if (e == 0) pf[kb][t][e] = DT<T>::from_f32(pvv);
+#else
+            pf[kb][t][e] = DT<T>::from_f32(pvv);
+#endif
+          }
+      const float lsum = (ls[0] + ls[1]) + (ls[2] + ls[3]);
+#if !(defined(SPATTEN_SM_ABL) && (SPATTEN_SM_ABL & 16))
+      if (m_new != m_run) {
+        const float alpha = __expf(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        m_run = m_new;
+      }
+#endif
+      l_run += lsum;
+      return;
+    }
+    float m_tile = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
+        float v = DT<T>::round(div_by_const(DT<T>::round(s[kb][r]), p.sqrt_d, rsqrt_d));
+        const int key = tile * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const bool inb = key < p.N;
+        if (STASH) {                                                                        // pre-mask (:116-119)
+          if (stash_vec) {
+            char* sw = lds + 2 * BUF + wave * (32 * SPITCH);
+            *reinterpret_cast<T*>(sw + qi * SPITCH + ((r & 3) + 8 * (r >> 2) + 4 * hi) * 2) = DT<T>::from_f32(v);
+          } else if (inb && qvalid) {
+            stashrow[key] = DT<T>::from_f32(v);
+          }
+        }
+        if (COLIMP) {
+          float cv = (inb && qvalid) ? v : 0.f;
+          cv = xor16_sum(group_sum<16>(cv));
+          if (qi == 0 && inb) atomicAdd(colrow + key, cv);
+        }
+        if (MASK) { if (inb) v = DT<T>::round(v + DT<T>::to_f32(maskrow[key])); }            // :132
+        v = (key < my_vis) ? v : -INFINITY;
+        s[kb][r] = v;
+        m_tile = fmaxf(m_tile, v);
+      }
+      if (STASH && stash_vec) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const char* sw = lds + 2 * BUF + wave * (32 * SPITCH);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int id = lane + 64 * i, row = id >> 2, c4 = id & 3;
+          const u32x4 piece = *reinterpret_cast<const u32x4*>(sw + row * SPITCH + c4 * 16);
+          const int qq = q0 + row, key0 = tile * 64 + kb * 32 + c4 * 8;
+          if (qq < p.q_len && key0 < p.N) {
+            T* dst = p.scores + b * p.sc_sb + h * p.sc_sh + (int64_t)qq * p.sc_sq + key0;
+            if (key0 + 8 <= p.N) *reinterpret_cast<u32x4*>(dst) = piece;
+            else {
+              const T* pe = reinterpret_cast<const T*>(&piece);
+              for (int e = 0; e < p.N - key0; ++e) dst[e] = pe[e];
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+    if (!attend) return;
+    m_tile = xor32_max(m_tile);
+    const float m_new = fmaxf(m_run, m_tile);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float m2 = m_use * kLog2e;
+    float lsum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], kLog2e, -m2));
+          lsum += pvv;
+          pf[kb][t][e] = DT<T>::from_f32(pvv);
+        }
+    if (m_new != m_run) {
+      const float alpha = __expf(m_run - m_use);
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      m_run = m_new;
+    }
+    l_run += lsum;
+  };
+
+  // ---- prologue (all 8 waves together): K(0) parked in stage 1's K area, stage 0 = { K(1), Vt(0) } --------------
+  load_k(0);
+  write_k(k_area(1));
+  load_stage(0);
+  write_stage(0);
+  __syncthreads();
+  if (wave_tiles > 0) qk(k_area(1));
+  __syncthreads();                                   // everyone is done with K(0): stage 1 may be filled
+  int next_stage = 1;                                // the stage whose pieces this thread holds in registers
+  if (next_stage < n_tiles) load_stage(next_stage);
+  if (grp == 1) {                                    // half 1 publishes its stage-1 pieces now, half 0 in its first vector phase
+    if (next_stage < n_tiles) { write_stage(next_stage); ++next_stage; if (next_stage < n_tiles) load_stage(next_stage); }
+  }
+  if (wave_tiles > 0) softmax_tile(0);
+  __syncthreads();
+  if (grp == 1) __syncthreads();                     // hold half 1 one phase behind
+
+  for (int t = 0; t < n_tiles; ++t) {
+    // ---- matrix phase of iteration t -----------------------------------------------------------------------
+    PF_STAMP(0);
+#if !(defined(SPATTEN_PP_ABL) && (SPATTEN_PP_ABL & 1))
+    if (t < wave_att_tiles) pv(v_area(t));
+    if (t + 1 < wave_tiles) qk(k_area(t));
+#endif
+    PF_STAMP(1);
+    __syncthreads();
+    PF_STAMP(2);
+    // ---- vector phase ----------------------------------------------------------------------------------------
+    if (next_stage < n_tiles) {
+      write_stage(next_stage);
+      ++next_stage;
+      if (next_stage < n_tiles) load_stage(next_stage);
+    }
+    PF_STAMP(3);
+#if !(defined(SPATTEN_PP_ABL) && (SPATTEN_PP_ABL & 2))
+    if (t + 1 < wave_tiles) softmax_tile(t + 1);
+#endif
+    PF_STAMP(4);
+    __syncthreads();
+    PF_STAMP(5);
+  }
+  if (grp == 0) __syncthreads();                     // same barrier count for both halves
+
+  // ---- epilogue: O = O^T / l, 4 consecutive dv per 8-byte store ---------------------------------
+  const float l_tot = xor32_sum(l_run);
+  const float inv = 1.f / l_tot;
+  if (qvalid) {
+    T* orow = p.out + b * p.out_sb + (int64_t)myq * p.out_sq + h * D;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dv = db * 32 + 8 * g + 4 * hi;
+        T v4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = DT<T>::from_f32(o[db][4 * g + e] * inv);
+        *reinterpret_cast<u32x2*>(orow + dv) = *reinterpret_cast<u32x2*>(v4);
+      }
+    }
+  }
+}
+
 static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 static inline int rows_leg(int dtype, int head_dim, int q_len) {
   return dtype == SPATTEN_F32 || q_len <= 8 || (head_dim != 64 && head_dim != 128);
 }
 static inline int rows_splits(int units) { int s = 256 / (units > 0 ? units : 1); return s < 1 ? 1 : (s > 64 ? 64 : s); }
 
+static int prefill_variant() {   // 0 = ping-pong 8-wave kernel (default), 1 = the 4-wave kernel (A/B experiments)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SPATTEN_PREFILL_4WAVE"); v = (e && atoi(e) != 0) ? 1 : 0; }
+  return v;
+}
+
 template <typename T, int D, bool ST, bool CI>
-static void launch_flash_m(const FlashParams<T>& p, dim3 grid, hipStream_t st) {
-  if (p.mask) hipLaunchKernelGGL((prefill_flash_kernel<T, D, ST, CI, true>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((prefill_flash_kernel<T, D, ST, CI, false>), grid, dim3(256), 0, st, p);
+static void launch_flash_m(const FlashParams<T>& p, hipStream_t st) {
+  if (prefill_variant() == 1) {
+    FlashParams<T> q = p;
+    q.nqb = ceil_div(p.q_len, 128);
+    const dim3 grid((unsigned)(q.nqb * p.H * p.B));
+    if (p.mask) hipLaunchKernelGGL((prefill_flash_kernel<T, D, ST, CI, true>), grid, dim3(256), 0, st, q);
+    else hipLaunchKernelGGL((prefill_flash_kernel<T, D, ST, CI, false>), grid, dim3(256), 0, st, q);
+    return;
+  }
+  const dim3 grid((unsigned)(p.nqb * p.H * p.B));
+  if (p.mask) hipLaunchKernelGGL((prefill_pp_kernel<T, D, ST, CI, true>), grid, dim3(512), 0, st, p);
+  else hipLaunchKernelGGL((prefill_pp_kernel<T, D, ST, CI, false>), grid, dim3(512), 0, st, p);
 }
 
 template <typename T, int D>
 static int launch_flash(const FlashParams<T>& p, hipStream_t st) {
-  const dim3 grid((unsigned)(ceil_div(p.q_len, 128) * p.H * p.B));
   const bool st_ = p.scores != nullptr, ci = p.col_imp != nullptr;
-  if (st_ && ci) launch_flash_m<T, D, true, true>(p, grid, st);
-  else if (st_) launch_flash_m<T, D, true, false>(p, grid, st);
-  else if (ci) launch_flash_m<T, D, false, true>(p, grid, st);
-  else launch_flash_m<T, D, false, false>(p, grid, st);
+  if (st_ && ci) launch_flash_m<T, D, true, true>(p, st);
+  else if (st_) launch_flash_m<T, D, true, false>(p, st);
+  else if (ci) launch_flash_m<T, D, false, true>(p, st);
+  else launch_flash_m<T, D, false, false>(p, st);
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }
 
@@ -609,10 +1008,16 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
     p.scores = (T*)scores; p.sc_sb = sc_sb; p.sc_sh = sc_sh; p.sc_sq = sc_sq;                          \
     p.col_imp = col_importance;                                                                        \
     p.B = batch; p.H = heads; p.Hkv = kv_heads; p.q_len = q_len; p.N = kv_len; p.Npad = npad;          \
-    p.causal = causal; p.sqrt_d = sqrtf((float)head_dim); p.nqb = ceil_div(q_len, 128);                \
+    p.causal = causal; p.sqrt_d = sqrtf((float)head_dim); p.nqb = ceil_div(q_len, 256);                \
     return launch_flash<T, DD>(p, st);                                                                 \
   }
   if (dtype == SPATTEN_BF16) { if (head_dim == 128) SPATTEN_FLASH(bf16_t, 128) else SPATTEN_FLASH(bf16_t, 64) }
   else { if (head_dim == 128) SPATTEN_FLASH(f16_t, 128) else SPATTEN_FLASH(f16_t, 64) }
 #undef SPATTEN_FLASH
 }
+
+#ifdef SPATTEN_PF_TRACE
+extern "C" int spatten_debug_set_pf_trace(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_pf_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
