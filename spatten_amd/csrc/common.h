@@ -156,6 +156,13 @@ constexpr int kDppMirror = 0x140;      // lane i <-> 15-i within 16
 constexpr int kDppRor4 = 0x124;        // rotate right by 4 within 16
 constexpr int kDppRor8 = 0x128;        // rotate right by 8 within 16 (== xor 8)
 
+// identity the optimiser cannot see through: keeps a cheap per-lane computation inside a loop instead of hoisted
+// (and then spilled) above it
+__device__ inline int opaque_lane(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 // max of three without the canonicalising v_max the compiler puts in front of fmaxf on values it cannot prove quiet
 // (MFMA results, bit-built floats): one VALU issue for two new values.  NaN inputs are not expected here.
 __device__ inline float max3_raw(float a, float b, float c) {

@@ -11,10 +11,12 @@
 //           contraction index (keys) contiguous per lane; inside every 32-key block the keys are permuted
 //           into the order in which a lane holds them after the Q·K^T product (no shuffles between the two
 //           products),
-//       (3) flash kernel: workgroup = 128 queries (4 waves x 32), key tiles of 64 staged in LDS
+//       (3) flash kernel: workgroup = 256 queries (8 waves x 32, one workgroup per CU), key tiles staged in LDS
 //           (XOR-swizzled 16-byte slots, conflict-free ds_read_b128), S^T = Kr·Qrot^T and O^T = Vt·P^T on
 //           v_mfma_f32_32x32x16_{bf16,f16}: a lane owns ONE query column, so the online softmax needs a
-//           single cross-lane exchange (lane <-> lane+32) per tile.
+//           single cross-lane exchange (lane <-> lane+32) per tile.  The two halves of the workgroup run one phase
+//           apart (matrix phase beside vector phase on every SIMD): (3b) 64-key tiles staged through registers,
+//           (3c) 128-key tiles brought in by LDS-DMA.
 //     The stash (pre-mask logits, modify_llama.py:116-119) and the column importance (kv_cache_token_pruning.py:51
 //     includes the acausal logits) are optional by-products; when requested, key tiles above the causal
 //     diagonal are still scored (but skip softmax / P·V).
@@ -122,410 +124,12 @@ template <int ROWB> __device__ inline int lds_off(int row, int slot) {
   return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
 }
 
-// STASH / COLIMP / MASK: compile the optional by-products out of the hot instantiation
-template <typename T, int D, bool STASH, bool COLIMP, bool MASK>
-__global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const FlashParams<T> p) {
-  constexpr int KK = D / 16;       // MFMA k-steps of the Q·K^T product
-  constexpr int DB = D / 32;       // 32-row blocks of O^T
-  constexpr int KROWB = D * 2;     // bytes per K row in LDS (256 / 128)
-  constexpr int KBYTES = 64 * KROWB, VBYTES = D * 128, BUF = KBYTES + VBYTES;
-  constexpr int KPC = 64 * (D / 8) / 256, VPC = D * 8 / 256;   // 16-byte pieces per thread per tile (K, Vt)
-  using frag = typename Mfma<T>::frag;
-  constexpr int SPITCH = 80;                                    // bytes per staged stash row (32 keys x 2 B, padded)
-  constexpr int SBYTES = STASH ? 4 * 32 * SPITCH : 0;           // per-wave 32 x 32 transpose tile for the stash
-  __shared__ __attribute__((aligned(16))) char lds[2 * BUF + SBYTES];   // double buffered [K tile | Vt tile] x 2 (+ stash)
-
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, qi = lane & 31, hi = lane >> 5;
-  // XCD-aware work order.  Workgroup i runs on XCD i % 8 (observed dispatch; used for speed only) and every query
-  // block of a head re-reads that head's K / Vt tiles, so the blocks of one head are kept on ONE XCD at a time:
-  // its private 4 MiB L2 then holds exactly the 2 x 2 MiB a head needs at N = 8192 instead of thrashing over 8 heads.
-  // Within a head: longest (latest) query blocks first.
-  const int nqb = p.nqb;
-  int h, qblk, b;
-  {
-    const int i = blockIdx.x;
-    const int per_b = p.H * nqb;                         // workgroups per batch element
-    b = i / per_b;
-    const int j = i - b * per_b;
-    if ((p.H & 7) == 0) {
-      const int xx = j & 7, ss = j >> 3;
-      h = xx + 8 * (ss / nqb);
-      qblk = nqb - 1 - (ss % nqb);
-    } else {                                             // head count not a multiple of 8: plain order
-      h = j / nqb;
-      qblk = nqb - 1 - (j % nqb);
-    }
-  }
-  const int hkv = p.Hkv == p.H ? h : h / (p.H / p.Hkv);
-  const int q0 = qblk * 128 + wave * 32;
-  const int myq = q0 + qi;
-  const bool qvalid = myq < p.q_len;
-  const int P = p.N - p.q_len;
-  const float rsqrt_d = 1.0f / p.sqrt_d;
-
-  frag qf[KK];
-  {
-    const T* qrow = p.qrot + ((int64_t)(b * p.H + h) * p.q_len + min(myq, p.q_len - 1)) * D;
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) qf[kk] = *reinterpret_cast<const frag*>(qrow + 16 * kk + 8 * hi);
-  }
-  f32x16 o[DB];
-#pragma unroll
-  for (int db = 0; db < DB; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  const int wg_q_end = min(p.q_len, qblk * 128 + 128);
-  const int att_keys = p.causal ? min(p.N, P + wg_q_end) : p.N;          // keys any query of this workgroup sees
-  const int n_att_tiles = (att_keys + 63) / 64;
-  const int n_tiles = (STASH || COLIMP) ? (p.N + 63) / 64 : n_att_tiles;
-  const int my_vis = p.causal ? min(p.N, P + myq + 1) : p.N;             // keys [0, my_vis) are visible to my query
-  // a tile needs no per-element visibility test when even this wave's FIRST query sees its last key
-  const int wave_full_keys = p.causal ? min(p.N, P + q0 + 1) : p.N;
-
-  const T* krb = p.kr + b * p.kv_sb + hkv * p.kv_sh;
-  const T* vtb = p.vt + ((int64_t)(b * p.Hkv + hkv) * D) * p.Npad;
-  const T* maskrow = MASK ? p.mask + b * p.mask_sb + (int64_t)min(myq, p.q_len - 1) * p.mask_sq : nullptr;
-  T* stashrow = STASH ? p.scores + b * p.sc_sb + h * p.sc_sh + (int64_t)min(myq, p.q_len - 1) * p.sc_sq : nullptr;
-  float* colrow = COLIMP ? p.col_imp + (int64_t)(b * p.H + h) * p.N : nullptr;
-  // 16-byte stash stores need 16-byte aligned rows (row pitch and base offsets multiples of 8 elements)
-  const bool stash_vec = STASH && ((p.sc_sq | p.sc_sh | p.sc_sb) % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.scores) & 15) == 0);
-
-  // ---- staging: global -> registers (issued early) -> LDS (written late).  Two K slots and two Vt slots; K runs ONE
-  // tile ahead of Vt so that the Q·K^T MFMAs of tile t+1 are independent of — and overlap — the softmax of tile t.
-  auto k_slot = [&](int i) -> char* { return lds + (i & 1) * BUF; };
-  auto v_slot = [&](int i) -> char* { return lds + (i & 1) * BUF + KBYTES; };
-  u32x4 kreg[KPC], vreg[VPC];
-  auto load_k = [&](int tile) {
-#pragma unroll
-    for (int i = 0; i < KPC; ++i) {
-      const int id = tid + 256 * i, row = id / (D / 8), slot = id % (D / 8);
-      const int j = min(tile * 64 + row, p.N - 1);     // rows past N are masked; stay inside the allocation
-      kreg[i] = *reinterpret_cast<const u32x4*>(krb + (int64_t)j * D + slot * 8);
-    }
-  };
-  auto load_v = [&](int tile) {
-#pragma unroll
-    for (int i = 0; i < VPC; ++i) {
-      const int id = tid + 256 * i, dv = id >> 3, slot = id & 7;
-      vreg[i] = *reinterpret_cast<const u32x4*>(vtb + (int64_t)dv * p.Npad + tile * 64 + slot * 8);
-    }
-  };
-  auto write_k = [&](char* buf) {
-#pragma unroll
-    for (int i = 0; i < KPC; ++i) {
-      const int id = tid + 256 * i, row = id / (D / 8), slot = id % (D / 8);
-      *reinterpret_cast<u32x4*>(buf + lds_off<KROWB>(row, slot)) = kreg[i];
-    }
-  };
-  auto write_v = [&](char* buf) {
-#pragma unroll
-    for (int i = 0; i < VPC; ++i) {
-      const int id = tid + 256 * i, dv = id >> 3, slot = id & 7;
-      *reinterpret_cast<u32x4*>(buf + lds_off<128>(dv, slot)) = vreg[i];
-    }
-  };
-  // S^T (64 keys x 32 queries per wave): the two key blocks are independent accumulators, interleaved
-  auto qk = [&](const char* kbuf, f32x16 (&acc)[2]) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-#if defined(SPATTEN_PF_ABL) && (SPATTEN_PF_ABL & 1)
-      const frag a0 = qf[(kk + 1) % KK], a1 = qf[(kk + 2) % KK];
-#else
-      const frag a0 = *reinterpret_cast<const frag*>(kbuf + lds_off<KROWB>(qi, 2 * kk + hi));
-      const frag a1 = *reinterpret_cast<const frag*>(kbuf + lds_off<KROWB>(32 + qi, 2 * kk + hi));
-#endif
-      acc[0] = Mfma<T>::mma(a0, qf[kk], acc[0]);
-      acc[1] = Mfma<T>::mma(a1, qf[kk], acc[1]);
-    }
-  };
-
-  // prologue: K(0), Vt(0) [, K(1)] resident; S(0) computed
-  load_k(0);
-  write_k(k_slot(0));
-  if (n_att_tiles > 0) { load_v(0); write_v(v_slot(0)); }
-  if (n_tiles > 1) { load_k(1); write_k(k_slot(1)); }
-  __syncthreads();
-  f32x16 s[2], sn[2];
-  qk(k_slot(0), s);
-
-  for (int tile = 0; tile < n_tiles; ++tile) {
-    const bool attend = tile < n_att_tiles;
-    const bool more_k = tile + 2 < n_tiles, more_v = tile + 1 < n_att_tiles;
-#if defined(SPATTEN_PF_ABL) && (SPATTEN_PF_ABL & 8)
-    if (tile < 0) { load_k(tile + 2); load_v(tile + 1); }
-#else
-    if (more_k) load_k(tile + 2);                        // in flight during this tile's MFMAs and softmax
-    if (more_v) load_v(tile + 1);
-#endif
-    const bool edge = tile * 64 + 64 > wave_full_keys;  // wave-uniform: some element needs the visibility test
-    if (!STASH && !COLIMP && !MASK && !edge && attend) {
-      // ---- hot path: fully visible tile, no by-products.  ONE basic block so that the compiler can weave the next
-      // tile's Q·K^T MFMAs (independent accumulators sn) into this tile's softmax VALU stream. -----------------
-      qk(k_slot(tile + 1), sn);                         // past the last tile this scores a stale slot; never used
-      float m_tile = -INFINITY;
-#ifndef SPATTEN_PF_PACK
-#define SPATTEN_PF_PACK 1
-#endif
-      float lsum = 0.f;
-      frag pf[2][2];
-#if SPATTEN_PF_PACK == 0
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = DT<T>::round(div_by_const(DT<T>::round(s[kb][r]), p.sqrt_d, rsqrt_d));
-          s[kb][r] = v;
-          m_tile = fmaxf(m_tile, v);
-        }
-      m_tile = xor32_max(m_tile);
-      const float m_new = fmaxf(m_run, m_tile);
-      const float m2 = m_new * kLog2e;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], kLog2e, -m2));
-            lsum += pv;
-            pf[kb][t][e] = DT<T>::from_f32(pv);
-          }
-#else
-      // No stash is written on this path, so the logits only feed the softmax: the matmul result is rounded to the
-      // model dtype like the reference's (modify_llama.py:111) but the "/ sqrt(d) -> dtype" step (:113) is folded into
-      // the exponent's fma un-rounded — at most one 16-bit ulp of a logit away from the reference, the same size as
-      // the accumulation-order effect the stash tolerance already allows — 5.5 instead of 11 VALU issues per score.
-      // The issue port, not the MFMA pipe, is what this loop saturates (PMC: tools/pmc_prefill.sh).
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-#if SPATTEN_PF_PACK == 2
-          const f32x2 v = {s[kb][r], s[kb][r + 1]};
-#else
-          const f32x2 v = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
-#endif
-          s[kb][r] = v[0];
-          s[kb][r + 1] = v[1];
-          m_tile = fmaxf(m_tile, fmaxf(v[0], v[1]));
-        }
-      m_tile = xor32_max(m_tile) * rsqrt_d;           // rsqrt_d > 0: max commutes with the scale
-      const float m_new = fmaxf(m_run, m_tile);
-      const float m2 = m_new * kLog2e;
-      const float c2 = rsqrt_d * kLog2e;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], c2, -m2));
-            lsum += pv;
-            pf[kb][t][e] = DT<T>::from_f32(pv);
-          }
-#endif
-      // 16 MFMAs woven into ~500 VALU instructions: one MFMA, then a slice of the VALU stream (T19)
-#ifndef SPATTEN_PF_SCHED
-#define SPATTEN_PF_SCHED 1
-#endif
-#if SPATTEN_PF_SCHED == 1
-#pragma unroll
-      for (int i = 0; i < 2 * KK; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 DS read (the next A fragment)
-        __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);   // a slice of VALU
-      }
-#elif SPATTEN_PF_SCHED == 2
-#pragma unroll
-      for (int i = 0; i < 2 * KK; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 34, 0);
-      }
-#elif SPATTEN_PF_SCHED == 3
-#pragma unroll
-      for (int i = 0; i < 2 * KK; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
-      }
-#elif SPATTEN_PF_SCHED == 4
-#pragma unroll
-      for (int i = 0; i < KK; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 56, 0);
-      }
-#endif
-      if (m_new != m_run) {
-        const float alpha = __expf(m_run - m_new);
-        l_run *= alpha;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-        m_run = m_new;
-      }
-      l_run += lsum;
-      const char* ldsV = v_slot(tile);
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int db = 0; db < DB; ++db) {
-#if defined(SPATTEN_PF_ABL) && (SPATTEN_PF_ABL & 2)
-            const frag a = qf[(db + 2 * kb + t) % KK];
-#else
-            const frag a = *reinterpret_cast<const frag*>(ldsV + lds_off<128>(db * 32 + qi, kb * 4 + t * 2 + hi));
-#endif
-            o[db] = Mfma<T>::mma(a, pf[kb][t], o[db]);
-          }
-#if defined(SPATTEN_PF_ABL) && (SPATTEN_PF_ABL & 16)
-      if (tile < 0) { write_k(k_slot(tile)); write_v(v_slot(tile + 1)); }
-#else
-      if (more_k) write_k(k_slot(tile));
-      if (more_v) write_v(v_slot(tile + 1));
-#endif
-#if !(defined(SPATTEN_PF_ABL) && (SPATTEN_PF_ABL & 4))
-      __syncthreads();
-#endif
-      s[0] = sn[0];
-      s[1] = sn[1];
-      continue;
-    }
-    if (tile + 1 < n_tiles) qk(k_slot(tile + 1), sn);   // next tile's scores
-    float m_tile = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
-        float v = DT<T>::round(div_by_const(DT<T>::round(s[kb][r]), p.sqrt_d, rsqrt_d));
-        if (STASH || COLIMP || MASK || edge) {
-          const int key = tile * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          const bool inb = key < p.N;
-          if (STASH) {                                                                        // pre-mask (:116-119)
-            if (stash_vec) {       // stage [query][key] in LDS; written out below as 16-byte row pieces
-              char* sw = lds + 2 * BUF + wave * (32 * SPITCH);
-              *reinterpret_cast<T*>(sw + qi * SPITCH + ((r & 3) + 8 * (r >> 2) + 4 * hi) * 2) = DT<T>::from_f32(v);
-            } else if (inb && qvalid) {
-              stashrow[key] = DT<T>::from_f32(v);
-            }
-          }
-          if (COLIMP) {
-            float cv = (inb && qvalid) ? v : 0.f;     // sum over this wave's 32 queries, then one atomic per key
-            cv = xor16_sum(group_sum<16>(cv));
-            if (qi == 0 && inb) atomicAdd(colrow + key, cv);
-          }
-          if (MASK) { if (inb) v = DT<T>::round(v + DT<T>::to_f32(maskrow[key])); }            // :132
-          v = (key < my_vis) ? v : -INFINITY;
-        }
-        s[kb][r] = v;
-        m_tile = fmaxf(m_tile, v);
-      }
-      if (STASH && stash_vec) {
-        // the wave's 32 queries x 32 keys of this key block, transposed through LDS: 64-byte row segments, 16 B / lane
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        const char* sw = lds + 2 * BUF + wave * (32 * SPITCH);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int id = lane + 64 * i, row = id >> 2, c4 = id & 3;
-          const u32x4 piece = *reinterpret_cast<const u32x4*>(sw + row * SPITCH + c4 * 16);
-          const int qq = q0 + row, key0 = tile * 64 + kb * 32 + c4 * 8;
-          if (qq < p.q_len && key0 < p.N) {
-            T* dst = p.scores + b * p.sc_sb + h * p.sc_sh + (int64_t)qq * p.sc_sq + key0;
-            if (key0 + 8 <= p.N) *reinterpret_cast<u32x4*>(dst) = piece;
-            else {
-              const T* pe = reinterpret_cast<const T*>(&piece);
-              for (int e = 0; e < p.N - key0; ++e) dst[e] = pe[e];
-            }
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
-    }
-    if (attend) {
-      // ---- online softmax: a lane and its partner (lane ^ 32) share one query --------------------
-      m_tile = xor32_max(m_tile);
-      const float m_new = fmaxf(m_run, m_tile);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float m2 = m_use * kLog2e;
-      float lsum = 0.f;
-      frag pf[2][2];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            // exp(s - m) as one fma + v_exp_f32 (a base-2 exponential); exp2(-inf) = 0 for masked keys
-            const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], kLog2e, -m2));
-            lsum += pv;
-            pf[kb][t][e] = DT<T>::from_f32(pv);
-          }
-        }
-      }
-      if (m_new != m_run) {                          // wave-divergent only in the first tiles of a row
-        const float alpha = __expf(m_run - m_use);
-        l_run *= alpha;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-        m_run = m_new;
-      }
-      l_run += lsum;
-      // ---- O^T (D dv x 32 queries) += Vt · P^T ---------------------------------------------------
-      const char* ldsV = v_slot(tile);
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-          for (int db = 0; db < DB; ++db) {          // DB independent accumulators back to back
-            const frag a = *reinterpret_cast<const frag*>(ldsV + lds_off<128>(db * 32 + qi, kb * 4 + t * 2 + hi));
-            o[db] = Mfma<T>::mma(a, pf[kb][t], o[db]);
-          }
-        }
-      }
-    }
-    if (more_k) write_k(k_slot(tile));                // K(tile+2) replaces K(tile), consumed one iteration ago
-    if (more_v) write_v(v_slot(tile + 1));
-    __syncthreads();
-    s[0] = sn[0];
-    s[1] = sn[1];
-  }
-
-  // ---- epilogue: O = O^T / l, 4 consecutive dv per 8-byte store ---------------------------------
-  const float l_tot = xor32_sum(l_run);
-  const float inv = 1.f / l_tot;
-  if (qvalid) {
-    T* orow = p.out + b * p.out_sb + (int64_t)myq * p.out_sq + h * D;
-#pragma unroll
-    for (int db = 0; db < DB; ++db) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int dv = db * 32 + 8 * g + 4 * hi;
-        T v4[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v4[e] = DT<T>::from_f32(o[db][4 * g + e] * inv);
-        *reinterpret_cast<u32x2*>(orow + dv) = *reinterpret_cast<u32x2*>(v4);
-      }
-    }
-  }
-}
-
-
 // ------------------------------------------------------------------------------------------------
 // (3b) ping-pong flash kernel: 8 waves = 256 queries per workgroup, one workgroup per CU, two waves per SIMD.
-// PMC of the 4-wave kernel above (tools/pmc_prefill.sh): the two waves that share a SIMD run the same code in
-// phase — both in their MFMA stretch (the matrix pipe alternates between them), then both in their softmax stretch
-// (the matrix pipe idles) — so the SIMD's time is the SUM of the two streams (MFMA pipe 33 % busy, issue port 73 %).
+// PMC of this round's first kernel (4 waves x 32 queries, two workgroups per CU; tools/pmc_prefill.sh): the two waves
+// that share a SIMD run the same code in phase — both in their MFMA stretch (the matrix pipe alternates between them),
+// then both in their softmax stretch (the matrix pipe idles) — so the SIMD's time is the SUM of the two streams
+// (MFMA pipe 33 % busy, issue port 73 %).
 // Here the two halves of the workgroup (waves 0-3 / 4-7, one of each on every SIMD) are held exactly one phase
 // apart by the workgroup barrier: while one half runs its matrix phase  { O += Vt(t)·P(t) ; S = K(t+1)·Q }
 // the other runs its vector phase  { publish staged K/V pieces to LDS, issue the next global loads, softmax(S) -> P },
@@ -549,7 +153,11 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
   const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);          // which half of the workgroup (wave-uniform)
   const int nqb = p.nqb;                                             // 256-query blocks per head
   int h, qblk, b;
-  {   // XCD-aware work order (see prefill_flash_kernel)
+  // XCD-aware work order.  Workgroup i runs on XCD i % 8 (observed dispatch; used for speed only) and every query block
+  // of a head re-reads that head's K / Vt tiles, so the blocks of one head are kept on ONE XCD at a time: its private
+  // 4 MiB L2 then holds exactly the 2 x 2 MiB a head needs at N = 8192 instead of thrashing over 8 heads.  Within a
+  // head: longest (latest) query blocks first.
+  {
     const int i = blockIdx.x;
     const int per_b = p.H * nqb;
     b = i / per_b;
@@ -706,16 +314,10 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-#if defined(SPATTEN_SM_ABL) && (SPATTEN_SM_ABL & 2)
-          const f32x2 v = f32x2{s[kb][r], s[kb][r + 1]};
-#else
           const f32x2 v = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
-#endif
           s[kb][r] = v[0];
           s[kb][r + 1] = v[1];
-#if !(defined(SPATTEN_SM_ABL) && (SPATTEN_SM_ABL & 8))
           mt[kb] = max3_raw(mt[kb], v[0], v[1]);
-#endif
         }
       const float m_tile = xor32_max(fmaxf(mt[0], mt[1])) * rsqrt_d;
       const float m_new = fmaxf(m_run, m_tile);
@@ -728,20 +330,11 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-#if defined(SPATTEN_SM_ABL) && (SPATTEN_SM_ABL & 1)
-            const float pvv = fmaf(s[kb][t * 8 + e], c2, -m2);
-#else
             const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], c2, -m2));
-#endif
             ls[e & 3] += pvv;
-#if defined(SPATTEN_SM_ABL) && (SPATTEN_SM_ABL & 4)
-            if (e == 0) pf[kb][t][e] = DT<T>::from_f32(pvv);
-#else
             pf[kb][t][e] = DT<T>::from_f32(pvv);
-#endif
           }
       const float lsum = (ls[0] + ls[1]) + (ls[2] + ls[3]);
-#if !(defined(SPATTEN_SM_ABL) && (SPATTEN_SM_ABL & 16))
       if (m_new != m_run) {
         const float alpha = __expf(m_run - m_new);
         l_run *= alpha;
@@ -751,7 +344,6 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
           for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
         m_run = m_new;
       }
-#endif
       l_run += lsum;
       return;
     }
@@ -850,10 +442,8 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
   for (int t = 0; t < n_tiles; ++t) {
     // ---- matrix phase of iteration t -----------------------------------------------------------------------
     PF_STAMP(0);
-#if !(defined(SPATTEN_PP_ABL) && (SPATTEN_PP_ABL & 1))
     if (t < wave_att_tiles) pv(v_area(t));
     if (t + 1 < wave_tiles) qk(k_area(t));
-#endif
     PF_STAMP(1);
     __syncthreads();
     PF_STAMP(2);
@@ -864,14 +454,363 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
       if (next_stage < n_tiles) load_stage(next_stage);
     }
     PF_STAMP(3);
-#if !(defined(SPATTEN_PP_ABL) && (SPATTEN_PP_ABL & 2))
     if (t + 1 < wave_tiles) softmax_tile(t + 1);
-#endif
     PF_STAMP(4);
     __syncthreads();
     PF_STAMP(5);
   }
   if (grp == 0) __syncthreads();                     // same barrier count for both halves
+
+  // ---- epilogue: O = O^T / l, 4 consecutive dv per 8-byte store ---------------------------------
+  const float l_tot = xor32_sum(l_run);
+  const float inv = 1.f / l_tot;
+  if (qvalid) {
+    T* orow = p.out + b * p.out_sb + (int64_t)myq * p.out_sq + h * D;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dv = db * 32 + 8 * g + 4 * hi;
+        T v4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = DT<T>::from_f32(o[db][4 * g + e] * inv);
+        *reinterpret_cast<u32x2*>(orow + dv) = *reinterpret_cast<u32x2*>(v4);
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// (3c) ping-pong flash kernel, 128-key tiles, K / Vt tiles brought in by LDS-DMA (global_load_lds_dwordx4: no staging
+// registers, no ds_write).  Same phase scheme as (3b); a phase now holds 64 MFMAs / 64 scores per lane, which halves
+// the per-phase fixed costs (barrier skew, pipeline fill, first-read latency) per unit of work.
+// Stage j = { K(j+1), Vt(j) } in slot j & 1 (64 KiB each at d = 128).  Every wave issues its 1-KiB pieces of stage
+// j+2 at the top of global phase 2j+2 — half 0 is then entering its matrix phase, half 1 its vector phase; the slot's
+// previous tenant (stage j) was last read in phase 2j+1 — and waits for them (vmcnt) before the barrier that ends
+// phase 2j+3; the stage is first read in phase 2j+4.
+// A DMA instruction writes 1 KiB of LDS linearly (lane l -> +16 l), so the XOR swizzle of the 16-byte slots is applied
+// on the GLOBAL side: lane (row, p) fetches logical slot p ^ f(row) of its row.
+// ------------------------------------------------------------------------------------------------
+// buffer-descriptor LDS-DMA helpers (device-only functions: the host pass of a __global__ template must not see the
+// target builtins)
+// lane l fetches 16 bytes at base + soff + voff(l) into lds_dst + 16 l (lds_dst wave-uniform); bytes beyond `bytes`
+// read as zero.  The descriptor is rebuilt from wave-uniform values at every call (a few SALU moves).
+__device__ inline void dma16(const void* base, int64_t bytes, char* lds_dst, int voff, int soff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0,
+                                                                     (int)(bytes < 0x7FFFFFFF ? bytes : 0x7FFFFFFF), 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
+
+template <int ROWB> __device__ inline int swz_slot(int row, int p) {   // logical slot stored at physical slot p
+  return ROWB == 256 ? (p ^ (row & 15)) : (p ^ ((row >> 1) & 7));
+}
+
+template <typename T, int D, bool STASH, bool COLIMP, bool MASK>
+__global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams<T> p) {
+  constexpr int KT = 128, NKB = KT / 32;                      // keys per tile, 32-key blocks per tile
+  constexpr int KK = D / 16, DB = D / 32, KROWB = D * 2;
+  constexpr int KBYTES = KT * KROWB, VBYTES = D * 256, BUF = KBYTES + VBYTES;   // Vt row = 128 keys = 256 B
+  constexpr int KINST = KBYTES / 1024 / 8, VINST = VBYTES / 1024 / 8;           // DMA instructions per wave per tile
+  constexpr int KROWS_PER_INST = 1024 / KROWB;                                  // K rows covered by one 1-KiB piece
+  using frag = typename Mfma<T>::frag;
+  constexpr int SPITCH = 80;
+  constexpr int SBYTES = STASH ? 8 * 32 * SPITCH : 0;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * BUF + SBYTES];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, qi = lane & 31, hi = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int grp = wave_u >> 2;
+  const int nqb = p.nqb;
+  int h, qblk, b;
+  {
+    const int i = blockIdx.x;
+    const int per_b = p.H * nqb;
+    b = i / per_b;
+    const int j = i - b * per_b;
+    if ((p.H & 7) == 0) {
+      const int xx = j & 7, ss = j >> 3;
+      h = xx + 8 * (ss / nqb);
+      qblk = nqb - 1 - (ss % nqb);
+    } else {
+      h = j / nqb;
+      qblk = nqb - 1 - (j % nqb);
+    }
+  }
+  const int hkv = p.Hkv == p.H ? h : h / (p.H / p.Hkv);
+  const int q0 = qblk * 256 + wave * 32;
+  const int myq = q0 + qi;
+  const bool qvalid = myq < p.q_len;
+  const int P = p.N - p.q_len;
+  const float rsqrt_d = 1.0f / p.sqrt_d;
+
+  frag qf[KK];
+  {
+    const T* qrow = p.qrot + ((int64_t)(b * p.H + h) * p.q_len + min(myq, p.q_len - 1)) * D;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) qf[kk] = *reinterpret_cast<const frag*>(qrow + 16 * kk + 8 * hi);
+  }
+  f32x16 o[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int wg_q_end = min(p.q_len, qblk * 256 + 256);
+  const int att_keys = p.causal ? min(p.N, P + wg_q_end) : p.N;
+  const int n_att_tiles = (att_keys + KT - 1) / KT;
+  const int n_tiles = (STASH || COLIMP) ? (p.N + KT - 1) / KT : n_att_tiles;
+  const int my_vis = p.causal ? min(p.N, P + myq + 1) : p.N;
+  const int wave_full_keys = p.causal ? min(p.N, P + q0 + 1) : p.N;
+  const int wave_att_tiles = p.causal ? min(n_att_tiles, (max(min(p.N, P + min(q0 + 32, p.q_len)), 0) + KT - 1) / KT) : n_att_tiles;
+  const int wave_tiles = (STASH || COLIMP) ? n_tiles : wave_att_tiles;
+
+  const T* krb = p.kr + b * p.kv_sb + hkv * p.kv_sh;
+  const T* vtb = p.vt + ((int64_t)(b * p.Hkv + hkv) * D) * p.Npad;
+  const T* maskrow = MASK ? p.mask + b * p.mask_sb + (int64_t)min(myq, p.q_len - 1) * p.mask_sq : nullptr;
+  T* stashrow = STASH ? p.scores + b * p.sc_sb + h * p.sc_sh + (int64_t)min(myq, p.q_len - 1) * p.sc_sq : nullptr;
+  float* colrow = COLIMP ? p.col_imp + (int64_t)(b * p.H + h) * p.N : nullptr;
+  const bool stash_vec = STASH && ((p.sc_sq | p.sc_sh | p.sc_sb) % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.scores) & 15) == 0);
+
+  auto k_area = [&](int stage) -> char* { return lds + (stage & 1) * BUF; };            // holds K(stage + 1)
+  auto v_area = [&](int stage) -> char* { return lds + (stage & 1) * BUF + KBYTES; };   // holds Vt(stage)
+  // buffer descriptors (wave-uniform): rows past N read as zeros (out of range), no clamping arithmetic per lane
+  const int64_t k_bytes = (int64_t)p.N * D * 2, v_bytes = (int64_t)D * p.Npad * 2;
+  // this wave's pieces of K tile `tile` -> area (rows [wave*KT/8, +KT/8)); per-lane byte offset within the tile
+  auto dma_k = [&](int tile, char* area) {
+    const int ln = opaque_lane(lane);   // recompute the per-lane offsets here: hoisted out of the tile loop they get
+                                        // spilled, and every reload's vmcnt(0) then serialises the DMA instructions
+#pragma unroll
+    for (int i = 0; i < KINST; ++i) {
+      const int piece = wave_u * KINST + i;                                  // 1-KiB piece index within the tile
+      const int row = piece * KROWS_PER_INST + ln / (KROWB / 16);
+      const int pslot = ln % (KROWB / 16);
+      const int voff = (row * D + swz_slot<KROWB>(row, pslot) * 8) * 2;
+      dma16(krb, k_bytes, area + piece * 1024, voff, tile * (KT * D * 2));
+    }
+  };
+  // Vt tile: D rows (dv) of 256 B (128 keys); this wave's rows [wave*D/8, +D/8), 4 rows per piece
+  auto dma_v = [&](int tile, char* area) {
+    const int ln = opaque_lane(lane);
+#pragma unroll
+    for (int i = 0; i < VINST; ++i) {
+      const int piece = wave_u * VINST + i;
+      const int dv = piece * 4 + (ln >> 4);
+      const int pslot = ln & 15;
+      const int voff = (dv * p.Npad + swz_slot<256>(dv, pslot) * 8) * 2;
+      dma16(vtb, v_bytes, area + piece * 1024, voff, tile * (KT * 2));
+    }
+  };
+  auto dma_stage = [&](int j) {
+    if (j + 1 < n_tiles) dma_k(j + 1, k_area(j));
+    if (j < n_att_tiles) dma_v(j, v_area(j));
+  };
+
+  f32x16 s[NKB];
+  frag pf[NKB][2];
+  constexpr int RING = 4;
+  auto qk = [&](const char* kbuf) {
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+    frag a[RING];
+    // address = (u ^ slot<<4) + block offset: one v_xor per read, nothing to keep in registers across the loop
+    const unsigned ku = (unsigned)(kbuf - lds) + qi * KROWB + (KROWB == 256 ? ((qi & 15) << 4) : (((qi >> 1) & 7) << 4));
+    auto kfrag = [&](int i) {   // step i: kb = i % NKB, kk = i / NKB
+      return *reinterpret_cast<const frag*>(lds + ((ku ^ ((2 * (i / NKB) + hi) << 4)) + (i % NKB) * 32 * KROWB));
+    };
+#pragma unroll
+    for (int i = 0; i < RING; ++i) a[i] = kfrag(i);
+#pragma unroll
+    for (int i = 0; i < NKB * KK; ++i) {
+      s[i % NKB] = Mfma<T>::mma(a[i % RING], qf[i / NKB], s[i % NKB]);
+      if (i + RING < NKB * KK) a[i % RING] = kfrag(i + RING);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, RING, 0);
+#pragma unroll
+    for (int i = 0; i < NKB * KK - RING; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, RING, 0);
+  };
+  auto pv = [&](const char* vbuf) {
+    frag a[RING];
+    const unsigned vu = (unsigned)(vbuf - lds) + qi * 256 + ((qi & 15) << 4);
+    auto vfrag = [&](int i) {   // step i: db = i % DB, (kb, t) = i / DB
+      const int db = i % DB, kt = i / DB, kb = kt >> 1, t = kt & 1;
+      return *reinterpret_cast<const frag*>(lds + ((vu ^ ((kb * 4 + t * 2 + hi) << 4)) + db * 32 * 256));
+    };
+#pragma unroll
+    for (int i = 0; i < RING; ++i) a[i] = vfrag(i);
+#pragma unroll
+    for (int i = 0; i < 2 * NKB * DB; ++i) {
+      const int db = i % DB, kt = i / DB;
+      o[db] = Mfma<T>::mma(a[i % RING], pf[kt >> 1][kt & 1], o[db]);
+      if (i + RING < 2 * NKB * DB) a[i % RING] = vfrag(i + RING);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, RING, 0);
+#pragma unroll
+    for (int i = 0; i < 2 * NKB * DB - RING; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, RING, 0);
+  };
+
+  auto softmax_tile = [&](int tile) {
+    const bool attend = tile < wave_att_tiles;
+    const bool edge = tile * KT + KT > wave_full_keys;
+    if (!STASH && !COLIMP && !MASK && !edge) {
+      // fully visible tile, no by-products: one reference rounding kept, "/ sqrt(d)" folded into the exponent
+      float mt[NKB];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        mt[kb] = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 v = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
+          s[kb][r] = v[0];
+          s[kb][r + 1] = v[1];
+          mt[kb] = max3_raw(mt[kb], v[0], v[1]);
+        }
+      }
+      const float m_tile = xor32_max(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3]))) * rsqrt_d;
+      const float m_new = fmaxf(m_run, m_tile);
+      const float m2 = m_new * kLog2e;
+      const float c2 = rsqrt_d * kLog2e;
+      float ls[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], c2, -m2));
+            ls[e & 3] += pvv;
+            pf[kb][t][e] = DT<T>::from_f32(pvv);
+          }
+      const float lsum = (ls[0] + ls[1]) + (ls[2] + ls[3]);
+      if (m_new != m_run) {
+        const float alpha = __expf(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        m_run = m_new;
+      }
+      l_run += lsum;
+      return;
+    }
+    float m_tile = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
+        float v = DT<T>::round(div_by_const(DT<T>::round(s[kb][r]), p.sqrt_d, rsqrt_d));
+        const int key = tile * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const bool inb = key < p.N;
+        if (STASH) {                                                                        // pre-mask (:116-119)
+          if (stash_vec) {
+            char* sw = lds + 2 * BUF + wave * (32 * SPITCH);
+            *reinterpret_cast<T*>(sw + qi * SPITCH + ((r & 3) + 8 * (r >> 2) + 4 * hi) * 2) = DT<T>::from_f32(v);
+          } else if (inb && qvalid) {
+            stashrow[key] = DT<T>::from_f32(v);
+          }
+        }
+        if (COLIMP) {
+          float cv = (inb && qvalid) ? v : 0.f;
+          cv = xor16_sum(group_sum<16>(cv));
+          if (qi == 0 && inb) atomicAdd(colrow + key, cv);
+        }
+        if (MASK) { if (inb) v = DT<T>::round(v + DT<T>::to_f32(maskrow[key])); }            // :132
+        v = (key < my_vis) ? v : -INFINITY;
+        s[kb][r] = v;
+        m_tile = fmaxf(m_tile, v);
+      }
+      if (STASH && stash_vec) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const char* sw = lds + 2 * BUF + wave * (32 * SPITCH);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int id = lane + 64 * i, row = id >> 2, c4 = id & 3;
+          const u32x4 piece = *reinterpret_cast<const u32x4*>(sw + row * SPITCH + c4 * 16);
+          const int qq = q0 + row, key0 = tile * KT + kb * 32 + c4 * 8;
+          if (qq < p.q_len && key0 < p.N) {
+            T* dst = p.scores + b * p.sc_sb + h * p.sc_sh + (int64_t)qq * p.sc_sq + key0;
+            if (key0 + 8 <= p.N) *reinterpret_cast<u32x4*>(dst) = piece;
+            else {
+              const T* pe = reinterpret_cast<const T*>(&piece);
+              for (int e = 0; e < p.N - key0; ++e) dst[e] = pe[e];
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+    if (!attend) return;
+    m_tile = xor32_max(m_tile);
+    const float m_new = fmaxf(m_run, m_tile);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float m2 = m_use * kLog2e;
+    float lsum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], kLog2e, -m2));
+          lsum += pvv;
+          pf[kb][t][e] = DT<T>::from_f32(pvv);
+        }
+    if (m_new != m_run) {
+      const float alpha = __expf(m_run - m_use);
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      m_run = m_new;
+    }
+    l_run += lsum;
+  };
+
+  // ---- prologue (all 8 waves together): K(0) parked in stage 1's K area, stage 0 = { K(1), Vt(0) } --------------
+  dma_k(0, k_area(1));
+  dma_stage(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0) (gfx9 encoding: vmcnt in bits 3:0 and 15:14)
+  __syncthreads();
+  if (wave_tiles > 0) qk(k_area(1));
+  __syncthreads();                                   // everyone is done with K(0): stage 1 may be filled
+  if (1 < n_tiles) dma_stage(1);
+  if (wave_tiles > 0) softmax_tile(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  if (grp == 1) __syncthreads();                     // hold half 1 one phase behind
+
+  // global phase 2t+2 is half 0's matrix phase of iteration t+1 and half 1's vector phase of iteration t: both issue
+  // stage t+2 there
+  for (int t = 0; t < n_tiles; ++t) {
+    // ---- matrix phase of iteration t -----------------------------------------------------------------------
+    if (grp == 0 && t >= 1 && t + 1 < n_tiles) dma_stage(t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t < wave_att_tiles) pv(v_area(t));
+    __builtin_amdgcn_sched_barrier(0);                   // P is dead from here on: keep S(t+1) out of its live range
+    if (t + 1 < wave_tiles) qk(k_area(t));
+    if (grp == 1) __builtin_amdgcn_s_waitcnt(0x0F70);    // half 1's pieces (issued one phase ago) have landed
+    __syncthreads();
+    // ---- vector phase ----------------------------------------------------------------------------------------
+    if (grp == 1 && t + 2 < n_tiles) dma_stage(t + 2);
+    if (t + 1 < wave_tiles) softmax_tile(t + 1);
+    if (grp == 0) __builtin_amdgcn_s_waitcnt(0x0F70);    // half 0's pieces (issued at the top of this iteration)
+    __syncthreads();
+  }
+  if (grp == 0) __syncthreads();
 
   // ---- epilogue: O = O^T / l, 4 consecutive dv per 8-byte store ---------------------------------
   const float l_tot = xor32_sum(l_run);
@@ -898,23 +837,26 @@ static inline int rows_leg(int dtype, int head_dim, int q_len) {
 }
 static inline int rows_splits(int units) { int s = 256 / (units > 0 ? units : 1); return s < 1 ? 1 : (s > 64 ? 64 : s); }
 
-static int prefill_variant() {   // 0 = ping-pong 8-wave kernel (default), 1 = the 4-wave kernel (A/B experiments)
+// Kernel choice.  No by-products (the prefill of the multi-turn protocol, the bench): 128-key tiles + LDS-DMA.  With a
+// stash / column-importance output the softmax phase carries the extra stores and reductions, and the 64-key kernel
+// (half the live scores per lane) is the one that stays out of scratch.  SPATTEN_PREFILL_VARIANT=1 forces the 64-key
+// kernel everywhere (A/B measurements).
+static int prefill_variant() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("SPATTEN_PREFILL_4WAVE"); v = (e && atoi(e) != 0) ? 1 : 0; }
+  if (v < 0) { const char* e = getenv("SPATTEN_PREFILL_VARIANT"); v = e ? atoi(e) : 0; if (v < 0 || v > 1) v = 0; }
   return v;
 }
 
 template <typename T, int D, bool ST, bool CI>
 static void launch_flash_m(const FlashParams<T>& p, hipStream_t st) {
-  if (prefill_variant() == 1) {
-    FlashParams<T> q = p;
-    q.nqb = ceil_div(p.q_len, 128);
-    const dim3 grid((unsigned)(q.nqb * p.H * p.B));
-    if (p.mask) hipLaunchKernelGGL((prefill_flash_kernel<T, D, ST, CI, true>), grid, dim3(256), 0, st, q);
-    else hipLaunchKernelGGL((prefill_flash_kernel<T, D, ST, CI, false>), grid, dim3(256), 0, st, q);
-    return;
-  }
   const dim3 grid((unsigned)(p.nqb * p.H * p.B));
+  if constexpr (!ST && !CI) {
+    if (prefill_variant() == 0) {
+      if (p.mask) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, false, true>), grid, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, false, false>), grid, dim3(512), 0, st, p);
+      return;
+    }
+  }
   if (p.mask) hipLaunchKernelGGL((prefill_pp_kernel<T, D, ST, CI, true>), grid, dim3(512), 0, st, p);
   else hipLaunchKernelGGL((prefill_pp_kernel<T, D, ST, CI, false>), grid, dim3(512), 0, st, p);
 }
@@ -946,7 +888,7 @@ extern "C" size_t spatten_prefill_workspace_bytes(int dtype, int batch, int head
     const int S = rows_splits((int)(units > (1u << 30) ? (1u << 30) : units));
     return 256 + align256(units * sizeof(unsigned)) + (S > 1 ? units * S * (head_dim + 2) * sizeof(unsigned long long) : 0);
   }
-  const size_t es = 2, npad = (size_t)ceil_div(kv_len, 64) * 64;
+  const size_t es = 2, npad = (size_t)ceil_div(kv_len, 128) * 128;
   return 256 + align256((size_t)batch * heads * q_len * head_dim * es) + align256((size_t)batch * kv_heads * head_dim * npad * es);
 }
 
@@ -981,7 +923,7 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
                        kv_heads, head_dim, kv_len, pos_q0, q_len, causal, S, st);
   }
 
-  const int npad = ceil_div(kv_len, 64) * 64;
+  const int npad = ceil_div(kv_len, 128) * 128;      // Vt rows padded to whole 128-key tiles (zeros beyond kv_len)
   void* qrot = ws;
   void* vt = ws + align256((size_t)batch * heads * q_len * head_dim * 2);
   // (1) rotated queries, contiguous [B,H,q,d]

@@ -16,5 +16,5 @@ for d in ("pmc_pf", "pmc_pf2", "pmc_pf3"):
         if ("prefill_pp" in r["Kernel_Name"] or "prefill_flash" in r["Kernel_Name"]) and ("Lb0ELb0ELb0E" in r["Kernel_Name"] or "false, false, false" in r["Kernel_Name"]) and r["Grid_Size"] == str(64*32*256):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in sorted(acc.items()):
-        print(f"{k:34s} {len(v):3d} {sum(v) / len(v):16.0f}  per wave-tile {sum(v) / len(v) / 532480:9.1f}")
+        print(f"{k:34s} {len(v):3d} {sum(v) / len(v):16.0f}  per wave-tile {sum(v) / len(v) / 266240:9.1f}")
 PY
