@@ -313,6 +313,13 @@ __device__ inline float div_by_const(float x, float c, float rc) {
   return fmaf(e, rc, y);
 }
 
+// The reference's "logits / sqrt(d) -> dtype" step (modify_llama.py:111-113) for a logit x that already IS a model-dtype
+// value.  bf16: round(x * (1/c)) equals round(x / c) for EVERY bf16 x at c = sqrt(128) (all 128 mantissas x all
+// exponents enumerated against the fp32 division; c = 8 and 16 are exact anyway), so the Newton correction is not
+// needed; f16 (11-bit mantissa) has inputs where it is.
+template <typename T> __device__ inline float logit_scale(float x, float c, float rc) { return div_by_const(x, c, rc); }
+template <> __device__ inline float logit_scale<bf16_t>(float x, float c, float rc) { return x * rc; }
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // progressive-quant key planes handed to decode_rows (decode_attn.hip); see pq.hip for the storage format

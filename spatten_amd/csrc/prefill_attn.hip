@@ -117,6 +117,7 @@ struct FlashParams {
 };
 
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kDeferMax = 8.0f;   // natural-log units of the scaled logits
 
 template <int ROWB> __device__ inline int lds_off(int row, int slot) {
   // 16-byte slots, XOR-swizzled so the 16 lanes of a ds_read_b128 group land on distinct bank quads
@@ -308,21 +309,22 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
     const bool attend = tile < wave_att_tiles;
     const bool edge = tile * 64 + 64 > wave_full_keys;
     if (!STASH && !COLIMP && !MASK && !edge) {
-      // fully visible tile, no by-products: one reference rounding kept, "/ sqrt(d)" folded into the exponent
+      // fully visible tile, no by-products; both reference roundings kept (see (3c))
       float mt[2] = {-INFINITY, -INFINITY};
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const f32x2 v = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
+          const f32x2 x = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
+          const f32x2 v = round2<T>(f32x2{logit_scale<T>(x[0], p.sqrt_d, rsqrt_d), logit_scale<T>(x[1], p.sqrt_d, rsqrt_d)});
           s[kb][r] = v[0];
           s[kb][r + 1] = v[1];
           mt[kb] = max3_raw(mt[kb], v[0], v[1]);
         }
-      const float m_tile = xor32_max(fmaxf(mt[0], mt[1])) * rsqrt_d;
-      const float m_new = fmaxf(m_run, m_tile);
+      const float m_tile = xor32_max(fmaxf(mt[0], mt[1]));
+      const bool move = __builtin_amdgcn_ballot_w64(m_tile - m_run > kDeferMax) != 0;   // deferred rescale, see (3c)
+      const float m_new = move ? fmaxf(m_run, m_tile) : m_run;
       const float m2 = m_new * kLog2e;
-      const float c2 = rsqrt_d * kLog2e;
       float ls[4] = {0.f, 0.f, 0.f, 0.f};         // independent partial sums: no 32-deep dependent add chain
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], c2, -m2));
+            const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], kLog2e, -m2));
             ls[e & 3] += pvv;
             pf[kb][t][e] = DT<T>::from_f32(pvv);
           }
@@ -664,23 +666,29 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     const bool attend = tile < wave_att_tiles;
     const bool edge = tile * KT + KT > wave_full_keys;
     if (!STASH && !COLIMP && !MASK && !edge) {
-      // fully visible tile, no by-products: one reference rounding kept, "/ sqrt(d)" folded into the exponent
+      // fully visible tile, no by-products.  Both reference roundings are kept (matmul -> dtype, "/ sqrt(d)" -> dtype,
+      // modify_llama.py:111-113): at large logits a 16-bit ulp is a visible change of P.
       float mt[NKB];
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
         mt[kb] = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const f32x2 v = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
+          const f32x2 x = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
+          const f32x2 v = round2<T>(f32x2{logit_scale<T>(x[0], p.sqrt_d, rsqrt_d), logit_scale<T>(x[1], p.sqrt_d, rsqrt_d)});
           s[kb][r] = v[0];
           s[kb][r + 1] = v[1];
           mt[kb] = max3_raw(mt[kb], v[0], v[1]);
         }
       }
-      const float m_tile = xor32_max(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3]))) * rsqrt_d;
-      const float m_new = fmaxf(m_run, m_tile);
+      const float m_tile = xor32_max(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3])));
+      // deferred rescale: the running maximum only moves (and O is only rescaled: 64 multiplies per lane) when some
+      // row of the wave outgrew it by more than kDeferMax; until then P = exp(s - m_run) <= e^kDeferMax, which bf16 P
+      // (constant relative precision) and the fp32 sums carry without loss.  O / l is mathematically unchanged.
+      // All of the previous tile's P·V is already in O (matrix phase, program order), so the decision covers it.
+      const bool move = __builtin_amdgcn_ballot_w64(m_tile - m_run > kDeferMax) != 0;   // -inf start: inf > thr
+      const float m_new = move ? fmaxf(m_run, m_tile) : m_run;
       const float m2 = m_new * kLog2e;
-      const float c2 = rsqrt_d * kLog2e;
       float ls[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)
@@ -688,7 +696,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], c2, -m2));
+            const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], kLog2e, -m2));
             ls[e & 3] += pvv;
             pf[kb][t][e] = DT<T>::from_f32(pvv);
           }

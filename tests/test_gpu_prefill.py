@@ -98,6 +98,36 @@ def test_prefill_vs_oracle(dt, d, P, ql):
     check_stash(st2, s, dt)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_prefill_deferred_rescale_spikes(dt):
+    """The no-stash flash path only moves its running maximum when a row outgrows it by more than a threshold.  Rare
+    and data dependent on random inputs, so force it: keys whose logits jump by > threshold (must rescale), by less
+    (deferred: P > 1 until the next move) and again by more, at different tiles, with per-row magnitudes."""
+    B, H, Hkv, d, P, ql = 1, 2, 2, 128, 768, 256
+    q, k, v, past = attn_inputs(B, H, Hkv, d, P, ql, dt, seed=4242)
+    N = P + ql
+    rng = np.random.default_rng(7)
+    # logit ~ a_q * b_j * 2 / sqrt(d) on the slowest rotary pair (dims 63 / 127: ~identity under RoPE at these positions)
+    a = orc.round_dt((6.0 * (0.5 + rng.random((B, H, ql)))).astype(np.float32), dt)
+    q[..., 63] = a
+    q[..., 127] = a
+    kc = np.concatenate([past[0], k], 2)
+    kc[..., 63] = 0
+    kc[..., 127] = 0
+    for pos, b in ((40, 4.0), (300, 9.0), (430, 11.0), (700, 22.0), (850, 23.5)):   # tiles 0, 2, 3, 5, 6 of 128 keys
+        kc[:, :, pos, 63] = b
+        kc[:, :, pos, 127] = b
+    kc = orc.round_dt(kc, dt)
+    past = (kc[:, :, :P], past[1])
+    k = kc[:, :, P:]
+    pos_ids = np.tile(np.arange(P, N)[None], (B, 1))
+    o, stash, _ = orc.attention_core(q, k, v, past[0], past[1], pos_ids, orc.causal_mask(B, ql, N, dt), dt)
+    assert np.diff(np.sort(stash[0, 0, 0, [40, 300, 430, 700]])).max() > 8.0        # the jumps are really there
+    for variant_stash in (False, True):
+        out, _, _ = run_prefill(q, k, v, past, dt, causal=True, stash=variant_stash)
+        np.testing.assert_allclose(out, o, **OUT_TOL[dt])
+
+
 # ---- the patched forward through a stub module with the transformers-4.33 attribute surface ---------
 class Fixed(nn.Module):
     def __init__(self):

@@ -61,3 +61,19 @@ def test_head_parallel_ranges_single_process():
     assert work is None and full.shape == (2, 1, 64)
     none, handle = hp.gather_heads(torch.zeros(2, 1, 64), async_op=True)
     assert none is None and handle.wait().shape == (2, 1, 64)
+
+
+def test_bf16_logit_scale_by_reciprocal_is_exact():
+    """The flash kernel scales a bf16 logit by 1/sqrt(128) with ONE multiply (csrc/common.h logit_scale): claimed equal
+    to the reference's fp32 division followed by the bf16 rounding for every bf16 input."""
+    import math
+    import numpy as np
+    from oracle import spatten_oracle as orc
+    c = np.float32(math.sqrt(128))
+    rc = np.float32(1.0) / c
+    m = np.arange(128, 256).astype(np.float32)
+    for e in range(-100, 100):
+        x = orc.round_dt(m * np.float32(2.0) ** np.float32(e), "bf16")
+        for sgn in (1.0, -1.0):
+            xs = (x * np.float32(sgn)).astype(np.float32)
+            assert np.array_equal(orc.round_dt((xs / c).astype(np.float32), "bf16"), orc.round_dt((xs * rc).astype(np.float32), "bf16")), e
