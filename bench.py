@@ -376,14 +376,14 @@ def main():
                 cp, sp = ops.rope_table(Np, d, dt, dev)
                 Krp2 = ops.rope_single(Kp2, cp, sp)
                 op = torch.empty(1, Np, HEADS * d, dtype=dt, device=dev)
-                for _ in range(2):
+                for _ in range(3):
                     ops.attn_prefill(Qp, Krp2, Vp2, Np, cp, sp, 0, causal=True, out=op)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for _ in range(5):
+                for _ in range(20):
                     ops.attn_prefill(Qp, Krp2, Vp2, Np, cp, sp, 0, causal=True, out=op)
                 torch.cuda.synchronize()
-                tp = (time.perf_counter() - t0) / 5
+                tp = (time.perf_counter() - t0) / 20
                 fl = 4 * HEADS * d * Np * (Np + 1) / 2
                 extras["prefill_8192_causal_ms_per_layer"] = round(tp * 1e3, 3)
                 extras["prefill_8192_causal_TFLOPs"] = round(fl / tp / 1e12, 1)

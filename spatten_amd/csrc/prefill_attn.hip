@@ -810,6 +810,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     if (t < wave_att_tiles) pv(v_area(t));
     __builtin_amdgcn_sched_barrier(0);                   // P is dead from here on: keep S(t+1) out of its live range
     if (t + 1 < wave_tiles) qk(k_area(t));
+
     if (grp == 1) __builtin_amdgcn_s_waitcnt(0x0F70);    // half 1's pieces (issued one phase ago) have landed
     __syncthreads();
     // ---- vector phase ----------------------------------------------------------------------------------------

@@ -13,15 +13,16 @@ for N in (2048, 8192):
     kr = ops.rope_single(k, cos, sin)
     out = torch.empty(B, N, H * d, device="cuda", dtype=dt)
     for name, kw in (("causal", dict(causal=True)), ("causal+colimp", dict(causal=True, col_importance=torch.zeros(B, H, N, device="cuda")))):
-        for _ in range(2):
+        reps = 20 if name == "causal" else 5
+        for _ in range(3):
             ops.attn_prefill(q, kr, v, N, cos, sin, 0, out=out, **kw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5):
+        for _ in range(reps):
             ops.attn_prefill(q, kr, v, N, cos, sin, 0, out=out, **kw)
         e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
+        ms = e0.elapsed_time(e1) / reps
         fl = 4 * B * H * d * N * (N + 1) / 2
         print(f"prefill N={N} {name}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s (causal flops)")
 # reference-parity mode: full stash [B,H,q,N] written (modify_llama.py:116-119)
