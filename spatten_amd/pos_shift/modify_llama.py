@@ -107,10 +107,12 @@ def llama_pos_shift_attention_forward(
             position_ids = position_ids.expand(bsz, q_len)
         position_ids = position_ids.contiguous()
 
-    stash = torch.empty(bsz, num_heads, q_len, kv_seq_len, dtype=dtype, device=device)
+    cascade = getattr(self, "_spatten_cascade", None)
+    # extension: no [B,H,q,N] stash for multi-token forwards (enable_spatten_llm(..., prefill_stash=False))
+    want_stash = q_len == 1 or output_attentions or cascade is not None or bool(getattr(self, "spatten_prefill_stash", True))
+    stash = torch.empty(bsz, num_heads, q_len, kv_seq_len, dtype=dtype, device=device) if want_stash else None
     if attention_mask is not None:
         attention_mask = attention_mask.to(dtype)
-    cascade = getattr(self, "_spatten_cascade", None)
     lse = torch.empty(bsz, num_heads, 1, 2, dtype=torch.float32, device=device) if (cascade and q_len == 1) else None
     if q_len == 1:
         slab.ensure_shadow(past_len)

@@ -189,6 +189,15 @@ def test_forward_matches_reference_goldens():
         assert new_past[0].shape == (B, Hkv, N, d) and np.array_equal(host(new_past[0]), want_k), name
         if pkv is not None:
             assert np.array_equal(host(pkv[0]), past[0])       # inputs never mutated
+        # extension flags (enable_spatten_llm(..., prefill_stash=False, assume_causal=True)): same output, no stash for
+        # multi-token forwards, the decode stash still written
+        if mask_kind == "causal":
+            m2 = StubAttn(H, Hkv, d)
+            m2.spatten_prefill_stash, m2.spatten_assume_causal = False, True
+            out2, _, _ = fwd(m2, q, k, v, pkv, pos, mask, dt)
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(host(out2), g[f"{name}_out"], err_msg=name, **OUT_TOL[dt])
+            assert (m2.attn_scores is None) == (ql > 1)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
