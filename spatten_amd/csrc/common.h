@@ -76,6 +76,12 @@ template <> struct Vec8<float> {
     r.b = *reinterpret_cast<const f32x4*>(p + 4);
     return r;
   }
+  __device__ static inline raw ldg_stream(const float* p) {
+    raw r;
+    r.a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    r.b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
+    return r;
+  }
   __device__ static inline void stg(float* p, const raw& r) {
     *reinterpret_cast<f32x4*>(p) = r.a;
     *reinterpret_cast<f32x4*>(p + 4) = r.b;
@@ -96,6 +102,7 @@ template <> struct Vec8<bf16_t> {
   using raw = u32x4;
   typedef bf16_t bf2 __attribute__((ext_vector_type(2)));
   __device__ static inline raw ldg(const bf16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
+  __device__ static inline raw ldg_stream(const bf16_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
   __device__ static inline void stg(bf16_t* p, const raw& r) { *reinterpret_cast<u32x4*>(p) = r; }
   __device__ static inline void unpack(const raw& r, float (&v)[8]) {
 #pragma unroll
@@ -120,6 +127,7 @@ template <> struct Vec8<f16_t> {
   using raw = u32x4;
   typedef f16_t h2 __attribute__((ext_vector_type(2)));
   __device__ static inline raw ldg(const f16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
+  __device__ static inline raw ldg_stream(const f16_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
   __device__ static inline void stg(f16_t* p, const raw& r) { *reinterpret_cast<u32x4*>(p) = r; }
   __device__ static inline void unpack(const raw& r, float (&v)[8]) {
 #pragma unroll
