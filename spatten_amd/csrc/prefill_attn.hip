@@ -514,7 +514,6 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   constexpr int KK = D / 16, DB = D / 32, KROWB = D * 2;
   constexpr int KBYTES = KT * KROWB, VBYTES = D * 256, BUF = KBYTES + VBYTES;   // Vt row = 128 keys = 256 B
   constexpr int KINST = KBYTES / 1024 / 8, VINST = VBYTES / 1024 / 8;           // DMA instructions per wave per tile
-  constexpr int KROWS_PER_INST = 1024 / KROWB;                                  // K rows covered by one 1-KiB piece
   using frag = typename Mfma<T>::frag;
   constexpr int SPITCH = 80;
   constexpr int SBYTES = STASH ? 8 * 32 * SPITCH : 0;
@@ -579,29 +578,32 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   auto v_area = [&](int stage) -> char* { return lds + (stage & 1) * BUF + KBYTES; };   // holds Vt(stage)
   // buffer descriptors (wave-uniform): rows past N read as zeros (out of range), no clamping arithmetic per lane
   const int64_t k_bytes = (int64_t)p.N * D * 2, v_bytes = (int64_t)D * p.Npad * 2;
-  // this wave's pieces of K tile `tile` -> area (rows [wave*KT/8, +KT/8)); per-lane byte offset within the tile
+  // This wave's 1-KiB pieces of a tile.  Lane (row-in-piece lr, physical slot ps) fetches logical slot ps ^ f(row); with
+  // f(row) = f(first row of the piece) ^ g(lr) (disjoint bits) the per-lane byte offset is ONE xor away from a value
+  // computed once per call, and everything wave-uniform (tile, piece) rides in the scalar offset.
+  // (opaque_lane: hoisted out of the tile loop the lane terms get spilled, and every reload's vmcnt(0) then
+  //  serialises the DMA instructions.)
   auto dma_k = [&](int tile, char* area) {
-    const int ln = opaque_lane(lane);   // recompute the per-lane offsets here: hoisted out of the tile loop they get
-                                        // spilled, and every reload's vmcnt(0) then serialises the DMA instructions
+    constexpr int LPRW = KROWB / 16;                                         // lanes per K row
+    const int ln = opaque_lane(lane);
+    const int lr = ln / LPRW, ps = ln % LPRW;
+    const int base = lr * KROWB + ((ps ^ (KROWB == 256 ? lr : (lr >> 1))) << 4);
 #pragma unroll
     for (int i = 0; i < KINST; ++i) {
       const int piece = wave_u * KINST + i;                                  // 1-KiB piece index within the tile
-      const int row = piece * KROWS_PER_INST + ln / (KROWB / 16);
-      const int pslot = ln % (KROWB / 16);
-      const int voff = (row * D + swz_slot<KROWB>(row, pslot) * 8) * 2;
-      dma16(krb, k_bytes, area + piece * 1024, voff, tile * (KT * D * 2));
+      const int fp = KROWB == 256 ? ((piece * 4) & 15) : ((piece * 4) & 7);  // swizzle key of the piece's first row
+      dma16(krb, k_bytes, area + piece * 1024, base ^ (fp << 4), tile * (KT * D * 2) + piece * 1024);
     }
   };
   // Vt tile: D rows (dv) of 256 B (128 keys); this wave's rows [wave*D/8, +D/8), 4 rows per piece
   auto dma_v = [&](int tile, char* area) {
     const int ln = opaque_lane(lane);
+    const int l4 = ln >> 4, ps = ln & 15;
+    const int base = l4 * p.Npad * 2 + ((ps ^ l4) << 4);
 #pragma unroll
     for (int i = 0; i < VINST; ++i) {
       const int piece = wave_u * VINST + i;
-      const int dv = piece * 4 + (ln >> 4);
-      const int pslot = ln & 15;
-      const int voff = (dv * p.Npad + swz_slot<256>(dv, pslot) * 8) * 2;
-      dma16(vtb, v_bytes, area + piece * 1024, voff, tile * (KT * 2));
+      dma16(vtb, v_bytes, area + piece * 1024, base ^ (((piece * 4) & 15) << 4), tile * (KT * 2) + piece * 4 * p.Npad * 2);
     }
   };
   auto dma_stage = [&](int j) {
