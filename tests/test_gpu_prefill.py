@@ -98,6 +98,28 @@ def test_prefill_vs_oracle(dt, d, P, ql):
     check_stash(st2, s, dt)
 
 
+@pytest.mark.parametrize("case", [("bf16", 128, 1, 4, 4, 0, 700), ("bf16", 128, 2, 4, 1, 411, 300), ("f16", 128, 1, 2, 2, 1000, 257),
+                                  ("bf16", 64, 1, 8, 2, 129, 520), ("f16", 64, 2, 2, 2, 0, 385), ("bf16", 128, 1, 2, 2, 255, 1)])
+def test_prefill_multi_block_shapes_vs_oracle(case):
+    """Several 256-query workgroups per head, ragged last blocks, tiles that straddle N, GQA, batch: the by-product-free
+    kernel (128-key tiles, LDS-DMA) and the stash kernel (64-key tiles) against the oracle."""
+    dt, d, B, H, Hkv, P, ql = case
+    q, k, v, past = attn_inputs(B, H, Hkv, d, P, ql, dt, seed=900 + P + ql)
+    N = P + ql
+    pos = np.tile(np.arange(P, N)[None], (B, 1))
+    o, stash, _ = orc.attention_core(q, k, v, None if past is None else past[0], None if past is None else past[1], pos,
+                                     orc.causal_mask(B, ql, N, dt), dt)
+    out, _, _ = run_prefill(q, k, v, past, dt, causal=True, stash=False)
+    np.testing.assert_allclose(out, o, **OUT_TOL[dt])
+    out, st, _ = run_prefill(q, k, v, past, dt, causal=True, stash=True)
+    np.testing.assert_allclose(out, o, **OUT_TOL[dt])
+    check_stash(st, stash, dt)
+    # non-causal (every key visible to every query), no mask
+    o2, _, _ = orc.attention_core(q, k, v, None if past is None else past[0], None if past is None else past[1], pos, None, dt)
+    out2, _, _ = run_prefill(q, k, v, past, dt, causal=False, stash=False)
+    np.testing.assert_allclose(out2, o2, **OUT_TOL[dt])
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 def test_prefill_deferred_rescale_spikes(dt):
     """The no-stash flash path only moves its running maximum when a row outgrows it by more than a threshold.  Rare
