@@ -352,19 +352,32 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
     float m_tile = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113), two scores at a time
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 x = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
+        const f32x2 v2 = round2<T>(f32x2{logit_scale<T>(x[0], p.sqrt_d, rsqrt_d), logit_scale<T>(x[1], p.sqrt_d, rsqrt_d)});
+        s[kb][r] = v2[0];
+        s[kb][r + 1] = v2[1];
+      }
+      if (STASH && stash_vec) {
+        // pre-mask stash (:116-119): registers 4g..4g+3 hold 4 consecutive keys -> one 8-byte LDS store per group
+        char* sw = lds + 2 * BUF + wave * (32 * SPITCH) + qi * SPITCH + 8 * hi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          T q4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q4[e] = DT<T>::from_f32(s[kb][4 * g + e]);       // exact: already model-dtype values
+          *reinterpret_cast<u32x2*>(sw + 16 * g) = *reinterpret_cast<u32x2*>(q4);
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
-        float v = DT<T>::round(div_by_const(DT<T>::round(s[kb][r]), p.sqrt_d, rsqrt_d));
+        float v = s[kb][r];
         const int key = tile * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         const bool inb = key < p.N;
-        if (STASH) {                                                                        // pre-mask (:116-119)
-          if (stash_vec) {
-            char* sw = lds + 2 * BUF + wave * (32 * SPITCH);
-            *reinterpret_cast<T*>(sw + qi * SPITCH + ((r & 3) + 8 * (r >> 2) + 4 * hi) * 2) = DT<T>::from_f32(v);
-          } else if (inb && qvalid) {
-            stashrow[key] = DT<T>::from_f32(v);
-          }
+        if (STASH && !stash_vec) {
+          if (inb && qvalid) stashrow[key] = DT<T>::from_f32(v);
         }
         if (COLIMP) {
           float cv = (inb && qvalid) ? v : 0.f;
