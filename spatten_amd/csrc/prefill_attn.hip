@@ -209,6 +209,15 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
   T* stashrow = STASH ? p.scores + b * p.sc_sb + h * p.sc_sh + (int64_t)min(myq, p.q_len - 1) * p.sc_sq : nullptr;
   float* colrow = COLIMP ? p.col_imp + (int64_t)(b * p.H + h) * p.N : nullptr;
   const bool stash_vec = STASH && ((p.sc_sq | p.sc_sh | p.sc_sb) % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.scores) & 15) == 0);
+  // COLIMP: B operand of the transposing product — perm[t][k][n] = 1 where column n is the key that the A operand's
+  // k-th element of chunk t holds (a lane's registers enumerate keys as (e&3) + 8(e>>2) + 16t + 4hi)
+  frag perm[2];
+  if (COLIMP) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) perm[t][e] = DT<T>::from_f32(qi == (e & 3) + 8 * (e >> 2) + 16 * t + 4 * hi ? 1.f : 0.f);
+  }
 
   auto k_area = [&](int stage) -> char* { return lds + (stage & 1) * BUF; };            // holds K(stage + 1)
   auto v_area = [&](int stage) -> char* { return lds + (stage & 1) * BUF + KBYTES; };   // holds Vt(stage)
@@ -371,6 +380,29 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
           *reinterpret_cast<u32x2*>(sw + 16 * g) = *reinterpret_cast<u32x2*>(q4);
         }
       }
+      if (COLIMP) {
+        // column sums over this wave's 32 queries (reference-mode importance, kv_cache_token_pruning.py:51, acausal
+        // logits included) on the matrix pipe: the rounded logits are exact model-dtype values, so S·Perm with a 0/1
+        // permutation matrix is an exact TRANSPOSE into the accumulator layout — afterwards a lane owns one KEY and 16
+        // of the 32 queries, and the sum over queries is 15 adds + one lane <-> lane+32 exchange, then ONE atomic
+        // instruction for the 32 keys (instead of 5 cross-lane adds per score and an atomic per register).
+        f32x16 ct;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ct[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          frag sf;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sf[e] = DT<T>::from_f32(qvalid ? s[kb][t * 8 + e] : 0.f);
+          ct = Mfma<T>::mma(sf, perm[t], ct);
+        }
+        float cs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cs += ct[r];
+        cs = xor32_sum(cs);
+        const int ckey = tile * 64 + kb * 32 + qi;
+        if (hi == 0 && ckey < p.N) atomicAdd(colrow + ckey, cs);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = s[kb][r];
@@ -378,11 +410,6 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
         const bool inb = key < p.N;
         if (STASH && !stash_vec) {
           if (inb && qvalid) stashrow[key] = DT<T>::from_f32(v);
-        }
-        if (COLIMP) {
-          float cv = (inb && qvalid) ? v : 0.f;
-          cv = xor16_sum(group_sum<16>(cv));
-          if (qi == 0 && inb) atomicAdd(colrow + key, cv);
         }
         if (MASK) { if (inb) v = DT<T>::round(v + DT<T>::to_f32(maskrow[key])); }            // :132
         v = (key < my_vis) ? v : -INFINITY;
