@@ -44,9 +44,10 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the dense / eager comparison legs")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL path even with one rank (testing)")
-    ap.add_argument("--gather", choices=["grouped", "per-layer"], default="grouped",
-                    help="N>1: issue the 32 per-layer all-gathers of a token as ONE RCCL group after the token's "
-                         "attention graph (default), or one eager collective per layer")
+    ap.add_argument("--gather", choices=["flat", "grouped", "per-layer"], default="flat",
+                    help="N>1, after a token's attention graph: ONE all-gather of the 32 layers' output slices, which "
+                         "live in one flat buffer (default); the 32 per-layer all-gathers as one RCCL group; or one "
+                         "eager collective per layer")
     return ap.parse_args()
 
 
@@ -154,9 +155,11 @@ def main():
     stash = [torch.empty(B, Hl, cap, dtype=dt, device=dev) for _ in range(L)]
     # attention outputs (and all-gather receive buffers) are double-buffered by the parity of the position in the
     # turn: the RCCL gather of token t then overlaps the attention graph of token t+1 without sharing a buffer
-    outs2 = [[torch.empty(B, Hl * d, dtype=dt, device=dev) for _ in range(L)] for _ in range(2)]
+    outs_flat = [torch.empty(L, B, Hl * d, dtype=dt, device=dev) for _ in range(2)]   # all layers' slices of one token
+    outs2 = [[outs_flat[par][l] for l in range(L)] for par in range(2)]
     outs = outs2[0]
     staging2 = [[hp.gather_staging(B, 1, d, dt, dev) for _ in range(L)] for _ in range(2)] if dist_on else None
+    staging_flat = [torch.empty(world_eff * L * B * Hl * d, dtype=dt, device=dev) for _ in range(2)] if dist_on else None
 
     def prune():
         ops.prune_layers(importance, Kp, Vp, CTX, lo, hi, IMPORTANT, dst=(Kd, Vd, Krd), plan=plan, idx=idx,
@@ -170,10 +173,12 @@ def main():
     def gather_token(par):
         """The exchange step of the head-parallel path: every layer's [B, H/N*d] slice -> [B, H*d] on all ranks.
         Collectives are NOT captured into HIP graphs (torch's RCCL watchdog aborts on captured work on this
-        stack), so they are issued eagerly after the token's attention graph: as one RCCL group of 32
-        all-gathers (one launch), or one by one with --gather per-layer.  Returns an object whose ``wait()``
+        stack), so they are issued eagerly after the token's attention graph: one all-gather of the flat
+        [L, B, H/N*d] buffer (default), the 32 per-layer all-gathers as one RCCL group, or one by one.  Returns an object whose ``wait()``
         orders the current stream after the collectives (no host block)."""
         import torch.distributed as dist
+        if args.gather == "flat":          # [world, L, B, H/N*d]: rank r's block holds its heads of every layer
+            return dist.all_gather_into_tensor(staging_flat[par], outs_flat[par].view(-1), async_op=True)
         oo, ss = outs2[par], staging2[par]
         if args.gather == "grouped" and hasattr(dist, "_coalescing_manager"):
             with dist._coalescing_manager(device=dev, async_ops=True) as cm:
