@@ -19,6 +19,9 @@ build/%.o: spatten_amd/csrc/%.hip spatten_amd/csrc/common.h include/spatten.h
 # the flash kernels: no SLP vectorisation — packed fp32 VALU (v_pk_mul/add/fma_f32) issued beside MFMAs costs ~+22
 # cycles per instruction on gfx950 (measured: 650 -> 740 TFLOP/s with the packing gone)
 FLAGS_prefill_attn := -fno-slp-vectorize
+# the decode kernels: the first 16 kernel-argument dwords are preloaded into SGPRs at wave launch (decode_lean_kernel
+# puts what the first K/V loads need there)
+FLAGS_decode_attn := -mllvm -amdgpu-kernarg-preload-count=16
 
 $(LIB): $(OBJS)
 	@mkdir -p spatten_amd/lib

@@ -112,7 +112,7 @@ __device__ inline void store_granule(unsigned long long* g, float v) {
 // NT: K/V rows are fetched with the non-temporal cache policy (each row is used once per launch: -0.5 us of 13.7 at
 // C2); off when several query rows (the rows leg of prefill) re-read the same K/V through L2.
 template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0, bool NT = LEAN>
-__global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const DecodeParams<T> p) {
+__device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   constexpr bool SCORES_ONLY = (MODE == 1);
   constexpr bool SCORES_IN = (MODE == 2);
   constexpr bool PQ = (KSRC != 0);
@@ -499,6 +499,26 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const Decod
   SPATTEN_TSTAMP(4);
 }
 
+template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0, bool NT = LEAN>
+__global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const DecodeParams<T> p) {
+  decode_body<T, D, UNR, MODE, LEAN, KSRC, NT>(p);
+}
+
+// The plain decode step with its launch-critical arguments FIRST and 32-bit strides: built with
+// -amdgpu-kernarg-preload-count=16 (Makefile) the first 16 kernel-argument dwords arrive in SGPRs with the wave, so
+// the first K/V tile loads are issued without waiting for a scalar load of the argument block (the other arguments
+// are fetched while those loads are in flight).
+template <typename T, int D, int UNR>
+__global__ __launch_bounds__(kDecodeThreads) void decode_lean_kernel(T* krc, T* vc, const T* k_new, const T* v_new,
+                                                                     int kv_sb, int kv_sh, int new_sb, int new_sh,
+                                                                     int N, int chunk, int H, const DecodeParams<T> rest) {
+  DecodeParams<T> p = rest;
+  p.krc = krc; p.vc = vc; p.k_new = k_new; p.v_new = v_new;
+  p.kv_sb = kv_sb; p.kv_sh = kv_sh; p.new_sb = new_sb; p.new_sh = new_sh;
+  p.N = N; p.chunk = chunk; p.H = H;
+  decode_body<T, D, UNR, 0, true, 0, true>(p);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -555,7 +575,12 @@ static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_onl
   const bool lean = p.n_q == 1 && p.Hkv == p.H && !p.mask && !p.pos_ids && !p.head_ids && !p.causal;
   if (lean && decode_unr_for(DT<T>::kId) == 4) {
     constexpr int U = sizeof(T) == 4 ? 2 : 4;
-    hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, true>), grid, dim3(kDecodeThreads), 0, stream, p);
+    const int64_t lim = 0x7FFFFFFF;
+    if (p.kv_sb <= lim && p.kv_sh <= lim && p.new_sb <= lim && p.new_sh <= lim)
+      hipLaunchKernelGGL((decode_lean_kernel<T, D, U>), grid, dim3(kDecodeThreads), 0, stream, p.krc, p.vc, p.k_new, p.v_new,
+                         (int)p.kv_sb, (int)p.kv_sh, (int)p.new_sb, (int)p.new_sh, p.N, p.chunk, p.H, p);
+    else
+      hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, true>), grid, dim3(kDecodeThreads), 0, stream, p);
     return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
   }
   switch (decode_unr_for(DT<T>::kId)) {
