@@ -288,7 +288,7 @@ def main():
                     traffic = int(json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["traffic_bytes_per_launch"])
             except Exception:
                 traffic = None
-            result["roofline"] = {"kernel": "decode_attn_kernel<bf16,128>", "bound": "hbm", "achieved": round(gbs, 1),
+            result["roofline"] = {"kernel": "decode_lean_kernel<bf16,128> (decode_attn.hip)", "bound": "hbm", "achieved": round(gbs, 1),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                   "traffic": traffic, "avg_launch_us": round(us, 3),
                                   "algorithmic_bytes_per_launch": int(algo_bytes)}

@@ -11,10 +11,10 @@ done
 python3 - $R $N <<'PY'
 import csv, glob, json, sys
 R, N = sys.argv[1], int(sys.argv[2])
-out = {"kernel": "decode_attn_kernel<bf16,128,4>", "workload": f"B=1 H=32 d=128 kv_len={N} bf16, stash on (tools/mb/decode_bench)"}
+out = {"kernel": "decode_lean_kernel<bf16,128,4> (= decode_body, plain decode step)", "workload": f"B=1 H=32 d=128 kv_len={N} bf16, stash on (tools/mb/decode_bench)"}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"{R}/gpurun_out/pmc_{c}/**/*counter_collection.csv", recursive=True)[0]
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "decode_attn_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c]
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if ("decode_attn_kernel" in r["Kernel_Name"] or "decode_lean_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == c]
     out[c + "_KiB_avg_per_launch"] = sum(v) / len(v)
     out[c + "_launches"] = len(v)
 out["fetch_bytes_corrected_x2"] = out["FETCH_SIZE_KiB_avg_per_launch"] * 2 * 1024
