@@ -66,7 +66,7 @@ struct DecodeParams {
   const uint8_t* pq_msb; const uint8_t* pq_lsb; const float* pq_scale; int64_t pl_sb, pl_sh, ps_sb, ps_sh;
   float pq_thr; int32_t* pq_need;   // [B*H]: written by the MSB pass (max prob < thr), read by the refetch pass
   unsigned long long* ws_part;   // [B*H*n_q, S, D+2] {value, tag} granules
-  unsigned* ws_cnt;     // [B*H*n_q]
+  unsigned* ws_cnt;     // [B*H*n_q][2]: {arrival counter, launch generation}
   int B, H, Hkv, N, pos_q, S, chunk, n_q, causal;
   float sqrt_d;
 };
@@ -91,8 +91,8 @@ __device__ inline void rope_pair(const float (&xlo)[8], const float (&xhi)[8], c
 }
 
 // one 8-byte {value, tag} granule of a published partial (tag != 0 <=> the value has landed)
-__device__ inline void store_granule(unsigned long long* g, float v) {
-  __hip_atomic_store(g, ((unsigned long long)1u << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+__device__ inline void store_granule(unsigned long long* g, float v, unsigned tag) {
+  __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -196,6 +196,10 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   };
   if (lo < hi) issue_tile(tile_a, lo);
   SPATTEN_TSTAMP(5);
+  // this unit's launch generation (tags of the published partials, see below): written by the previous launch's merger,
+  // so it comes from memory — fetched with a VECTOR load queued behind the first tile (a scalar load would be waited
+  // for with the kernel arguments, 2-3 us before anything else happens)
+  const unsigned gen = p.S > 1 ? p.ws_cnt[2 * unit + 1 + opaque_lane(0)] : 0u;
 
   // ---- un-rotated query + its table row ----------------------------------------------------------
   typename D8::packed q_lo, q_hi;                // rotated query, packed in the model dtype (exact: it IS rounded)
@@ -399,16 +403,19 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   // store = sc1): the data is its own flag, so nobody waits for store acknowledgements.  The ticket
   // tells the last arriver that every other split has ISSUED its granules; it then reads them with
   // agent-scope loads (placement independent across the 8 XCD L2s) and re-reads the rare granule whose
-  // tag has not landed yet.  It finally clears the tags and the counter for the next launch.
+  // tag has not landed yet.  The tag is the unit's launch GENERATION + 1 (a word next to the counter, advanced by
+  // the merger): granules of earlier launches never match, so nothing has to be cleared for the next launch
+  // (clearing S x (D+2) granules cost the merger 0.3 us of a 13 us kernel).
   unsigned long long* ws = p.ws_part + ((int64_t)unit * p.S) * (D + 2);
   unsigned long long* part = ws + (int64_t)split * (D + 2);
+  const unsigned tag = (gen & 0x7FFFFFFFu) + 1u;
   // the ticket is drawn by the LAST wave, which has no stores in flight: on CDNA4 vmcnt also counts stores, so a
   // wave that just issued granules would wait for their write-through acknowledgements before it sees its ticket
   if (tid == kDecodeThreads - 1)
-    s_ticket = __hip_atomic_fetch_add(p.ws_cnt + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (tid < D && tid < kDecodeThreads - kWave) store_granule(part + tid, o_tot);
-  if (D > kDecodeThreads - kWave && tid >= kDecodeThreads - kWave && tid < D) store_granule(part + tid, o_tot);   // D = 256 only
-  if (tid == (D < kDecodeThreads - kWave ? D : 0)) { store_granule(part + D, m_run); store_granule(part + D + 1, l_tot); }
+    s_ticket = __hip_atomic_fetch_add(p.ws_cnt + 2 * unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < D && tid < kDecodeThreads - kWave) store_granule(part + tid, o_tot, tag);
+  if (D > kDecodeThreads - kWave && tid >= kDecodeThreads - kWave && tid < D) store_granule(part + tid, o_tot, tag);   // D = 256 only
+  if (tid == (D < kDecodeThreads - kWave ? D : 0)) { store_granule(part + D, m_run, tag); store_granule(part + D + 1, l_tot, tag); }
   __syncthreads();
   SPATTEN_TSTAMP(3);
   if (s_ticket != (unsigned)(p.S - 1)) return;
@@ -423,7 +430,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
     for (int s0 = g; s0 < p.S; s0 += KB * G) {
       unsigned long long ga[KB], gm[KB], gl[KB];
       int spins = 0;
-      unsigned tags;
+      bool landed;
       do {   // every load is issued before any tag is looked at: ONE round trip (a short-circuiting `&&` chain makes
              // the compiler wait for each split's granules before it loads the next split's)
 #pragma unroll
@@ -434,10 +441,12 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
           gm[k] = __hip_atomic_load(q + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           gl[k] = __hip_atomic_load(q + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        tags = 1u;
+        unsigned diff = 0u;                      // bitwise, not &&: all loads stay in one round trip
 #pragma unroll
-        for (int k = 0; k < KB; ++k) tags &= (unsigned)(ga[k] >> 32) & (unsigned)(gm[k] >> 32) & (unsigned)(gl[k] >> 32);
-      } while (tags == 0u && ++spins < (1 << 20));   // bounded: a granule that was issued always lands
+        for (int k = 0; k < KB; ++k)
+          diff |= ((unsigned)(ga[k] >> 32) ^ tag) | ((unsigned)(gm[k] >> 32) ^ tag) | ((unsigned)(gl[k] >> 32) ^ tag);
+        landed = diff == 0u;
+      } while (!landed && ++spins < (1 << 20));   // bounded: a granule that was issued always lands
       float a[KB], ms[KB], ls[KB];
 #pragma unroll
       for (int k = 0; k < KB; ++k) {
@@ -445,14 +454,6 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
         a[k] = live ? __uint_as_float((unsigned)ga[k]) : 0.f;
         ms[k] = live ? __uint_as_float((unsigned)gm[k]) : -INFINITY;
         ls[k] = live ? __uint_as_float((unsigned)gl[k]) : 0.f;
-      }
-      // every granule this thread read has landed: clear its tag for the next launch (re-arm)
-#pragma unroll
-      for (int k = 0; k < KB; ++k) {
-        if ((s0 + k * G) < p.S) {
-          unsigned long long* q = ws + (int64_t)(s0 + k * G) * (D + 2);
-          q[e] = 0ull;                           // only this thread reads q[e]; (m, l) are shared: cleared below
-        }
       }
       float mn = mg;
 #pragma unroll
@@ -469,8 +470,6 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
       mg = mn;
     }
   }
-  __syncthreads();                               // every thread is done with the shared (m, l) granules
-  if (tid < p.S) { ws[(int64_t)tid * (D + 2) + D] = 0ull; ws[(int64_t)tid * (D + 2) + D + 1] = 0ull; }
   if (G > 1) {                                   // fold the thread groups through LDS
     if (g < G) { s_o[g][e] = og; if (e == 0) { s_o[g][D] = mg; s_o[g][D + 1] = lg; } }
     __syncthreads();
@@ -494,7 +493,8 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   if (tid == 0) {
     if (p.lse != nullptr) { p.lse[unit * 2] = mg; p.lse[unit * 2 + 1] = lg; }
     if (KSRC == 1) p.pq_need[unit] = (1.0f / lg) < p.pq_thr ? 1 : 0;
-    __hip_atomic_store(p.ws_cnt + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    p.ws_cnt[2 * unit + 1] = gen + 1u;                                                         // next launch: new tag
+    __hip_atomic_store(p.ws_cnt + 2 * unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm the counter
   }
   SPATTEN_TSTAMP(4);
 }
@@ -609,7 +609,7 @@ static int dispatch_decode(DecodeParams<T>& p, int d, int n_active, bool scores_
   }
 }
 
-static size_t decode_cnt_bytes(size_t units) { return (units * sizeof(unsigned) + 255) / 256 * 256; }
+static size_t decode_cnt_bytes(size_t units) { return (units * 2 * sizeof(unsigned) + 255) / 256 * 256; }
 
 // shared by spatten_attn_decode and the small-q / fp32 leg of spatten_attn_prefill
 int decode_rows(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sq, void* k_cache, void* kr_cache,

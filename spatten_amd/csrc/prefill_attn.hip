@@ -937,7 +937,7 @@ extern "C" size_t spatten_prefill_workspace_bytes(int dtype, int batch, int head
   if (rows_leg(dtype, head_dim, q_len)) {
     const size_t units = (size_t)batch * heads * q_len;
     const int S = rows_splits((int)(units > (1u << 30) ? (1u << 30) : units));
-    return 256 + align256(units * sizeof(unsigned)) + (S > 1 ? units * S * (head_dim + 2) * sizeof(unsigned long long) : 0);
+    return 256 + align256(units * 2 * sizeof(unsigned)) + (S > 1 ? units * S * (head_dim + 2) * sizeof(unsigned long long) : 0);
   }
   const size_t es = 2, npad = (size_t)ceil_div(kv_len, 128) * 128;
   return 256 + align256((size_t)batch * heads * q_len * head_dim * es) + align256((size_t)batch * kv_heads * head_dim * npad * es);
@@ -963,9 +963,9 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
     if (col_importance) return SPATTEN_ERR_UNSUPPORTED;   // by-product of the flash leg only (use the stash here)
     const size_t units = (size_t)batch * heads * q_len;
     const int S = rows_splits((int)units);
-    if (S > 1 && hipMemsetAsync(ws, 0, align256(units * sizeof(unsigned)), st) != hipSuccess) return SPATTEN_ERR_LAUNCH;
+    if (S > 1 && hipMemsetAsync(ws, 0, align256(units * 2 * sizeof(unsigned)), st) != hipSuccess) return SPATTEN_ERR_LAUNCH;
     // granule tags must start cleared too; the merger re-arms them, so only a fresh workspace needs this
-    if (S > 1 && hipMemsetAsync(ws + align256(units * sizeof(unsigned)), 0,
+    if (S > 1 && hipMemsetAsync(ws + align256(units * 2 * sizeof(unsigned)), 0,
                                 units * S * (head_dim + 2) * sizeof(unsigned long long), st) != hipSuccess)
       return SPATTEN_ERR_LAUNCH;
     return decode_rows(dtype, q, q_sb, q_sh, q_sq, nullptr, const_cast<void*>(kr_cache), const_cast<void*>(v_cache),

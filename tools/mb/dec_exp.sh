@@ -7,7 +7,7 @@ for f in prune cascade pq; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -fno-slp-vectorize -c spatten_amd/csrc/prefill_attn.hip -o /tmp/dex/prefill_attn.o &
 wait
 for var in "$@"; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w $var -c spatten_amd/csrc/decode_attn.hip -o /tmp/dex/decode_attn.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -mllvm -amdgpu-kernarg-preload-count=16 $var -c spatten_amd/csrc/decode_attn.hip -o /tmp/dex/decode_attn.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o spatten_amd/lib/libspatten_hip.so /tmp/dex/*.o
   echo "== flags: [$var]"
   for i in 1 2; do python bench.py --steps 256 --warmup 64 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['avg_launch_us'])"; done
