@@ -148,6 +148,31 @@ def test_decode_workspace_rearms_across_launches():
         assert torch.equal(o, outs[0])
 
 
+def test_decode_workspace_generations_with_changing_splits_and_lengths():
+    """The published partials are tagged with the unit's launch generation and never cleared: launches that change the
+    split count and the cache length on ONE workspace must never pick up a stale partial of an earlier launch."""
+    from spatten_amd import ops
+    dt, B, H, d, N = "bf16", 2, 8, 128, 3000
+    q, k, v, past = attn_inputs(B, H, H, d, N - 1, 1, dt, seed=11)
+    kc = dev(np.concatenate([past[0], k], 2), dt)
+    vc = dev(np.concatenate([past[1], v], 2), dt)
+    cos, sin = ops.rope_table(N, d, TORCH_DT[dt], "cuda")
+    krc = ops.rope_single(kc, cos, sin)
+    qd = dev(q[:, :, 0], dt)
+    ws = ops.DecodeWorkspace(B, H, d, "cuda")
+    ref = {}
+    for n in (3000, 1200, 400):                       # single-split launches: no merge, the reference per length
+        ref[n] = ops.attn_decode(qd, None, krc, vc, n, cos, sin, n - 1, n_splits=1, workspace=ws)
+    rng = np.random.default_rng(0)
+    for it in range(120):
+        n = int(rng.choice([3000, 1200, 400]))
+        splits = int(rng.choice([2, 3, 5, 8, 16])) if n > 400 else int(rng.choice([2, 3]))
+        out = ops.attn_decode(qd, None, krc, vc, n, cos, sin, n - 1, n_splits=splits, workspace=ws)
+        # the merge order differs from the single-split sum only in fp32 rounding, then both round to bf16
+        assert torch.allclose(out.float(), ref[n].float(), atol=2e-3, rtol=1e-2), (it, n, splits)
+    torch.cuda.synchronize()
+
+
 def test_decode_errors():
     from spatten_amd import ops
     dt = torch.bfloat16
