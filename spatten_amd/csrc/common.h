@@ -328,6 +328,23 @@ __device__ inline float div_by_const(float x, float c, float rc) {
 template <typename T> __device__ inline float logit_scale(float x, float c, float rc) { return div_by_const(x, c, rc); }
 template <> __device__ inline float logit_scale<bf16_t>(float x, float c, float rc) { return x * rc; }
 
+template <typename T>
+__device__ inline void rope_pair(const float (&xlo)[8], const float (&xhi)[8], const float (&c)[8],
+                                 const float (&s)[8], float (&ylo)[8], float (&yhi)[8]) {
+  // y = x*cos + rotate_half(x)*sin with rotate_half(x) = cat(-x[d/2:], x[:d/2])   (modify_llama.py:21-28)
+  // each of the three torch ops rounds to the model dtype.
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float a_lo = DT<T>::round(xlo[i] * c[i]);
+    const float b_lo = DT<T>::round(-xhi[i] * s[i]);
+    const float a_hi = DT<T>::round(xhi[i] * c[i]);
+    const float b_hi = DT<T>::round(xlo[i] * s[i]);
+    ylo[i] = DT<T>::round(a_lo + b_lo);
+    yhi[i] = DT<T>::round(a_hi + b_hi);
+  }
+}
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // progressive-quant key planes handed to decode_rows (decode_attn.hip); see pq.hip for the storage format

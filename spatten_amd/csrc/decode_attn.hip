@@ -73,23 +73,6 @@ struct DecodeParams {
 
 constexpr int kDecodeThreads = 256;
 
-template <typename T>
-__device__ inline void rope_pair(const float (&xlo)[8], const float (&xhi)[8], const float (&c)[8],
-                                 const float (&s)[8], float (&ylo)[8], float (&yhi)[8]) {
-  // y = x*cos + rotate_half(x)*sin with rotate_half(x) = cat(-x[d/2:], x[:d/2])   (modify_llama.py:21-28)
-  // each of the three torch ops rounds to the model dtype.
-#pragma clang fp contract(off)
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float a_lo = DT<T>::round(xlo[i] * c[i]);
-    const float b_lo = DT<T>::round(-xhi[i] * s[i]);
-    const float a_hi = DT<T>::round(xhi[i] * c[i]);
-    const float b_hi = DT<T>::round(xlo[i] * s[i]);
-    ylo[i] = DT<T>::round(a_lo + b_lo);
-    yhi[i] = DT<T>::round(a_hi + b_hi);
-  }
-}
-
 // one 8-byte {value, tag} granule of a published partial (tag != 0 <=> the value has landed)
 __device__ inline void store_granule(unsigned long long* g, float v, unsigned tag) {
   __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,

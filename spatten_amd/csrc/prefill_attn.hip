@@ -3,10 +3,10 @@
 // Three legs behind one entry point (spatten_attn_prefill):
 //   * rows leg  (fp32, very short q, head_dim 256): the decode kernel, one softmax row per workgroup column
 //     (decode_rows in decode_attn.hip) — exact fp32, no matrix cores needed for a handful of rows.
-//   * flash leg (bf16/f16, head_dim 64/128): compute-bound -> MFMA.  Two preparation kernels and the flash
-//     kernel on the same stream:
-//       (1) rope kernel: Q rows -> Qrot scratch (reference rounding, modify_llama.py:92);  K is NOT rotated
-//           here: the cache already carries the rotated shadow Kr (see decode_attn.hip),
+//   * flash leg (bf16/f16, head_dim 64/128): compute-bound -> MFMA.  One preparation kernel and the flash kernel on
+//     the same stream:
+//       (1) the queries are rotated in the flash kernel's prologue (reference rounding, modify_llama.py:92);  K is NOT
+//           rotated here: the cache already carries the rotated shadow Kr (see decode_attn.hip),
 //       (2) vt kernel: V [keys][d] -> Vt [d][keys] scratch so that the P·V matrix product finds its
 //           contraction index (keys) contiguous per lane; inside every 32-key block the keys are permuted
 //           into the order in which a lane holds them after the Q·K^T product (no shuffles between the two
@@ -104,7 +104,9 @@ __global__ __launch_bounds__(256) void vt_kernel(const uint16_t* __restrict__ v,
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 struct FlashParams {
-  const T* qrot;      // [B,H,q_len,D] contiguous
+  const T* q; int64_t q_sb, q_sh, q_sq;   // un-rotated queries [B,H,q_len,D] (any strides, d contiguous)
+  const T* cos; const T* sin; int table_rows;             // rotary half tables [rows, D/2]
+  const int64_t* pos_ids; int64_t pos_sb; int pos_q0;     // query positions: pos_ids[b][i] or pos_q0 + i
   const T* kr;        // rotated shadow [B,Hkv,cap,D]
   int64_t kv_sb, kv_sh;
   const T* vt;        // [B,Hkv,D,Npad]
@@ -179,11 +181,27 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
   const int P = p.N - p.q_len;
   const float rsqrt_d = 1.0f / p.sqrt_d;
 
+  // Q fragments, rotated here (modify_llama.py:92, the reference's three rounded ops): fragment kk holds elements
+  // [16kk + 8hi, +8) of the row, so kk and kk + KK/2 are exactly the (x[i], x[i + d/2]) pairs RoPE combines
   frag qf[KK];
   {
-    const T* qrow = p.qrot + ((int64_t)(b * p.H + h) * p.q_len + min(myq, p.q_len - 1)) * D;
+    const int qq = min(myq, p.q_len - 1);
+    const T* qrow = p.q + b * p.q_sb + h * p.q_sh + (int64_t)qq * p.q_sq;
+    int ps = p.pos_ids ? (int)p.pos_ids[b * p.pos_sb + qq] : p.pos_q0 + qq;
+    ps = min(max(ps, 0), p.table_rows - 1);
+    const T* cr = p.cos + (int64_t)ps * (D / 2);
+    const T* sr = p.sin + (int64_t)ps * (D / 2);
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) qf[kk] = *reinterpret_cast<const frag*>(qrow + 16 * kk + 8 * hi);
+    for (int kk = 0; kk < KK / 2; ++kk) {
+      float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8];
+      Vec8<T>::unpack(Vec8<T>::ldg(qrow + 16 * kk + 8 * hi), xlo);
+      Vec8<T>::unpack(Vec8<T>::ldg(qrow + D / 2 + 16 * kk + 8 * hi), xhi);
+      Vec8<T>::unpack(Vec8<T>::ldg(cr + 16 * kk + 8 * hi), cc);
+      Vec8<T>::unpack(Vec8<T>::ldg(sr + 16 * kk + 8 * hi), ss);
+      rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { qf[kk][e] = DT<T>::from_f32(ylo[e]); qf[kk + KK / 2][e] = DT<T>::from_f32(yhi[e]); }
+    }
   }
   f32x16 o[DB];
 #pragma unroll
@@ -585,11 +603,27 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   const int P = p.N - p.q_len;
   const float rsqrt_d = 1.0f / p.sqrt_d;
 
+  // Q fragments, rotated here (modify_llama.py:92, the reference's three rounded ops): fragment kk holds elements
+  // [16kk + 8hi, +8) of the row, so kk and kk + KK/2 are exactly the (x[i], x[i + d/2]) pairs RoPE combines
   frag qf[KK];
   {
-    const T* qrow = p.qrot + ((int64_t)(b * p.H + h) * p.q_len + min(myq, p.q_len - 1)) * D;
+    const int qq = min(myq, p.q_len - 1);
+    const T* qrow = p.q + b * p.q_sb + h * p.q_sh + (int64_t)qq * p.q_sq;
+    int ps = p.pos_ids ? (int)p.pos_ids[b * p.pos_sb + qq] : p.pos_q0 + qq;
+    ps = min(max(ps, 0), p.table_rows - 1);
+    const T* cr = p.cos + (int64_t)ps * (D / 2);
+    const T* sr = p.sin + (int64_t)ps * (D / 2);
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) qf[kk] = *reinterpret_cast<const frag*>(qrow + 16 * kk + 8 * hi);
+    for (int kk = 0; kk < KK / 2; ++kk) {
+      float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8];
+      Vec8<T>::unpack(Vec8<T>::ldg(qrow + 16 * kk + 8 * hi), xlo);
+      Vec8<T>::unpack(Vec8<T>::ldg(qrow + D / 2 + 16 * kk + 8 * hi), xhi);
+      Vec8<T>::unpack(Vec8<T>::ldg(cr + 16 * kk + 8 * hi), cc);
+      Vec8<T>::unpack(Vec8<T>::ldg(sr + 16 * kk + 8 * hi), ss);
+      rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { qf[kk][e] = DT<T>::from_f32(ylo[e]); qf[kk + KK / 2][e] = DT<T>::from_f32(yhi[e]); }
+    }
   }
   f32x16 o[DB];
 #pragma unroll
@@ -926,11 +960,6 @@ static int launch_flash(const FlashParams<T>& p, hipStream_t st) {
 
 using namespace spatten;
 
-extern "C" int spatten_rope_single(int dtype, const void* x, int64_t x_sb, int64_t x_sh, int64_t x_sn, void* y,
-                                   int64_t y_sb, int64_t y_sh, int64_t y_sn, const void* cos, const void* sin,
-                                   int table_rows, const int64_t* position_ids, int64_t pos_sb, int pos0,
-                                   int batch, int heads, int n, int head_dim, void* stream);
-
 extern "C" size_t spatten_prefill_workspace_bytes(int dtype, int batch, int heads, int kv_heads, int head_dim,
                                                   int q_len, int kv_len) {
   if (batch <= 0 || heads <= 0 || kv_heads <= 0 || head_dim <= 0 || q_len <= 0 || kv_len <= 0) return 0;
@@ -940,7 +969,7 @@ extern "C" size_t spatten_prefill_workspace_bytes(int dtype, int batch, int head
     return 256 + align256(units * 2 * sizeof(unsigned)) + (S > 1 ? units * S * (head_dim + 2) * sizeof(unsigned long long) : 0);
   }
   const size_t es = 2, npad = (size_t)ceil_div(kv_len, 128) * 128;
-  return 256 + align256((size_t)batch * heads * q_len * head_dim * es) + align256((size_t)batch * kv_heads * head_dim * npad * es);
+  return 256 + align256((size_t)batch * kv_heads * head_dim * npad * es);      // the key-contiguous copy of V
 }
 
 extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sq,
@@ -975,13 +1004,8 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
   }
 
   const int npad = ceil_div(kv_len, 128) * 128;      // Vt rows padded to whole 128-key tiles (zeros beyond kv_len)
-  void* qrot = ws;
-  void* vt = ws + align256((size_t)batch * heads * q_len * head_dim * 2);
-  // (1) rotated queries, contiguous [B,H,q,d]
-  int rc = spatten_rope_single(dtype, q, q_sb, q_sh, q_sq, qrot, (int64_t)heads * q_len * head_dim,
-                               (int64_t)q_len * head_dim, head_dim, cos, sin, table_rows, position_ids, pos_sb, pos_q0,
-                               batch, heads, q_len, head_dim, stream);
-  if (rc != SPATTEN_OK) return rc;
+  void* vt = ws;
+  // (1) the queries are rotated inside the flash kernel (its prologue)
   // (2) key-contiguous V
   {
     const dim3 grid((unsigned)(npad / 64), (unsigned)kv_heads, (unsigned)batch);
@@ -995,7 +1019,10 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
 #define SPATTEN_FLASH(T, DD)                                                                           \
   {                                                                                                    \
     FlashParams<T> p;                                                                                  \
-    p.qrot = (const T*)qrot; p.kr = (const T*)kr_cache; p.kv_sb = kv_sb; p.kv_sh = kv_sh;              \
+    p.q = (const T*)q; p.q_sb = q_sb; p.q_sh = q_sh; p.q_sq = q_sq;                                    \
+    p.cos = (const T*)cos; p.sin = (const T*)sin; p.table_rows = table_rows;                           \
+    p.pos_ids = position_ids; p.pos_sb = pos_sb; p.pos_q0 = pos_q0;                                    \
+    p.kr = (const T*)kr_cache; p.kv_sb = kv_sb; p.kv_sh = kv_sh;                                       \
     p.vt = (const T*)vt; p.mask = (const T*)mask; p.mask_sb = mask_sb; p.mask_sq = mask_sq;            \
     p.out = (T*)out; p.out_sb = out_sb; p.out_sq = out_sq;                                             \
     p.scores = (T*)scores; p.sc_sb = sc_sb; p.sc_sh = sc_sh; p.sc_sq = sc_sq;                          \
