@@ -335,75 +335,67 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
   auto softmax_tile = [&](int tile) {
     const bool attend = tile < wave_att_tiles;
     const bool edge = tile * 64 + 64 > wave_full_keys;
-    if (!STASH && !COLIMP && !MASK && !edge) {
-      // fully visible tile, no by-products; both reference roundings kept (see (3c))
-      float mt[2] = {-INFINITY, -INFINITY};
+    // (1) both reference roundings of every logit (matmul -> dtype, "/ sqrt(d)" -> dtype, modify_llama.py:111-113),
+    //     two scores at a time; afterwards s holds exact model-dtype values
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2 x = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
-          const f32x2 v = round2<T>(f32x2{logit_scale<T>(x[0], p.sqrt_d, rsqrt_d), logit_scale<T>(x[1], p.sqrt_d, rsqrt_d)});
-          s[kb][r] = v[0];
-          s[kb][r + 1] = v[1];
-          mt[kb] = max3_raw(mt[kb], v[0], v[1]);
-        }
-      const float m_tile = xor32_max(fmaxf(mt[0], mt[1]));
-      const bool move = __builtin_amdgcn_ballot_w64(m_tile - m_run > kDeferMax) != 0;   // deferred rescale, see (3c)
-      const float m_new = move ? fmaxf(m_run, m_tile) : m_run;
-      const float m2 = m_new * kLog2e;
-      float ls[4] = {0.f, 0.f, 0.f, 0.f};         // independent partial sums: no 32-deep dependent add chain
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], kLog2e, -m2));
-            ls[e & 3] += pvv;
-            pf[kb][t][e] = DT<T>::from_f32(pvv);
-          }
-      const float lsum = (ls[0] + ls[1]) + (ls[2] + ls[3]);
-      if (m_new != m_run) {
-        const float alpha = __expf(m_run - m_new);
-        l_run *= alpha;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-        m_run = m_new;
-      }
-      l_run += lsum;
-      return;
-    }
-    float m_tile = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113), two scores at a time
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const f32x2 x = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
-        const f32x2 v2 = round2<T>(f32x2{logit_scale<T>(x[0], p.sqrt_d, rsqrt_d), logit_scale<T>(x[1], p.sqrt_d, rsqrt_d)});
-        s[kb][r] = v2[0];
-        s[kb][r + 1] = v2[1];
+        const f32x2 v = round2<T>(f32x2{logit_scale<T>(x[0], p.sqrt_d, rsqrt_d), logit_scale<T>(x[1], p.sqrt_d, rsqrt_d)});
+        s[kb][r] = v[0];
+        s[kb][r + 1] = v[1];
       }
-      if (STASH && stash_vec) {
-        // pre-mask stash (:116-119): registers 4g..4g+3 hold 4 consecutive keys -> one 8-byte LDS store per group
-        char* sw = lds + 2 * BUF + wave * (32 * SPITCH) + qi * SPITCH + 8 * hi;
+    // (2) by-products, from the pre-mask logits
+    if (STASH) {                                                                             // :116-119
+      if (stash_vec) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          T q4[4];
+        for (int kb = 0; kb < 2; ++kb) {
+          // registers 4g..4g+3 hold 4 consecutive keys -> one 8-byte LDS store per group; then the wave's 32 queries x
+          // 32 keys leave as 64-byte row segments, 16 B per lane
+          char* sw = lds + 2 * BUF + wave * (32 * SPITCH);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) q4[e] = DT<T>::from_f32(s[kb][4 * g + e]);       // exact: already model-dtype values
-          *reinterpret_cast<u32x2*>(sw + 16 * g) = *reinterpret_cast<u32x2*>(q4);
+          for (int g = 0; g < 4; ++g) {
+            T q4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q4[e] = DT<T>::from_f32(s[kb][4 * g + e]);
+            *reinterpret_cast<u32x2*>(sw + qi * SPITCH + 8 * hi + 16 * g) = *reinterpret_cast<u32x2*>(q4);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int id = lane + 64 * i, row = id >> 2, c4 = id & 3;
+            const u32x4 piece = *reinterpret_cast<const u32x4*>(sw + row * SPITCH + c4 * 16);
+            const int qq = q0 + row, key0 = tile * 64 + kb * 32 + c4 * 8;
+            if (qq < p.q_len && key0 < p.N) {
+              T* dst = p.scores + b * p.sc_sb + h * p.sc_sh + (int64_t)qq * p.sc_sq + key0;
+              if (key0 + 8 <= p.N) *reinterpret_cast<u32x4*>(dst) = piece;
+              else {
+                const T* pe = reinterpret_cast<const T*>(&piece);
+                for (int e = 0; e < p.N - key0; ++e) dst[e] = pe[e];
+              }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+      } else if (qvalid) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = tile * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key < p.N) stashrow[key] = DT<T>::from_f32(s[kb][r]);
+          }
       }
-      if (COLIMP) {
-        // column sums over this wave's 32 queries (reference-mode importance, kv_cache_token_pruning.py:51, acausal
-        // logits included) on the matrix pipe: the rounded logits are exact model-dtype values, so S·Perm with a 0/1
-        // permutation matrix is an exact TRANSPOSE into the accumulator layout — afterwards a lane owns one KEY and 16
-        // of the 32 queries, and the sum over queries is 15 adds + one lane <-> lane+32 exchange, then ONE atomic
-        // instruction for the 32 keys (instead of 5 cross-lane adds per score and an atomic per register).
+    }
+    if (COLIMP) {
+      // column sums over this wave's 32 queries (reference-mode importance, kv_cache_token_pruning.py:51, acausal
+      // logits included) on the matrix pipe: the rounded logits are exact model-dtype values, so S·Perm with a 0/1
+      // permutation matrix is an exact TRANSPOSE into the accumulator layout — afterwards a lane owns one KEY and 16
+      // of the 32 queries, and the sum over queries is 15 adds + one lane <-> lane+32 exchange, then ONE atomic
+      // instruction for the 32 keys (instead of 5 cross-lane adds per score and an atomic per register).
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
         f32x16 ct;
 #pragma unroll
         for (int r = 0; r < 16; ++r) ct[r] = 0.f;
@@ -421,57 +413,54 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
         const int ckey = tile * 64 + kb * 32 + qi;
         if (hi == 0 && ckey < p.N) atomicAdd(colrow + ckey, cs);
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = s[kb][r];
-        const int key = tile * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const bool inb = key < p.N;
-        if (STASH && !stash_vec) {
-          if (inb && qvalid) stashrow[key] = DT<T>::from_f32(v);
-        }
-        if (MASK) { if (inb) v = DT<T>::round(v + DT<T>::to_f32(maskrow[key])); }            // :132
-        v = (key < my_vis) ? v : -INFINITY;
-        s[kb][r] = v;
-        m_tile = fmaxf(m_tile, v);
-      }
-      if (STASH && stash_vec) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        const char* sw = lds + 2 * BUF + wave * (32 * SPITCH);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int id = lane + 64 * i, row = id >> 2, c4 = id & 3;
-          const u32x4 piece = *reinterpret_cast<const u32x4*>(sw + row * SPITCH + c4 * 16);
-          const int qq = q0 + row, key0 = tile * 64 + kb * 32 + c4 * 8;
-          if (qq < p.q_len && key0 < p.N) {
-            T* dst = p.scores + b * p.sc_sb + h * p.sc_sh + (int64_t)qq * p.sc_sq + key0;
-            if (key0 + 8 <= p.N) *reinterpret_cast<u32x4*>(dst) = piece;
-            else {
-              const T* pe = reinterpret_cast<const T*>(&piece);
-              for (int e = 0; e < p.N - key0; ++e) dst[e] = pe[e];
-            }
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
     }
-    if (!attend) return;
-    m_tile = xor32_max(m_tile);
-    const float m_new = fmaxf(m_run, m_tile);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float m2 = m_use * kLog2e;
-    float lsum = 0.f;
+    if (!attend) return;                            // a tile above this wave's diagonal: scored for the by-products only
+    float m_new, m_base;                            // new running max; the max the exponentials are taken against
+    if (!MASK && !edge) {
+      // (3a) fully visible tile.  Deferred rescale: the running maximum only moves (and O is only rescaled: 64
+      //      multiplies per lane) when some row of the wave outgrew it by more than kDeferMax, see (3c)
+      float mt[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mt[kb] = max3_raw(mt[kb], s[kb][r], s[kb][r + 1]);
+      const float m_tile = xor32_max(fmaxf(mt[0], mt[1]));
+      const bool move = __builtin_amdgcn_ballot_w64(m_tile - m_run > kDeferMax) != 0;
+      m_new = move ? fmaxf(m_run, m_tile) : m_run;
+      m_base = m_new;
+    } else {
+      // (3b) explicit mask and / or a tile that straddles the causal diagonal: per-element visibility
+      float m_tile = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = s[kb][r];
+          const int key = tile * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (MASK) { if (key < p.N) v = DT<T>::round(v + DT<T>::to_f32(maskrow[key])); }   // :132
+          v = (key < my_vis) ? v : -INFINITY;
+          s[kb][r] = v;
+          m_tile = fmaxf(m_tile, v);
+        }
+      m_tile = xor32_max(m_tile);
+      m_new = fmaxf(m_run, m_tile);
+      m_base = (m_new == -INFINITY) ? 0.f : m_new;  // a fully masked row: exp2(-inf) = 0 for every key
+    }
+    const float m2 = m_base * kLog2e;
+    float ls[4] = {0.f, 0.f, 0.f, 0.f};             // independent partial sums: no 32-deep dependent add chain
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
+          // exp(s - m) as one fma + v_exp_f32 (a base-2 exponential)
           const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], kLog2e, -m2));
-          lsum += pvv;
+          ls[e & 3] += pvv;
           pf[kb][t][e] = DT<T>::from_f32(pvv);
         }
     if (m_new != m_run) {
-      const float alpha = __expf(m_run - m_use);
+      const float alpha = __expf(m_run - m_base);
       l_run *= alpha;
 #pragma unroll
       for (int db = 0; db < DB; ++db)
@@ -479,7 +468,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
         for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
       m_run = m_new;
     }
-    l_run += lsum;
+    l_run += (ls[0] + ls[1]) + (ls[2] + ls[3]);
   };
 
   // ---- prologue (all 8 waves together): K(0) parked in stage 1's K area, stage 0 = { K(1), Vt(0) } --------------
