@@ -555,16 +555,14 @@ template <int ROWB> __device__ inline int swz_slot(int row, int p) {   // logica
   return ROWB == 256 ? (p ^ (row & 15)) : (p ^ ((row >> 1) & 7));
 }
 
-template <typename T, int D, bool STASH, bool COLIMP, bool MASK>
+template <typename T, int D, bool MASK>
 __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams<T> p) {
   constexpr int KT = 128, NKB = KT / 32;                      // keys per tile, 32-key blocks per tile
   constexpr int KK = D / 16, DB = D / 32, KROWB = D * 2;
   constexpr int KBYTES = KT * KROWB, VBYTES = D * 256, BUF = KBYTES + VBYTES;   // Vt row = 128 keys = 256 B
   constexpr int KINST = KBYTES / 1024 / 8, VINST = VBYTES / 1024 / 8;           // DMA instructions per wave per tile
   using frag = typename Mfma<T>::frag;
-  constexpr int SPITCH = 80;
-  constexpr int SBYTES = STASH ? 8 * 32 * SPITCH : 0;
-  __shared__ __attribute__((aligned(1024))) char lds[2 * BUF + SBYTES];
+  __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, qi = lane & 31, hi = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -624,18 +622,15 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   const int wg_q_end = min(p.q_len, qblk * 256 + 256);
   const int att_keys = p.causal ? min(p.N, P + wg_q_end) : p.N;
   const int n_att_tiles = (att_keys + KT - 1) / KT;
-  const int n_tiles = (STASH || COLIMP) ? (p.N + KT - 1) / KT : n_att_tiles;
+  const int n_tiles = n_att_tiles;
   const int my_vis = p.causal ? min(p.N, P + myq + 1) : p.N;
   const int wave_full_keys = p.causal ? min(p.N, P + q0 + 1) : p.N;
   const int wave_att_tiles = p.causal ? min(n_att_tiles, (max(min(p.N, P + min(q0 + 32, p.q_len)), 0) + KT - 1) / KT) : n_att_tiles;
-  const int wave_tiles = (STASH || COLIMP) ? n_tiles : wave_att_tiles;
+  const int wave_tiles = wave_att_tiles;
 
   const T* krb = p.kr + b * p.kv_sb + hkv * p.kv_sh;
   const T* vtb = p.vt + ((int64_t)(b * p.Hkv + hkv) * D) * p.Npad;
   const T* maskrow = MASK ? p.mask + b * p.mask_sb + (int64_t)min(myq, p.q_len - 1) * p.mask_sq : nullptr;
-  T* stashrow = STASH ? p.scores + b * p.sc_sb + h * p.sc_sh + (int64_t)min(myq, p.q_len - 1) * p.sc_sq : nullptr;
-  float* colrow = COLIMP ? p.col_imp + (int64_t)(b * p.H + h) * p.N : nullptr;
-  const bool stash_vec = STASH && ((p.sc_sq | p.sc_sh | p.sc_sb) % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.scores) & 15) == 0);
 
   auto k_area = [&](int stage) -> char* { return lds + (stage & 1) * BUF; };            // holds K(stage + 1)
   auto v_area = [&](int stage) -> char* { return lds + (stage & 1) * BUF + KBYTES; };   // holds Vt(stage)
@@ -728,109 +723,56 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   };
 
   auto softmax_tile = [&](int tile) {
-    const bool attend = tile < wave_att_tiles;
     const bool edge = tile * KT + KT > wave_full_keys;
-    if (!STASH && !COLIMP && !MASK && !edge) {
-      // fully visible tile, no by-products.  Both reference roundings are kept (matmul -> dtype, "/ sqrt(d)" -> dtype,
-      // modify_llama.py:111-113): at large logits a 16-bit ulp is a visible change of P.
+    // both reference roundings of every logit (matmul -> dtype, "/ sqrt(d)" -> dtype, modify_llama.py:111-113), two
+    // scores at a time: at large logits a 16-bit ulp is a visible change of P
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 x = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
+        const f32x2 v = round2<T>(f32x2{logit_scale<T>(x[0], p.sqrt_d, rsqrt_d), logit_scale<T>(x[1], p.sqrt_d, rsqrt_d)});
+        s[kb][r] = v[0];
+        s[kb][r + 1] = v[1];
+      }
+    float m_new, m_base;                            // new running max; the max the exponentials are taken against
+    if (!MASK && !edge) {
+      // fully visible tile.  Deferred rescale: the running maximum only moves (and O is only rescaled: 64 multiplies
+      // per lane) when some row of the wave outgrew it by more than kDeferMax; until then P = exp(s - m_run) <=
+      // e^kDeferMax, which bf16 P (constant relative precision) and the fp32 sums carry without loss.  O / l is
+      // mathematically unchanged.  All of the previous tile's P·V is already in O (matrix phase, program order), so
+      // the decision covers it.
       float mt[NKB];
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
         mt[kb] = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2 x = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
-          const f32x2 v = round2<T>(f32x2{logit_scale<T>(x[0], p.sqrt_d, rsqrt_d), logit_scale<T>(x[1], p.sqrt_d, rsqrt_d)});
-          s[kb][r] = v[0];
-          s[kb][r + 1] = v[1];
-          mt[kb] = max3_raw(mt[kb], v[0], v[1]);
-        }
+        for (int r = 0; r < 16; r += 2) mt[kb] = max3_raw(mt[kb], s[kb][r], s[kb][r + 1]);
       }
       const float m_tile = xor32_max(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3])));
-      // deferred rescale: the running maximum only moves (and O is only rescaled: 64 multiplies per lane) when some
-      // row of the wave outgrew it by more than kDeferMax; until then P = exp(s - m_run) <= e^kDeferMax, which bf16 P
-      // (constant relative precision) and the fp32 sums carry without loss.  O / l is mathematically unchanged.
-      // All of the previous tile's P·V is already in O (matrix phase, program order), so the decision covers it.
       const bool move = __builtin_amdgcn_ballot_w64(m_tile - m_run > kDeferMax) != 0;   // -inf start: inf > thr
-      const float m_new = move ? fmaxf(m_run, m_tile) : m_run;
-      const float m2 = m_new * kLog2e;
-      float ls[4] = {0.f, 0.f, 0.f, 0.f};
+      m_new = move ? fmaxf(m_run, m_tile) : m_run;
+      m_base = m_new;
+    } else {
+      // explicit mask and / or a tile that straddles the causal diagonal: per-element visibility
+      float m_tile = -INFINITY;
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], kLog2e, -m2));
-            ls[e & 3] += pvv;
-            pf[kb][t][e] = DT<T>::from_f32(pvv);
-          }
-      const float lsum = (ls[0] + ls[1]) + (ls[2] + ls[3]);
-      if (m_new != m_run) {
-        const float alpha = __expf(m_run - m_new);
-        l_run *= alpha;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-        m_run = m_new;
-      }
-      l_run += lsum;
-      return;
+        for (int r = 0; r < 16; ++r) {
+          float v = s[kb][r];
+          const int key = tile * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (MASK) { if (key < p.N) v = DT<T>::round(v + DT<T>::to_f32(maskrow[key])); }   // :132
+          v = (key < my_vis) ? v : -INFINITY;
+          s[kb][r] = v;
+          m_tile = fmaxf(m_tile, v);
+        }
+      m_tile = xor32_max(m_tile);
+      m_new = fmaxf(m_run, m_tile);
+      m_base = (m_new == -INFINITY) ? 0.f : m_new;  // a fully masked row: exp2(-inf) = 0 for every key
     }
-    float m_tile = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
-        float v = DT<T>::round(div_by_const(DT<T>::round(s[kb][r]), p.sqrt_d, rsqrt_d));
-        const int key = tile * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const bool inb = key < p.N;
-        if (STASH) {                                                                        // pre-mask (:116-119)
-          if (stash_vec) {
-            char* sw = lds + 2 * BUF + wave * (32 * SPITCH);
-            *reinterpret_cast<T*>(sw + qi * SPITCH + ((r & 3) + 8 * (r >> 2) + 4 * hi) * 2) = DT<T>::from_f32(v);
-          } else if (inb && qvalid) {
-            stashrow[key] = DT<T>::from_f32(v);
-          }
-        }
-        if (COLIMP) {
-          float cv = (inb && qvalid) ? v : 0.f;
-          cv = xor16_sum(group_sum<16>(cv));
-          if (qi == 0 && inb) atomicAdd(colrow + key, cv);
-        }
-        if (MASK) { if (inb) v = DT<T>::round(v + DT<T>::to_f32(maskrow[key])); }            // :132
-        v = (key < my_vis) ? v : -INFINITY;
-        s[kb][r] = v;
-        m_tile = fmaxf(m_tile, v);
-      }
-      if (STASH && stash_vec) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        const char* sw = lds + 2 * BUF + wave * (32 * SPITCH);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int id = lane + 64 * i, row = id >> 2, c4 = id & 3;
-          const u32x4 piece = *reinterpret_cast<const u32x4*>(sw + row * SPITCH + c4 * 16);
-          const int qq = q0 + row, key0 = tile * KT + kb * 32 + c4 * 8;
-          if (qq < p.q_len && key0 < p.N) {
-            T* dst = p.scores + b * p.sc_sb + h * p.sc_sh + (int64_t)qq * p.sc_sq + key0;
-            if (key0 + 8 <= p.N) *reinterpret_cast<u32x4*>(dst) = piece;
-            else {
-              const T* pe = reinterpret_cast<const T*>(&piece);
-              for (int e = 0; e < p.N - key0; ++e) dst[e] = pe[e];
-            }
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
-    }
-    if (!attend) return;
-    m_tile = xor32_max(m_tile);
-    const float m_new = fmaxf(m_run, m_tile);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float m2 = m_use * kLog2e;
-    float lsum = 0.f;
+    const float m2 = m_base * kLog2e;
+    float ls[4] = {0.f, 0.f, 0.f, 0.f};             // independent partial sums
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -838,11 +780,11 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], kLog2e, -m2));
-          lsum += pvv;
+          ls[e & 3] += pvv;
           pf[kb][t][e] = DT<T>::from_f32(pvv);
         }
     if (m_new != m_run) {
-      const float alpha = __expf(m_run - m_use);
+      const float alpha = __expf(m_run - m_base);
       l_run *= alpha;
 #pragma unroll
       for (int db = 0; db < DB; ++db)
@@ -850,7 +792,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
         for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
       m_run = m_new;
     }
-    l_run += lsum;
+    l_run += (ls[0] + ls[1]) + (ls[2] + ls[3]);
   };
 
   // ---- prologue (all 8 waves together): K(0) parked in stage 1's K area, stage 0 = { K(1), Vt(0) } --------------
@@ -926,8 +868,8 @@ static void launch_flash_m(const FlashParams<T>& p, hipStream_t st) {
   const dim3 grid((unsigned)(p.nqb * p.H * p.B));
   if constexpr (!ST && !CI) {
     if (prefill_variant() == 0) {
-      if (p.mask) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, false, true>), grid, dim3(512), 0, st, p);
-      else hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, false, false>), grid, dim3(512), 0, st, p);
+      if (p.mask) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, true>), grid, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false>), grid, dim3(512), 0, st, p);
       return;
     }
   }
