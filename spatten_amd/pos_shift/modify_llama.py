@@ -120,7 +120,8 @@ def llama_pos_shift_attention_forward(
             query_states.view(bsz, num_heads, head_dim), slab.k, slab.kr, slab.v, kv_seq_len, cos, sin, past_len,
             k_new=key_states.view(bsz, num_kv_heads, head_dim), v_new=value_states.view(bsz, num_kv_heads, head_dim),
             position_ids=None if position_ids is None else position_ids[:, 0],
-            mask=None if attention_mask is None else attention_mask[:, 0, 0, :],
+            # with assume_causal the HF mask of a single-token step (all zeros) is not read: the lean decode kernel
+            mask=None if (attention_mask is None or getattr(self, "spatten_assume_causal", False)) else attention_mask[:, 0, 0, :],
             scores=stash.view(bsz, num_heads, kv_seq_len), lse=None if lse is None else lse.view(bsz, num_heads, 2))
         slab.length = slab.rot_len = kv_seq_len
         attn_output = attn_output.view(bsz, 1, num_heads * head_dim)
@@ -129,7 +130,9 @@ def llama_pos_shift_attention_forward(
         slab.v[:, :, past_len:kv_seq_len].copy_(value_states.view(bsz, q_len, num_kv_heads, head_dim).transpose(1, 2))
         slab.length = kv_seq_len
         slab.ensure_shadow(kv_seq_len)
-        assume_causal = bool(getattr(self, "spatten_assume_causal", False)) and attention_mask is not None
+        # a mask that IS the HF causal mask lets the kernel skip the tiles above the diagonal and never read the mask
+        assume_causal = attention_mask is not None and (bool(getattr(self, "spatten_assume_causal", False))
+                                                        or _mask_is_causal(attention_mask, past_len))
         attn_output = ops.attn_prefill(
             query_states.view(bsz, q_len, num_heads, head_dim).transpose(1, 2), slab.kr, slab.v, kv_seq_len,
             cos, sin, past_len, causal=assume_causal, position_ids=position_ids,
@@ -165,6 +168,27 @@ def llama_pos_shift_attention_forward(
 
     new_past = slab.views() if use_cache else None                                # :100
     return attn_output, attn_weights, new_past
+
+
+def _mask_is_causal(mask: torch.Tensor, past_len: int) -> bool:
+    """True when ``mask`` [B,1,q,N] is exactly the additive causal mask transformers 4.33 builds (0 for j <= P + i,
+    finfo.min above).  HF hands the SAME tensor object to every decoder layer of a forward, so the answer (one device
+    comparison and one host sync per prefill forward) is remembered on the tensor."""
+    cached = getattr(mask, "_spatten_is_causal", None)
+    if cached is not None and cached[0] == (mask._version, past_len):
+        return cached[1]
+    q_len, n = mask.shape[-2], mask.shape[-1]
+    i = torch.arange(q_len, device=mask.device)[:, None]
+    j = torch.arange(n, device=mask.device)[None, :]
+    lo = torch.finfo(mask.dtype).min
+    want = torch.where(j <= past_len + i, torch.zeros((), dtype=mask.dtype, device=mask.device),
+                       torch.full((), lo, dtype=mask.dtype, device=mask.device))
+    ok = bool((mask == want).all().item())
+    try:
+        mask._spatten_is_causal = ((mask._version, past_len), ok)
+    except Exception:       # a tensor subclass that refuses attributes: just recompute next time
+        pass
+    return ok
 
 
 def attention_modules(model):

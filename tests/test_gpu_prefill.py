@@ -220,6 +220,13 @@ def test_forward_matches_reference_goldens():
             torch.cuda.synchronize()
             np.testing.assert_allclose(host(out2), g[f"{name}_out"], err_msg=name, **OUT_TOL[dt])
             assert (m2.attn_scores is None) == (ql > 1)
+            # default flags: the HF causal mask is recognised (once per mask tensor) and the causal kernel path is taken
+            from spatten_amd.pos_shift.modify_llama import _mask_is_causal
+            if ql > 1:
+                assert _mask_is_causal(mask, P) and mask._spatten_is_causal[1] is True
+                bad = mask.clone()
+                bad[0, 0, ql - 1, 0] = torch.finfo(bad.dtype).min          # a padding-style hole: not purely causal
+                assert not _mask_is_causal(bad, P)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f32"])

@@ -38,3 +38,18 @@ for _ in range(3): ops.attn_prefill(q, kr, v, N, cos, sin, 0, causal=True, out=o
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 3
 print(f"prefill N={N} causal+stash: {ms:.3f} ms  (stash {st.numel()*2/2**30:.2f} GiB -> {st.numel()*2/ms/1e9:.2f} TB/s of stash writes)")
+# explicit HF-style additive causal mask [B,1,q,N] (what transformers 4.33 passes; the plugin reads it unless assume_causal)
+N = 4096
+q = torch.randn(B, H, N, d, device="cuda", dtype=dt); k = torch.randn(B, H, N, d, device="cuda", dtype=dt); v = torch.randn(B, H, N, d, device="cuda", dtype=dt)
+cos, sin = ops.rope_table(N, d, dt, "cuda"); kr = ops.rope_single(k, cos, sin)
+out = torch.empty(B, N, H * d, device="cuda", dtype=dt)
+i = torch.arange(N, device="cuda")
+mask = torch.where(i[None, :] <= i[:, None], 0.0, torch.finfo(dt).min).to(dt)[None].contiguous()
+for name, kw in (("mask, no stash", dict(mask=mask)), ("causal flag, no stash", dict(causal=True))):
+    for _ in range(2): ops.attn_prefill(q, kr, v, N, cos, sin, 0, out=out, **kw)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): ops.attn_prefill(q, kr, v, N, cos, sin, 0, out=out, **kw)
+    e1.record(); torch.cuda.synchronize()
+    print(f"prefill N={N} {name}: {e0.elapsed_time(e1) / 5:.3f} ms")
