@@ -478,7 +478,7 @@ def main():
             sh = np.empty((1, HEADS, n), np.uint16)
             co.attn_decode_raw("bf16", qh, kc, vc, cs, sn, None, oh, sh, 1, HEADS, HEADS, d, n, n - 1)   # warm
             reps, t0 = 0, time.perf_counter()
-            while reps < 3 or (time.perf_counter() - t0 < 8.0 and reps < 64):
+            while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 4096):     # ~10 s of CPU work
                 co.attn_decode_raw("bf16", qh, kc, vc, cs, sn, None, oh, sh, 1, HEADS, HEADS, d, n, n - 1)
                 reps += 1
             t_dec = (time.perf_counter() - t0) / reps
