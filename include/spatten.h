@@ -20,7 +20,7 @@
  *
  * Entry points with no numeric counterpart in the reference ("parity unpinned": restated from the
  * RTL control flow): spatten_importance_accumulate (cascade importance),
- * spatten_head_scores, spatten_pq_pack / spatten_attn_decode_pq (progressive quantisation).
+ * spatten_head_scores, spatten_pq_pack / the pq_* fields of spatten_attn_decode_args (progressive quantisation).
  */
 #ifndef SPATTEN_H_
 #define SPATTEN_H_
@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SPATTEN_ABI_VERSION 1
+#define SPATTEN_ABI_VERSION 2
 
 typedef enum {
   SPATTEN_F32 = 0,
@@ -45,7 +45,8 @@ typedef enum {
   SPATTEN_ERR_INVALID = -1,     /* bad pointer / shape / stride / dtype */
   SPATTEN_ERR_UNSUPPORTED = -2, /* head_dim or size outside the compiled range */
   SPATTEN_ERR_WINDOW = -3,      /* top-k window holds fewer than k candidates (reference: torch.topk RuntimeError) */
-  SPATTEN_ERR_LAUNCH = -4       /* hipLaunch failed; see hipGetLastError on the caller side */
+  SPATTEN_ERR_LAUNCH = -4,      /* hipLaunch failed; see hipGetLastError on the caller side */
+  SPATTEN_ERR_TIMEOUT = -5      /* a kernel gave up waiting for another workgroup's data (device error word set) */
 } spatten_status_t;
 
 int spatten_abi_version(void);
@@ -55,11 +56,18 @@ const char* spatten_status_string(int status);
  * Workspace.  Split-N decode keeps per-(b,h,split) partials (fp32) and one arrival counter per
  * (b,h).  The caller allocates `spatten_decode_workspace_bytes` bytes ONCE, zero-fills it once
  * (hipMemset) and may reuse it for every launch on the same stream (the kernel re-arms the
- * counters itself).
+ * counters itself).  Layout: a 256-byte header (word 0: device error flag), the counters, then one
+ * FIXED region of max_splits partials per (b,h) — launches with different split counts, head
+ * subsets or key sources never alias another unit's region.
  * ---------------------------------------------------------------------------------------------- */
+#define SPATTEN_DECODE_MAX_SPLITS 64
 size_t spatten_decode_workspace_bytes(int batch, int heads, int head_dim, int max_splits);
 /* Split count the library would pick for this shape (>=1).  `n_splits` <= 0 in the calls below means "auto". */
 int spatten_decode_auto_splits(int batch, int heads, int head_dim, int kv_len);
+/* The ONE synchronising call of the library: waits for `stream`, reads the workspace's error flag back and clears
+ * it.  SPATTEN_OK, or SPATTEN_ERR_TIMEOUT when a split-N merge expired its (bounded) wait for a partial — the outputs
+ * of that launch were poisoned with NaN instead of being merged from incomplete data. */
+int spatten_decode_workspace_status(void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Decode attention (q_len == 1), fused:  modify_llama.py:86-147.
@@ -87,6 +95,7 @@ int spatten_decode_auto_splits(int batch, int heads, int head_dim, int kv_len);
  *   scores   optional [B, H, kv_len] the stash: raw scaled logits BEFORE mask/softmax, rounded like the
  *                                 reference (matmul -> dtype, /sqrt(d) -> dtype) (:111-119), strides sc_sb, sc_sh
  *   lse      optional [B, H, 2] fp32: (row max of masked logits, sum exp(logit - max))  -> max prob = 1/sum
+ *   workspace  sized with spatten_decode_workspace_bytes(batch, heads, head_dim, SPATTEN_DECODE_MAX_SPLITS)
  * ---------------------------------------------------------------------------------------------- */
 int spatten_attn_decode(int dtype,
                         const void* q, int64_t q_sb, int64_t q_sh,
@@ -103,27 +112,63 @@ int spatten_attn_decode(int dtype,
                         int kv_len, int pos_q, int n_splits,
                         void* stream);
 
-/* spatten_attn_decode with the SpAtten extras:
+/* The same decode step with every SpAtten extra, as ONE argument block (zero-fill it, set struct_size, fill what
+ * you use; fields up to and including n_splits mean exactly what the positional form documents):
+ *   workspace_splits           the max_splits the workspace was sized with (0 = SPATTEN_DECODE_MAX_SPLITS)
  *   head_ids / n_active_heads  head pruning: only the listed query heads are launched (ascending int32 list in
  *                              DEVICE memory, NULL = all); rows of pruned heads in out / scores / lse are left untouched
  *   flags                      SPATTEN_DECODE_SCORES_ONLY: write the stash and lse only (no V traffic, no output) —
- *                              pass 1 of local V pruning (scores, lse required; k_new must be NULL) */
+ *                              pass 1 of local V pruning (scores, lse required; k_new must be NULL)
+ *   importance_acc ...         cascade (cumulative) importance, README.md:11, fused and deferred by one step: while this
+ *                              step's keys stream, acc[h, j] += exp(prev_scores[b,h,j] - prev_lse[b,h,0]) / prev_lse[b,h,1]
+ *                              for j < prev_len — the softmax probabilities of the PREVIOUS decode step, whose stash and
+ *                              (max, sum) were written by that step's launch (strides prev_sb, prev_sh; acc [H, >=prev_len]
+ *                              fp32, stride acc_sh).  The last step before a prune is folded by spatten_importance_accumulate.
+ *                              Needs mask == NULL (a single-token step sees every key).
+ *   head_abs_acc               head pruning (README.md:21): fp32 [B*H]; head_abs_acc[b*H+h] += sum_e |out[b, h*d+e]| of the value
+ *                              this call leaves in `out` (deterministic order) — the cumulative head importance
+ *   pq_*                       progressive quantisation (MatrixFetcher.scala:48-51,341-348; RequantDecision.scala:44-72;
+ *                              SpAttenController.scala:35-39,402): keys come from the MSB / LSB planes written by
+ *                              spatten_pq_pack instead of kr_cache (two launches of the decode kernel: pass 1 = logits from
+ *                              the MSB plane, softmax, P.V with the un-quantised V, need_lsb = max_j prob_j < threshold per
+ *                              head; pass 2 = flagged heads refetch the LSB plane and are recomputed once, confident heads
+ *                              return at once).  pq_need_lsb: int32 [B*H] scratch / output (required).  k_new and flags
+ *                              must be NULL / 0 in this mode (append with spatten_kv_append + spatten_pq_pack first);
+ *                              `scores` then holds the logits of the quantised keys that the output was computed from. */
 #define SPATTEN_DECODE_SCORES_ONLY 1
-int spatten_attn_decode_ex(int dtype,
-                           const void* q, int64_t q_sb, int64_t q_sh,
-                           void* k_cache, void* kr_cache, void* v_cache, int64_t kv_sb, int64_t kv_sh,
-                           const void* k_new, const void* v_new, int64_t new_sb, int64_t new_sh,
-                           const void* cos, const void* sin, int table_rows,
-                           const int64_t* position_ids, int64_t pos_sb,
-                           const void* mask, int64_t mask_sb,
-                           void* out, int64_t out_sb,
-                           void* scores, int64_t sc_sb, int64_t sc_sh,
-                           float* lse,
-                           void* workspace,
-                           int batch, int heads, int kv_heads, int head_dim,
-                           int kv_len, int pos_q, int n_splits,
-                           const int32_t* head_ids, int n_active_heads, int flags,
-                           void* stream);
+typedef struct spatten_decode_args {
+  uint32_t struct_size;            /* sizeof(spatten_decode_args_t) of the caller */
+  int32_t dtype;
+  const void* q; int64_t q_sb, q_sh;
+  void* k_cache; void* kr_cache; void* v_cache; int64_t kv_sb, kv_sh;
+  const void* k_new; const void* v_new; int64_t new_sb, new_sh;
+  const void* cos; const void* sin; int32_t table_rows; int32_t pad0_;
+  const int64_t* position_ids; int64_t pos_sb;
+  const void* mask; int64_t mask_sb;
+  void* out; int64_t out_sb;
+  void* scores; int64_t sc_sb, sc_sh;
+  float* lse;
+  void* workspace; int32_t workspace_splits;
+  int32_t batch, heads, kv_heads, head_dim, kv_len, pos_q, n_splits;
+  const int32_t* head_ids; int32_t n_active_heads; int32_t flags;
+  const void* prev_scores; int64_t prev_sb, prev_sh; const float* prev_lse; int32_t prev_len; int32_t pad1_;
+  float* importance_acc; int64_t acc_sh;
+  float* head_abs_acc;
+  const void* pq_msb; const void* pq_lsb; const float* pq_scale;
+  int64_t pq_pl_sb, pq_pl_sh, pq_sc_sb, pq_sc_sh;
+  float pq_threshold; int32_t pad2_;
+  int32_t* pq_need_lsb;
+} spatten_decode_args_t;
+int spatten_attn_decode_args(const spatten_decode_args_t* args, void* stream);
+
+/* KV append without attention (modify_llama.py:95-100 + the shadow row): k_new / v_new [B,Hkv,n,d] (strides new_sb,
+ * new_sh, new_sn; d contiguous) are written to rows [row0, row0+n) of k_cache / v_cache, and their rotation at slot
+ * positions row0+i to kr_cache (all three [B,Hkv,cap,d], strides kv_sb, kv_sh, rows contiguous).  Used by the modes
+ * whose attention launch does not append (progressive quantisation, local V pruning) and by prefill. */
+int spatten_kv_append(int dtype, const void* k_new, const void* v_new, int64_t new_sb, int64_t new_sh, int64_t new_sn,
+                      void* k_cache, void* kr_cache, void* v_cache, int64_t kv_sb, int64_t kv_sh,
+                      const void* cos, const void* sin, int table_rows,
+                      int batch, int kv_heads, int n, int head_dim, int row0, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Prefill attention (q_len >= 1), flash-style, same semantics as above for a block of queries.
@@ -258,19 +303,7 @@ int spatten_pv_gather(int dtype, const void* stash, int64_t sc_sb, int64_t sc_sh
 int spatten_pq_pack(int dtype, const void* kr_cache, int64_t kv_sb, int64_t kv_sh, void* msb, void* lsb, float* scale,
                     int64_t pl_sb, int64_t pl_sh, int64_t sc_sb, int64_t sc_sh, int batch, int kv_heads, int head_dim,
                     int row_lo, int row_hi, void* stream);
-size_t spatten_pq_scratch_bytes(int batch, int heads, int head_dim, int kv_len);
-/* decode step over the planes (two launches of the decode kernel): pass 1 = logits from the MSB plane, softmax, P.V
- * with the un-quantised V, and need_lsb = (max_j prob_j < threshold) per head; pass 2 = flagged heads refetch the LSB
- * plane and are recomputed once (confident heads return at once).  q [B,H,d] un-rotated (rotated at pos_q);
- * need_lsb optional int32 [B*H] (which heads refetched; when NULL the flags live in scratch); scratch =
- * spatten_pq_scratch_bytes; workspace = the decode workspace (spatten_decode_workspace_bytes). */
-int spatten_attn_decode_pq(int dtype, const void* q, int64_t q_sb, int64_t q_sh,
-                           const void* msb, const void* lsb, const float* scale,
-                           int64_t pl_sb, int64_t pl_sh, int64_t sc_sb, int64_t sc_sh,
-                           const void* v_cache, int64_t kv_sb, int64_t kv_sh,
-                           const void* cos, const void* sin, int table_rows, int pos_q, float threshold,
-                           void* out, int64_t out_sb, int32_t* need_lsb, void* scratch, void* workspace,
-                           int batch, int heads, int kv_heads, int head_dim, int kv_len, void* stream);
+/* The decode step over the planes is spatten_attn_decode_args with the pq_* fields set. */
 
 #ifdef __cplusplus
 }

@@ -289,6 +289,42 @@ def head_prune_select(scores: np.ndarray, keep: int) -> np.ndarray:
     return topk_window(scores[None, :], 0, scores.shape[0], keep)[0]
 
 
+def head_prune_cascade(layer_scores: Sequence[np.ndarray], keep: Sequence[int],
+                       prev_kept: Optional[Sequence[Optional[np.ndarray]]] = None) -> List[np.ndarray]:
+    """Cascade head pruning at one prune event (README.md:21: heads "selected on the fly", and a head pruned in one
+    layer is gone in all following layers; ranked by the same top-k engine as tokens).  Restated rule: head importance
+    accumulates layer over layer (cum_l = sum_{l' <= l} scores_{l'}); layer l keeps the ``keep[l]`` best heads among
+    those layer l-1 just kept and — if it pruned before — those it still had (``prev_kept[l]``); ties: lowest id.
+    Returns the ascending kept ids per layer."""
+    H = layer_scores[0].shape[0]
+    cum = np.zeros(H, np.float32)
+    alive = np.ones(H, bool)
+    out = []
+    for l, sc in enumerate(layer_scores):
+        cum = (cum + sc.astype(np.float32)).astype(np.float32)
+        if prev_kept is not None and prev_kept[l] is not None:
+            mine = np.zeros(H, bool)
+            mine[prev_kept[l]] = True
+            alive = alive & mine
+        k = min(int(keep[l]), H, int(alive.sum()))
+        ids = topk_window(np.where(alive, cum, -np.inf).astype(np.float32)[None, :], 0, H, k)[0]
+        alive = np.zeros(H, bool)
+        alive[ids] = True
+        out.append(ids)
+    return out
+
+
+def pq_logits(qr: np.ndarray, msb, lsb, scale, threshold: float, lsb_bits: int = 4):
+    """The logits a progressive-quant decode step actually uses (pass-1 MSB logits, or the refetched 8-bit logits for
+    the rows whose pass-1 max probability is below ``threshold``) and the refetch flags.  qr [B,H,d]; planes [B,H,L,d].
+    Returns (logits [B,H,L] fp32, need [B,H] bool)."""
+    d = qr.shape[-1]
+    s1 = np.einsum("bhd,bhld->bhl", qr.astype(np.float32), pq_dequant(msb, None, scale, lsb_bits)) / np.float32(math.sqrt(d))
+    need = softmax_probs(s1).max(axis=-1) < np.float32(threshold)
+    s2 = np.einsum("bhd,bhld->bhl", qr.astype(np.float32), pq_dequant(msb, lsb, scale, lsb_bits)) / np.float32(math.sqrt(d))
+    return np.where(need[..., None], s2, s1).astype(np.float32), need
+
+
 def pq_quantize(K: np.ndarray, bits: int = 8, lsb_bits: int = 4):
     """Progressive-quantisation storage (MatrixFetcher.scala:48-51,341-348;
     SpAttenController.scala:35-39): symmetric per-row linear quantiser to ``bits``

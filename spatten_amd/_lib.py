@@ -7,7 +7,38 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_int, c_int32, c_int64, c_size_t, c_void_p, POINTER, c_float
+from ctypes import c_char_p, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p, POINTER, c_float
+
+ABI_VERSION = 2
+DECODE_MAX_SPLITS = 64
+
+
+class DecodeArgs(ctypes.Structure):
+    """``spatten_decode_args_t`` (include/spatten.h): the argument block of ``spatten_attn_decode_args``."""
+    _fields_ = [
+        ("struct_size", c_uint32), ("dtype", c_int32),
+        ("q", c_void_p), ("q_sb", c_int64), ("q_sh", c_int64),
+        ("k_cache", c_void_p), ("kr_cache", c_void_p), ("v_cache", c_void_p), ("kv_sb", c_int64), ("kv_sh", c_int64),
+        ("k_new", c_void_p), ("v_new", c_void_p), ("new_sb", c_int64), ("new_sh", c_int64),
+        ("cos", c_void_p), ("sin", c_void_p), ("table_rows", c_int32), ("pad0_", c_int32),
+        ("position_ids", c_void_p), ("pos_sb", c_int64),
+        ("mask", c_void_p), ("mask_sb", c_int64),
+        ("out", c_void_p), ("out_sb", c_int64),
+        ("scores", c_void_p), ("sc_sb", c_int64), ("sc_sh", c_int64),
+        ("lse", c_void_p),
+        ("workspace", c_void_p), ("workspace_splits", c_int32),
+        ("batch", c_int32), ("heads", c_int32), ("kv_heads", c_int32), ("head_dim", c_int32), ("kv_len", c_int32),
+        ("pos_q", c_int32), ("n_splits", c_int32),
+        ("head_ids", c_void_p), ("n_active_heads", c_int32), ("flags", c_int32),
+        ("prev_scores", c_void_p), ("prev_sb", c_int64), ("prev_sh", c_int64), ("prev_lse", c_void_p),
+        ("prev_len", c_int32), ("pad1_", c_int32),
+        ("importance_acc", c_void_p), ("acc_sh", c_int64),
+        ("head_abs_acc", c_void_p),
+        ("pq_msb", c_void_p), ("pq_lsb", c_void_p), ("pq_scale", c_void_p),
+        ("pq_pl_sb", c_int64), ("pq_pl_sh", c_int64), ("pq_sc_sb", c_int64), ("pq_sc_sh", c_int64),
+        ("pq_threshold", c_float), ("pad2_", c_int32),
+        ("pq_need_lsb", c_void_p),
+    ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libspatten_hip.so")
@@ -17,6 +48,10 @@ _lib = None
 
 class SpattenLibraryError(RuntimeError):
     pass
+
+
+class SpattenDeviceTimeout(RuntimeError):
+    """A kernel's bounded wait for another workgroup's data expired (SPATTEN_ERR_TIMEOUT)."""
 
 
 def _declare(lib):
@@ -33,8 +68,12 @@ def _declare(lib):
     lib.spatten_attn_decode.argtypes = [
         i, p, i64, i64, p, p, p, i64, i64, p, p, i64, i64, p, p, i, p, i64, p, i64, p, i64, p, i64, i64, p, p,
         i, i, i, i, i, i, i, p]
-    lib.spatten_attn_decode_ex.restype = c_int
-    lib.spatten_attn_decode_ex.argtypes = lib.spatten_attn_decode.argtypes[:-1] + [p, i, i, p]
+    lib.spatten_attn_decode_args.restype = c_int
+    lib.spatten_attn_decode_args.argtypes = [POINTER(DecodeArgs), p]
+    lib.spatten_decode_workspace_status.restype = c_int
+    lib.spatten_decode_workspace_status.argtypes = [p, p]
+    lib.spatten_kv_append.restype = c_int
+    lib.spatten_kv_append.argtypes = [i, p, p, i64, i64, i64, p, p, p, i64, i64, p, p, i, i, i, i, i, i, p]
     lib.spatten_importance_accumulate.restype = c_int
     lib.spatten_importance_accumulate.argtypes = [i, p, i64, i64, i64, p, p, i64, i64, p, i64, i, i, i, i, i, p]
     lib.spatten_row_lse.restype = c_int
@@ -47,11 +86,6 @@ def _declare(lib):
     lib.spatten_pv_gather.argtypes = [i, p, i64, i64, p, p, i64, p, i64, i64, p, i64, i, p, i64, i, i, i, i, p]
     lib.spatten_pq_pack.restype = c_int
     lib.spatten_pq_pack.argtypes = [i, p, i64, i64, p, p, p, i64, i64, i64, i64, i, i, i, i, i, p]
-    lib.spatten_pq_scratch_bytes.restype = c_size_t
-    lib.spatten_pq_scratch_bytes.argtypes = [i, i, i, i]
-    lib.spatten_attn_decode_pq.restype = c_int
-    lib.spatten_attn_decode_pq.argtypes = [i, p, i64, i64, p, p, p, i64, i64, i64, i64, p, i64, i64, p, p, i, i, c_float,
-                                           p, i64, p, p, p, i, i, i, i, i, p]
     lib.spatten_prefill_workspace_bytes.restype = c_size_t
     lib.spatten_prefill_workspace_bytes.argtypes = [i, i, i, i, i, i, i]
     lib.spatten_attn_prefill.restype = c_int
@@ -85,7 +119,7 @@ def load():
         except OSError as e:  # missing libamdhip64 etc.
             raise SpattenLibraryError(f"cannot load {LIB_PATH}: {e}") from e
         _declare(lib)
-        if lib.spatten_abi_version() != 1:
+        if lib.spatten_abi_version() != ABI_VERSION:
             raise SpattenLibraryError("libspatten_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -96,4 +130,6 @@ def check(status: int, what: str):
         msg = load().spatten_status_string(status).decode()
         if status == -3:
             raise ValueError(f"{what}: {msg}")
+        if status == -5:
+            raise SpattenDeviceTimeout(f"{what}: {msg} — the affected outputs were poisoned with NaN")
         raise RuntimeError(f"{what}: {msg} (status {status})")

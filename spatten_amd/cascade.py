@@ -40,18 +40,22 @@ class CascadeImportance:
         self.acc[layer] = ops.importance_compact(self.acc[layer], idx, start, tail_lo, L, capacity or self.acc[layer].shape[1])
 
 
-def local_v_decode(q, kr_cache, v_cache, kv_len, cos, sin, pos_q, keep, mask=None, workspace=None):
+def local_v_decode(q, kr_cache, v_cache, kv_len, cos, sin, pos_q, keep, mask=None, workspace=None, out=None, stash=None,
+                   lse=None):
     """Decode step with local V pruning: (1) scores + (max, sum) without touching V, (2) per-(b,h) top-``keep`` of the
-    masked logits (same order as the probabilities), (3) P·V over the kept rows only.  Returns (out [B,H*d], stash)."""
+    masked logits (same order as the probabilities), (3) P·V over the kept rows only.  Returns (out [B,H*d], stash);
+    ``stash`` [B,H,>=kv_len] / ``lse`` [B,H,2] may be caller buffers."""
     B, H, d = q.shape
-    stash = torch.empty(B, H, kv_len, dtype=q.dtype, device=q.device)
-    lse = torch.empty(B, H, 2, dtype=torch.float32, device=q.device)
+    if stash is None:
+        stash = torch.empty(B, H, kv_len, dtype=q.dtype, device=q.device)
+    if lse is None:
+        lse = torch.empty(B, H, 2, dtype=torch.float32, device=q.device)
     ops.attn_decode(q, None, kr_cache, v_cache, kv_len, cos, sin, pos_q, mask=mask, scores=stash, lse=lse,
                     scores_only=True, workspace=workspace)
     keep = min(keep, kv_len)
-    logits = stash if mask is None else (stash + mask[:, None, :])
+    logits = stash[:, :, :kv_len] if mask is None else (stash[:, :, :kv_len] + mask[:, None, :])
     idx = ops.topk_select(logits.reshape(B * H, kv_len), 0, kv_len, keep)
-    out = ops.pv_gather(stash, lse, v_cache, idx, mask=mask)
+    out = ops.pv_gather(stash, lse, v_cache, idx, mask=mask, out=out)
     return out, stash
 
 

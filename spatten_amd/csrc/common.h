@@ -255,6 +255,55 @@ template <> struct Dot8<f16_t> {
   }
 };
 
+// o[e] += p0 * x0[e] + p1 * x1[e] over two rows of 8 model-dtype elements (P·V of the decode kernel, two keys at a
+// time).  16-bit types: v_perm_b32 pairs element e of the two rows into one dword and the packed dot instruction takes
+// the probability pair (rounded to the model dtype — the reference rounds P to the dtype before P·V as well,
+// modify_llama.py:135-138) against it: 2 VALU ops per 2 products instead of 4 (unpack, unpack, fma, fma).
+template <typename T> struct PairFma;
+template <> struct PairFma<float> {
+  using prob2 = f32x2;
+  __device__ static inline prob2 pack_p(float p0, float p1) { return f32x2{p0, p1}; }
+  __device__ static inline void fma(float (&o)[8], const Vec8<float>::raw& x0, const Vec8<float>::raw& x1, prob2 pp) {
+    float a[8], b[8];
+    Vec8<float>::unpack(x0, a);
+    Vec8<float>::unpack(x1, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = fmaf(pp[1], b[e], fmaf(pp[0], a[e], o[e]));
+  }
+};
+template <> struct PairFma<bf16_t> {
+  using prob2 = uint32_t;
+  typedef bf16_t bf2 __attribute__((ext_vector_type(2)));
+  __device__ static inline prob2 pack_p(float p0, float p1) {
+    bf2 b = __builtin_convertvector(f32x2{p0, p1}, bf2);
+    return *reinterpret_cast<uint32_t*>(&b);
+  }
+  __device__ static inline void fma(float (&o)[8], const u32x4& x0, const u32x4& x1, prob2 pp) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t lo = __builtin_amdgcn_perm(x1[i], x0[i], 0x05040100u), hi = __builtin_amdgcn_perm(x1[i], x0[i], 0x07060302u);
+      o[2 * i] = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<bf2*>(&lo), *reinterpret_cast<bf2*>(&pp), o[2 * i], false);
+      o[2 * i + 1] = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<bf2*>(&hi), *reinterpret_cast<bf2*>(&pp), o[2 * i + 1], false);
+    }
+  }
+};
+template <> struct PairFma<f16_t> {
+  using prob2 = uint32_t;
+  typedef f16_t h2 __attribute__((ext_vector_type(2)));
+  __device__ static inline prob2 pack_p(float p0, float p1) {
+    h2 h = {(f16_t)p0, (f16_t)p1};
+    return *reinterpret_cast<uint32_t*>(&h);
+  }
+  __device__ static inline void fma(float (&o)[8], const u32x4& x0, const u32x4& x1, prob2 pp) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t lo = __builtin_amdgcn_perm(x1[i], x0[i], 0x05040100u), hi = __builtin_amdgcn_perm(x1[i], x0[i], 0x07060302u);
+      o[2 * i] = __builtin_amdgcn_fdot2(*reinterpret_cast<h2*>(&lo), *reinterpret_cast<h2*>(&pp), o[2 * i], false);
+      o[2 * i + 1] = __builtin_amdgcn_fdot2(*reinterpret_cast<h2*>(&hi), *reinterpret_cast<h2*>(&pp), o[2 * i + 1], false);
+    }
+  }
+};
+
 // dot product of 8 query elements with the 8 unsigned nibbles of one dword of a 4-bit plane (progressive-quant keys).
 // 16-bit types: OR a nibble pair into the mantissas of two constants (bf16 128.0 / f16 1024.0 -> exactly 128+n /
 // 1024+n), feed the pair to the packed dot instruction against the query pair, and take the constant out again
@@ -353,5 +402,35 @@ struct PQKeys {
   int64_t pl_sb, pl_sh, sc_sb, sc_sh;
   float threshold; int32_t* need;
 };
+
+// Host-side description of one launch of the decode kernel family (decode_attn.hip); filled by the C-ABI entry points
+// (spatten_attn_decode*, the rows leg of spatten_attn_prefill).  Strides in elements.
+struct DecodeCall {
+  int dtype = 0;
+  const void* q = nullptr; int64_t q_sb = 0, q_sh = 0, q_sq = 0;
+  void* k_cache = nullptr; void* kr_cache = nullptr; void* v_cache = nullptr; int64_t kv_sb = 0, kv_sh = 0;
+  const void* k_new = nullptr; const void* v_new = nullptr; int64_t new_sb = 0, new_sh = 0;
+  const void* cos = nullptr; const void* sin = nullptr; int table_rows = 0;
+  const int64_t* position_ids = nullptr; int64_t pos_sb = 0;
+  const void* mask = nullptr; int64_t mask_sb = 0, mask_sq = 0;
+  void* out = nullptr; int64_t out_sb = 0, out_sq = 0;
+  void* scores = nullptr; int64_t sc_sb = 0, sc_sh = 0, sc_sq = 0;
+  float* lse = nullptr;
+  // split-N workspace: [256 B header: word 0 = error flag][units x {counter, generation}][units x ws_splits x (D+2) granules]
+  void* workspace = nullptr; size_t ws_units = 0; int ws_splits = 0;
+  int batch = 0, heads = 0, kv_heads = 0, head_dim = 0, kv_len = 0, pos_q = 0, n_q = 1, causal = 0, n_splits = 0;
+  int vis0 = 0;   // causal: keys visible to query row 0 (0 = kv_len - n_q + 1, the HF rule for a block that ENDS the cache)
+  const int32_t* head_ids = nullptr; int n_active = 0; int flags = 0;
+  const PQKeys* pq = nullptr;
+  // cascade importance, deferred by one step: the PREVIOUS step's stash + (max, sum) are folded into acc by this launch
+  const void* prev_scores = nullptr; int64_t pv_sb = 0, pv_sh = 0; const float* prev_lse = nullptr;
+  float* acc = nullptr; int64_t acc_sh = 0; int prev_len = 0;
+  float* head_abs = nullptr;   // [B*H] head importance accumulators (n_q == 1 only)
+};
+int decode_rows(const DecodeCall& c, hipStream_t stream);
+
+constexpr int kDecodeMaxSplits = 64;
+constexpr size_t kDecodeWsHeader = 256;
+inline size_t decode_cnt_bytes(size_t units) { return (units * 2 * sizeof(unsigned) + 255) / 256 * 256; }
 
 }  // namespace spatten

@@ -61,13 +61,18 @@ struct DecodeParams {
   T* scores; int64_t sc_sb, sc_sh, sc_sq;
   float* lse;
   const int32_t* head_ids;   // optional: blockIdx.y -> query head (head pruning: only the kept heads are launched)
-  const float* scores_in; int64_t si_sb, si_sh;   // optional: final fp32 logits given: no K traffic
   // progressive-quant key planes (KSRC != 0, pq.hip): 4-bit MSB / LSB planes [B,Hkv,cap,D/2] + per-row scale
   const uint8_t* pq_msb; const uint8_t* pq_lsb; const float* pq_scale; int64_t pl_sb, pl_sh, ps_sb, ps_sh;
   float pq_thr; int32_t* pq_need;   // [B*H]: written by the MSB pass (max prob < thr), read by the refetch pass
-  unsigned long long* ws_part;   // [B*H*n_q, S, D+2] {value, tag} granules
-  unsigned* ws_cnt;     // [B*H*n_q][2]: {arrival counter, launch generation}
-  int B, H, Hkv, N, pos_q, S, chunk, n_q, causal;
+  // cascade importance (CASC): the previous step's stash + (max, sum) folded into acc while this step's keys stream
+  const T* prev_scores; int64_t pv_sb, pv_sh; const float* prev_lse; float* acc; int64_t acc_sh; int prev_len;
+  float* head_abs;      // optional [B*H]: += sum_e |out[b, h, e]| (head importance, README.md:21), by the unit's last writer
+  unsigned long long* ws_part;   // [units][ws_unit] {value, tag} granules; split s of a unit at s * (D + 2)
+  unsigned* ws_cnt;     // [units][2]: {arrival counter, launch generation}
+  unsigned* ws_err;     // device error word (workspace header)
+  int64_t ws_unit;      // granules reserved per unit = ws_splits * (D + 2): FIXED per workspace, so launches with
+                        // different split counts / head subsets / key sources never alias another unit's partials
+  int B, H, Hkv, N, pos_q, S, chunk, n_q, causal, vis0, append;   // causal: query row qi sees keys [0, vis0 + qi)
   float sqrt_d;
 };
 
@@ -80,8 +85,7 @@ __device__ inline void store_granule(unsigned long long* g, float v, unsigned ta
 }
 
 // MODE 0: the fused decode step.  MODE 1 (scores only): stash + (max, sum), no V traffic, no output — first pass of
-// local V pruning.  MODE 2 (scores in): the final fp32 logits are given, no K traffic — last pass of the
-// progressive-quantisation path.  Compile-time so the hot instantiation carries no extra branches.
+// local V pruning.  Compile-time so the hot instantiation carries no extra branches.
 // LEAN: the plain decode step (one query row, MHA, no mask / position tensor / head list) — the common case gets an
 // instantiation that reads fewer kernel arguments (one scalar-load batch instead of three dependent ones: ~1 us of
 // launch-to-first-load latency on a 14 us kernel) and carries no integer divisions.
@@ -94,13 +98,13 @@ __device__ inline void store_granule(unsigned long long* g, float v, unsigned ta
 //  the rest of the kernel time is launch + first-byte latency + the merge tail.)
 // NT: K/V rows are fetched with the non-temporal cache policy (each row is used once per launch: -0.5 us of 13.7 at
 // C2); off when several query rows (the rows leg of prefill) re-read the same K/V through L2.
-template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0, bool NT = LEAN>
+// CASC: cascade (cumulative) importance, deferred by one step — see DecodeParams.
+template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0, bool NT = LEAN, bool CASC = false>
 __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   constexpr bool SCORES_ONLY = (MODE == 1);
-  constexpr bool SCORES_IN = (MODE == 2);
   constexpr bool PQ = (KSRC != 0);
   constexpr int LPR = D / 16;                    // lanes per row
-  constexpr int RPI = kDecodeThreads / LPR;      // rows per iteration of the workgroup
+  constexpr int RPI = kDecodeThreads / LPR;      // rows per row-group (one per thread group of LPR lanes)
   constexpr int TILE = RPI * UNR;
   constexpr int HALF = D / 2;
   constexpr int G = (kDecodeThreads / D) > 0 ? (kDecodeThreads / D) : 1;   // merge thread groups
@@ -128,29 +132,49 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   if (KSRC == 2 && p.pq_need[unit] == 0) return;   // confident head: the MSB pass already produced its output
 
   // keys this query may attend to (HF causal: j <= P + i with P = N - n_q); the stash covers all N
-  const int n_vis = (!LEAN && p.causal) ? min(p.N, p.N - p.n_q + qi + 1) : p.N;
+  const int n_vis = (!LEAN && p.causal) ? min(p.N, p.vis0 + qi) : p.N;
+  // rows [lo, hi_all) of this split: chunks are balanced (ceil(N / S), any N) and need not be whole tiles — the last
+  // tile of a chunk runs with fewer live row-groups
   const int lo = split * p.chunk;
-  const int hi = min(lo + p.chunk, (p.scores != nullptr) ? p.N : n_vis);
+  const int hi_all = min(lo + p.chunk, (p.scores != nullptr) ? p.N : n_vis);
+  // The split that ends at N appends the new token (row N-1): its K/V rows come from k_new / v_new, not from the
+  // cache, so it is scored as ONE EXTRA ROW beside the tile and the tile covers the rows already cached, [lo, hi).
+  const bool owns_new = p.append && lo < p.N && hi_all == p.N;
+  const int hi = owns_new ? hi_all - 1 : hi_all;
 
   T* krbase = p.krc + b * p.kv_sb + hkv * p.kv_sh;
   T* vbase = p.vc + b * p.kv_sb + hkv * p.kv_sh;
-  const bool owns_new = (p.k_new != nullptr) && lo < p.N && hi == p.N;   // this workgroup appends row N-1
 
-  // ---- loads of the first tile go out before anything else --------------------------------------
+  // ---- every load of the first tile goes out before anything is waited for -----------------------------------------
+  // A tile = UNR row-groups (16-bit dtypes at d = 128: 10 x 32 = 320 rows, 160 registers of K/V in flight per lane):
+  // at Llama-2-7B decode sizes a split's whole chunk (N / 8 <= 320 rows) is ONE tile.  The memory system is saturated
+  // by the other 255 workgroups, so each dependent request -> wait -> compute round costs ~5k cycles of queueing delay
+  // whatever its size (a chunk of 264 rows run as 128 + 128 + 8 measured 15.8k cycles of streaming against 9.4k for
+  // 2 x 128): rounds, not bytes, are what a small launch must minimise.
+  // Vector loads of a wave return IN ORDER and the compiler only places an exact `s_waitcnt vmcnt(N)` in front of a use
+  // when no control flow surrounds the loads, so the issue order below IS the schedule: query + its rotary row, the
+  // keys, the new token's key, the values, the new token's value — all unconditional (rows past the chunk's end
+  // re-read its last row: cache hits; a launch that appends nothing reads the query in place of the new token) — and
+  // then the arithmetic in the same order: rotate the query, score row-group u while u+1.. are still in flight,
+  // softmax, P·V of value group u while u+1.. are still in flight.  (With the loads under `if (u < ng)` the compiler
+  // fell back to vmcnt(0) after the last issue and ALL arithmetic ran after the stream: 9.0 us for a kernel whose
+  // stream alone takes 6.5.)
   struct Tile {
     raw_t k_lo[UNR], k_hi[UNR], v_lo[UNR], v_hi[UNR];
     uint32_t pm_lo[UNR], pm_hi[UNR], pl_lo[UNR], pl_hi[UNR];   // PQ: 8 nibbles each (elements [8c,8c+8) / [d/2+8c, ..))
     float pscale[UNR];
+    T prev[UNR];                                               // CASC: the previous step's logit of the row
   };
   Tile tile_a;
   const uint8_t* pq_m = PQ ? p.pq_msb + b * p.pl_sb + hkv * p.pl_sh : nullptr;
   const uint8_t* pq_l = KSRC == 2 ? p.pq_lsb + b * p.pl_sb + hkv * p.pl_sh : nullptr;
   const float* pq_s = PQ ? p.pq_scale + b * p.ps_sb + hkv * p.ps_sh : nullptr;
-  auto issue_tile = [&](Tile& tl, int t0) {
+  const T* prevp = CASC ? p.prev_scores + b * p.pv_sb + h * p.pv_sh : nullptr;
+  auto row_of = [&](int t0, int u) { return max(min(t0 + u * RPI + r, hi - 1), 0); };   // (an empty split reads row 0)
+  auto issue_keys = [&](Tile& tl, int t0) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      int j = t0 + u * RPI + r;
-      j = j < hi ? j : hi - 1;
+      const int j = row_of(t0, u);
       if (PQ) {
         const int64_t po = (int64_t)j * HALF + 4 * c;   // a plane row is D/2 bytes
         tl.pm_lo[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pq_m + po));
@@ -160,51 +184,69 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
           tl.pl_hi[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pq_l + po + HALF / 2));
         }
         tl.pscale[u] = pq_s[j];
-      }
-      const T* kp = krbase + (int64_t)j * D;
-      const T* vp = vbase + (int64_t)j * D;
-      if (owns_new && j == p.N - 1) {   // the token being appended: source = k_new / v_new (un-rotated)
-        kp = p.k_new + b * p.new_sb + hkv * p.new_sh;
-        vp = p.v_new + b * p.new_sb + hkv * p.new_sh;
-      }
-      if (!SCORES_IN && !PQ) {
+      } else {
+        const T* kp = krbase + (int64_t)j * D;
         tl.k_lo[u] = NT ? V8::ldg_stream(kp + 8 * c) : V8::ldg(kp + 8 * c);
         tl.k_hi[u] = NT ? V8::ldg_stream(kp + HALF + 8 * c) : V8::ldg(kp + HALF + 8 * c);
       }
-      if (!SCORES_ONLY || owns_new) {
+      if (CASC) tl.prev[u] = prevp[max(min(j, p.prev_len - 1), 0)];
+    }
+  };
+  auto issue_values = [&](Tile& tl, int t0) {
+    if (!SCORES_ONLY) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const T* vp = vbase + (int64_t)row_of(t0, u) * D;
         tl.v_lo[u] = NT ? V8::ldg_stream(vp + 8 * c) : V8::ldg(vp + 8 * c);
         tl.v_hi[u] = NT ? V8::ldg_stream(vp + HALF + 8 * c) : V8::ldg(vp + HALF + 8 * c);
       }
     }
   };
-  if (lo < hi) issue_tile(tile_a, lo);
-  SPATTEN_TSTAMP(5);
-  // this unit's launch generation (tags of the published partials, see below): written by the previous launch's merger,
-  // so it comes from memory — fetched with a VECTOR load queued behind the first tile (a scalar load would be waited
-  // for with the kernel arguments, 2-3 us before anything else happens)
-  const unsigned gen = p.S > 1 ? p.ws_cnt[2 * unit + 1 + opaque_lane(0)] : 0u;
+  auto groups_of = [&](int t0) { return max(0, min(UNR, (hi - t0 + RPI - 1) / RPI)); };
 
-  // ---- un-rotated query + its table row ----------------------------------------------------------
-  typename D8::packed q_lo, q_hi;                // rotated query, packed in the model dtype (exact: it IS rounded)
-  typename NibbleDot<T>::packed qn_lo, qn_hi;    // PQ: the same rotated query, arranged for the nibble dot product
-  raw_t n_raw[2];
+  raw_t q_raw[4], n_raw[2], nk_raw[2], nv_raw[2];
   {
     const T* qp = p.q + b * p.q_sb + h * p.q_sh + (LEAN ? 0 : qi * p.q_sq);
     int pq = (!LEAN && p.pos_ids) ? (int)p.pos_ids[b * p.pos_sb + qi] : p.pos_q + qi;
     pq = min(max(pq, 0), p.table_rows - 1);
-    const raw_t q0 = V8::ldg(qp + 8 * c);
-    const raw_t q1 = V8::ldg(qp + HALF + 8 * c);
-    const raw_t q2 = V8::ldg(p.cos + (int64_t)pq * HALF + 8 * c);
-    const raw_t q3 = V8::ldg(p.sin + (int64_t)pq * HALF + 8 * c);
-    if (owns_new) {   // the appended key is rotated at its slot index N-1 (modify_llama.py:103-104)
-      n_raw[0] = V8::ldg(p.cos + (int64_t)(p.N - 1) * HALF + 8 * c);
-      n_raw[1] = V8::ldg(p.sin + (int64_t)(p.N - 1) * HALF + 8 * c);
-    }
+    q_raw[0] = V8::ldg(qp + 8 * c);
+    q_raw[1] = V8::ldg(qp + HALF + 8 * c);
+    q_raw[2] = V8::ldg(p.cos + (int64_t)pq * HALF + 8 * c);
+    q_raw[3] = V8::ldg(p.sin + (int64_t)pq * HALF + 8 * c);
+  }
+  issue_keys(tile_a, lo);
+  {   // the new token's un-rotated key and the rotary row of its slot N-1 (modify_llama.py:103-104)
+    const T* kp = p.k_new + b * p.new_sb + hkv * p.new_sh;      // (always readable: see `append`)
+    nk_raw[0] = V8::ldg(kp + 8 * c);
+    nk_raw[1] = V8::ldg(kp + HALF + 8 * c);
+    const int nr = min(p.N, p.table_rows) - 1;
+    n_raw[0] = V8::ldg(p.cos + (int64_t)nr * HALF + 8 * c);
+    n_raw[1] = V8::ldg(p.sin + (int64_t)nr * HALF + 8 * c);
+  }
+  issue_values(tile_a, lo);
+  {
+    const T* vp = p.v_new + b * p.new_sb + hkv * p.new_sh;
+    nv_raw[0] = V8::ldg(vp + 8 * c);
+    nv_raw[1] = V8::ldg(vp + HALF + 8 * c);
+  }
+  // this unit's launch generation (tags of the published partials, see below): written by the previous launch's merger,
+  // so it comes from memory — a VECTOR load queued behind the tile (a scalar load would be waited for with the kernel
+  // arguments, before anything else happens).  (No workspace: ws_cnt points at the rotary table.)
+  const unsigned gen = p.ws_cnt[(p.S > 1 ? 2 * unit + 1 : 0) + opaque_lane(0)];
+  // nothing that consumes a load may be scheduled above this point: left alone, the scheduler hoists the query
+  // rotation (and the wait for the query) in front of the tile loads, which then leave one memory latency late
+  __builtin_amdgcn_sched_barrier(0);
+  SPATTEN_TSTAMP(5);
+
+  // ---- rotate the query (its data was requested first, so it is here long before the keys) -----------------------
+  typename D8::packed q_lo, q_hi;                // rotated query, packed in the model dtype (exact: it IS rounded)
+  typename NibbleDot<T>::packed qn_lo, qn_hi;    // PQ: the same rotated query, arranged for the nibble dot product
+  {
     float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8];
-    V8::unpack(q0, xlo);
-    V8::unpack(q1, xhi);
-    V8::unpack(q2, cc);
-    V8::unpack(q3, ss);
+    V8::unpack(q_raw[0], xlo);
+    V8::unpack(q_raw[1], xhi);
+    V8::unpack(q_raw[2], cc);
+    V8::unpack(q_raw[3], ss);
     rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
     q_lo = D8::pack(ylo);
     q_hi = D8::pack(yhi);
@@ -214,7 +256,15 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   const float rsqrt_d = 1.0f / p.sqrt_d;
   const T* maskp = (!LEAN && p.mask) ? p.mask + b * p.mask_sb + qi * p.mask_sq : nullptr;
   T* stashp = p.scores ? p.scores + b * p.sc_sb + h * p.sc_sh + (LEAN ? 0 : qi * p.sc_sq) : nullptr;
-  T* kbase = p.kc ? p.kc + b * p.kv_sb + hkv * p.kv_sh : nullptr;
+  // CASC: (max, sum) of the previous step's row — wave-uniform, but fetched per lane behind the tile loads like `gen`
+  float casc_m = 0.f, casc_rl = 0.f;
+  float* accp = nullptr;
+  if (CASC) {
+    const float* ml = p.prev_lse + 2 * (b * p.H + h) + opaque_lane(0);
+    casc_m = (ml[0] == -INFINITY) ? 0.f : ml[0];
+    casc_rl = 1.0f / ml[1];
+    accp = p.acc + h * p.acc_sh;
+  }
 
   // per-THREAD online softmax (the LPR lanes of a row share its score, so they agree): no barrier and
   // no cross-lane maximum inside the loop; the row groups are reconciled once, after the loop.
@@ -223,78 +273,79 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) { olo[i] = 0.f; ohi[i] = 0.f; }
 
-  auto process_tile = [&](Tile& tl, int t0) {
+  // with_new (wave-uniform): this is the tile after which the owning split also scores the appended row
+  auto process_tile = [&](Tile& tl, int t0, int ng, bool with_new) {
     float mk[UNR];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) mk[u] = maskp ? DT<T>::to_f32(maskp[min(t0 + u * RPI + r, n_vis - 1)]) : 0.f;
+    for (int u = 0; u < UNR; ++u) mk[u] = (maskp && u < ng) ? DT<T>::to_f32(maskp[min(t0 + u * RPI + r, n_vis - 1)]) : 0.f;
 
-    if (owns_new && t0 + TILE >= p.N) {
-      // append in place: K un-rotated (modify_llama.py:95-100), its rotation into the shadow, V
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int j = t0 + u * RPI + r;
-        if (j == p.N - 1) {
-          float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8];
-          V8::unpack(tl.k_lo[u], xlo);
-          V8::unpack(tl.k_hi[u], xhi);
-          V8::unpack(n_raw[0], cc);
-          V8::unpack(n_raw[1], ss);
-          rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
-          if (kbase) {
-            V8::stg(kbase + (int64_t)j * D + 8 * c, tl.k_lo[u]);
-            V8::stg(kbase + (int64_t)j * D + HALF + 8 * c, tl.k_hi[u]);
-          }
-          tl.k_lo[u] = V8::pack(ylo);
-          tl.k_hi[u] = V8::pack(yhi);
-          V8::stg(krbase + (int64_t)j * D + 8 * c, tl.k_lo[u]);
-          V8::stg(krbase + (int64_t)j * D + HALF + 8 * c, tl.k_hi[u]);
-          V8::stg(vbase + (int64_t)j * D + 8 * c, tl.v_lo[u]);
-          V8::stg(vbase + (int64_t)j * D + HALF + 8 * c, tl.v_hi[u]);
-        }
-      }
-    }
-
-    // ---- scores of the UNR row groups as independent instruction streams (ILP: one wave per SIMD has nothing
-    // else to hide a dependent VALU chain behind), then ONE per-thread softmax update, then P·V ------------
+    // ---- scores of the row groups, in the order their keys arrive (the values are still in flight) ------------
     float sc[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      if (SCORES_IN) sc[u] = p.scores_in[b * p.si_sb + h * p.si_sh + min(t0 + u * RPI + r, hi - 1)];
-      else if (PQ) {
-        // sum_i q_i * q8_i with q8 = 16 * sext(msb nibble) + lsb nibble; the row scale is applied after the reduction
-        float a = NibbleDot<T>::dot(qn_lo, tl.pm_lo[u] ^ 0x88888888u, 8.f) + NibbleDot<T>::dot(qn_hi, tl.pm_hi[u] ^ 0x88888888u, 8.f);
-        a *= 16.f;
-        if (KSRC == 2) a += NibbleDot<T>::dot(qn_lo, tl.pl_lo[u], 0.f) + NibbleDot<T>::dot(qn_hi, tl.pl_hi[u], 0.f);
-        sc[u] = a;
-      } else sc[u] = D8::dot(q_hi, tl.k_hi[u], D8::dot(q_lo, tl.k_lo[u], 0.f));
+      sc[u] = 0.f;
+      if (u < ng) {
+        if (PQ) {
+          // sum_i q_i * q8_i with q8 = 16 * sext(msb nibble) + lsb nibble; the row scale is applied after the reduction
+          float a = NibbleDot<T>::dot(qn_lo, tl.pm_lo[u] ^ 0x88888888u, 8.f) + NibbleDot<T>::dot(qn_hi, tl.pm_hi[u] ^ 0x88888888u, 8.f);
+          a *= 16.f;
+          if (KSRC == 2) a += NibbleDot<T>::dot(qn_lo, tl.pl_lo[u], 0.f) + NibbleDot<T>::dot(qn_hi, tl.pl_hi[u], 0.f);
+          sc[u] = group_sum<LPR>(a) * tl.pscale[u] / p.sqrt_d;   // fp32 logits
+        } else {
+          const float a = group_sum<LPR>(D8::dot(q_hi, tl.k_hi[u], D8::dot(q_lo, tl.k_lo[u], 0.f)));
+          // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
+          sc[u] = DT<T>::round(div_by_const(DT<T>::round(a), p.sqrt_d, rsqrt_d));
+        }
+      }
     }
-    if (PQ) {
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) sc[u] = group_sum<LPR>(sc[u]) * tl.pscale[u] / p.sqrt_d;   // fp32 logits
-    } else if (!SCORES_IN) {
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) sc[u] = group_sum<LPR>(sc[u]);
-      // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) sc[u] = DT<T>::round(div_by_const(DT<T>::round(sc[u]), p.sqrt_d, rsqrt_d));
+    // ---- the appended token (owning split, after its last tile): K un-rotated into the cache (modify_llama.py:95-100),
+    // its rotation into the shadow, V — stored by the lanes of row-group slot 0 — and its logit, one extra row that
+    // those lanes fold into their softmax
+    float s_new = -INFINITY;
+    if (with_new) {
+      float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8];
+      V8::unpack(nk_raw[0], xlo);
+      V8::unpack(nk_raw[1], xhi);
+      V8::unpack(n_raw[0], cc);
+      V8::unpack(n_raw[1], ss);
+      rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
+      const raw_t r_lo = V8::pack(ylo), r_hi = V8::pack(yhi);
+      const int jn = p.N - 1;
+      if (r == 0) {
+        T* kbase = p.kc ? p.kc + b * p.kv_sb + hkv * p.kv_sh : nullptr;
+        if (kbase) {
+          V8::stg(kbase + (int64_t)jn * D + 8 * c, nk_raw[0]);
+          V8::stg(kbase + (int64_t)jn * D + HALF + 8 * c, nk_raw[1]);
+        }
+        V8::stg(krbase + (int64_t)jn * D + 8 * c, r_lo);
+        V8::stg(krbase + (int64_t)jn * D + HALF + 8 * c, r_hi);
+      }
+      const float a = group_sum<LPR>(D8::dot(q_hi, D8::pack(yhi), D8::dot(q_lo, D8::pack(ylo), 0.f)));
+      float s = DT<T>::round(div_by_const(DT<T>::round(a), p.sqrt_d, rsqrt_d));
+      if (r == 0) {
+        if (stashp != nullptr && c == 0) stashp[jn] = DT<T>::from_f32(s);              // pre-mask (:116-119)
+        if (maskp != nullptr) s = DT<T>::round(s + DT<T>::to_f32(maskp[jn]));           // :132
+        s_new = jn < n_vis ? s : -INFINITY;
+      }
     }
 #ifdef SPATTEN_TRACE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tracing build only: when has ALL of the tile landed?
     SPATTEN_TSTAMP(7);
 #endif
-    float m_new = m_run;
+    float m_new = fmaxf(m_run, s_new);
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int j = t0 + u * RPI + r;
-      const bool valid = j < hi;
+      const bool valid = u < ng && j < hi;
       float s = sc[u];
       if (stashp != nullptr && c == 0 && valid) stashp[j] = DT<T>::from_f32(s);       // pre-mask (:116-119)
+      if (CASC && c == 0 && valid && j < p.prev_len)                                  // last step's probability of key j
+        atomicAdd(accp + j, __expf(DT<T>::to_f32(tl.prev[u]) - casc_m) * casc_rl);
       if (maskp != nullptr) s = DT<T>::round(s + mk[u]);                               // :132
       s = (valid && j < n_vis) ? s : -INFINITY;
       sc[u] = s;
       m_new = fmaxf(m_new, s);
     }
-    if (m_new > m_run) {                           // rare after the first tile
+    if (m_new > m_run) {                           // first tile; rare afterwards
       const float alpha = __expf(m_run - m_new);   // m_run = -inf -> 0
       l_run *= alpha;
 #pragma unroll
@@ -307,22 +358,44 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
       pj[u] = (sc[u] == -INFINITY) ? 0.f : __expf(sc[u] - m_run);
       l_run += pj[u];
     }
+    // ---- P·V, two value rows at a time, in arrival order --------------------------------------------------------
     if (!SCORES_ONLY) {
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        float vlo[8], vhi[8];
-        V8::unpack(tl.v_lo[u], vlo);
-        V8::unpack(tl.v_hi[u], vhi);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { olo[i] = fmaf(pj[u], vlo[i], olo[i]); ohi[i] = fmaf(pj[u], vhi[i], ohi[i]); }
+      for (int u = 0; u < UNR; u += 2) {
+        if (u + 1 < ng) {
+          const typename PairFma<T>::prob2 pp = PairFma<T>::pack_p(pj[u], pj[u + 1]);
+          PairFma<T>::fma(olo, tl.v_lo[u], tl.v_lo[u + 1], pp);
+          PairFma<T>::fma(ohi, tl.v_hi[u], tl.v_hi[u + 1], pp);
+        } else if (u < ng) {                       // odd group count: the last row alone
+          const typename PairFma<T>::prob2 pp = PairFma<T>::pack_p(pj[u], 0.f);
+          PairFma<T>::fma(olo, tl.v_lo[u], tl.v_lo[u], pp);
+          PairFma<T>::fma(ohi, tl.v_hi[u], tl.v_hi[u], pp);
+        }
+      }
+      if (with_new) {                              // the appended row: its V goes to the cache and into the product
+        const float pn = (s_new == -INFINITY) ? 0.f : __expf(s_new - m_run);
+        l_run += pn;
+        const typename PairFma<T>::prob2 pp = PairFma<T>::pack_p(pn, 0.f);
+        PairFma<T>::fma(olo, nv_raw[0], nv_raw[0], pp);
+        PairFma<T>::fma(ohi, nv_raw[1], nv_raw[1], pp);
+        if (r == 0) {
+          V8::stg(vbase + (int64_t)(p.N - 1) * D + 8 * c, nv_raw[0]);
+          V8::stg(vbase + (int64_t)(p.N - 1) * D + HALF + 8 * c, nv_raw[1]);
+        }
       }
     }
   };
-  for (int t0 = lo; t0 < hi; t0 += TILE) {
-    if (t0 != lo) issue_tile(tile_a, t0);
-    process_tile(tile_a, t0);
+  process_tile(tile_a, lo, groups_of(lo), owns_new && lo + TILE >= hi);   // straight-line from the loads to their uses
+  for (int t0 = lo + TILE; t0 < hi; t0 += TILE) {
+    issue_keys(tile_a, t0);
+    issue_values(tile_a, t0);
+    process_tile(tile_a, t0, groups_of(t0), owns_new && t0 + TILE >= hi);
   }
 
+#ifdef SPATTEN_EXP_NOREDUCE   // A/B harness only: what does everything after the streaming loop cost?
+  if (tid < D) p.out[b * p.out_sb + h * D + tid] = DT<T>::from_f32(olo[0] + l_run + m_run);
+  return;
+#endif
   SPATTEN_TSTAMP(1);
   // ---- reconcile the row groups: per-wave max and sums (registers only), then ONE LDS hop across the waves ------
   // (measured alternatives: an extra barrier for a workgroup-wide max first — same time; LDS over the 16 DPP rows
@@ -372,12 +445,28 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
     l_tot = (s_o[0][D] * w0 + s_o[1][D] * w1) + (s_o[2][D] * w2 + s_o[3][D] * w3);
     m_run = m_wg;
   }
+#ifdef SPATTEN_EXP_NOMERGE    // A/B harness only: what do publish + ticket + merge cost?
+  if (tid < D) p.out[b * p.out_sb + h * D + tid] = DT<T>::from_f32(o_tot / l_tot);
+  return;
+#endif
   SPATTEN_TSTAMP(2);
   T* outp = p.out + b * p.out_sb + (LEAN ? 0 : qi * p.out_sq) + h * D;
+  // head importance (head pruning): head_abs[unit] += sum_e |out[e]| of the value this launch leaves in `out` — summed
+  // in a fixed order (deterministic); under progressive quantisation the MSB pass adds only for confident heads and
+  // the refetch pass for the heads it recomputes.  Called by every thread of the workgroup (uniform condition).
+  auto add_head_abs = [&](float val, bool active, bool commit) {
+    float v = wave_sum(active ? fabsf(DT<T>::round(val)) : 0.f);
+    __syncthreads();
+    if (lane == 0) s_o[0][wave] = v;
+    __syncthreads();
+    if (tid == 0 && commit) p.head_abs[unit] += (s_o[0][0] + s_o[0][1]) + (s_o[0][2] + s_o[0][3]);
+  };
   if (p.S == 1) {
     if (!SCORES_ONLY && tid < D) outp[tid] = DT<T>::from_f32(o_tot / l_tot);
     if (p.lse != nullptr && tid == 0) { p.lse[unit * 2] = m_run; p.lse[unit * 2 + 1] = l_tot; }
-    if (KSRC == 1 && tid == 0) p.pq_need[unit] = (1.0f / l_tot) < p.pq_thr ? 1 : 0;   // max prob = exp(0) / sum
+    const bool need1 = KSRC == 1 && (1.0f / l_tot) < p.pq_thr;                          // max prob = exp(0) / sum
+    if (KSRC == 1 && tid == 0) p.pq_need[unit] = need1 ? 1 : 0;
+    if (!SCORES_ONLY && p.head_abs != nullptr) add_head_abs(o_tot / l_tot, tid < D, !need1);
     return;
   }
 
@@ -388,8 +477,10 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   // agent-scope loads (placement independent across the 8 XCD L2s) and re-reads the rare granule whose
   // tag has not landed yet.  The tag is the unit's launch GENERATION + 1 (a word next to the counter, advanced by
   // the merger): granules of earlier launches never match, so nothing has to be cleared for the next launch
-  // (clearing S x (D+2) granules cost the merger 0.3 us of a 13 us kernel).
-  unsigned long long* ws = p.ws_part + ((int64_t)unit * p.S) * (D + 2);
+  // (clearing S x (D+2) granules cost the merger 0.3 us of a 13 us kernel).  A unit's region is FIXED
+  // (unit * ws_unit, whatever this launch's S): a launch that skips a unit (head list, confident PQ heads) leaves
+  // its generation and its region alone, so a later launch can never meet another unit's granules under its own tag.
+  unsigned long long* ws = p.ws_part + (int64_t)unit * p.ws_unit;
   unsigned long long* part = ws + (int64_t)split * (D + 2);
   const unsigned tag = (gen & 0x7FFFFFFFu) + 1u;
   // the ticket is drawn by the LAST wave, which has no stores in flight: on CDNA4 vmcnt also counts stores, so a
@@ -409,6 +500,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   constexpr int KB = 8;                          // splits per thread per round trip
   const int e = tid % D, g = tid / D;
   float mg = -INFINITY, lg = 0.f, og = 0.f;
+  bool expired = false;
   if (g < G) {
     for (int s0 = g; s0 < p.S; s0 += KB * G) {
       unsigned long long ga[KB], gm[KB], gl[KB];
@@ -429,7 +521,8 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
         for (int k = 0; k < KB; ++k)
           diff |= ((unsigned)(ga[k] >> 32) ^ tag) | ((unsigned)(gm[k] >> 32) ^ tag) | ((unsigned)(gl[k] >> 32) ^ tag);
         landed = diff == 0u;
-      } while (!landed && ++spins < (1 << 20));   // bounded: a granule that was issued always lands
+      } while (!landed && ++spins < (1 << 16));   // bounded: a granule that was issued always lands — if not, fail loudly
+      expired |= !landed;
       float a[KB], ms[KB], ls[KB];
 #pragma unroll
       for (int k = 0; k < KB; ++k) {
@@ -453,6 +546,10 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
       mg = mn;
     }
   }
+  if (expired) {   // never merge incomplete data silently: flag the workspace and poison this unit's output
+    atomicOr(p.ws_err, 1u);
+    og = __builtin_nanf("");
+  }
   if (G > 1) {                                   // fold the thread groups through LDS
     if (g < G) { s_o[g][e] = og; if (e == 0) { s_o[g][D] = mg; s_o[g][D + 1] = lg; } }
     __syncthreads();
@@ -473,6 +570,11 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
     }
   }
   if (!SCORES_ONLY && g == 0) outp[e] = DT<T>::from_f32(og / lg);
+  if (!SCORES_ONLY && p.head_abs != nullptr) {
+    if (KSRC == 1 && tid == 0) s_ticket = (1.0f / lg) < p.pq_thr ? 1u : 0u;               // reuse the ticket word
+    if (KSRC == 1) __syncthreads();
+    add_head_abs(og / lg, g == 0, !(KSRC == 1 && s_ticket != 0u));
+  }
   if (tid == 0) {
     if (p.lse != nullptr) { p.lse[unit * 2] = mg; p.lse[unit * 2 + 1] = lg; }
     if (KSRC == 1) p.pq_need[unit] = (1.0f / lg) < p.pq_thr ? 1 : 0;
@@ -482,101 +584,78 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   SPATTEN_TSTAMP(4);
 }
 
-template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0, bool NT = LEAN>
+template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0, bool NT = LEAN, bool CASC = false>
 __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const DecodeParams<T> p) {
-  decode_body<T, D, UNR, MODE, LEAN, KSRC, NT>(p);
+  decode_body<T, D, UNR, MODE, LEAN, KSRC, NT, CASC>(p);
 }
 
 // The plain decode step with its launch-critical arguments FIRST and 32-bit strides: built with
-// -amdgpu-kernarg-preload-count=16 (Makefile) the first 16 kernel-argument dwords arrive in SGPRs with the wave, so
-// the first K/V tile loads are issued without waiting for a scalar load of the argument block (the other arguments
-// are fetched while those loads are in flight).
-template <typename T, int D, int UNR>
-__global__ __launch_bounds__(kDecodeThreads) void decode_lean_kernel(T* krc, T* vc, const T* k_new, const T* v_new,
-                                                                     int kv_sb, int kv_sh, int new_sb, int new_sh,
-                                                                     int N, int chunk, int H, const DecodeParams<T> rest) {
+// -amdgpu-kernarg-preload-count=16 (Makefile) the first 16 kernel-argument dwords — everything the query and the K/V
+// tile loads need (q is dense [B,H,D] here) — arrive in SGPRs with the wave, so those loads are issued without waiting
+// for a scalar load of the argument block (the other arguments are fetched while they are in flight).
+template <typename T, int D, int UNR, bool CASC>
+__global__ __launch_bounds__(kDecodeThreads) void decode_lean_kernel(T* krc, T* vc, const T* q, const T* cos, const T* sin,
+                                                                     int kv_sb, int kv_sh, int N, int chunk, int H, int pos_q,
+                                                                     const DecodeParams<T> rest) {
   DecodeParams<T> p = rest;
-  p.krc = krc; p.vc = vc; p.k_new = k_new; p.v_new = v_new;
-  p.kv_sb = kv_sb; p.kv_sh = kv_sh; p.new_sb = new_sb; p.new_sh = new_sh;
-  p.N = N; p.chunk = chunk; p.H = H;
-  decode_body<T, D, UNR, 0, true, 0, true>(p);
+  p.krc = krc; p.vc = vc; p.q = q; p.cos = cos; p.sin = sin;
+  p.kv_sb = kv_sb; p.kv_sh = kv_sh; p.q_sb = (int64_t)H * D; p.q_sh = D;
+  p.N = N; p.chunk = chunk; p.H = H; p.pos_q = pos_q;
+  decode_body<T, D, UNR, 0, true, 0, true, CASC>(p);
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-// row-groups per tile (UNR): tuning knob, overridable with SPATTEN_DECODE_UNR (1|2|4) for experiments
-static int decode_unr_for(int dtype) {
-  static int env = -1;
-  if (env < 0) {
-    const char* e = getenv("SPATTEN_DECODE_UNR");
-    env = e ? atoi(e) : 0;
-  }
-  int u = env > 0 ? env : (dtype == SPATTEN_F32 ? 2 : 4);
-  if (dtype == SPATTEN_F32 && u > 2) u = 2;
-  return (u == 1 || u == 2 || u == 4 || u == 8) ? u : 4;
-}
-static inline int decode_tile_rows(int d, int dtype) { return (kDecodeThreads / (d / 16)) * decode_unr_for(dtype); }
+// row-groups per tile: 16-bit dtypes 10 (d = 128: 320 rows — a whole Llama-2-7B split — in flight per workgroup)
+template <typename T, int D> constexpr int decode_unr() { return sizeof(T) == 4 ? (D == 256 ? 2 : 4) : (D == 256 ? 4 : 10); }
+static inline int decode_group_rows(int d) { return kDecodeThreads / (d / 16); }
 
-static int auto_splits(int units, int d, int kv_len, int dtype) {
-  const int tile = decode_tile_rows(d, dtype);
-  const int max_by_len = ceil_div(kv_len, tile);
+static int auto_splits(int units, int d, int kv_len) {
   // one workgroup per CU (256 CUs): measured best at Llama-2-7B decode sizes — more splits shorten each
   // workgroup's stream but lengthen the merge (a memory round trip per batch of partials)
   int s = 256 / (units > 0 ? units : 1);
   static int env_s = -1;
   if (env_s < 0) { const char* e = getenv("SPATTEN_DECODE_SPLITS"); env_s = e ? atoi(e) : 0; }
   if (env_s > 0) s = env_s;
+  const int max_by_len = ceil_div(kv_len, 2 * decode_group_rows(d));   // at least two row-groups per split
   if (s > max_by_len) s = max_by_len;
   if (s < 1) s = 1;
-  if (s > 64) s = 64;
+  if (s > kDecodeMaxSplits) s = kDecodeMaxSplits;
   return s;
 }
 
 template <typename T, int D>
 static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_only, hipStream_t stream) {
+  constexpr int U = decode_unr<T, D>();
   const dim3 grid((unsigned)p.S, (unsigned)n_active, (unsigned)(p.B * p.n_q));
+  const dim3 blk(kDecodeThreads);
   if (scores_only) {
-    if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((decode_attn_kernel<T, D, 2, 1>), grid, dim3(kDecodeThreads), 0, stream, p);
-    else hipLaunchKernelGGL((decode_attn_kernel<T, D, 4, 1>), grid, dim3(kDecodeThreads), 0, stream, p);
-    return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
-  }
-  if (p.pq_msb != nullptr) {   // progressive-quant keys: pass 1 on the MSB plane, then the refetch pass (same grid)
+    hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 1>), grid, blk, 0, stream, p);
+  } else if (p.pq_msb != nullptr) {   // progressive-quant keys: pass 1 on the MSB plane, then the refetch pass (same grid)
     if constexpr (D == 256) return SPATTEN_ERR_UNSUPPORTED;
     else {
-      constexpr int U = sizeof(T) == 4 ? 2 : 4;
-      hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, false, 1, true>), grid, dim3(kDecodeThreads), 0, stream, p);
-      hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, false, 2, true>), grid, dim3(kDecodeThreads), 0, stream, p);
-      return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+      // the fused cascade accumulation rides on pass 1 only (pass 2 re-streams the flagged heads: no double count)
+      if (p.acc != nullptr) hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, false, 1, true, true>), grid, blk, 0, stream, p);
+      else hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, false, 1, true>), grid, blk, 0, stream, p);
+      hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, false, 2, true>), grid, blk, 0, stream, p);
     }
-  }
-  if (p.scores_in != nullptr) {
-    if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((decode_attn_kernel<T, D, 2, 2>), grid, dim3(kDecodeThreads), 0, stream, p);
-    else hipLaunchKernelGGL((decode_attn_kernel<T, D, 4, 2>), grid, dim3(kDecodeThreads), 0, stream, p);
-    return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
-  }
-  const bool lean = p.n_q == 1 && p.Hkv == p.H && !p.mask && !p.pos_ids && !p.head_ids && !p.causal;
-  if (lean && decode_unr_for(DT<T>::kId) == 4) {
-    constexpr int U = sizeof(T) == 4 ? 2 : 4;
+  } else {
+    const bool lean = p.n_q == 1 && p.Hkv == p.H && !p.mask && !p.pos_ids && !p.head_ids && !p.causal &&
+                      p.q_sh == D && p.q_sb == (int64_t)p.H * D;
     const int64_t lim = 0x7FFFFFFF;
-    if (p.kv_sb <= lim && p.kv_sh <= lim && p.new_sb <= lim && p.new_sh <= lim)
-      hipLaunchKernelGGL((decode_lean_kernel<T, D, U>), grid, dim3(kDecodeThreads), 0, stream, p.krc, p.vc, p.k_new, p.v_new,
-                         (int)p.kv_sb, (int)p.kv_sh, (int)p.new_sb, (int)p.new_sh, p.N, p.chunk, p.H, p);
-    else
-      hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, true>), grid, dim3(kDecodeThreads), 0, stream, p);
-    return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
-  }
-  switch (decode_unr_for(DT<T>::kId)) {
-    case 1: hipLaunchKernelGGL((decode_attn_kernel<T, D, 1>), grid, dim3(kDecodeThreads), 0, stream, p); break;
-    case 2: hipLaunchKernelGGL((decode_attn_kernel<T, D, 2>), grid, dim3(kDecodeThreads), 0, stream, p); break;
-    case 8:
-      if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((decode_attn_kernel<T, D, 2>), grid, dim3(kDecodeThreads), 0, stream, p);
-      else hipLaunchKernelGGL((decode_attn_kernel<T, D, 8>), grid, dim3(kDecodeThreads), 0, stream, p);
-      break;
-    default: {
-      constexpr int U = sizeof(T) == 4 ? 2 : 4;
-      if (p.n_q == 1) hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, false, 0, true>), grid, dim3(kDecodeThreads), 0, stream, p);
-      else hipLaunchKernelGGL((decode_attn_kernel<T, D, U>), grid, dim3(kDecodeThreads), 0, stream, p);
+    const bool small = p.kv_sb <= lim && p.kv_sh <= lim;
+    const bool casc = p.acc != nullptr;
+    if (lean && small) {
+      if (casc) hipLaunchKernelGGL((decode_lean_kernel<T, D, U, true>), grid, blk, 0, stream, p.krc, p.vc, p.q, p.cos, p.sin,
+                                   (int)p.kv_sb, (int)p.kv_sh, p.N, p.chunk, p.H, p.pos_q, p);
+      else hipLaunchKernelGGL((decode_lean_kernel<T, D, U, false>), grid, blk, 0, stream, p.krc, p.vc, p.q, p.cos, p.sin,
+                              (int)p.kv_sb, (int)p.kv_sh, p.N, p.chunk, p.H, p.pos_q, p);
+    } else if (p.n_q == 1) {
+      if (casc) hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, false, 0, true, true>), grid, blk, 0, stream, p);
+      else hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, false, 0, true>), grid, blk, 0, stream, p);
+    } else {
+      hipLaunchKernelGGL((decode_attn_kernel<T, D, U>), grid, blk, 0, stream, p);
     }
   }
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
@@ -592,65 +671,65 @@ static int dispatch_decode(DecodeParams<T>& p, int d, int n_active, bool scores_
   }
 }
 
-static size_t decode_cnt_bytes(size_t units) { return (units * 2 * sizeof(unsigned) + 255) / 256 * 256; }
-
-// shared by spatten_attn_decode and the small-q / fp32 leg of spatten_attn_prefill
-int decode_rows(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sq, void* k_cache, void* kr_cache,
-                void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* k_new, const void* v_new, int64_t new_sb,
-                int64_t new_sh, const void* cos, const void* sin, int table_rows, const int64_t* position_ids,
-                int64_t pos_sb, const void* mask, int64_t mask_sb, int64_t mask_sq, void* out, int64_t out_sb,
-                int64_t out_sq, void* scores, int64_t sc_sb, int64_t sc_sh, int64_t sc_sq, float* lse, void* workspace,
-                size_t workspace_units, int batch, int heads, int kv_heads, int head_dim, int kv_len, int pos_q,
-                int n_q, int causal, int n_splits, hipStream_t stream, const int32_t* head_ids, int n_active,
-                int flags, const float* scores_in, int64_t si_sb, int64_t si_sh, const PQKeys* pq) {
-  const bool scores_only = (flags & SPATTEN_DECODE_SCORES_ONLY) != 0;
-  if (!q || (!kr_cache && !scores_in && !pq) || !cos || !sin || (!scores_only && (!out || !v_cache))) return SPATTEN_ERR_INVALID;
-  if (scores_only && (!scores || !lse || k_new)) return SPATTEN_ERR_INVALID;
-  if (!head_ids) n_active = heads;
-  if (n_active <= 0 || n_active > heads) return SPATTEN_ERR_INVALID;
-  if (batch <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads != 0 || kv_len <= 0 || pos_q < 0 || n_q <= 0)
+// shared by the decode entry points and the small-q / fp32 leg of spatten_attn_prefill
+int decode_rows(const DecodeCall& c, hipStream_t stream) {
+  const bool scores_only = (c.flags & SPATTEN_DECODE_SCORES_ONLY) != 0;
+  const PQKeys* pq = c.pq;
+  if (!c.q || (!c.kr_cache && !pq) || !c.cos || !c.sin || (!scores_only && (!c.out || !c.v_cache))) return SPATTEN_ERR_INVALID;
+  if (scores_only && (!c.scores || !c.lse || c.k_new)) return SPATTEN_ERR_INVALID;
+  int n_active = c.head_ids ? c.n_active : c.heads;
+  if (n_active <= 0 || n_active > c.heads) return SPATTEN_ERR_INVALID;
+  if (c.batch <= 0 || c.heads <= 0 || c.kv_heads <= 0 || c.heads % c.kv_heads != 0 || c.kv_len <= 0 || c.pos_q < 0 || c.n_q <= 0)
     return SPATTEN_ERR_INVALID;
-  if ((k_new == nullptr) != (v_new == nullptr)) return SPATTEN_ERR_INVALID;
-  if (k_new && n_q != 1) return SPATTEN_ERR_INVALID;
-  if (pq && (!pq->msb || !pq->lsb || !pq->scale || !pq->need || k_new || n_q != 1 || scores_in || scores_only))
+  if ((c.k_new == nullptr) != (c.v_new == nullptr)) return SPATTEN_ERR_INVALID;
+  if (c.k_new && c.n_q != 1) return SPATTEN_ERR_INVALID;
+  if (pq && (!pq->msb || !pq->lsb || !pq->scale || !pq->need || c.k_new || c.n_q != 1 || scores_only))
     return SPATTEN_ERR_INVALID;
-  if (table_rows < kv_len || (!position_ids && pos_q + n_q > table_rows)) return SPATTEN_ERR_INVALID;
-  if (head_dim != 64 && head_dim != 128 && head_dim != 256) return SPATTEN_ERR_UNSUPPORTED;
-  if (dtype != SPATTEN_F32 && dtype != SPATTEN_F16 && dtype != SPATTEN_BF16) return SPATTEN_ERR_INVALID;
-  const int units = batch * heads * n_q;          // workspace is indexed by the FULL head id
-  const int tile = decode_tile_rows(head_dim, dtype);
-  int S = n_splits > 0 ? n_splits : auto_splits(batch * n_active * n_q, head_dim, kv_len, dtype);
-  if (S > ceil_div(kv_len, tile)) S = ceil_div(kv_len, tile);
-  if (S > 64) S = 64;
-  // chunk = rows per split, a multiple of the tile so every split starts tile-aligned
-  const int chunk = ceil_div(ceil_div(kv_len, S), tile) * tile;
-  S = ceil_div(kv_len, chunk);
-  if (S > 1 && (!workspace || (size_t)units > workspace_units)) return SPATTEN_ERR_INVALID;
-  const size_t cnt_bytes = decode_cnt_bytes(workspace_units);
+  if (c.acc && (!c.prev_scores || !c.prev_lse || c.mask || c.n_q != 1 || c.prev_len < 0 || c.prev_len > c.kv_len || scores_only))
+    return SPATTEN_ERR_INVALID;
+  if (c.table_rows < c.kv_len || (!c.position_ids && c.pos_q + c.n_q > c.table_rows)) return SPATTEN_ERR_INVALID;
+  if (c.head_dim != 64 && c.head_dim != 128 && c.head_dim != 256) return SPATTEN_ERR_UNSUPPORTED;
+  if (c.dtype != SPATTEN_F32 && c.dtype != SPATTEN_F16 && c.dtype != SPATTEN_BF16) return SPATTEN_ERR_INVALID;
+  const int units = c.batch * c.heads * c.n_q;          // workspace is indexed by the FULL head id
+  const int ws_splits = c.ws_splits > 0 ? c.ws_splits : kDecodeMaxSplits;
+  int S = c.n_splits > 0 ? c.n_splits : auto_splits(c.batch * n_active * c.n_q, c.head_dim, c.kv_len);
+  if (S > c.kv_len) S = c.kv_len;
+  if (S > kDecodeMaxSplits) S = kDecodeMaxSplits;
+  // balanced chunks: ceil(N / S) rows per split (rounded up to the 8 rows of a stash line), whatever N is
+  const int chunk = ceil_div(ceil_div(c.kv_len, S), 8) * 8;
+  S = ceil_div(c.kv_len, chunk);
+  if (S > 1 && (!c.workspace || (size_t)units > c.ws_units || S > ws_splits)) return SPATTEN_ERR_INVALID;
+  const size_t cnt_bytes = decode_cnt_bytes(c.ws_units);
 
 #define SPATTEN_FILL(T)                                                                                  \
   DecodeParams<T> p;                                                                                     \
-  p.q = (const T*)q; p.q_sb = q_sb; p.q_sh = q_sh; p.q_sq = q_sq;                                        \
-  p.kc = (T*)k_cache; p.krc = (T*)kr_cache; p.vc = (T*)v_cache; p.kv_sb = kv_sb; p.kv_sh = kv_sh;        \
-  p.k_new = (const T*)k_new; p.v_new = (const T*)v_new; p.new_sb = new_sb; p.new_sh = new_sh;            \
-  p.cos = (const T*)cos; p.sin = (const T*)sin; p.table_rows = table_rows;                               \
-  p.pos_ids = position_ids; p.pos_sb = pos_sb;                                                           \
-  p.mask = (const T*)mask; p.mask_sb = mask_sb; p.mask_sq = mask_sq;                                     \
-  p.out = (T*)out; p.out_sb = out_sb; p.out_sq = out_sq;                                                 \
-  p.scores = (T*)scores; p.sc_sb = sc_sb; p.sc_sh = sc_sh; p.sc_sq = sc_sq;                              \
-  p.lse = lse; p.head_ids = head_ids;                                                                    \
-  p.scores_in = scores_in; p.si_sb = si_sb; p.si_sh = si_sh;                                             \
+  p.q = (const T*)c.q; p.q_sb = c.q_sb; p.q_sh = c.q_sh; p.q_sq = c.q_sq;                                \
+  p.kc = (T*)c.k_cache; p.krc = (T*)c.kr_cache; p.vc = (T*)c.v_cache; p.kv_sb = c.kv_sb; p.kv_sh = c.kv_sh; \
+  p.append = c.k_new != nullptr;                                                                         \
+  p.k_new = (const T*)(c.k_new ? c.k_new : c.q); p.v_new = (const T*)(c.k_new ? c.v_new : c.q);           \
+  p.new_sb = c.k_new ? c.new_sb : c.q_sb; p.new_sh = c.k_new ? c.new_sh : c.q_sh;                        \
+  p.cos = (const T*)c.cos; p.sin = (const T*)c.sin; p.table_rows = c.table_rows;                         \
+  p.pos_ids = c.position_ids; p.pos_sb = c.pos_sb;                                                       \
+  p.mask = (const T*)c.mask; p.mask_sb = c.mask_sb; p.mask_sq = c.mask_sq;                               \
+  p.out = (T*)c.out; p.out_sb = c.out_sb; p.out_sq = c.out_sq;                                           \
+  p.scores = (T*)c.scores; p.sc_sb = c.sc_sb; p.sc_sh = c.sc_sh; p.sc_sq = c.sc_sq;                      \
+  p.lse = c.lse; p.head_ids = c.head_ids;                                                                \
   p.pq_msb = pq ? pq->msb : nullptr; p.pq_lsb = pq ? pq->lsb : nullptr; p.pq_scale = pq ? pq->scale : nullptr; \
   p.pl_sb = pq ? pq->pl_sb : 0; p.pl_sh = pq ? pq->pl_sh : 0; p.ps_sb = pq ? pq->sc_sb : 0; p.ps_sh = pq ? pq->sc_sh : 0; \
   p.pq_thr = pq ? pq->threshold : 0.f; p.pq_need = pq ? pq->need : nullptr;                              \
-  p.ws_cnt = (unsigned*)workspace;                                                                       \
-  p.ws_part = workspace ? (unsigned long long*)((char*)workspace + cnt_bytes) : nullptr;                              \
-  p.B = batch; p.H = heads; p.Hkv = kv_heads; p.N = kv_len; p.pos_q = pos_q; p.S = S; p.chunk = chunk;   \
-  p.n_q = n_q; p.causal = causal;                                                                        \
-  p.sqrt_d = sqrtf((float)head_dim);                                                                     \
-  return dispatch_decode<T>(p, head_dim, n_active, scores_only, stream);
+  p.prev_scores = (const T*)c.prev_scores; p.pv_sb = c.pv_sb; p.pv_sh = c.pv_sh; p.prev_lse = c.prev_lse; \
+  p.acc = c.prev_len > 0 ? c.acc : nullptr; p.acc_sh = c.acc_sh; p.prev_len = c.prev_len;               \
+  p.head_abs = c.head_abs;                                                                               \
+  p.ws_err = (unsigned*)c.workspace;                                                                     \
+  p.ws_cnt = c.workspace ? (unsigned*)((char*)c.workspace + kDecodeWsHeader) : (unsigned*)c.cos;         \
+  p.ws_part = c.workspace ? (unsigned long long*)((char*)c.workspace + kDecodeWsHeader + cnt_bytes) : nullptr; \
+  p.ws_unit = (int64_t)ws_splits * (c.head_dim + 2);                                                     \
+  p.B = c.batch; p.H = c.heads; p.Hkv = c.kv_heads; p.N = c.kv_len; p.pos_q = c.pos_q; p.S = S; p.chunk = chunk; \
+  p.n_q = c.n_q; p.causal = c.causal; p.vis0 = c.vis0 > 0 ? c.vis0 : c.kv_len - c.n_q + 1;                \
+  p.sqrt_d = sqrtf((float)c.head_dim);                                                                   \
+  return dispatch_decode<T>(p, c.head_dim, n_active, scores_only, stream);
 
-  switch (dtype) {
+  switch (c.dtype) {
     case SPATTEN_F32: { SPATTEN_FILL(float) }
     case SPATTEN_F16: { SPATTEN_FILL(f16_t) }
     default: { SPATTEN_FILL(bf16_t) }
@@ -665,27 +744,56 @@ using namespace spatten;
 extern "C" size_t spatten_decode_workspace_bytes(int batch, int heads, int head_dim, int max_splits) {
   if (batch <= 0 || heads <= 0 || head_dim <= 0 || max_splits <= 0) return 0;
   const size_t units = (size_t)batch * heads;
-  return decode_cnt_bytes(units) + units * max_splits * (head_dim + 2) * sizeof(unsigned long long);
+  return kDecodeWsHeader + decode_cnt_bytes(units) + units * max_splits * (head_dim + 2) * sizeof(unsigned long long);
 }
 
 extern "C" int spatten_decode_auto_splits(int batch, int heads, int head_dim, int kv_len) {
   if (batch <= 0 || heads <= 0 || kv_len <= 0 || (head_dim != 64 && head_dim != 128 && head_dim != 256)) return 1;
-  return auto_splits(batch * heads, head_dim, kv_len, SPATTEN_BF16);
+  return auto_splits(batch * heads, head_dim, kv_len);
 }
 
-extern "C" int spatten_attn_decode_ex(int dtype, const void* q, int64_t q_sb, int64_t q_sh, void* k_cache,
-                                      void* kr_cache, void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* k_new,
-                                      const void* v_new, int64_t new_sb, int64_t new_sh, const void* cos,
-                                      const void* sin, int table_rows, const int64_t* position_ids,
-                                      int64_t pos_sb, const void* mask, int64_t mask_sb, void* out,
-                                      int64_t out_sb, void* scores, int64_t sc_sb, int64_t sc_sh, float* lse,
-                                      void* workspace, int batch, int heads, int kv_heads, int head_dim,
-                                      int kv_len, int pos_q, int n_splits, const int32_t* head_ids,
-                                      int n_active_heads, int flags, void* stream) {
-  return decode_rows(dtype, q, q_sb, q_sh, 0, k_cache, kr_cache, v_cache, kv_sb, kv_sh, k_new, v_new, new_sb, new_sh,
-                     cos, sin, table_rows, position_ids, pos_sb, mask, mask_sb, 0, out, out_sb, 0, scores, sc_sb,
-                     sc_sh, 0, lse, workspace, (size_t)batch * heads, batch, heads, kv_heads, head_dim, kv_len, pos_q,
-                     1, 0, n_splits, (hipStream_t)stream, head_ids, n_active_heads, flags, nullptr, 0, 0, nullptr);
+extern "C" int spatten_decode_workspace_status(void* workspace, void* stream) {
+  if (!workspace) return SPATTEN_ERR_INVALID;
+  unsigned flag = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemcpyAsync(&flag, workspace, sizeof(flag), hipMemcpyDeviceToHost, st) != hipSuccess) return SPATTEN_ERR_LAUNCH;
+  if (hipStreamSynchronize(st) != hipSuccess) return SPATTEN_ERR_LAUNCH;
+  if (flag == 0) return SPATTEN_OK;
+  (void)hipMemsetAsync(workspace, 0, sizeof(flag), st);
+  return SPATTEN_ERR_TIMEOUT;
+}
+
+extern "C" int spatten_attn_decode_args(const spatten_decode_args_t* a, void* stream) {
+  if (!a || a->struct_size != sizeof(spatten_decode_args_t)) return SPATTEN_ERR_INVALID;
+  DecodeCall c;
+  c.dtype = a->dtype;
+  c.q = a->q; c.q_sb = a->q_sb; c.q_sh = a->q_sh;
+  c.k_cache = a->k_cache; c.kr_cache = a->kr_cache; c.v_cache = a->v_cache; c.kv_sb = a->kv_sb; c.kv_sh = a->kv_sh;
+  c.k_new = a->k_new; c.v_new = a->v_new; c.new_sb = a->new_sb; c.new_sh = a->new_sh;
+  c.cos = a->cos; c.sin = a->sin; c.table_rows = a->table_rows;
+  c.position_ids = a->position_ids; c.pos_sb = a->pos_sb;
+  c.mask = a->mask; c.mask_sb = a->mask_sb;
+  c.out = a->out; c.out_sb = a->out_sb;
+  c.scores = a->scores; c.sc_sb = a->sc_sb; c.sc_sh = a->sc_sh;
+  c.lse = a->lse;
+  c.workspace = a->workspace; c.ws_units = (size_t)(a->batch > 0 && a->heads > 0 ? (size_t)a->batch * a->heads : 0);
+  c.ws_splits = a->workspace_splits > 0 ? a->workspace_splits : kDecodeMaxSplits;
+  c.batch = a->batch; c.heads = a->heads; c.kv_heads = a->kv_heads; c.head_dim = a->head_dim; c.kv_len = a->kv_len;
+  c.pos_q = a->pos_q; c.n_q = 1; c.causal = 0; c.n_splits = a->n_splits;
+  c.head_ids = a->head_ids; c.n_active = a->n_active_heads; c.flags = a->flags;
+  c.prev_scores = a->prev_scores; c.pv_sb = a->prev_sb; c.pv_sh = a->prev_sh; c.prev_lse = a->prev_lse;
+  c.acc = a->importance_acc; c.acc_sh = a->acc_sh; c.prev_len = a->prev_len;
+  c.head_abs = a->head_abs_acc;
+  PQKeys keys;
+  if (a->pq_msb) {
+    if (!a->pq_lsb || !a->pq_scale || !a->pq_need_lsb) return SPATTEN_ERR_INVALID;
+    if (a->head_dim != 64 && a->head_dim != 128) return SPATTEN_ERR_UNSUPPORTED;
+    keys.msb = (const uint8_t*)a->pq_msb; keys.lsb = (const uint8_t*)a->pq_lsb; keys.scale = a->pq_scale;
+    keys.pl_sb = a->pq_pl_sb; keys.pl_sh = a->pq_pl_sh; keys.sc_sb = a->pq_sc_sb; keys.sc_sh = a->pq_sc_sh;
+    keys.threshold = a->pq_threshold; keys.need = a->pq_need_lsb;
+    c.pq = &keys;
+  }
+  return decode_rows(c, (hipStream_t)stream);
 }
 
 extern "C" int spatten_attn_decode(int dtype, const void* q, int64_t q_sb, int64_t q_sh, void* k_cache,
@@ -696,10 +804,22 @@ extern "C" int spatten_attn_decode(int dtype, const void* q, int64_t q_sb, int64
                                    int64_t out_sb, void* scores, int64_t sc_sb, int64_t sc_sh, float* lse,
                                    void* workspace, int batch, int heads, int kv_heads, int head_dim,
                                    int kv_len, int pos_q, int n_splits, void* stream) {
-  return spatten_attn_decode_ex(dtype, q, q_sb, q_sh, k_cache, kr_cache, v_cache, kv_sb, kv_sh, k_new, v_new, new_sb,
-                                new_sh, cos, sin, table_rows, position_ids, pos_sb, mask, mask_sb, out, out_sb, scores,
-                                sc_sb, sc_sh, lse, workspace, batch, heads, kv_heads, head_dim, kv_len, pos_q, n_splits,
-                                nullptr, 0, 0, stream);
+  spatten_decode_args_t a = {};
+  a.struct_size = sizeof(a);
+  a.dtype = dtype;
+  a.q = q; a.q_sb = q_sb; a.q_sh = q_sh;
+  a.k_cache = k_cache; a.kr_cache = kr_cache; a.v_cache = v_cache; a.kv_sb = kv_sb; a.kv_sh = kv_sh;
+  a.k_new = k_new; a.v_new = v_new; a.new_sb = new_sb; a.new_sh = new_sh;
+  a.cos = cos; a.sin = sin; a.table_rows = table_rows;
+  a.position_ids = position_ids; a.pos_sb = pos_sb;
+  a.mask = mask; a.mask_sb = mask_sb;
+  a.out = out; a.out_sb = out_sb;
+  a.scores = scores; a.sc_sb = sc_sb; a.sc_sh = sc_sh;
+  a.lse = lse;
+  a.workspace = workspace; a.workspace_splits = SPATTEN_DECODE_MAX_SPLITS;
+  a.batch = batch; a.heads = heads; a.kv_heads = kv_heads; a.head_dim = head_dim; a.kv_len = kv_len;
+  a.pos_q = pos_q; a.n_splits = n_splits;
+  return spatten_attn_decode_args(&a, stream);
 }
 
 #ifdef SPATTEN_TRACE

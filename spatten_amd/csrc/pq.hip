@@ -12,15 +12,6 @@
 
 namespace spatten {
 
-int decode_rows(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sq, void* k_cache, void* kr_cache,
-                void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* k_new, const void* v_new, int64_t new_sb,
-                int64_t new_sh, const void* cos, const void* sin, int table_rows, const int64_t* position_ids,
-                int64_t pos_sb, const void* mask, int64_t mask_sb, int64_t mask_sq, void* out, int64_t out_sb,
-                int64_t out_sq, void* scores, int64_t sc_sb, int64_t sc_sh, int64_t sc_sq, float* lse, void* workspace,
-                size_t workspace_units, int batch, int heads, int kv_heads, int head_dim, int kv_len, int pos_q,
-                int n_q, int causal, int n_splits, hipStream_t stream, const int32_t* head_ids, int n_active,
-                int flags, const float* scores_in, int64_t si_sb, int64_t si_sh, const PQKeys* pq);
-
 // ---- pack: rows [lo, hi) of kr [B,Hkv,cap,D] -> msb/lsb [B,Hkv,cap,D/2] bytes, scale [B,Hkv,cap] fp32 ------------
 // 16 lanes per row (8 elements each); symmetric per-row 8-bit quantiser: scale = amax/127, q = clip(rint(x/scale)).
 template <typename T, int D>
@@ -88,36 +79,4 @@ extern "C" int spatten_pq_pack(int dtype, const void* kr_cache, int64_t kv_sb, i
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }
 
-static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
-
-extern "C" size_t spatten_pq_scratch_bytes(int batch, int heads, int head_dim, int kv_len) {
-  if (batch <= 0 || heads <= 0 || head_dim <= 0 || kv_len <= 0) return 0;
-  return 256 + al256((size_t)batch * heads * sizeof(int32_t));      // the need_lsb flags when the caller passes none
-}
-
-// Two launches of the decode kernel (decode_attn.hip, KSRC = 1 then 2) over the same grid:
-//   pass 1  K from the MSB plane (68 B / row at d = 128) + V: logits, softmax, P·V, and need_lsb = max prob < threshold
-//           from the merged softmax sum — for a confident head this IS the result;
-//   pass 2  workgroups of confident heads return at once; flagged heads recompute the row ONCE from MSB | LSB + V.
-// A head that is never flagged costs 68 + 256 B per key row instead of 512 (bf16 K + V).
-extern "C" int spatten_attn_decode_pq(int dtype, const void* q, int64_t q_sb, int64_t q_sh, const void* msb,
-                                      const void* lsb, const float* scale, int64_t pl_sb, int64_t pl_sh,
-                                      int64_t sc_sb, int64_t sc_sh, const void* v_cache, int64_t kv_sb, int64_t kv_sh,
-                                      const void* cos, const void* sin, int table_rows, int pos_q, float threshold,
-                                      void* out, int64_t out_sb, int32_t* need_lsb, void* scratch, void* workspace,
-                                      int batch, int heads, int kv_heads, int head_dim, int kv_len, void* stream) {
-  if (!q || !msb || !lsb || !scale || !v_cache || !cos || !sin || !out || (!scratch && !need_lsb)) return SPATTEN_ERR_INVALID;
-  if (batch <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads || kv_len <= 0 || pos_q < 0 || pos_q >= table_rows)
-    return SPATTEN_ERR_INVALID;
-  if (dtype != SPATTEN_F32 && dtype != SPATTEN_F16 && dtype != SPATTEN_BF16) return SPATTEN_ERR_INVALID;
-  if (head_dim != 64 && head_dim != 128) return SPATTEN_ERR_UNSUPPORTED;
-  PQKeys keys;
-  keys.msb = (const uint8_t*)msb; keys.lsb = (const uint8_t*)lsb; keys.scale = scale;
-  keys.pl_sb = pl_sb; keys.pl_sh = pl_sh; keys.sc_sb = sc_sb; keys.sc_sh = sc_sh;
-  keys.threshold = threshold;
-  keys.need = need_lsb ? need_lsb : (int32_t*)(((uintptr_t)scratch + 255) / 256 * 256);
-  return decode_rows(dtype, q, q_sb, q_sh, 0, nullptr, nullptr, const_cast<void*>(v_cache), kv_sb, kv_sh, nullptr, nullptr,
-                     0, 0, cos, sin, table_rows, nullptr, 0, nullptr, 0, 0, out, out_sb, 0, nullptr, 0, 0, 0, nullptr,
-                     workspace, (size_t)batch * heads, batch, heads, kv_heads, head_dim, kv_len, pos_q, 1, 0, 0,
-                     (hipStream_t)stream, nullptr, 0, 0, nullptr, 0, 0, &keys);
-}
+// The decode step over the planes: spatten_attn_decode_args with the pq_* fields set (decode_attn.hip, KSRC = 1 / 2).

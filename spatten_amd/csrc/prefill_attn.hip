@@ -26,16 +26,6 @@
 
 namespace spatten {
 
-int decode_rows(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sq, void* k_cache, void* kr_cache,
-                void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* k_new, const void* v_new, int64_t new_sb,
-                int64_t new_sh, const void* cos, const void* sin, int table_rows, const int64_t* position_ids,
-                int64_t pos_sb, const void* mask, int64_t mask_sb, int64_t mask_sq, void* out, int64_t out_sb,
-                int64_t out_sq, void* scores, int64_t sc_sb, int64_t sc_sh, int64_t sc_sq, float* lse, void* workspace,
-                size_t workspace_units, int batch, int heads, int kv_heads, int head_dim, int kv_len, int pos_q,
-                int n_q, int causal, int n_splits, hipStream_t stream, const int32_t* head_ids = nullptr,
-                int n_active = 0, int flags = 0, const float* scores_in = nullptr, int64_t si_sb = 0, int64_t si_sh = 0,
-                const PQKeys* pq = nullptr);
-
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifdef SPATTEN_PF_TRACE   // developer instrumentation (tools/probe_pf_trace.py): phase timestamps of workgroup 0
 __device__ unsigned long long* g_pf_trace = nullptr;
@@ -847,6 +837,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   }
 }
 
+constexpr int kRowsPerLaunch = 4096;   // query rows per launch of the rows leg
 static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 static inline int rows_leg(int dtype, int head_dim, int q_len) {
   return dtype == SPATTEN_F32 || q_len <= 8 || (head_dim != 64 && head_dim != 128);
@@ -895,9 +886,9 @@ extern "C" size_t spatten_prefill_workspace_bytes(int dtype, int batch, int head
                                                   int q_len, int kv_len) {
   if (batch <= 0 || heads <= 0 || kv_heads <= 0 || head_dim <= 0 || q_len <= 0 || kv_len <= 0) return 0;
   if (rows_leg(dtype, head_dim, q_len)) {
-    const size_t units = (size_t)batch * heads * q_len;
+    const size_t units = (size_t)batch * heads * (size_t)(q_len < kRowsPerLaunch ? q_len : kRowsPerLaunch);
     const int S = rows_splits((int)(units > (1u << 30) ? (1u << 30) : units));
-    return 256 + align256(units * 2 * sizeof(unsigned)) + (S > 1 ? units * S * (head_dim + 2) * sizeof(unsigned long long) : 0);
+    return 256 + kDecodeWsHeader + decode_cnt_bytes(units) + (S > 1 ? units * S * (head_dim + 2) * sizeof(unsigned long long) : 0);
   }
   const size_t es = 2, npad = (size_t)ceil_div(kv_len, 128) * 128;
   return 256 + align256((size_t)batch * kv_heads * head_dim * npad * es);      // the key-contiguous copy of V
@@ -921,17 +912,36 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
 
   if (rows_leg(dtype, head_dim, q_len)) {
     if (col_importance) return SPATTEN_ERR_UNSUPPORTED;   // by-product of the flash leg only (use the stash here)
-    const size_t units = (size_t)batch * heads * q_len;
-    const int S = rows_splits((int)units);
-    if (S > 1 && hipMemsetAsync(ws, 0, align256(units * 2 * sizeof(unsigned)), st) != hipSuccess) return SPATTEN_ERR_LAUNCH;
-    // granule tags must start cleared too; the merger re-arms them, so only a fresh workspace needs this
-    if (S > 1 && hipMemsetAsync(ws + align256(units * 2 * sizeof(unsigned)), 0,
-                                units * S * (head_dim + 2) * sizeof(unsigned long long), st) != hipSuccess)
-      return SPATTEN_ERR_LAUNCH;
-    return decode_rows(dtype, q, q_sb, q_sh, q_sq, nullptr, const_cast<void*>(kr_cache), const_cast<void*>(v_cache),
-                       kv_sb, kv_sh, nullptr, nullptr, 0, 0, cos, sin, table_rows, position_ids, pos_sb, mask, mask_sb,
-                       mask_sq, out, out_sb, out_sq, scores, sc_sb, sc_sh, sc_sq, nullptr, ws, units, batch, heads,
-                       kv_heads, head_dim, kv_len, pos_q0, q_len, causal, S, st);
+    // one decode workgroup column per query row; query rows go out in slices of kRowsPerLaunch so that grid.z
+    // (B * rows) stays inside the launch limit whatever q_len is.  Every row re-streams K/V (through L2): the cost
+    // is O(q_len * kv_len) memory traffic — this leg is for exactness (fp32) and short blocks, not for long prefill.
+    const int rows_per = max(1, min(kRowsPerLaunch, 65535 / batch));
+    for (int i0 = 0; i0 < q_len; i0 += rows_per) {
+      const int nq = min(rows_per, q_len - i0);
+      const size_t units = (size_t)batch * heads * nq;
+      const int S = rows_splits((int)units);
+      const size_t cnt = kDecodeWsHeader + decode_cnt_bytes(units);
+      // counters / generations start cleared; granule tags too (a workspace reused across shapes may hold stale ones)
+      if (S > 1 && hipMemsetAsync(ws, 0, cnt + units * S * (head_dim + 2) * sizeof(unsigned long long), st) != hipSuccess)
+        return SPATTEN_ERR_LAUNCH;
+      const int es = dtype == SPATTEN_F32 ? 4 : 2;
+      DecodeCall c;
+      c.dtype = dtype;
+      c.q = (const char*)q + (int64_t)i0 * q_sq * es; c.q_sb = q_sb; c.q_sh = q_sh; c.q_sq = q_sq;
+      c.kr_cache = const_cast<void*>(kr_cache); c.v_cache = const_cast<void*>(v_cache); c.kv_sb = kv_sb; c.kv_sh = kv_sh;
+      c.cos = cos; c.sin = sin; c.table_rows = table_rows;
+      c.position_ids = position_ids ? position_ids + i0 : nullptr; c.pos_sb = pos_sb;
+      c.mask = mask ? (const char*)mask + (int64_t)i0 * mask_sq * es : nullptr; c.mask_sb = mask_sb; c.mask_sq = mask_sq;
+      c.out = (char*)out + (int64_t)i0 * out_sq * es; c.out_sb = out_sb; c.out_sq = out_sq;
+      c.scores = scores ? (char*)scores + (int64_t)i0 * sc_sq * es : nullptr; c.sc_sb = sc_sb; c.sc_sh = sc_sh; c.sc_sq = sc_sq;
+      c.workspace = ws; c.ws_units = units; c.ws_splits = S;
+      c.batch = batch; c.heads = heads; c.kv_heads = kv_heads; c.head_dim = head_dim;
+      c.kv_len = kv_len; c.pos_q = pos_q0 + i0; c.n_q = nq; c.causal = causal; c.n_splits = S;
+      c.vis0 = kv_len - q_len + i0 + 1;          // HF causal rule for row i0 of the whole block
+      const int rc = decode_rows(c, st);
+      if (rc != SPATTEN_OK) return rc;
+    }
+    return SPATTEN_OK;
   }
 
   const int npad = ceil_div(kv_len, 128) * 128;      // Vt rows padded to whole 128-key tiles (zeros beyond kv_len)

@@ -302,6 +302,47 @@ __global__ __launch_bounds__(256) void rope_single_kernel(const T* __restrict__ 
   V8::stg(yp + half + 8 * c, V8::pack(yhi));
 }
 
+// ================================================================================================
+// KV append without attention: rows [row0, row0+n) of k / v, and their rotation at the slot index into the shadow
+// (modify_llama.py:95-104).  One thread per (b, h, row, group of 8 column pairs).
+// ================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void kv_append_kernel(const T* __restrict__ k_new, const T* __restrict__ v_new,
+                                                        int64_t new_sb, int64_t new_sh, int64_t new_sn,
+                                                        T* __restrict__ kc, T* __restrict__ krc, T* __restrict__ vc,
+                                                        int64_t kv_sb, int64_t kv_sh, const T* __restrict__ cos,
+                                                        const T* __restrict__ sin, int table_rows, int B, int H, int n,
+                                                        int d, int row0) {
+  const int half = d / 2;
+  const int gpr = half / 8;
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)B * H * n * gpr;
+  if (g >= total) return;
+  const int c = (int)(g % gpr);
+  const long long rowid = g / gpr;
+  const int i = (int)(rowid % n);
+  const int h = (int)((rowid / n) % H);
+  const int b = (int)(rowid / ((long long)n * H));
+  const int ps = min(row0 + i, table_rows - 1);
+  using V8 = Vec8<T>;
+  const T* kp = k_new + b * new_sb + h * new_sh + (int64_t)i * new_sn;
+  const T* vp = v_new + b * new_sb + h * new_sh + (int64_t)i * new_sn;
+  const int64_t dst = b * kv_sb + h * kv_sh + (int64_t)(row0 + i) * d;
+  const typename V8::raw k0 = V8::ldg(kp + 8 * c), k1 = V8::ldg(kp + half + 8 * c);
+  const typename V8::raw v0 = V8::ldg(vp + 8 * c), v1 = V8::ldg(vp + half + 8 * c);
+  float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8];
+  V8::unpack(k0, xlo);
+  V8::unpack(k1, xhi);
+  V8::unpack(V8::ldg(cos + (int64_t)ps * half + 8 * c), cc);
+  V8::unpack(V8::ldg(sin + (int64_t)ps * half + 8 * c), ss);
+  rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
+  if (kc) { V8::stg(kc + dst + 8 * c, k0); V8::stg(kc + dst + half + 8 * c, k1); }
+  V8::stg(krc + dst + 8 * c, V8::pack(ylo));
+  V8::stg(krc + dst + half + 8 * c, V8::pack(yhi));
+  V8::stg(vc + dst + 8 * c, v0);
+  V8::stg(vc + dst + half + 8 * c, v1);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -448,6 +489,30 @@ extern "C" int spatten_rope_single(int dtype, const void* x, int64_t x_sb, int64
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }
 
+extern "C" int spatten_kv_append(int dtype, const void* k_new, const void* v_new, int64_t new_sb, int64_t new_sh,
+                                 int64_t new_sn, void* k_cache, void* kr_cache, void* v_cache, int64_t kv_sb,
+                                 int64_t kv_sh, const void* cos, const void* sin, int table_rows, int batch,
+                                 int kv_heads, int n, int head_dim, int row0, void* stream) {
+  if (!valid_dtype(dtype) || !k_new || !v_new || !kr_cache || !v_cache || !cos || !sin) return SPATTEN_ERR_INVALID;
+  if (batch <= 0 || kv_heads <= 0 || n < 0 || row0 < 0 || table_rows < row0 + n) return SPATTEN_ERR_INVALID;
+  if (head_dim <= 0 || head_dim % 16 != 0) return SPATTEN_ERR_UNSUPPORTED;
+  if (n == 0) return SPATTEN_OK;
+  const long long total = (long long)batch * kv_heads * n * (head_dim / 16);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+#define SPATTEN_APPEND(T)                                                                                          \
+  hipLaunchKernelGGL((kv_append_kernel<T>), grid, dim3(256), 0, st, (const T*)k_new, (const T*)v_new, new_sb, new_sh, \
+                     new_sn, (T*)k_cache, (T*)kr_cache, (T*)v_cache, kv_sb, kv_sh, (const T*)cos, (const T*)sin,       \
+                     table_rows, batch, kv_heads, n, head_dim, row0)
+  switch (dtype) {
+    case SPATTEN_F32: SPATTEN_APPEND(float); break;
+    case SPATTEN_F16: SPATTEN_APPEND(f16_t); break;
+    default: SPATTEN_APPEND(bf16_t);
+  }
+#undef SPATTEN_APPEND
+  return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+}
+
 extern "C" int spatten_abi_version(void) { return SPATTEN_ABI_VERSION; }
 
 extern "C" const char* spatten_status_string(int status) {
@@ -457,6 +522,7 @@ extern "C" const char* spatten_status_string(int status) {
     case SPATTEN_ERR_UNSUPPORTED: return "unsupported shape";
     case SPATTEN_ERR_WINDOW: return "top-k window holds fewer than k candidates";
     case SPATTEN_ERR_LAUNCH: return "kernel launch failed";
+    case SPATTEN_ERR_TIMEOUT: return "a kernel gave up waiting for another workgroup's data";
     default: return "unknown status";
   }
 }

@@ -24,15 +24,21 @@ _FAMILIES: Dict[str, Callable] = {"llama": _patch_llama}
 
 
 def enable_spatten_llm(model, start_size, important_size, recent_size, importance_mode="reference",
-                       prefill_stash=True, assume_causal=False):
-    """``importance_mode="cascade"`` (extension, parity unpinned) makes the patched forward accumulate softmax
-    probabilities per (layer, head, key) and the returned cache prune by them instead of by the last step's logits.
+                       prefill_stash=True, assume_causal=False, head_keep=None, pq_threshold=None, local_v_keep=None):
+    """The reference's four positional arguments (enable_spatten_llm.py:5) plus opt-in extensions:
 
-    ``prefill_stash=False`` (extension): forwards with ``q_len > 1`` do not materialise ``self.attn_scores``
-    ([B,H,q,N]: 4 GiB per layer at q = N = 8192; the reference writes it on every forward, modify_llama.py:116-119) —
-    it is set to ``None`` there.  The caller protocol (run_spatten_llama.py:71-79) prunes from the LAST DECODE step's
-    stash, which is still written.  ``assume_causal=True``: a non-None HF mask at ``q_len > 1`` is taken to be the
-    causal mask and not read (tiles above the diagonal are skipped)."""
+    ``prefill_stash=False``: forwards with ``q_len > 1`` do not materialise ``self.attn_scores`` ([B,H,q,N]: 4 GiB per
+    layer at q = N = 8192; the reference writes it on every forward, modify_llama.py:116-119) — it is ``None`` there.  The
+    caller protocol (run_spatten_llama.py:71-79) prunes from the LAST DECODE step's stash, which is still written.
+    ``assume_causal=True``: the HF mask / position_ids of a forward are taken to be what transformers 4.33 builds
+    (causal mask, positions arange(past, past+q)) and are not read: tiles above the diagonal are skipped and a
+    single-token step runs the lean decode kernel.
+
+    SpAtten semantics the reference's Python does not implement (PARITY UNPINNED; spatten_amd/extensions.py):
+    ``importance_mode="cascade"`` (cumulative importance = running sum of softmax probabilities, accumulated inside the
+    decode launch), ``head_keep`` (cascade head pruning: int or one int per layer), ``pq_threshold`` (progressive
+    quantisation of the keys at decode: MSB plane first, LSB refetch below this max-probability), ``local_v_keep``
+    (local V pruning at decode: fraction of the keys whose V row is fetched)."""
     model_type = model.config.model_type
     patch = next((fn for key, fn in _FAMILIES.items() if key in model_type), None)
     if patch is None:
@@ -40,19 +46,22 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     k_dim, v_dim = patch(model)
     cache = SpAttenKVCache(start_size=start_size, recent_size=recent_size, important_size=important_size,
                            k_seq_dim=k_dim, v_seq_dim=v_dim, importance_mode=importance_mode)
-    if not prefill_stash or assume_causal:
-        from .pos_shift.modify_llama import attention_modules
+    from .pos_shift.modify_llama import attention_modules
 
-        if importance_mode == "cascade" and not prefill_stash:
-            raise ValueError("importance_mode='cascade' accumulates from the prefill stash: prefill_stash must stay True")
-        for m in attention_modules(model):
-            m.spatten_prefill_stash = bool(prefill_stash)
-            m.spatten_assume_causal = bool(assume_causal)
-    if importance_mode == "cascade":
-        from .pos_shift.modify_llama import attention_modules
+    mods = attention_modules(model)                                # model.modules() order = layer order (:74-77)
+    extended = importance_mode == "cascade" or head_keep is not None or pq_threshold is not None or local_v_keep is not None
+    if importance_mode == "cascade" and not prefill_stash:
+        raise ValueError("importance_mode='cascade' accumulates from the prefill stash: prefill_stash must stay True")
+    for m in mods:
+        m.spatten_prefill_stash = bool(prefill_stash)
+        m.spatten_assume_causal = bool(assume_causal)
+        m._spatten_ext = None
+        m._spatten_rope = None
+    if extended:
+        from .extensions import SpattenExtensions
 
-        mods = attention_modules(model)                            # model.modules() order = layer order (:74-77)
-        cache._cascade_modules = mods
+        cache.ext = SpattenExtensions(cache, len(mods), cascade=importance_mode == "cascade", head_keep=head_keep,
+                                      pq_threshold=pq_threshold, local_v_keep=local_v_keep)
         for layer, m in enumerate(mods):
-            m._spatten_cascade = (cache, layer)
+            m._spatten_ext = (cache.ext, layer)
     return cache

@@ -1,0 +1,227 @@
+"""SpAtten's cascade semantics wired INTO the plugin surface — opt-in keyword arguments of
+``enable_spatten_llm``; with none of them set the plugin is the reference's behaviour and this module is never touched.
+
+PARITY UNPINNED: the reference's Python implements none of this (README.md:11,21 describe it, the RTL under
+spatten_hardware/ carries the control flow); the rules are restated in oracle/spatten_oracle.py and the tests compare
+against those restatements.
+
+    importance_mode="cascade"   cumulative token importance = running sum of softmax probabilities (README.md:11; trace
+                                flag if_accumulate_importance).  Decode steps fold the PREVIOUS step's probabilities into
+                                the accumulator inside the attention launch (no extra kernel); the last step before a
+                                prune is folded by the prune.
+    head_keep=k | [k_0..k_L-1]  cascade head pruning (README.md:21): head importance = cumulative sum |attn_out_h|
+                                (accumulated by the attention launch's merge step), summed layer over layer; at every
+                                prune event layer l keeps the k_l best heads among those layer l-1 kept (and it kept
+                                before) — once pruned, a head stays pruned here and in all later layers.  Pruned heads are
+                                not launched; their slice of attn_output is zero.
+    pq_threshold=t              progressive quantisation of the keys at decode (RequantDecision.scala:44-72;
+                                MatrixFetcher.scala:341-348): MSB plane first, LSB refetch for heads whose max probability
+                                is below t.
+    local_v_keep=f              local V pruning at decode (SpAttenController.scala:546-558,591-612): only the
+                                ceil(f * kv_len) most probable keys of a head fetch their V row.
+All modes assume the HF causal mask (a single-token step sees every key), like ``assume_causal=True``.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Union
+
+import torch
+
+from . import kv_slab, ops
+
+
+class LayerState:
+    """Per-layer device state of the extensions: double-buffered stash / (max, sum) (the previous step's pair feeds the
+    fused cascade accumulation), the accumulators, the kept-head list."""
+
+    def __init__(self):
+        self.stash: List[Optional[torch.Tensor]] = [None, None]     # [B, H, cap] model dtype
+        self.lse: List[Optional[torch.Tensor]] = [None, None]       # [B, H, 2] fp32
+        self.parity = 0
+        self.pending_len = 0            # rows of stash[parity ^ 1] not yet folded into acc (0 = nothing pending)
+        self.acc: Optional[torch.Tensor] = None                     # [H, cap] fp32 cumulative importance
+        self.head_abs: Optional[torch.Tensor] = None                # [B*H] fp32: sum |attn_out| per (b, h), decode steps
+        self.head_abs_prefill: Optional[torch.Tensor] = None        # [H] fp32: the same from multi-token forwards
+        self.head_ids: Optional[torch.Tensor] = None                # int32 ascending kept heads (None = all)
+        self.pruned_ids: Optional[torch.Tensor] = None              # int64 pruned heads
+        self.need_lsb: Optional[torch.Tensor] = None                # int32 [B*H]
+        self.out: Optional[torch.Tensor] = None                     # [B, H*d], zero in the pruned heads' slices
+
+    def ensure(self, B, H, d, n, dtype, device, want_acc):
+        cap = kv_slab.round_capacity(n + kv_slab.GROW)
+        if self.stash[0] is None or self.stash[0].shape[0] != B or self.stash[0].shape[2] < n:
+            old = self.stash
+            self.stash = [torch.zeros(B, H, cap, dtype=dtype, device=device) for _ in range(2)]
+            for i in range(2):          # a pending stash survives the growth
+                if old[i] is not None and old[i].shape[0] == B:
+                    self.stash[i][:, :, :old[i].shape[2]] = old[i]
+            if self.lse[0] is None or self.lse[0].shape[0] != B:
+                self.lse = [torch.zeros(B, H, 2, dtype=torch.float32, device=device) for _ in range(2)]
+                self.pending_len = 0
+        if want_acc and (self.acc is None or self.acc.shape[1] < n):
+            grown = torch.zeros(H, cap, dtype=torch.float32, device=device)
+            if self.acc is not None:
+                grown[:, :self.acc.shape[1]] = self.acc
+            self.acc = grown
+        if self.head_abs is None or self.head_abs.numel() != B * H:
+            self.head_abs = torch.zeros(B * H, dtype=torch.float32, device=device)
+            self.head_abs_prefill = torch.zeros(H, dtype=torch.float32, device=device)
+        if self.need_lsb is None or self.need_lsb.numel() != B * H:
+            self.need_lsb = torch.zeros(B * H, dtype=torch.int32, device=device)
+        if self.out is None or self.out.shape != (B, H * d) or self.out.dtype != dtype:
+            self.out = torch.zeros(B, H * d, dtype=dtype, device=device)
+
+
+def _per_layer(x, n_layers: int, name: str):
+    if x is None:
+        return None
+    if isinstance(x, (int, float)):
+        return [x] * n_layers
+    x = list(x)
+    if len(x) != n_layers:
+        raise ValueError(f"{name} needs one entry per layer ({n_layers}), got {len(x)}")
+    return x
+
+
+class SpattenExtensions:
+    def __init__(self, cache, n_layers: int, cascade: bool = False,
+                 head_keep: Union[None, int, Sequence[int]] = None, pq_threshold: Optional[float] = None,
+                 local_v_keep: Optional[float] = None):
+        if pq_threshold is not None and local_v_keep is not None:
+            raise ValueError("pq_threshold and local_v_keep cannot be combined (the local-V pass scores from the bf16 shadow)")
+        if local_v_keep is not None and not (0.0 < float(local_v_keep) <= 1.0):
+            raise ValueError("local_v_keep is a fraction in (0, 1]")
+        self.cache = cache
+        self.n_layers = n_layers
+        self.cascade = bool(cascade)
+        self.head_keep = _per_layer(head_keep, n_layers, "head_keep")
+        if self.head_keep is not None and any(b > a for a, b in zip(self.head_keep, self.head_keep[1:])):
+            raise ValueError("head_keep must not grow from layer to layer (a pruned head stays pruned in later layers)")
+        self.pq_threshold = None if pq_threshold is None else float(pq_threshold)
+        self.local_v_keep = None if local_v_keep is None else float(local_v_keep)
+        self.layers = [LayerState() for _ in range(n_layers)]
+        self.n_lsb_refetch = 0          # diagnostics: filled by stats()
+
+    # ------------------------------------------------------------------------------------------------
+    # attention forward, q_len == 1
+    # ------------------------------------------------------------------------------------------------
+    def decode_step(self, layer: int, q, k_new, v_new, slab, kv_len: int, past_len: int, cos, sin):
+        """q [B,H,d], k_new / v_new [B,Hkv,d].  Returns (attn_output [B, H*d], stash view [B,H,1,kv_len])."""
+        st = self.layers[layer]
+        B, H, d = q.shape
+        st.ensure(B, H, d, kv_len, q.dtype, q.device, self.cascade)
+        cur = st.parity
+        st.parity ^= 1
+        stash, lse = st.stash[cur], st.lse[cur]
+        casc = None
+        if self.cascade and st.pending_len > 0:
+            casc = (st.acc, st.stash[cur ^ 1], st.lse[cur ^ 1], min(st.pending_len, kv_len))
+        head_abs = st.head_abs if self.head_keep is not None else None
+        if self.pq_threshold is not None:
+            ops.kv_append(k_new[:, :, None], v_new[:, :, None], slab.k, slab.kr, slab.v, past_len, cos, sin)
+            slab.ensure_pq(kv_len)
+            ops.attn_decode(q, None, None, slab.v, kv_len, cos, sin, past_len, out=st.out, scores=stash, lse=lse,
+                            head_ids=st.head_ids, cascade=casc, pq=(slab.pq, self.pq_threshold, st.need_lsb),
+                            head_abs=head_abs)
+        elif self.local_v_keep is not None:
+            from .cascade import local_v_decode
+            ops.kv_append(k_new[:, :, None], v_new[:, :, None], slab.k, slab.kr, slab.v, past_len, cos, sin)
+            keep = max(1, min(kv_len, math.ceil(self.local_v_keep * kv_len)))
+            local_v_decode(q, slab.kr, slab.v, kv_len, cos, sin, past_len, keep, out=st.out, stash=stash, lse=lse)
+            if casc is not None:        # the scores-only launch does not carry the fused accumulation
+                ops.importance_accumulate(st.acc, casc[1][:, :, None, :casc[3]], casc[2][:, :, None, :])
+            if st.pruned_ids is not None:
+                st.out.view(B, H, d).index_fill_(1, st.pruned_ids, 0)
+            if head_abs is not None:
+                ops.head_scores(st.out, H, st.head_abs_prefill)
+        else:
+            ops.attn_decode(q, slab.k, slab.kr, slab.v, kv_len, cos, sin, past_len, k_new=k_new, v_new=v_new,
+                            out=st.out, scores=stash, lse=lse, head_ids=st.head_ids, cascade=casc, head_abs=head_abs)
+        if self.cascade:
+            st.pending_len = kv_len
+        return st.out, stash[:, :, None, :kv_len]
+
+    # ------------------------------------------------------------------------------------------------
+    # attention forward, q_len > 1: by-products of the flash path
+    # ------------------------------------------------------------------------------------------------
+    def after_prefill(self, layer: int, attn_output, stash, mask, num_heads: int, causal: bool = True):
+        """attn_output [B,q,H*d]; stash [B,H,q,N] or None; mask additive [B,q,N] or None (then ``causal``)."""
+        st = self.layers[layer]
+        B, q_len = attn_output.shape[0], attn_output.shape[1]
+        d = attn_output.shape[2] // num_heads
+        if self.cascade:
+            if stash is None:
+                raise RuntimeError("importance_mode='cascade' needs the multi-token stash (prefill_stash=True)")
+            n = stash.shape[-1]
+            st.ensure(B, num_heads, d, n, attn_output.dtype, attn_output.device, True)
+            self.flush(layer)
+            ops.importance_accumulate(st.acc, stash, None, mask, causal=causal)
+        if self.head_keep is not None:
+            st.ensure(B, num_heads, d, 1, attn_output.dtype, attn_output.device, False)
+            if st.pruned_ids is not None:
+                attn_output.view(B, q_len, num_heads, d).index_fill_(2, st.pruned_ids, 0)
+            ops.head_scores(attn_output, num_heads, st.head_abs_prefill)
+
+    def flush(self, layer: int):
+        """Fold the last decode step's probabilities (still pending) into the accumulator."""
+        st = self.layers[layer]
+        if self.cascade and st.pending_len > 0:
+            last = st.parity ^ 1
+            n = st.pending_len
+            ops.importance_accumulate(st.acc, st.stash[last][:, :, None, :n], st.lse[last][:, :, None, :])
+            st.pending_len = 0
+
+    # ------------------------------------------------------------------------------------------------
+    # prune event
+    # ------------------------------------------------------------------------------------------------
+    def head_scores(self, layer: int) -> torch.Tensor:
+        st = self.layers[layer]
+        H = st.head_abs_prefill.numel()
+        return st.head_abs.view(-1, H).sum(0) + st.head_abs_prefill
+
+    def select_heads(self):
+        """Cascade head pruning at a prune event: cumulative scores layer over layer, layer l picks its k_l best among
+        the heads layer l-1 kept and it has not pruned before (ties: lowest head id)."""
+        if self.head_keep is None or self.layers[0].head_abs is None:
+            return
+        dev = self.layers[0].head_abs.device
+        H = self.layers[0].head_abs_prefill.numel()
+        cum = torch.zeros(H, dtype=torch.float32, device=dev)
+        alive = torch.ones(H, dtype=torch.bool, device=dev)
+        neg = torch.full((H,), float("-inf"), dtype=torch.float32, device=dev)
+        for layer, st in enumerate(self.layers):
+            if st.head_abs is None:
+                break
+            cum = cum + self.head_scores(layer)
+            if st.head_ids is not None:
+                mine = torch.zeros(H, dtype=torch.bool, device=dev)
+                mine[st.head_ids.long()] = True
+                alive = alive & mine
+            k = min(int(self.head_keep[layer]), H)
+            k = min(k, int(alive.sum().item()))
+            ids = ops.topk_select(torch.where(alive, cum, neg)[None, :].contiguous(), 0, H, k)[0].contiguous()
+            alive = torch.zeros(H, dtype=torch.bool, device=dev)
+            alive[ids.long()] = True
+            st.head_ids = ids if k < H else None
+            st.pruned_ids = (~alive).nonzero().flatten() if k < H else None
+            if st.out is not None:
+                st.out.zero_()
+
+    def before_prune(self):
+        for layer in range(self.n_layers):
+            self.flush(layer)
+        self.select_heads()
+
+    def compact_importance(self, layer: int, idx, start: int, tail_lo: int, seq_len: int):
+        st = self.layers[layer]
+        if st.acc is not None:
+            st.acc = ops.importance_compact(st.acc, idx, start, tail_lo, seq_len, st.acc.shape[1])
+        st.pending_len = 0
+
+    def stats(self):
+        """Host-readable summary (synchronises): kept heads per layer, LSB refetches of the last step."""
+        out = {"kept_heads": [None if st.head_ids is None else st.head_ids.cpu().tolist() for st in self.layers]}
+        if self.pq_threshold is not None:
+            out["lsb_refetch_last_step"] = [None if st.need_lsb is None else int(st.need_lsb.sum().item()) for st in self.layers]
+        return out

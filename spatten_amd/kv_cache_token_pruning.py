@@ -57,7 +57,7 @@ class SpAttenKVCache:
         # "cascade"  : importance = running sum of softmax probabilities over every forward since the key entered
         #              the cache (SpAtten paper / README.md:11; PARITY UNPINNED), accumulated by the patched forward.
         self.importance_mode = importance_mode
-        self.cascade = None                 # spatten_amd.cascade.CascadeImportance, created by the first forward
+        self.ext = None                     # spatten_amd.extensions.SpattenExtensions (enable_spatten_llm's opt-in modes)
         self.importance_score: Optional[List[torch.Tensor]] = None
         self.keep_indices: Optional[torch.Tensor] = None      # int32 [layers, H, important] of the last prune
         self.n_pruned_last = 0
@@ -91,6 +91,9 @@ class SpAttenKVCache:
                 f"top-k window [{lo},{hi}) holds fewer than important_size={self.important_size} candidates "
                 f"(seq_len={seq_len}, num_coming={num_coming})")
         n_layers = len(past_key_values)
+        ops.check_workspaces()              # a natural sync point: surface a device-side merge timeout, if any
+        if self.ext is not None:
+            self.ext.before_prune()         # fold the pending decode step, pick the heads that survive
         if self.importance_mode == "cascade":
             return self._prune_cascade(past_key_values, seq_len, num_coming, lo, hi, new_len)
         if len(attn_score_all) != n_layers:
@@ -107,47 +110,60 @@ class SpAttenKVCache:
         Ks, Vs = _common_strides(Ks, Vs)
         B, H, _, d = Ks[0].shape
         cap = kv_slab.round_capacity(new_len + max(int(num_coming), 0))
-        rope = kv_slab.rope_tables(cap, d, Ks[0].dtype, Ks[0].device)
+        base, scaling = _rope_of(past_key_values)
+        rope = kv_slab.rope_tables(cap, d, Ks[0].dtype, Ks[0].device, base, scaling)
         Kn, Vn, Krn, idx = ops.prune_layers(scores, Ks, Vs, seq_len, lo, hi, self.important_size,
                                             capacity=cap, rope=rope)
         self.keep_indices = idx
         self.n_pruned_last = seq_len - new_len
         self.n_pruned_total += self.n_pruned_last
         out = []
-        for k, v, kr in zip(Kn, Vn, Krn):
+        for layer, (k, v, kr) in enumerate(zip(Kn, Vn, Krn)):
             # remember the slab (spare capacity + rotated shadow) on the tensor HF will hand back to the forward
-            kv_slab.attach(k, v, kr, new_len)
+            kv_slab.attach(k, v, kr, new_len, base, scaling)
+            if self.ext is not None:
+                self.ext.layers[layer].pending_len = 0
             out.append([k, v])
         return out                                                            # list of lists (:72-96)
-
 
     def _prune_cascade(self, past_key_values, seq_len, num_coming, lo, hi, new_len):
         """Same window / row map as the reference prune, but ranked by the accumulated probabilities; the
         accumulators are compacted with the cache so they keep describing the surviving keys."""
-        if self.cascade is None:
+        if self.ext is None or any(st.acc is None for st in self.ext.layers[:len(past_key_values)]):
             raise RuntimeError("cascade importance has not been accumulated: run the patched forward first "
                                "(enable_spatten_llm(..., importance_mode='cascade'))")
         out, idxs = [], []
         self.importance_score = []
+        base, scaling = _rope_of(past_key_values)
         for layer, (K, V) in enumerate(past_key_values):
             K, V = _rows(K), _rows(V)
             if V.stride() != K.stride():
                 K, V = K.contiguous(), V.contiguous()
             d = K.shape[3]
-            acc = self.cascade.acc[layer]
+            acc = self.ext.layers[layer].acc
             self.importance_score.append(acc[:, :seq_len])
             idx = ops.topk_select(acc[:, :seq_len], lo, hi, self.important_size)
             cap = kv_slab.round_capacity(new_len + max(int(num_coming), 0))
-            rope = kv_slab.rope_tables(cap, d, K.dtype, K.device)
+            rope = kv_slab.rope_tables(cap, d, K.dtype, K.device, base, scaling)
             k, v, kr = ops.kv_compact(K, V, idx, self.start_size, hi, L=seq_len, capacity=cap, rope=rope)
-            self.cascade.compact(layer, idx, self.start_size, hi, seq_len)
-            kv_slab.attach(k, v, kr, new_len)
+            self.ext.compact_importance(layer, idx, self.start_size, hi, seq_len)
+            kv_slab.attach(k, v, kr, new_len, base, scaling)
             out.append([k, v])
             idxs.append(idx)
         self.keep_indices = torch.stack(idxs)
         self.n_pruned_last = seq_len - new_len
         self.n_pruned_total += self.n_pruned_last
         return out
+
+
+def _rope_of(past_key_values):
+    """(base, scaling) the incoming cache was rotated with: the prune rebuilds the rotated shadow at the NEW slot
+    positions and must use the tables of the model's rotary embedding (the reference always goes through
+    ``self.rotary_emb``, modify_llama.py:89), not a default base."""
+    slab = kv_slab.slab_of(past_key_values[0][0])
+    if slab is None:
+        return 10000.0, None        # foreign tensors: the next forward re-rotates them with the module's tables anyway
+    return slab.base, slab.scaling
 
 
 def _rows(t: torch.Tensor) -> torch.Tensor:

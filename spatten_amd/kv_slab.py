@@ -26,35 +26,46 @@ CAP_ROUND = 128
 # headroom reserved when a slab has to grow (tokens)
 GROW = 256
 
-_rope_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+_rope_cache = ops._LRU(8)      # bounded: (device, dtype, d, table identity) -> half tables
+
+# how often slab_for had to re-copy a whole cache because the caller's (K, V) pair had lost its slab — a silent
+# performance cliff (one full copy of the layer's cache per forward) made visible: see slab_for
+recopy_events = 0
 
 
 def round_capacity(n: int) -> int:
     return (int(n) + CAP_ROUND - 1) // CAP_ROUND * CAP_ROUND
 
 
-def rope_tables(n: int, d: int, dtype: torch.dtype, device, base: float = 10000.0):
-    """Half rotary tables [>=n, d/2] in the model dtype, cached per (device, dtype, d, base), grown on demand."""
-    key = (str(device), dtype, d, float(base))
+def rope_tables(n: int, d: int, dtype: torch.dtype, device, base: float = 10000.0, scaling: Optional[tuple] = None):
+    """Half rotary tables [>=n, d/2] in the model dtype, cached per (device, dtype, d, base, scaling), grown on demand.
+    ``scaling`` = None | ("linear", factor): transformers 4.33 LlamaLinearScalingRotaryEmbedding (config.rope_scaling)."""
+    key = (str(device), dtype, d, float(base), scaling)
     t = _rope_cache.get(key)
     if t is None or t[0].shape[0] < n:
         rows = max(4096, 1 << (max(n, 1) - 1).bit_length())
-        t = _rope_cache[key] = ops.rope_table(rows, d, dtype, device, base)
+        t = _rope_cache.put(key, ops.rope_table(rows, d, dtype, device, base, scaling))
     return t
 
 
 class KVSlab:
-    __slots__ = ("k", "kr", "v", "length", "rot_len", "base", "__weakref__")
+    __slots__ = ("k", "kr", "v", "length", "rot_len", "base", "scaling", "pq", "pq_len", "__weakref__")
 
-    def __init__(self, k, kr, v, length, rot_len, base=10000.0):
+    def __init__(self, k, kr, v, length, rot_len, base=10000.0, scaling=None):
         self.k, self.kr, self.v = k, kr, v          # full-capacity planes [B,Hkv,cap,d]
         self.length = length                        # rows live in k / v
         self.rot_len = rot_len                      # rows of kr that are valid
-        self.base = base
+        self.base, self.scaling = float(base), scaling
+        self.pq = None                              # ops.PQPlanes of kr (progressive quantisation), built on demand
+        self.pq_len = 0                             # rows of the planes that are valid
 
     @property
     def capacity(self) -> int:
         return self.k.shape[2]
+
+    def tables(self, rows: Optional[int] = None):
+        B, H, cap, d = self.k.shape
+        return rope_tables(max(cap, rows or 0), d, self.k.dtype, self.k.device, self.base, self.scaling)
 
     def views(self):
         kv = self.k[:, :, :self.length]
@@ -65,29 +76,45 @@ class KVSlab:
     def ensure_shadow(self, upto: int):
         """Rotate rows [rot_len, upto) of k at their slot index into kr (modify_llama.py:103-104)."""
         if self.rot_len < upto:
-            B, H, cap, d = self.k.shape
-            cos, sin = rope_tables(cap, d, self.k.dtype, self.k.device, self.base)
+            cos, sin = self.tables()
             ops.build_shadow(self.k, self.kr, self.rot_len, upto, cos, sin)
             self.rot_len = upto
 
+    def ensure_pq(self, upto: int):
+        """Quantise rows [pq_len, upto) of the rotated shadow into the MSB / LSB planes."""
+        if self.pq is None:
+            B, H, cap, d = self.k.shape
+            self.pq = ops.PQPlanes(B, H, cap, d, self.k.device)
+            self.pq_len = 0
+        if self.pq_len < upto:
+            ops.pq_pack(self.kr, self.pq, self.pq_len, upto)
+            self.pq_len = upto
 
-def attach(k_view: torch.Tensor, v_view: torch.Tensor, kr_view: torch.Tensor, length: int, base: float = 10000.0) -> KVSlab:
+
+def attach(k_view: torch.Tensor, v_view: torch.Tensor, kr_view: torch.Tensor, length: int, base: float = 10000.0,
+           scaling=None) -> KVSlab:
     """Register freshly produced planes (views ``x[:, :, :length]`` of capacity slabs, see ops.prune_layers)."""
     k, v, kr = (x._base if x._base is not None else x for x in (k_view, v_view, kr_view))
-    slab = KVSlab(k, kr, v, length, length, base)
+    slab = KVSlab(k, kr, v, length, length, base, scaling)
     k_view._spatten_slab = slab
     return slab
 
 
+def slab_of(k_view: Optional[torch.Tensor]) -> Optional[KVSlab]:
+    return getattr(k_view, "_spatten_slab", None) if k_view is not None else None
+
+
 def slab_for(k_view: Optional[torch.Tensor], v_view: Optional[torch.Tensor], need: int, batch: int, kv_heads: int,
-             d: int, dtype, device, base: float = 10000.0) -> KVSlab:
+             d: int, dtype, device, base: float = 10000.0, scaling=None) -> KVSlab:
     """The slab behind a past ``(K, V)`` pair with room for ``need`` rows; creates / grows it when the
-    views are foreign tensors (first call, or a caller that re-wrapped them)."""
+    views are foreign tensors (first call, or a caller that re-wrapped them) or were rotated with other tables."""
+    global recopy_events
     P = 0 if k_view is None else k_view.shape[2]
-    slab = getattr(k_view, "_spatten_slab", None) if k_view is not None else None
+    slab = slab_of(k_view)
     ok = (slab is not None and slab.length == P and slab.k.data_ptr() == k_view.data_ptr()
           and slab.v.data_ptr() == v_view.data_ptr() and slab.k.stride() == k_view.stride())
-    if ok and slab.capacity >= need:
+    same_rope = ok and slab.base == float(base) and slab.scaling == scaling
+    if ok and same_rope and slab.capacity >= need:
         return slab
     cap = round_capacity(need + GROW)
     k = torch.empty(batch, kv_heads, cap, d, dtype=dtype, device=device)
@@ -95,9 +122,18 @@ def slab_for(k_view: Optional[torch.Tensor], v_view: Optional[torch.Tensor], nee
     v = torch.empty_like(k)
     rot = 0
     if P:
+        if not ok:
+            # a (K, V) pair that is not one of our views: its whole cache is copied and re-rotated on this forward.
+            # Correct, but a cliff if it happens every step (a caller that clones / re-wraps past_key_values).
+            recopy_events += 1
+            if recopy_events in (1, 10, 100, 1000):
+                import warnings
+                warnings.warn(f"spatten_amd: past_key_values arrived without their KV slab ({recopy_events} time(s)): the "
+                              f"cache ({P} rows) was copied and re-rotated — keep the tensors the forward returned",
+                              RuntimeWarning, stacklevel=3)
         k[:, :, :P].copy_(k_view)
         v[:, :, :P].copy_(v_view)
-        if ok:                                   # growing our own slab: the shadow moves along
+        if ok and same_rope:                     # growing our own slab: the shadow moves along
             kr[:, :, :slab.rot_len].copy_(slab.kr[:, :, :slab.rot_len])
             rot = slab.rot_len
-    return KVSlab(k, kr, v, P, rot, base)
+    return KVSlab(k, kr, v, P, rot, base, scaling)

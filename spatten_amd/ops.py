@@ -5,6 +5,7 @@ PyTorch is plumbing here: it owns device memory and the stream; every op below p
 """
 from __future__ import annotations
 
+import ctypes
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -38,46 +39,90 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 # ------------------------------------------------------------------------------------------------
 # rotary table in the model dtype, first d/2 columns (transformers 4.33 LlamaRotaryEmbedding)
 # ------------------------------------------------------------------------------------------------
-def rope_table(n: int, d: int, dtype: torch.dtype, device, base: float = 10000.0) -> Tuple[torch.Tensor, torch.Tensor]:
+def rope_table(n: int, d: int, dtype: torch.dtype, device, base: float = 10000.0,
+               scaling: Optional[tuple] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """cos, sin [n, d/2] = the distinct half of the 4.33 table ``emb = cat(freqs, freqs)``
     (modify_llama.py:89).  Computed in fp32 on the host CPU exactly like the reference module
-    (inv_freq, outer product, cos/sin, ``.to(dtype)``) and uploaded once."""
-    inv_freq = 1.0 / (base ** (torch.arange(0, d, 2).float() / d))
+    (inv_freq, outer product, cos/sin, ``.to(dtype)``) and uploaded once.
+    ``scaling``: None (LlamaRotaryEmbedding) or ("linear", f): positions / f (transformers 4.33
+    LlamaLinearScalingRotaryEmbedding, config.rope_scaling = {"type": "linear", "factor": f})."""
     t = torch.arange(n, dtype=torch.float32)
+    if scaling is not None:
+        if scaling[0] != "linear":
+            raise NotImplementedError(f"rope scaling {scaling!r}")
+        t = t / float(scaling[1])
+    inv_freq = 1.0 / (base ** (torch.arange(0, d, 2).float() / d))
     freqs = torch.einsum("i,j->ij", t, inv_freq)
     return freqs.cos().to(dtype).to(device).contiguous(), freqs.sin().to(dtype).to(device).contiguous()
 
 
-class DecodeWorkspace:
-    """Split-N partials + arrival counters (zero-filled once, re-armed by the kernel)."""
+class _LRU:
+    """Small bounded cache for per-(shape, stream) scratch buffers: a process that cycles through many streams or
+    shapes does not accumulate device memory for its lifetime (oldest entry dropped first)."""
 
-    def __init__(self, batch: int, heads: int, head_dim: int, device, max_splits: int = 64):
+    def __init__(self, capacity: int):
+        self.capacity, self.d = capacity, {}
+
+    def get(self, key):
+        v = self.d.get(key)
+        if v is not None:
+            self.d[key] = self.d.pop(key)          # move to the young end
+        return v
+
+    def put(self, key, value):
+        self.d.pop(key, None)
+        self.d[key] = value
+        while len(self.d) > self.capacity:
+            self.d.pop(next(iter(self.d)))
+        return value
+
+    def values(self):
+        return list(self.d.values())
+
+
+class DecodeWorkspace:
+    """Split-N partials + arrival counters + error word (zero-filled once, re-armed by the kernel)."""
+
+    def __init__(self, batch: int, heads: int, head_dim: int, device, max_splits: int = _lib.DECODE_MAX_SPLITS):
         lib = _lib.load()
         self.max_splits = max_splits
         self.key = (batch, heads, head_dim)
         nbytes = lib.spatten_decode_workspace_bytes(batch, heads, head_dim, max_splits)
         self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
 
+    def check(self):
+        """Synchronises the current stream; raises SpattenDeviceTimeout if a split-N merge of an earlier launch gave
+        up waiting for a partial (its outputs were poisoned with NaN)."""
+        _lib.check(_lib.load().spatten_decode_workspace_status(self.buf.data_ptr(), _stream()), "decode workspace")
 
-_ws_cache = {}
+
+_ws_cache = _LRU(16)
 
 
 def _workspace(batch, heads, head_dim, device) -> DecodeWorkspace:
     key = (batch, heads, head_dim, str(device), torch.cuda.current_stream().cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None:
-        ws = _ws_cache[key] = DecodeWorkspace(batch, heads, head_dim, device)
+        ws = _ws_cache.put(key, DecodeWorkspace(batch, heads, head_dim, device))
     return ws
 
 
-def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: torch.Tensor, v_cache: torch.Tensor, kv_len: int,
-                cos: torch.Tensor, sin: torch.Tensor, pos_q: int,
+def check_workspaces():
+    """Error words of every cached decode workspace (one stream sync each) — called at natural sync points."""
+    for ws in _ws_cache.values():
+        ws.check()
+
+
+def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: Optional[torch.Tensor], v_cache: torch.Tensor,
+                kv_len: int, cos: torch.Tensor, sin: torch.Tensor, pos_q: int,
                 k_new: Optional[torch.Tensor] = None, v_new: Optional[torch.Tensor] = None,
                 position_ids: Optional[torch.Tensor] = None,
                 mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                 scores: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,
                 n_splits: int = 0, workspace: Optional[DecodeWorkspace] = None,
-                head_ids: Optional[torch.Tensor] = None, scores_only: bool = False) -> torch.Tensor:
+                head_ids: Optional[torch.Tensor] = None, scores_only: bool = False,
+                cascade: Optional[tuple] = None, pq: Optional[tuple] = None,
+                head_abs: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused decode attention (modify_llama.py:86-147 at q_len=1).
 
     q [B,H,d]; k_cache (un-rotated, only appended to) / kr_cache (rotated shadow, see build_shadow) /
@@ -86,16 +131,25 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: torc
     position_ids optional int64 [B] device tensor (overrides pos_q without a host sync);
     scores (stash) [B,H,>=kv_len]; lse [B,H,2] fp32 (row max, sum exp); head_ids int32 ascending list of the
     heads to run (head pruning; rows of the others are left untouched); scores_only: stash + lse only, no V
-    traffic (pass 1 of local V pruning).  Returns out [B, H*d]."""
-    _dev(q, k_cache, kr_cache, v_cache, cos, sin, k_new, v_new, mask, out, scores, lse, position_ids)
+    traffic (pass 1 of local V pruning).
+    cascade = (acc [H,>=prev_len] fp32, prev_scores [B,H,>=prev_len], prev_lse [B,H,2], prev_len): the PREVIOUS decode
+    step's softmax probabilities are added to acc while this step streams (cumulative importance, no extra launch).
+    pq = (PQPlanes, threshold, need_lsb int32 [B*H]): keys come from the progressive-quantisation planes (MSB pass,
+    LSB refetch for heads whose max probability is below threshold) instead of kr_cache.
+    head_abs fp32 [B*H]: += sum |out| per (b, h) (cumulative head importance for head pruning).
+    Returns out [B, H*d]."""
+    _dev(q, k_cache, kr_cache, v_cache, cos, sin, k_new, v_new, mask, out, scores, lse, position_ids, head_abs)
     if position_ids is not None and position_ids.dtype != torch.int64:
         raise TypeError("position_ids must be int64")
     lib = _lib.load()
     B, H, d = q.shape
-    Hkv, cap = kr_cache.shape[1], kr_cache.shape[2]
-    if q.stride(2) != 1 or kr_cache.stride(3) != 1 or kr_cache.stride(2) != d or v_cache.stride() != kr_cache.stride() \
-            or (k_cache is not None and k_cache.stride() != kr_cache.stride()):
+    Hkv, cap = v_cache.shape[1], v_cache.shape[2]
+    if q.stride(2) != 1 or v_cache.stride(3) != 1 or v_cache.stride(2) != d \
+            or (kr_cache is not None and kr_cache.stride() != v_cache.stride()) \
+            or (k_cache is not None and k_cache.stride() != v_cache.stride()):
         raise ValueError("q/k_cache/kr_cache/v_cache need contiguous rows (pitch d) and identical strides")
+    if kr_cache is None and pq is None:
+        raise ValueError("kr_cache (or pq planes) required")
     if k_new is not None and k_cache is None:
         raise ValueError("appending needs the un-rotated k_cache")
     if kv_len > cap or max(kv_len, pos_q + 1) > cos.shape[0] or cos.shape[1] * 2 != d:
@@ -113,30 +167,80 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: torc
         raise ValueError("n_splits exceeds workspace")
     if head_ids is not None and (head_ids.dtype != torch.int32 or not head_ids.is_cuda or head_ids.dim() != 1):
         raise TypeError("head_ids must be a 1-D int32 device tensor")
-    rc = lib.spatten_attn_decode_ex(
-        _dt(q), q.data_ptr(), q.stride(0), q.stride(1),
-        _ptr(k_cache), kr_cache.data_ptr(), v_cache.data_ptr(), kr_cache.stride(0), kr_cache.stride(1),
-        _ptr(k_new), _ptr(v_new), 0 if k_new is None else k_new.stride(0), 0 if k_new is None else k_new.stride(1),
-        cos.data_ptr(), sin.data_ptr(), cos.shape[0],
-        _ptr(position_ids), 0 if position_ids is None else position_ids.stride(0),
-        _ptr(mask), 0 if mask is None else mask.stride(0),
-        out.data_ptr(), out.stride(0),
-        _ptr(scores), 0 if scores is None else scores.stride(0), 0 if scores is None else scores.stride(1),
-        _ptr(lse), ws.buf.data_ptr(),
-        B, H, Hkv, d, kv_len, pos_q, n_splits,
-        _ptr(head_ids), 0 if head_ids is None else head_ids.numel(), 1 if scores_only else 0, _stream())
-    _lib.check(rc, "spatten_attn_decode")
+    a = _lib.DecodeArgs()
+    a.struct_size = ctypes.sizeof(_lib.DecodeArgs)
+    a.dtype = _dt(q)
+    a.q, a.q_sb, a.q_sh = q.data_ptr(), q.stride(0), q.stride(1)
+    a.k_cache, a.kr_cache, a.v_cache = _ptr(k_cache), _ptr(kr_cache), v_cache.data_ptr()
+    a.kv_sb, a.kv_sh = v_cache.stride(0), v_cache.stride(1)
+    if k_new is not None:
+        a.k_new, a.v_new, a.new_sb, a.new_sh = k_new.data_ptr(), v_new.data_ptr(), k_new.stride(0), k_new.stride(1)
+    a.cos, a.sin, a.table_rows = cos.data_ptr(), sin.data_ptr(), cos.shape[0]
+    if position_ids is not None:
+        a.position_ids, a.pos_sb = position_ids.data_ptr(), position_ids.stride(0)
+    if mask is not None:
+        a.mask, a.mask_sb = mask.data_ptr(), mask.stride(0)
+    a.out, a.out_sb = out.data_ptr(), out.stride(0)
+    if scores is not None:
+        a.scores, a.sc_sb, a.sc_sh = scores.data_ptr(), scores.stride(0), scores.stride(1)
+    a.lse = _ptr(lse)
+    a.workspace, a.workspace_splits = ws.buf.data_ptr(), ws.max_splits
+    a.batch, a.heads, a.kv_heads, a.head_dim, a.kv_len, a.pos_q, a.n_splits = B, H, Hkv, d, kv_len, pos_q, n_splits
+    if head_ids is not None:
+        a.head_ids, a.n_active_heads = head_ids.data_ptr(), head_ids.numel()
+    a.flags = 1 if scores_only else 0
+    if cascade is not None:
+        acc, prev_scores, prev_lse, prev_len = cascade
+        _dev(acc, prev_scores, prev_lse)
+        if acc.dtype != torch.float32 or acc.stride(1) != 1 or acc.shape[0] != H or acc.shape[1] < prev_len \
+                or prev_scores.stride(-1) != 1 or prev_lse.dtype != torch.float32 or not prev_lse.is_contiguous():
+            raise ValueError("cascade: acc fp32 [H, >=prev_len], prev_scores [B,H,>=prev_len] rows contiguous, prev_lse [B,H,2]")
+        a.importance_acc, a.acc_sh = acc.data_ptr(), acc.stride(0)
+        a.prev_scores, a.prev_sb, a.prev_sh = prev_scores.data_ptr(), prev_scores.stride(0), prev_scores.stride(1)
+        a.prev_lse, a.prev_len = prev_lse.data_ptr(), prev_len
+    if head_abs is not None:
+        if head_abs.dtype != torch.float32 or head_abs.numel() != B * H or not head_abs.is_contiguous():
+            raise ValueError("head_abs must be a contiguous fp32 [B*H] tensor")
+        a.head_abs_acc = head_abs.data_ptr()
+    if pq is not None:
+        planes, threshold, need_lsb = pq
+        _dev(planes.msb, need_lsb)
+        a.pq_msb, a.pq_lsb, a.pq_scale = planes.msb.data_ptr(), planes.lsb.data_ptr(), planes.scale.data_ptr()
+        a.pq_pl_sb, a.pq_pl_sh = planes.msb.stride(0), planes.msb.stride(1)
+        a.pq_sc_sb, a.pq_sc_sh = planes.scale.stride(0), planes.scale.stride(1)
+        a.pq_threshold, a.pq_need_lsb = float(threshold), need_lsb.data_ptr()
+    _lib.check(lib.spatten_attn_decode_args(ctypes.byref(a), _stream()), "spatten_attn_decode")
     return out
 
 
-_pf_ws = {}
+def kv_append(k_new: torch.Tensor, v_new: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: torch.Tensor,
+              v_cache: torch.Tensor, row0: int, cos: torch.Tensor, sin: torch.Tensor):
+    """Rows [row0, row0+n) of the slab planes from k_new / v_new [B,Hkv,n,d] (any strides, d contiguous): K un-rotated,
+    its rotation at the slot positions into the shadow, V (modify_llama.py:95-104 without the cat)."""
+    _dev(k_new, v_new, k_cache, kr_cache, v_cache, cos, sin)
+    B, Hkv, n, d = k_new.shape
+    if k_new.stride(3) != 1 or v_new.stride() != k_new.stride():
+        raise ValueError("k_new / v_new need contiguous d and identical strides")
+    if kr_cache.stride(3) != 1 or kr_cache.stride(2) != d or v_cache.stride() != kr_cache.stride() \
+            or (k_cache is not None and k_cache.stride() != kr_cache.stride()):
+        raise ValueError("cache planes need contiguous rows (pitch d) and identical strides")
+    if row0 + n > kr_cache.shape[2] or row0 + n > cos.shape[0]:
+        raise ValueError("append exceeds cache capacity or rotary table")
+    rc = _lib.load().spatten_kv_append(_dt(k_new), k_new.data_ptr(), v_new.data_ptr(), k_new.stride(0), k_new.stride(1),
+                                       k_new.stride(2), _ptr(k_cache), kr_cache.data_ptr(), v_cache.data_ptr(),
+                                       kr_cache.stride(0), kr_cache.stride(1), cos.data_ptr(), sin.data_ptr(), cos.shape[0],
+                                       B, Hkv, n, d, row0, _stream())
+    _lib.check(rc, "spatten_kv_append")
+
+
+_pf_ws = _LRU(4)
 
 
 def _prefill_workspace(nbytes: int, device) -> torch.Tensor:
     key = (str(device), torch.cuda.current_stream().cuda_stream)
     buf = _pf_ws.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = _pf_ws[key] = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        buf = _pf_ws.put(key, torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device))
     return buf
 
 
@@ -448,31 +552,15 @@ def pq_pack(kr_cache: torch.Tensor, planes: PQPlanes, lo: int, hi: int):
     _lib.check(rc, "spatten_pq_pack")
 
 
-_pq_scratch = {}
-
-
 def attn_decode_pq(q: torch.Tensor, planes: PQPlanes, v_cache: torch.Tensor, kv_len: int, cos: torch.Tensor,
                    sin: torch.Tensor, pos_q: int, threshold: float, out: Optional[torch.Tensor] = None,
-                   need_lsb: Optional[torch.Tensor] = None, workspace: Optional[DecodeWorkspace] = None) -> torch.Tensor:
+                   need_lsb: Optional[torch.Tensor] = None, workspace: Optional[DecodeWorkspace] = None,
+                   head_ids: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,
+                   scores: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Decode over progressively quantised keys: MSB-plane pass, LSB refetch for heads whose max probability is
     below ``threshold``, softmax + P·V with the un-quantised V.  q [B,H,d]; need_lsb optional int32 [B*H]."""
-    _dev(q, planes.msb, v_cache, cos, sin, out, need_lsb)
-    lib = _lib.load()
     B, H, d = q.shape
-    Hkv = v_cache.shape[1]
-    if out is None:
-        out = torch.empty(B, H * d, dtype=q.dtype, device=q.device)
-    ws = workspace or _workspace(B, H, d, q.device)
-    nbytes = lib.spatten_pq_scratch_bytes(B, H, d, kv_len)
-    key = (str(q.device), torch.cuda.current_stream().cuda_stream)
-    scratch = _pq_scratch.get(key)
-    if scratch is None or scratch.numel() < nbytes:
-        scratch = _pq_scratch[key] = torch.empty(int(nbytes * 1.5), dtype=torch.uint8, device=q.device)
-    rc = lib.spatten_attn_decode_pq(_dt(q), q.data_ptr(), q.stride(0), q.stride(1), planes.msb.data_ptr(),
-                                    planes.lsb.data_ptr(), planes.scale.data_ptr(), planes.msb.stride(0), planes.msb.stride(1),
-                                    planes.scale.stride(0), planes.scale.stride(1), v_cache.data_ptr(), v_cache.stride(0),
-                                    v_cache.stride(1), cos.data_ptr(), sin.data_ptr(), cos.shape[0], pos_q, float(threshold),
-                                    out.data_ptr(), out.stride(0), _ptr(need_lsb), scratch.data_ptr(), ws.buf.data_ptr(),
-                                    B, H, Hkv, d, kv_len, _stream())
-    _lib.check(rc, "spatten_attn_decode_pq")
-    return out
+    if need_lsb is None:
+        need_lsb = torch.empty(B * H, dtype=torch.int32, device=q.device)
+    return attn_decode(q, None, None, v_cache, kv_len, cos, sin, pos_q, out=out, workspace=workspace,
+                       head_ids=head_ids, lse=lse, scores=scores, pq=(planes, threshold, need_lsb))

@@ -48,12 +48,32 @@ def _cfg(self, name, *fallbacks, default=None):
     return default
 
 
-def _rope_base(self) -> float:
+def _rope_params(self):
+    """(base, scaling) of the module's rotary embedding.  The reference calls ``self.rotary_emb(value_states, seq_len=)``
+    (modify_llama.py:89), so whatever table that module builds is what it rotates with: the plain 4.33
+    LlamaRotaryEmbedding (``base``), or the linear-scaling subclass (``scaling_factor``; config.rope_scaling type
+    "linear").  Dynamic-NTK tables change with the sequence length — every cached key would have to be re-rotated when
+    the table is rebuilt, which the rotated shadow cannot follow: rejected loudly instead of diverging silently."""
     rot = getattr(self, "rotary_emb", None)
+    cfg = getattr(self, "config", None)
     base = getattr(rot, "base", None)
     if base is None:
-        base = getattr(getattr(self, "config", None), "rope_theta", None)
-    return float(base) if base is not None else 10000.0
+        base = getattr(cfg, "rope_theta", None)
+    base = float(base) if base is not None else 10000.0
+    rs = getattr(cfg, "rope_scaling", None)
+    kind = type(rot).__name__ if rot is not None else ""
+    factor = getattr(rot, "scaling_factor", None)
+    if isinstance(rs, dict) and rs.get("type", rs.get("rope_type")) not in (None, "default"):
+        rtype = rs.get("type", rs.get("rope_type"))
+        factor = rs.get("factor", factor)
+        if rtype != "linear":
+            raise NotImplementedError(f"rope_scaling type {rtype!r}: only the static tables (plain, linear) are supported")
+        return base, ("linear", float(factor))
+    if "DynamicNTK" in kind:
+        raise NotImplementedError("LlamaDynamicNTKScalingRotaryEmbedding: only the static tables (plain, linear) are supported")
+    if "LinearScaling" in kind and factor is not None:
+        return base, ("linear", float(factor))
+    return base, None
 
 
 def llama_pos_shift_attention_forward(
@@ -89,14 +109,24 @@ def llama_pos_shift_attention_forward(
     dtype, device = query_states.dtype, query_states.device
     past_len = 0 if past_key_value is None else past_key_value[0].shape[-2]       # :86-88
     kv_seq_len = past_len + q_len
+    ext = getattr(self, "_spatten_ext", None)         # (SpattenExtensions, layer index) — opt-in SpAtten semantics
+    assume_causal = bool(getattr(self, "spatten_assume_causal", False)) or ext is not None
     if attention_mask is not None and attention_mask.size() != (bsz, 1, q_len, kv_seq_len):   # :127-131
         raise ValueError(
             f"Attention mask should be of size {(bsz, 1, q_len, kv_seq_len)}, but is {attention_mask.size()}")
 
-    base = _rope_base(self)
+    rope = getattr(self, "_spatten_rope", None)       # (base, scaling), resolved once per module
+    if rope is None:
+        rope = self._spatten_rope = _rope_params(self)
+    base, scaling = rope
     pk, pv = (None, None) if past_key_value is None else (past_key_value[0], past_key_value[1])
-    slab = kv_slab.slab_for(pk, pv, kv_seq_len, bsz, num_kv_heads, head_dim, dtype, device, base)
-    cos, sin = kv_slab.rope_tables(max(slab.capacity, kv_seq_len), head_dim, dtype, device, base)
+    slab = kv_slab.slab_for(pk, pv, kv_seq_len, bsz, num_kv_heads, head_dim, dtype, device, base, scaling)
+    cos, sin = slab.tables(kv_seq_len)
+    if position_ids is not None and assume_causal:
+        # HF's own position_ids at this call are arange(past_len, past_len + q_len) (4.33 LlamaModel.forward): with
+        # assume_causal the tensor is not read — the query positions are a launch constant, which is what lets a
+        # single-token step run the lean decode kernel (no position tensor, no mask)
+        position_ids = None
     if position_ids is not None:
         position_ids = position_ids.to(device=device, dtype=torch.int64)
         if position_ids.dim() == 1:
@@ -107,48 +137,45 @@ def llama_pos_shift_attention_forward(
             position_ids = position_ids.expand(bsz, q_len)
         position_ids = position_ids.contiguous()
 
-    cascade = getattr(self, "_spatten_cascade", None)
     # extension: no [B,H,q,N] stash for multi-token forwards (enable_spatten_llm(..., prefill_stash=False))
-    want_stash = q_len == 1 or output_attentions or cascade is not None or bool(getattr(self, "spatten_prefill_stash", True))
-    stash = torch.empty(bsz, num_heads, q_len, kv_seq_len, dtype=dtype, device=device) if want_stash else None
-    if attention_mask is not None:
+    want_stash = q_len == 1 or output_attentions or bool(getattr(self, "spatten_prefill_stash", True))
+    if attention_mask is not None and not (assume_causal and not output_attentions):
         attention_mask = attention_mask.to(dtype)
-    lse = torch.empty(bsz, num_heads, 1, 2, dtype=torch.float32, device=device) if (cascade and q_len == 1) else None
+    slab.ensure_shadow(past_len)                     # a foreign past: its rows get their rotation now (:103-104)
     if q_len == 1:
-        slab.ensure_shadow(past_len)
-        attn_output = ops.attn_decode(
-            query_states.view(bsz, num_heads, head_dim), slab.k, slab.kr, slab.v, kv_seq_len, cos, sin, past_len,
-            k_new=key_states.view(bsz, num_kv_heads, head_dim), v_new=value_states.view(bsz, num_kv_heads, head_dim),
-            position_ids=None if position_ids is None else position_ids[:, 0],
-            # with assume_causal the HF mask of a single-token step (all zeros) is not read: the lean decode kernel
-            mask=None if (attention_mask is None or getattr(self, "spatten_assume_causal", False)) else attention_mask[:, 0, 0, :],
-            scores=stash.view(bsz, num_heads, kv_seq_len), lse=None if lse is None else lse.view(bsz, num_heads, 2))
+        q3 = query_states.view(bsz, num_heads, head_dim)
+        k3, v3 = key_states.view(bsz, num_kv_heads, head_dim), value_states.view(bsz, num_kv_heads, head_dim)
+        if ext is not None:
+            attn_output, stash = ext[0].decode_step(ext[1], q3, k3, v3, slab, kv_seq_len, past_len, cos, sin)
+        else:
+            stash = torch.empty(bsz, num_heads, 1, kv_seq_len, dtype=dtype, device=device)
+            attn_output = ops.attn_decode(
+                q3, slab.k, slab.kr, slab.v, kv_seq_len, cos, sin, past_len, k_new=k3, v_new=v3,
+                position_ids=None if position_ids is None else position_ids[:, 0],
+                # with assume_causal the HF mask of a single-token step (all zeros) is not read: the lean decode kernel
+                mask=None if (attention_mask is None or assume_causal) else attention_mask[:, 0, 0, :],
+                scores=stash.view(bsz, num_heads, kv_seq_len))
         slab.length = slab.rot_len = kv_seq_len
         attn_output = attn_output.view(bsz, 1, num_heads * head_dim)
     else:
-        slab.k[:, :, past_len:kv_seq_len].copy_(key_states.view(bsz, q_len, num_kv_heads, head_dim).transpose(1, 2))
-        slab.v[:, :, past_len:kv_seq_len].copy_(value_states.view(bsz, q_len, num_kv_heads, head_dim).transpose(1, 2))
-        slab.length = kv_seq_len
-        slab.ensure_shadow(kv_seq_len)
+        stash = torch.empty(bsz, num_heads, q_len, kv_seq_len, dtype=dtype, device=device) if want_stash else None
+        ops.kv_append(key_states.view(bsz, q_len, num_kv_heads, head_dim).transpose(1, 2),
+                      value_states.view(bsz, q_len, num_kv_heads, head_dim).transpose(1, 2),
+                      slab.k, slab.kr, slab.v, past_len, cos, sin)                 # :95-104 without the cat
+        slab.length = slab.rot_len = kv_seq_len
         # a mask that IS the HF causal mask lets the kernel skip the tiles above the diagonal and never read the mask
-        assume_causal = attention_mask is not None and (bool(getattr(self, "spatten_assume_causal", False))
-                                                        or _mask_is_causal(attention_mask, past_len))
+        causal = attention_mask is not None and (assume_causal or _mask_is_causal(attention_mask, past_len))
         attn_output = ops.attn_prefill(
             query_states.view(bsz, q_len, num_heads, head_dim).transpose(1, 2), slab.kr, slab.v, kv_seq_len,
-            cos, sin, past_len, causal=assume_causal, position_ids=position_ids,
-            mask=None if (attention_mask is None or assume_causal) else attention_mask[:, 0],
+            cos, sin, past_len, causal=causal, position_ids=position_ids,
+            mask=None if (attention_mask is None or causal) else attention_mask[:, 0],
             scores=stash)
+        if ext is not None:
+            ext[0].after_prefill(ext[1], attn_output, stash, None if (attention_mask is None or causal) else attention_mask[:, 0],
+                                 num_heads, causal)
 
     # store attention scores for deciding which token to prune (:116-119) — raw scaled logits, pre-mask
     self.attn_scores = stash
-    if cascade is not None:          # extension: cumulative importance = sum of softmax probabilities (parity unpinned)
-        kv_cache, layer = cascade
-        if kv_cache.cascade is None:
-            from ..cascade import CascadeImportance
-            n_layers = sum(1 for _ in attention_modules_of(kv_cache, self))
-            kv_cache.cascade = CascadeImportance(n_layers, num_heads, kv_slab.round_capacity(kv_seq_len + kv_slab.GROW), device)
-        kv_cache.cascade.accumulate(layer, stash, lse,
-                                    None if attention_mask is None else attention_mask[:, 0])
 
     if attn_output.size() != (bsz, q_len, hidden_size):                           # :140-147
         raise ValueError(
@@ -163,7 +190,7 @@ def llama_pos_shift_attention_forward(
 
     attn_weights = None
     if output_attentions:                                                         # :135-137 on request only
-        logits = stash if attention_mask is None else stash + attention_mask
+        logits = stash if attention_mask is None else stash + attention_mask.to(dtype)
         attn_weights = torch.softmax(logits, dim=-1, dtype=torch.float32).to(dtype)
 
     new_past = slab.views() if use_cache else None                                # :100
@@ -194,12 +221,6 @@ def _mask_is_causal(mask: torch.Tensor, past_len: int) -> bool:
 def attention_modules(model):
     """The patched attention modules in ``model.modules()`` order (= layer order, run_spatten_llama.py:74-77)."""
     return [m for m in model.modules() if _is_llama_attention(m)]
-
-
-def attention_modules_of(kv_cache, any_module):
-    """All modules sharing ``kv_cache``'s cascade state (registered by enable_spatten_llm)."""
-    reg = getattr(kv_cache, "_cascade_modules", None)
-    return reg if reg is not None else [any_module]
 
 
 def _is_llama_attention(module) -> bool:

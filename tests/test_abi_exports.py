@@ -17,7 +17,8 @@ def declared_functions():
 def test_header_declares_the_hot_path():
     names = declared_functions()
     for must in ("spatten_attn_decode", "spatten_attn_prefill", "spatten_topk_select", "spatten_kv_compact",
-                 "spatten_prune_layers", "spatten_importance", "spatten_rope_single", "spatten_abi_version"):
+                 "spatten_prune_layers", "spatten_importance", "spatten_rope_single", "spatten_abi_version",
+                 "spatten_attn_decode_args", "spatten_kv_append", "spatten_decode_workspace_status"):
         assert must in names
 
 
@@ -30,11 +31,28 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, f"declared in include/spatten.h but not exported: {missing}"
     lib.spatten_abi_version.restype = ctypes.c_int
-    assert lib.spatten_abi_version() == 1
+    assert lib.spatten_abi_version() == 2
     lib.spatten_status_string.restype = ctypes.c_char_p
     assert lib.spatten_status_string(-3).decode().startswith("top-k window")
     lib.spatten_decode_workspace_bytes.restype = ctypes.c_size_t
     assert lib.spatten_decode_workspace_bytes(1, 32, 128, 64) > 32 * 64 * 130 * 8
+
+
+def test_decode_args_struct_matches_the_header():
+    """The ctypes mirror of spatten_decode_args_t has the C compiler's size and field offsets."""
+    import subprocess
+    import tempfile
+    from spatten_amd._lib import DecodeArgs
+    fields = [f[0] for f in DecodeArgs._fields_]
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "spatten.h"\nint main(){printf("%zu", sizeof(spatten_decode_args_t));' + \
+        "".join(f'printf(" %zu", offsetof(spatten_decode_args_t, {f}));' for f in fields) + "return 0;}"
+    with tempfile.TemporaryDirectory() as td:
+        src, exe = os.path.join(td, "s.c"), os.path.join(td, "s")
+        open(src, "w").write(prog)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        nums = [int(x) for x in subprocess.check_output([exe]).split()]
+    assert nums[0] == ctypes.sizeof(DecodeArgs)
+    assert nums[1:] == [getattr(DecodeArgs, f).offset for f in fields]
 
 
 def test_ctypes_layer_declares_every_symbol():

@@ -59,6 +59,47 @@ def test_cascade_importance_accumulate_and_compact(dt):
     assert np.array_equal(host(ci.acc[0])[:, :want.shape[1]], want)
 
 
+@pytest.mark.parametrize("dt,B", [("bf16", 1), ("f32", 2)])
+def test_cascade_accumulation_fused_into_the_decode_step(dt, B):
+    """Cumulative importance without a second kernel: each decode launch folds the PREVIOUS step's softmax probabilities
+    (that step's stash + (max, sum)) into the accumulator while its own keys stream; the last step is folded by
+    spatten_importance_accumulate at the prune.  Result = the oracle's running sum over all steps."""
+    from spatten_amd import ops
+    H, d, P, steps = 4, 128, 700, 5
+    qs, ks, vs, past = attn_inputs(B, H, H, d, P, steps, dt, seed=17)     # `steps` new tokens after P cached ones
+    cap = P + steps + 3
+    kc = torch.zeros(B, H, cap, d, dtype=TORCH_DT[dt], device="cuda")
+    krc, vc = torch.zeros_like(kc), torch.zeros_like(kc)
+    kc[:, :, :P], vc[:, :, :P] = dev(past[0], dt), dev(past[1], dt)
+    c, s = orc.rope_table(cap, d, dt)
+    cos, sin = dev(c[:, : d // 2], dt), dev(s[:, : d // 2], dt)
+    ops.build_shadow(kc, krc, 0, P, cos, sin)
+    acc = torch.zeros(H, cap, dtype=torch.float32, device="cuda")
+    want = np.zeros((H, cap), np.float32)
+    stash = [torch.zeros(B, H, cap, dtype=TORCH_DT[dt], device="cuda") for _ in range(2)]
+    lse = [torch.zeros(B, H, 2, dtype=torch.float32, device="cuda") for _ in range(2)]
+    pk, pv = past
+    for t in range(steps):
+        n = P + t + 1
+        cur, prv = t & 1, (t & 1) ^ 1
+        ops.attn_decode(dev(qs[:, :, t], dt), kc, krc, vc, n, cos, sin, n - 1, k_new=dev(ks[:, :, t], dt),
+                        v_new=dev(vs[:, :, t], dt), scores=stash[cur], lse=lse[cur],
+                        cascade=(acc, stash[prv], lse[prv], n - 1) if t > 0 else None)
+        _, st, (pk, pv) = orc.attention_core(qs[:, :, t:t + 1], ks[:, :, t:t + 1], vs[:, :, t:t + 1], pk, pv,
+                                             np.full((B, 1), n - 1), None, dt)
+        torch.cuda.synchronize()
+        # the oracle accumulates from the KERNEL's stash (16-bit stashes may differ by an ulp in < 2 % of entries)
+        want[:, :n] = orc.cascade_importance_accumulate(want[:, :n], host(stash[cur][:, :, :n])[:, :, None, :])
+        if t > 0:     # everything up to the previous step is in the accumulator after this launch
+            prev_want = want[:, :n].copy()
+            prev_want -= orc.softmax_probs(host(stash[cur][:, :, :n])[:, :, None, :]).sum(axis=(0, 2))
+            np.testing.assert_allclose(host(acc)[:, :n], prev_want, rtol=2e-3, atol=2e-5)
+    n = P + steps
+    ops.importance_accumulate(acc, stash[(steps - 1) & 1][:, :, None, :n], lse[(steps - 1) & 1][:, :, None, :])   # the flush
+    np.testing.assert_allclose(host(acc)[:, :n], want[:, :n], rtol=2e-3, atol=2e-5)
+    assert float(host(acc)[:, n:].max()) == 0.0
+
+
 @pytest.mark.parametrize("dt,Hkv", [("bf16", 8), ("f16", 2), ("f32", 8)])
 def test_local_value_pruning_vs_oracle(dt, Hkv):
     from spatten_amd.cascade import local_v_decode

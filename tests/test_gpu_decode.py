@@ -173,6 +173,71 @@ def test_decode_workspace_generations_with_changing_splits_and_lengths():
     torch.cuda.synchronize()
 
 
+def test_decode_workspace_mixed_head_subsets_pq_and_splits():
+    """ONE workspace shared by launches that differ in split count, in the set of heads they run (head pruning) and in
+    the key source (progressive quantisation, whose refetch pass only merges the flagged heads): every unit owns a
+    fixed partial region and its own generation, so no launch can pick up another unit's — or an older launch's —
+    partials.  (Round-1 advisor finding: regions used to be laid out by the launch's split count.)"""
+    from spatten_amd import ops
+    dt, B, H, d, N = "bf16", 1, 32, 128, 2081
+    q, k, v, past = attn_inputs(B, H, H, d, N - 1, 1, dt, seed=13)
+    kc = dev(np.concatenate([past[0], k], 2), dt)
+    vc = dev(np.concatenate([past[1], v], 2), dt)
+    cos, sin = ops.rope_table(N, d, TORCH_DT[dt], "cuda")
+    krc = ops.rope_single(kc, cos, sin)
+    planes = ops.PQPlanes(B, H, N, d, "cuda")
+    ops.pq_pack(krc, planes, 0, N)
+    qd = dev(q[:, :, 0], dt)
+    ws = ops.DecodeWorkspace(B, H, d, "cuda")
+    ref = ops.attn_decode(qd, None, krc, vc, N, cos, sin, N - 1, n_splits=1, workspace=ws).view(B, H, d)
+    # per-head pass-1 confidence -> a threshold that flags about half of the heads for the refetch pass
+    lse = torch.empty(B, H, 2, dtype=torch.float32, device="cuda")
+    ops.attn_decode_pq(qd, planes, vc, N, cos, sin, N - 1, 0.0, workspace=ws, lse=lse)
+    thr = float((1.0 / lse[0, :, 1]).median())
+    need0 = torch.empty(B * H, dtype=torch.int32, device="cuda")
+    ref_pq = ops.attn_decode_pq(qd, planes, vc, N, cos, sin, N - 1, thr, need_lsb=need0, workspace=ws).view(B, H, d).clone()
+    assert 0 < int(need0.sum()) < H
+    rng = np.random.default_rng(1)
+    for it in range(150):
+        kind = it % 3
+        splits = int(rng.choice([0, 2, 5, 8, 10, 16]))
+        if kind == 0:      # all heads
+            out = ops.attn_decode(qd, None, krc, vc, N, cos, sin, N - 1, n_splits=splits, workspace=ws).view(B, H, d)
+            assert torch.allclose(out.float(), ref.float(), atol=2e-3, rtol=1e-2), (it, splits)
+        elif kind == 1:    # a head subset (24 of 32 -> a different auto split count than 32 heads)
+            keep = np.sort(rng.choice(H, size=int(rng.choice([8, 24, 31])), replace=False)).astype(np.int32)
+            hid = torch.from_numpy(keep).cuda()
+            out = torch.full((B, H * d), float("nan"), dtype=TORCH_DT[dt], device="cuda")
+            ops.attn_decode(qd, None, krc, vc, N, cos, sin, N - 1, n_splits=splits, workspace=ws, out=out, head_ids=hid)
+            o3 = out.view(B, H, d)
+            assert torch.allclose(o3[:, hid.long()].float(), ref[:, hid.long()].float(), atol=2e-3, rtol=1e-2), (it, splits)
+            rest = np.setdiff1d(np.arange(H), keep)
+            assert torch.isnan(o3[:, torch.from_numpy(rest).cuda()].float()).all()
+        else:              # PQ: pass 2 merges only the flagged heads
+            need = torch.empty(B * H, dtype=torch.int32, device="cuda")
+            out = ops.attn_decode_pq(qd, planes, vc, N, cos, sin, N - 1, thr, need_lsb=need, workspace=ws).view(B, H, d)
+            assert torch.equal(need, need0), it
+            assert torch.allclose(out.float(), ref_pq.float(), atol=2e-3, rtol=1e-2), it
+    ws.check()             # no merge ever expired its wait
+
+
+@pytest.mark.parametrize("dt,d", [("bf16", 128), ("f32", 64)])
+def test_kv_append_matches_rope_kernel(dt, d):
+    """spatten_kv_append = copy of K / V rows + the rotation at the slot index into the shadow (bit exact)."""
+    from spatten_amd import ops
+    B, Hkv, n, row0, cap = 2, 3, 5, 37, 64
+    k = dev(orc.synth_normal(5, 0, (B, n, Hkv, d), dt), dt).transpose(1, 2)      # the projection's [B,n,H,d] viewed [B,H,n,d]
+    v = dev(orc.synth_normal(5, 1, (B, n, Hkv, d), dt), dt).transpose(1, 2)
+    cos, sin = ops.rope_table(cap, d, TORCH_DT[dt], "cuda")
+    kc, krc, vc = (torch.full((B, Hkv, cap, d), float("nan"), dtype=TORCH_DT[dt], device="cuda") for _ in range(3))
+    ops.kv_append(k, v, kc, krc, vc, row0, cos, sin)
+    torch.cuda.synchronize()
+    assert torch.equal(kc[:, :, row0:row0 + n], k) and torch.equal(vc[:, :, row0:row0 + n], v)
+    assert torch.equal(krc[:, :, row0:row0 + n], ops.rope_single(k, cos, sin, pos0=row0))
+    for t in (kc, krc, vc):
+        assert torch.isnan(t[:, :, :row0].float()).all() and torch.isnan(t[:, :, row0 + n:].float()).all()
+
+
 def test_decode_errors():
     from spatten_amd import ops
     dt = torch.bfloat16

@@ -151,6 +151,12 @@ def test_multi_turn_protocol_matches_reference_semantics(capsys):
     assert "SpAttenKVCache: keep start: 4" in capsys.readouterr().out
 
 
+def acc_of(kv_cache, layer, n):
+    """Cumulative importance of a layer INCLUDING the decode step still pending in the fused accumulation."""
+    kv_cache.ext.flush(layer)
+    return kv_cache.ext.layers[layer].acc[:, :n].cpu().numpy()
+
+
 def test_multi_turn_protocol_cascade_importance_mode():
     """Extension (parity unpinned): importance = accumulated softmax probabilities; the patched forward accumulates,
     the cache prunes by them and carries the accumulators through the prune.  GPU vs the oracle's restatement."""
@@ -169,7 +175,7 @@ def test_multi_turn_protocol_cascade_importance_mode():
             space_needed = prompt.shape[1] + MAX_GEN
             Lc = past_r[0][0].shape[2]
             for i in range(L):        # accumulators agree before the prune
-                np.testing.assert_allclose(kv_cache.cascade.acc[i][:, :Lc].cpu().numpy(), ref.acc[i][:, :Lc], rtol=2e-3, atol=2e-5)
+                np.testing.assert_allclose(acc_of(kv_cache, i, Lc), ref.acc[i][:, :Lc], rtol=2e-3, atol=2e-5)
             past_g = kv_cache.apply_token_pruning(past_g, space_needed, None)
             if Lc + space_needed > START + IMPORTANT + RECENT:
                 lo, hi = START, min(Lc - RECENT + space_needed, Lc)
@@ -188,3 +194,125 @@ def test_multi_turn_protocol_cascade_importance_mode():
         assert tg == tr, f"turn {turn}"
         assert past_g[0][0].shape[2] == past_r[0][0].shape[2]
     assert kv_cache.n_pruned_total > 0
+
+
+class ExtReplica(NumpyReplica):
+    """NumpyReplica + the oracle's restatements of head pruning / progressive quantisation / local V pruning at
+    single-token steps (the modes enable_spatten_llm wires into the patched forward)."""
+
+    def __init__(self, model, cascade=False, head_keep=None, pq_threshold=None, local_v_keep=None):
+        super().__init__(model, cascade)
+        self.head_keep, self.pq_threshold, self.local_v_keep = head_keep, pq_threshold, local_v_keep
+        self.head_abs = [np.zeros(H, np.float32) for _ in range(L)]
+        self.kept = [None] * L
+        self.need = [None] * L
+
+    def select_heads(self):
+        if self.head_keep is not None:
+            self.kept = orc.head_prune_cascade(self.head_abs, [self.head_keep] * L, self.kept)
+
+    def forward(self, ids, past):
+        B, q = ids.shape
+        P = 0 if past is None else past[0][0].shape[2]
+        N = P + q
+        pos = np.tile(np.arange(P, N)[None], (B, 1))
+        mask = orc.causal_mask(B, q, N, "f32")
+        x = self.emb[ids]
+        new_past = []
+        sp = lambda t: np.swapaxes(t.reshape(B, q, H, D), 1, 2)
+        for i, w in enumerate(self.w):
+            qh, kh, vh = sp(x @ w["q_proj"].T), sp(x @ w["k_proj"].T), sp(x @ w["v_proj"].T)
+            pk, pv = (None, None) if past is None else past[i]
+            if q == 1 and (self.pq_threshold is not None or self.local_v_keep is not None):
+                kc, vc = np.concatenate([pk, kh], 2), np.concatenate([pv, vh], 2)
+                cos, sin = orc.rope_table(N, D, "f32")
+                qr = orc.apply_rotary_pos_emb_single(qh, cos, sin, pos, "f32")[:, :, 0]
+                kr = orc.apply_rotary_pos_emb_single(kc, cos, sin, np.arange(N)[None], "f32")
+                if self.pq_threshold is not None:
+                    msb, lsb, scale = orc.pq_quantize(kr)
+                    logits, self.need[i] = orc.pq_logits(qr, msb, lsb, scale, self.pq_threshold)
+                    o = np.einsum("bhl,bhld->bhd", orc.softmax_probs(logits), vc)
+                else:
+                    logits = np.einsum("bhd,bhld->bhl", qr, kr) / np.float32(np.sqrt(D))
+                    keep = max(1, min(N, int(np.ceil(self.local_v_keep * N))))
+                    o = orc.local_value_prune(orc.softmax_probs(logits), vc, keep)
+                o, stash, kv = o.reshape(B, 1, H * D), logits[:, :, None, :], (kc, vc)
+            else:
+                o, stash, kv = orc.attention_core(qh, kh, vh, pk, pv, pos, mask, "f32")
+            if self.kept[i] is not None:                         # pruned heads contribute nothing
+                o = o.reshape(B, q, H, D).copy()
+                o[:, :, np.setdiff1d(np.arange(H), self.kept[i])] = 0
+                o = o.reshape(B, q, H * D)
+            self.head_abs[i] = self.head_abs[i] + orc.head_scores(o, H)
+            self.stash[i] = stash
+            if self.cascade:
+                self.accumulate(i, stash, mask)
+            x = x + o @ w["o_proj"].T
+            new_past.append(kv)
+        return x @ self.lm.T, new_past
+
+
+@pytest.mark.parametrize("mode", ["head", "pq", "local_v", "head+pq+cascade"])
+def test_multi_turn_protocol_extension_modes(mode):
+    """configs[2] / configs[4] through the plugin surface: head pruning, progressive quantisation and local V pruning are
+    reached by enable_spatten_llm kwargs and run inside llama_pos_shift_attention_forward + apply_token_pruning; GPU vs
+    the oracle replica, multi-turn, fp32 (PARITY UNPINNED: the oracle's restatement of the RTL rules)."""
+    from spatten_amd import enable_spatten_llm
+    torch.manual_seed(3)
+    model = TinyLlama().cuda().float()
+    for p in model.parameters():
+        p.data.mul_(0.6)
+    kw = {}
+    if "head" in mode:
+        kw["head_keep"] = 3
+    if "pq" in mode:
+        kw["pq_threshold"] = 0.06
+    if "local_v" in mode:
+        kw["local_v_keep"] = 0.4
+    cascade = "cascade" in mode
+    ref = ExtReplica(model, cascade=cascade, **kw)
+    kv_cache = enable_spatten_llm(model, START, IMPORTANT, RECENT, importance_mode="cascade" if cascade else "reference", **kw)
+    attn_modules = [m for m in model.modules() if type(m).__name__ == "LlamaAttention"]
+    rng = np.random.default_rng(4)
+    prompts = [rng.integers(0, VOCAB, size=n)[None] for n in (38, 26, 31)]
+    past_g = past_r = None
+    for turn, prompt in enumerate(prompts):
+        if turn > 0:
+            space_needed = prompt.shape[1] + MAX_GEN
+            Lc = past_r[0][0].shape[2]
+            scores = [m.attn_scores for m in attn_modules]
+            past_g = kv_cache.apply_token_pruning(past_g, space_needed, scores)
+            ref.select_heads()
+            if "head" in mode:
+                for i in range(L):
+                    got = kv_cache.ext.layers[i].head_ids
+                    got = np.arange(H) if got is None else got.cpu().numpy()
+                    assert np.array_equal(got, ref.kept[i]), f"turn {turn} layer {i}: kept heads"
+            assert Lc + space_needed > START + IMPORTANT + RECENT
+            lo, hi = START, min(Lc - RECENT + space_needed, Lc)
+            new_r = []
+            for i in range(L):
+                imp = ref.acc[i][:, :Lc] if cascade else orc.importance(ref.stash[i], "f32")
+                idx = orc.topk_window(imp, lo, hi, IMPORTANT)
+                live = np.arange(H) if ref.kept[i] is None else ref.kept[i]      # a pruned head's rows are dead weight
+                assert np.array_equal(kv_cache.keep_indices[i].cpu().numpy()[live], idx[live]), f"turn {turn} layer {i}"
+                idx_g = kv_cache.keep_indices[i].cpu().numpy()                     # follow the GPU for dead heads
+                Kn, Vn = orc.kv_compact(past_r[i][0], past_r[i][1], idx_g, START, hi)
+                if cascade:
+                    a = ref.acc[i][:, :Lc]
+                    ref.acc[i] = np.concatenate([a[:, :START], np.take_along_axis(a, idx_g, 1), a[:, hi:]], 1)
+                new_r.append((Kn, Vn))
+            past_r = new_r
+        tg, past_g, lg_ = greedy(lambda i, p: model(i, p), torch.from_numpy(prompt).cuda(), past_g,
+                                 lambda a: torch.tensor(a, device="cuda"))
+        tr, past_r, lr_ = greedy(ref.forward, prompt, past_r, lambda a: np.asarray(a))
+        assert tg == tr, f"turn {turn}: generated tokens differ {tg} vs {tr}"
+        np.testing.assert_allclose(lg_.cpu().numpy(), lr_, atol=5e-4, rtol=5e-4)
+        if "pq" in mode:
+            for i in range(L):
+                need_g = kv_cache.ext.layers[i].need_lsb.cpu().numpy().reshape(1, H).astype(bool)
+                live = np.arange(H) if ref.kept[i] is None else ref.kept[i]
+                assert np.array_equal(need_g[:, live], ref.need[i][:, live]), f"turn {turn} layer {i}: refetch flags"
+    assert kv_cache.n_pruned_total > 0
+    if "head" in mode:
+        assert all(k is not None and len(k) == 3 for k in ref.kept)

@@ -7,7 +7,8 @@
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 1, N = argc > 2 ? atoi(argv[2]) : 2048, ns = argc > 3 ? atoi(argv[3]) : 0;
   const int stash = argc > 4 ? atoi(argv[4]) : 1;
-  const int H = 32, d = 128, L = 32;
+  const int L = argc > 5 ? atoi(argv[5]) : 32;   // layers rotated over: 32 x 34 MB streams from HBM, 4 x 34 MB stays in the 256 MB Infinity Cache
+  const int H = 32, d = 128;
   const size_t row = (size_t)d * 2, per = (size_t)B * H * (N + 128) * row;
   std::vector<void*> kr(L), v(L);
   for (int l = 0; l < L; ++l) { (void)hipMalloc(&kr[l], per); (void)hipMalloc(&v[l], per); (void)hipMemset(kr[l], 0x3c, per); (void)hipMemset(v[l], 0x3c, per); }
@@ -35,6 +36,6 @@ int main(int argc, char** argv) {
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1e3 / (reps * L), bytes = 2.0 * B * H * N * row;
-  printf("B=%d N=%d ns=%d stash=%d UNR=%s: %.2f us/launch  %.2f TB/s\n", B, N, ns, stash, getenv("SPATTEN_DECODE_UNR") ? getenv("SPATTEN_DECODE_UNR") : "-", us, bytes / us / 1e6);
+  printf("B=%d N=%d ns=%d stash=%d layers=%d: %.2f us/launch  %.2f TB/s\n", B, N, ns, stash, L, us, bytes / us / 1e6);
   return 0;
 }
