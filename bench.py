@@ -11,13 +11,19 @@ max_gen_len, run_spatten_llama.py:61) starts with the prune event of all layers 
 stashed scores of the 4096-token cache + fused gather/compaction + rotated-shadow rebuild) that takes the
 cache from 4096 to 2048 rows.  Inputs are synthetic, resident in HBM before the timed region.
 
-N > 1: head-parallel (spatten_amd/parallel.py).  Weak scaling: the batch grows with N (B = N sequences), every
-rank owns H/N heads of every sequence — the same KV bytes per rank as the single-GPU run — and each layer
-all-gathers its [B, H/N*d] output slice over RCCL.
+The timed region always STARTS AT A TURN BOUNDARY (slot 0 = the prune event): K timed steps contain ceil(K / 64)
+prune events, whatever K the caller picks — never fewer than the workload's one-per-64-tokens.
+
+N > 1: head-parallel (spatten_amd/parallel.py); `python bench.py --gpus N` spawns its own N ranks (torch.distributed.run
+on a free local port) when it is not already running under a launcher.  --scaling weak (default): the batch grows with
+N (B = N sequences), every rank owns H/N heads of every sequence — the same KV bytes per rank as the single-GPU run.
+--scaling strong: ONE sequence (B = 1) split over the ranks, H/N heads each (BASELINE.json configs[2] / [4]: 4 resp.
+5 heads per GPU at N = 8).  Either way each token all-gathers the layers' [B, H/N*d] output slices over RCCL.
 
 Prints ONE JSON line (rank 0).  `value` = whole-job tokens/s.  `roofline` describes the dominant kernel
-(decode attention, HBM-bound); `cpu_baseline` times the C port of the reference (oracle/oracle.c — it re-rotates
-the whole K cache every step, as the reference does) on the host cores, on a bounded sample.
+(decode attention, HBM-bound); `cpu_baseline` times the torch-CPU mirror of the reference's op sequence
+(oracle/torch_mirror.py — it re-`cat`s and re-rotates the whole K cache every step, as the reference does) on the host
+cores, on a bounded sample.
 """
 import argparse
 import json
@@ -40,6 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the dense / eager comparison legs")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
@@ -96,8 +103,187 @@ def time_region(fn, steps, dist_on):
     return el
 
 
+def _physical_cores() -> int:
+    try:
+        import subprocess
+        out = subprocess.run(["lscpu", "-p=core,socket"], capture_output=True, text=True).stdout
+        cores = {ln for ln in out.splitlines() if ln and not ln.startswith("#")}
+        return max(1, len(cores))
+    except Exception:
+        return max(1, (os.cpu_count() or 2) // 2)
+
+
+def _cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(L, new_len, lo, hi):
+    """The reference path on the host CPU (checker code from oracle/, used here only as the timed baseline)."""
+    import statistics
+
+    import numpy as np
+    from oracle import c_oracle as co, torch_mirror as tm
+
+    H, d, n = HEADS, HEAD_DIM, new_len + TURN // 2
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(0)
+    q4 = torch.randn(1, H, 1, d, generator=g).to(dt)
+    pk, pv = torch.randn(1, H, n - 1, d, generator=g).to(dt), torch.randn(1, H, n - 1, d, generator=g).to(dt)
+    K4, V4 = torch.randn(1, H, CTX, d, generator=g).to(dt), torch.randn(1, H, CTX, d, generator=g).to(dt)
+    st4 = torch.randn(1, H, 1, CTX, generator=g).to(dt)
+    cos, sin = tm.rotary_table(n, d, dt)
+
+    def med(fn, budget_s, warm=3, min_reps=5):
+        for _ in range(warm):
+            fn()
+        ts, t_end = [], time.perf_counter() + budget_s
+        while len(ts) < min_reps or (time.perf_counter() < t_end and len(ts) < 4096):
+            t = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t)
+        return statistics.median(ts), len(ts)
+
+    phys = _physical_cores()
+    legs = {}
+    old_threads = torch.get_num_threads()
+    with torch.no_grad():
+        for threads, budget in ((phys, 8.0), (1, 3.0)):
+            torch.set_num_threads(threads)
+            t_dec, n_dec = med(lambda: tm.decode_core(q4, q4, q4, pk, pv, cos, sin), budget)
+            t_pr, n_pr = med(lambda: tm.prune_layer(K4, V4, st4, START, RECENT, IMPORTANT, 0), budget / 4, warm=1, min_reps=3)
+            legs[threads] = (t_dec, t_pr, n_dec, n_pr)
+    torch.set_num_threads(old_threads)
+    tps = lambda t_dec, t_pr: 1.0 / (L * t_dec + L * t_pr / TURN)
+    t_dec, t_pr, n_dec, n_pr = legs[phys]
+    out = {"value": round(tps(t_dec, t_pr), 4), "unit": "tokens/s", "cores": phys, "kind": "port",
+           "sample": f"{n_dec} decode-attention layer steps at kv_len {n} + {n_pr} one-layer prune events (4096 -> 2048), median, "
+                     f"torch-CPU mirror of the reference's op sequence (oracle/torch_mirror.py), extrapolated to {L} layers per "
+                     f"token and one prune per {TURN} tokens",
+           "ms_per_layer_decode": round(t_dec * 1e3, 3), "ms_per_layer_prune": round(t_pr * 1e3, 3),
+           "one_thread": {"value": round(tps(*legs[1][:2]), 4), "ms_per_layer_decode": round(legs[1][0] * 1e3, 3),
+                          "ms_per_layer_prune": round(legs[1][1] * 1e3, 3)},
+           "cpu_model": _cpu_model(), "logical_cpus": os.cpu_count(), "physical_cores": phys,
+           "accepted_vs_reference": "profiles/r02_cpu_port_vs_reference.json (mirror / imported reference = 0.87-0.97 decode, "
+                                    "0.89-0.98 prune, build container, 1 and 8 threads)"}
+    try:      # the C port beside it (-march=native build on this host when gcc is there)
+        co.load(native=True)
+        rs = np.random.default_rng(0)
+        mk = lambda *s: (rs.standard_normal(s).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        qh, kc, vc, cs, sn = mk(1, H, d), mk(1, H, n, d), mk(1, H, n, d), mk(n, d // 2), mk(n, d // 2)
+        oh, sh = np.empty((1, H * d), np.uint16), np.empty((1, H, n), np.uint16)
+        score, kfull = rs.standard_normal((H, CTX)).astype(np.float32), mk(1, H, CTX, d)
+
+        def c_prune():
+            ix = co.topk_window(score, lo, hi, IMPORTANT, "f32")
+            co.kv_compact_raw("bf16", kfull, ix, START, hi)
+            co.kv_compact_raw("bf16", kfull, ix, START, hi)
+        cport = {}
+        for threads in (min(phys, H), 1):
+            co.set_threads(threads)
+            td, _ = med(lambda: co.attn_decode_raw("bf16", qh, kc, vc, cs, sn, None, oh, sh, 1, H, H, d, n, n - 1), 2.0)
+            tp, _ = med(c_prune, 0.5, warm=1, min_reps=3)
+            cport[str(threads)] = {"value": round(tps(td, tp), 4), "ms_per_layer_decode": round(td * 1e3, 3),
+                                   "ms_per_layer_prune": round(tp * 1e3, 3)}
+        out["c_port_by_threads"] = cport
+    except Exception as e:
+        out["c_port_error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
+def plugin_path_tokens_per_s(dev, dt, n_tokens=48):
+    """The DROP-IN number: tokens/s through the patched HF forward itself (`llama_pos_shift_attention_forward`, called per
+    layer with the arguments transformers 4.33 passes — hidden states, a zero mask, position_ids, the layer's (K, V)
+    pair — including the module's q/k/v/o projections and every per-call host step), eager launches, Llama-2-7B geometry,
+    2048-row pruned cache.  Next to it the same with enable_spatten_llm(assume_causal=True)."""
+    from types import SimpleNamespace
+
+    from torch import nn
+
+    from spatten_amd import enable_spatten_llm
+
+    class LlamaAttention(nn.Module):
+        def __init__(self):
+            super().__init__()
+            hid = HEADS * HEAD_DIM
+            self.config = SimpleNamespace(pretraining_tp=1)
+            self.num_heads = self.num_key_value_heads = HEADS
+            self.num_key_value_groups, self.head_dim, self.hidden_size = 1, HEAD_DIM, hid
+            for nme in ("q_proj", "k_proj", "v_proj", "o_proj"):
+                lin = nn.Linear(hid, hid, bias=False, dtype=dt, device=dev)
+                nn.init.normal_(lin.weight, std=hid ** -0.5)
+                setattr(self, nme, lin)
+
+    class Stack(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.config = SimpleNamespace(model_type="llama")
+            self.layers = nn.ModuleList([LlamaAttention() for _ in range(LAYERS)])
+
+    out = {}
+    P = START + IMPORTANT + RECENT
+    with torch.no_grad():
+        model = Stack()
+        for flag in (False, True):
+            import contextlib
+            import io
+            with contextlib.redirect_stdout(io.StringIO()):       # the constructor prints the reference's banner
+                enable_spatten_llm(model, START, IMPORTANT, RECENT, prefill_stash=False, assume_causal=flag)
+            hid = HEADS * HEAD_DIM
+            x = torch.randn(1, P, hid, device=dev, dtype=torch.float32).to(dt)
+            mask = torch.zeros(1, 1, P, P, dtype=dt, device=dev).masked_fill_(
+                torch.ones(P, P, dtype=torch.bool, device=dev).triu(1), torch.finfo(dt).min)
+            pos = torch.arange(P, device=dev)[None]
+            past = []
+            for m in model.layers:                                   # prefill: fills every layer's cache
+                _, _, kv = m(x, attention_mask=mask, position_ids=pos, past_key_value=None, use_cache=True)
+                past.append(kv)
+            del mask
+            xt = torch.randn(1, 1, hid, device=dev, dtype=torch.float32).to(dt)
+
+            def token(t):
+                n = past[0][0].shape[2]
+                zm = torch.zeros(1, 1, 1, n + 1, dtype=dt, device=dev)
+                pid = torch.full((1, 1), n, dtype=torch.long, device=dev)
+                for i, m in enumerate(model.layers):
+                    _, _, past[i] = m(xt, attention_mask=zm, position_ids=pid, past_key_value=past[i], use_cache=True)
+            for t in range(4):
+                token(t)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t in range(n_tokens):
+                token(t)
+            torch.cuda.synchronize()
+            out["plugin_path_assume_causal_tokens_per_s" if flag else "plugin_path_tokens_per_s"] = round(
+                n_tokens / (time.perf_counter() - t0), 2)
+            del past
+    return out
+
+
+def self_spawn(args) -> int:
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU, RCCL over a free
+    local port) and hand their output through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -105,7 +291,11 @@ def main():
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:             # --force-dist without a launcher: any free port
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -121,7 +311,7 @@ def main():
 
     dt = torch.bfloat16
     hp = HeadParallel(HEADS)
-    B, Hl, d, L = world, hp.local_heads, HEAD_DIM, LAYERS
+    B, Hl, d, L = (1 if args.scaling == "strong" else world), hp.local_heads, HEAD_DIM, LAYERS
     world_eff = hp.world
     new_len = START + IMPORTANT + RECENT                     # 2048
     cap = kv_slab.round_capacity(new_len + TURN)             # 2176
@@ -224,9 +414,12 @@ def main():
 
     pending = [None, None]                    # in-flight gather per output buffer parity
 
+    # slot of step i: the warm-up ENDS at a turn boundary, so the timed region starts with slot 0 (the prune event)
+    base_slot = (-args.warmup) % TURN
+
     def run_steps(n, first=0):
         for i in range(first, first + n):
-            slot = i % TURN
+            slot = (base_slot + i) % TURN
             par = slot & 1
             if dist_on and pending[par] is not None:
                 pending[par].wait()            # the gather that still reads this parity's outputs (token i-2)
@@ -250,13 +443,14 @@ def main():
         "metric": "decode tokens/sec (attention path), Llama-2-7B N=4k, 50% token prune",
         "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "llama2-7b attention path: 4096-token KV cache -> per-head top-k prune to 2048 "
                                "(start 4 / important 1020 / recent 1024) -> decode, 64-token turns",
                    "layers": L, "heads": HEADS, "head_dim": d, "batch": B, "kv_len_before_prune": CTX,
                    "kv_len_after_prune": new_len, "turn_tokens": TURN,
-                   "parallelism": (f"head-parallel x{world} (H/{world} heads per rank; RCCL all-gather of every layer's output, "
-                                   f"{args.gather})") if dist_on else "single GPU",
+                   "prune_events_in_timed_region": -(-args.steps // TURN),
+                   "parallelism": (f"head-parallel x{world}, {args.scaling} scaling (B = {B}, H/{world} heads per rank; RCCL "
+                                   f"all-gather of every layer's output, {args.gather})") if dist_on else "single GPU",
                    "launch": "hip-graph" if graphs is not None else "eager"},
     }
 
@@ -374,6 +568,10 @@ def main():
                 extras["dense_torch_sdpa_error"] = f"{type(e).__name__}: {e}"
             extras["speedup_vs_dense_eager"] = round(tokens_per_s / extras["dense_eager_posshift_tokens_per_s"], 2)
             extras["speedup_vs_dense_fused"] = round(tokens_per_s / extras["dense_fused_tokens_per_s"], 2)
+            try:
+                extras.update(plugin_path_tokens_per_s(dev, dt))
+            except Exception as e:
+                extras["plugin_path_error"] = f"{type(e).__name__}: {e}"
             # ---- other rows of the scope table, measured on the same box (not part of `value`) -----------------
             try:
                 Np = 8192                                                   # C4: causal prefill, q = N = 8192, one layer
@@ -462,41 +660,13 @@ def main():
                 extras["side_measurements_error"] = f"{type(e).__name__}: {e}"
             result["extras"] = extras
 
-        # ---- CPU baseline: the C port of the reference on the host cores, bounded sample ------------------
+        # ---- CPU baseline: the reference's op sequence on the host cores, bounded sample -------------------------------
+        # `value` = the torch-CPU mirror of the reference path (oracle/torch_mirror.py: the same eager torch ops the
+        # reference's Python issues, timed within +-20 % of the imported reference in the build container —
+        # profiles/r02_cpu_port_vs_reference.json) at all physical cores; beside it the same at one thread and the C
+        # port (oracle/oracle.c, OpenMP over heads).
         if not args.no_cpu_baseline and not dist_on:
-            import numpy as np
-            from oracle import c_oracle as co              # checker / baseline only
-            threads = min(os.cpu_count() or 1, 32)
-            co.load(native=True)                           # -march=native build on this host when gcc is there
-            co.set_threads(threads)
-            n = new_len + TURN // 2
-            rs = np.random.default_rng(0)
-            mk = lambda *s: (rs.standard_normal(s).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
-            qh, kc, vc = mk(1, HEADS, d), mk(1, HEADS, n, d), mk(1, HEADS, n, d)
-            cs, sn = mk(n, d // 2), mk(n, d // 2)
-            oh = np.empty((1, HEADS * d), np.uint16)
-            sh = np.empty((1, HEADS, n), np.uint16)
-            co.attn_decode_raw("bf16", qh, kc, vc, cs, sn, None, oh, sh, 1, HEADS, HEADS, d, n, n - 1)   # warm
-            reps, t0 = 0, time.perf_counter()
-            while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 4096):     # ~10 s of CPU work
-                co.attn_decode_raw("bf16", qh, kc, vc, cs, sn, None, oh, sh, 1, HEADS, HEADS, d, n, n - 1)
-                reps += 1
-            t_dec = (time.perf_counter() - t0) / reps
-            score = rs.standard_normal((HEADS, CTX)).astype(np.float32)
-            kfull = mk(1, HEADS, CTX, d)
-            t0 = time.perf_counter()
-            for _ in range(3):
-                ix = co.topk_window(score, lo, hi, IMPORTANT, "f32")
-                co.kv_compact_raw("bf16", kfull, ix, START, hi)
-                co.kv_compact_raw("bf16", kfull, ix, START, hi)
-            t_prune = (time.perf_counter() - t0) / 3
-            cpu_tps = 1.0 / (L * t_dec + L * t_prune / TURN)
-            result["cpu_baseline"] = {"value": round(cpu_tps, 4), "unit": "tokens/s", "cores": threads, "kind": "port",
-                                      "sample": f"{reps} decode-attention layer steps at kv_len {n} + 3 one-layer prune events "
-                                                f"(C port of the reference, OpenMP over heads), extrapolated to {L} layers per token "
-                                                f"and one prune per {TURN} tokens",
-                                      "ms_per_layer_decode": round(t_dec * 1e3, 3), "ms_per_layer_prune": round(t_prune * 1e3, 3),
-                                      "host_cpus": os.cpu_count()}
+            result["cpu_baseline"] = cpu_baseline(L, new_len, lo, hi)
     if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()

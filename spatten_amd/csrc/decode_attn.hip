@@ -72,11 +72,12 @@ struct DecodeParams {
   unsigned* ws_err;     // device error word (workspace header)
   int64_t ws_unit;      // granules reserved per unit = ws_splits * (D + 2): FIXED per workspace, so launches with
                         // different split counts / head subsets / key sources never alias another unit's partials
-  int B, H, Hkv, N, pos_q, S, chunk, n_q, causal, vis0, append;   // causal: query row qi sees keys [0, vis0 + qi)
+  int B, H, Hkv, N, pos_q, S, chunk, n_q, causal, vis0, append, poll_merge;   // causal: query row qi sees keys [0, vis0 + qi)
   float sqrt_d;
 };
 
 constexpr int kDecodeThreads = 256;
+constexpr int kDecodeCoResident = 256;   // workgroups the chip starts without waiting for another to finish: one per CU
 
 // one 8-byte {value, tag} granule of a published partial (tag != 0 <=> the value has landed)
 __device__ inline void store_granule(unsigned long long* g, float v, unsigned tag) {
@@ -483,26 +484,40 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   unsigned long long* ws = p.ws_part + (int64_t)unit * p.ws_unit;
   unsigned long long* part = ws + (int64_t)split * (D + 2);
   const unsigned tag = (gen & 0x7FFFFFFFu) + 1u;
-  // the ticket is drawn by the LAST wave, which has no stores in flight: on CDNA4 vmcnt also counts stores, so a
-  // wave that just issued granules would wait for their write-through acknowledgements before it sees its ticket
-  if (tid == kDecodeThreads - 1)
-    s_ticket = __hip_atomic_fetch_add(p.ws_cnt + 2 * unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // Who merges.  poll_merge (the host sets it when the whole grid is co-resident BY CONSTRUCTION: no more workgroups than
+  // CUs, so every workgroup is running or will be started without any other having to finish): the unit's LAST split
+  // merges; it simply polls the other splits' granules until their tags match — the hand-off is ONE memory hop, no
+  // ticket round trip in front of it.  Otherwise (more workgroups than the chip holds at once: a polling workgroup
+  // could wait for one that cannot start) the last ARRIVER merges: a ticket tells it that every split has at least
+  // issued its granules, so its polling is bounded by store latency, never by scheduling.
+  if (!p.poll_merge) {
+    // the ticket is drawn by the LAST wave, which has no stores in flight: on CDNA4 vmcnt also counts stores, so a
+    // wave that just issued granules would wait for their write-through acknowledgements before it sees its ticket
+    if (tid == kDecodeThreads - 1)
+      s_ticket = __hip_atomic_fetch_add(p.ws_cnt + 2 * unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (tid < D && tid < kDecodeThreads - kWave) store_granule(part + tid, o_tot, tag);
   if (D > kDecodeThreads - kWave && tid >= kDecodeThreads - kWave && tid < D) store_granule(part + tid, o_tot, tag);   // D = 256 only
   if (tid == (D < kDecodeThreads - kWave ? D : 0)) { store_granule(part + D, m_run, tag); store_granule(part + D + 1, l_tot, tag); }
-  __syncthreads();
-  SPATTEN_TSTAMP(3);
-  if (s_ticket != (unsigned)(p.S - 1)) return;
+  if (p.poll_merge) {
+    if (split != p.S - 1) return;
+  } else {
+    __syncthreads();
+    SPATTEN_TSTAMP(3);
+    if (s_ticket != (unsigned)(p.S - 1)) return;
+  }
 
   // merge in ONE round trip: thread (g, e) takes splits s = g, g+G, ...; every load below — its partial-o
   // elements and the (m, l) of the same splits — is independent.  Each group folds its splits relative to
   // its own running max; the groups are then folded through LDS.
   constexpr int KB = 8;                          // splits per thread per round trip
+  // up to KB splits: ONE thread group folds them all (no LDS fold, no barrier); more: G groups take every G-th split
+  const int Gr = p.S > KB ? G : 1;
   const int e = tid % D, g = tid / D;
   float mg = -INFINITY, lg = 0.f, og = 0.f;
   bool expired = false;
-  if (g < G) {
-    for (int s0 = g; s0 < p.S; s0 += KB * G) {
+  if (g < Gr) {
+    for (int s0 = g; s0 < p.S; s0 += KB * Gr) {
       unsigned long long ga[KB], gm[KB], gl[KB];
       int spins = 0;
       bool landed;
@@ -510,7 +525,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
              // the compiler wait for each split's granules before it loads the next split's)
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
-          const int sc_ = (s0 + k * G) < p.S ? (s0 + k * G) : g;
+          const int sc_ = (s0 + k * Gr) < p.S ? (s0 + k * Gr) : g;
           const unsigned long long* q = ws + (int64_t)sc_ * (D + 2);
           ga[k] = __hip_atomic_load(q + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           gm[k] = __hip_atomic_load(q + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -526,7 +541,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
       float a[KB], ms[KB], ls[KB];
 #pragma unroll
       for (int k = 0; k < KB; ++k) {
-        const bool live = (s0 + k * G) < p.S;
+        const bool live = (s0 + k * Gr) < p.S;
         a[k] = live ? __uint_as_float((unsigned)ga[k]) : 0.f;
         ms[k] = live ? __uint_as_float((unsigned)gm[k]) : -INFINITY;
         ls[k] = live ? __uint_as_float((unsigned)gl[k]) : 0.f;
@@ -550,18 +565,18 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
     atomicOr(p.ws_err, 1u);
     og = __builtin_nanf("");
   }
-  if (G > 1) {                                   // fold the thread groups through LDS
-    if (g < G) { s_o[g][e] = og; if (e == 0) { s_o[g][D] = mg; s_o[g][D + 1] = lg; } }
+  if (Gr > 1) {                                  // fold the thread groups through LDS
+    if (g < Gr) { s_o[g][e] = og; if (e == 0) { s_o[g][D] = mg; s_o[g][D + 1] = lg; } }
     __syncthreads();
     if (g == 0) {
       float mn = mg;
 #pragma unroll
-      for (int gg = 1; gg < G; ++gg) mn = fmaxf(mn, s_o[gg][D]);
+      for (int gg = 1; gg < Gr; ++gg) mn = fmaxf(mn, s_o[gg][D]);
       const float mu = (mn == -INFINITY) ? 0.f : mn;
       const float w0 = __expf(mg - mu);
       og *= w0; lg *= w0;
 #pragma unroll
-      for (int gg = 1; gg < G; ++gg) {
+      for (int gg = 1; gg < Gr; ++gg) {
         const float w = __expf(s_o[gg][D] - mu);
         og = fmaf(s_o[gg][e], w, og);
         lg = fmaf(s_o[gg][D + 1], w, lg);
@@ -579,7 +594,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
     if (p.lse != nullptr) { p.lse[unit * 2] = mg; p.lse[unit * 2 + 1] = lg; }
     if (KSRC == 1) p.pq_need[unit] = (1.0f / lg) < p.pq_thr ? 1 : 0;
     p.ws_cnt[2 * unit + 1] = gen + 1u;                                                         // next launch: new tag
-    __hip_atomic_store(p.ws_cnt + 2 * unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm the counter
+    if (!p.poll_merge) __hip_atomic_store(p.ws_cnt + 2 * unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm the counter
   }
   SPATTEN_TSTAMP(4);
 }
@@ -700,6 +715,12 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   S = ceil_div(c.kv_len, chunk);
   if (S > 1 && (!c.workspace || (size_t)units > c.ws_units || S > ws_splits)) return SPATTEN_ERR_INVALID;
   const size_t cnt_bytes = decode_cnt_bytes(c.ws_units);
+  // single-hop merge (see the kernel): only when the grid cannot outnumber the workgroup slots of the chip.  Causal
+  // multi-row launches are excluded (their later splits may be empty and return early... they still publish, but keep
+  // the conservative protocol there); SPATTEN_DECODE_POLL=0 forces the ticket protocol (A/B measurements).
+  static int env_poll = -1;
+  if (env_poll < 0) { const char* e = getenv("SPATTEN_DECODE_POLL"); env_poll = e ? atoi(e) : 1; }
+  const int poll_merge = (env_poll != 0 && S > 1 && c.n_q == 1 && (long long)S * n_active * c.batch <= kDecodeCoResident) ? 1 : 0;
 
 #define SPATTEN_FILL(T)                                                                                  \
   DecodeParams<T> p;                                                                                     \
@@ -726,6 +747,7 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   p.ws_unit = (int64_t)ws_splits * (c.head_dim + 2);                                                     \
   p.B = c.batch; p.H = c.heads; p.Hkv = c.kv_heads; p.N = c.kv_len; p.pos_q = c.pos_q; p.S = S; p.chunk = chunk; \
   p.n_q = c.n_q; p.causal = c.causal; p.vis0 = c.vis0 > 0 ? c.vis0 : c.kv_len - c.n_q + 1;                \
+  p.poll_merge = poll_merge;                                                                             \
   p.sqrt_d = sqrtf((float)c.head_dim);                                                                   \
   return dispatch_decode<T>(p, c.head_dim, n_active, scores_only, stream);
 
