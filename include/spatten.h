@@ -305,6 +305,27 @@ int spatten_pq_pack(int dtype, const void* kr_cache, int64_t kv_sb, int64_t kv_s
                     int row_lo, int row_hi, void* stream);
 /* The decode step over the planes is spatten_attn_decode_args with the pq_* fields set. */
 
+/* Prefill over the planes (BASELINE.json configs[3]: prefill + progressive quantisation).  Same query / value / output /
+ * mask / position arguments as spatten_attn_prefill; the keys come from the MSB / LSB planes: pass 1 scores every query
+ * row from the MSB plane (logits in fp32), need_lsb[b,h,i] = (max_j prob_ij < threshold) per QUERY ROW (int32 [B,H,q_len],
+ * contiguous, written by the call), pass 2 refetches the LSB plane and recomputes the flagged rows once
+ * (RequantDecision.scala:44-72, SpAttenController.scala:402).  bf16 / f16, head_dim 64 / 128 (the MFMA flash kernel). */
+size_t spatten_prefill_pq_workspace_bytes(int dtype, int batch, int heads, int kv_heads, int head_dim,
+                                          int q_len, int kv_len);
+int spatten_attn_prefill_pq(int dtype,
+                            const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sq,
+                            const void* msb, const void* lsb, const float* scale,
+                            int64_t pl_sb, int64_t pl_sh, int64_t sc_sb, int64_t sc_sh,
+                            const void* v_cache, int64_t kv_sb, int64_t kv_sh,
+                            const void* cos, const void* sin, int table_rows,
+                            const int64_t* position_ids, int64_t pos_sb,
+                            const void* mask, int64_t mask_sb, int64_t mask_sq,
+                            void* out, int64_t out_sb, int64_t out_sq,
+                            int32_t* need_lsb, float threshold, void* workspace,
+                            int batch, int heads, int kv_heads, int head_dim,
+                            int q_len, int kv_len, int pos_q0, int causal,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

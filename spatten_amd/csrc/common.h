@@ -429,6 +429,12 @@ struct DecodeCall {
 };
 int decode_rows(const DecodeCall& c, hipStream_t stream);
 
+// planes -> integer-valued keys in the model dtype (msb*16 and msb*16+lsb, both exact) + scale / sqrt(d) per key
+// (pq.hip; used by the progressive-quant prefill)
+int pq_expand(int dtype, const void* msb, const void* lsb, const float* scale, int64_t pl_sb, int64_t pl_sh, int64_t sc_sb,
+              int64_t sc_sh, void* k_msb, void* k_full, float* kscale, int batch, int kv_heads, int head_dim, int rows,
+              hipStream_t stream);
+
 constexpr int kDecodeMaxSplits = 64;
 constexpr size_t kDecodeWsHeader = 256;
 inline size_t decode_cnt_bytes(size_t units) { return (units * 2 * sizeof(unsigned) + 255) / 256 * 256; }

@@ -100,7 +100,8 @@ __device__ inline void store_granule(unsigned long long* g, float v, unsigned ta
 // NT: K/V rows are fetched with the non-temporal cache policy (each row is used once per launch: -0.5 us of 13.7 at
 // C2); off when several query rows (the rows leg of prefill) re-read the same K/V through L2.
 // CASC: cascade (cumulative) importance, deferred by one step — see DecodeParams.
-template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0, bool NT = LEAN, bool CASC = false>
+template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0, bool NT = LEAN, bool CASC = false,
+          bool PIPE = false>
 __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   constexpr bool SCORES_ONLY = (MODE == 1);
   constexpr bool PQ = (KSRC != 0);
@@ -167,6 +168,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
     T prev[UNR];                                               // CASC: the previous step's logit of the row
   };
   Tile tile_a;
+  Tile tile_b;   // PIPE only: the second half of the double buffer (dead code otherwise)
   const uint8_t* pq_m = PQ ? p.pq_msb + b * p.pl_sb + hkv * p.pl_sh : nullptr;
   const uint8_t* pq_l = KSRC == 2 ? p.pq_lsb + b * p.pl_sb + hkv * p.pl_sh : nullptr;
   const float* pq_s = PQ ? p.pq_scale + b * p.ps_sb + hkv * p.ps_sh : nullptr;
@@ -386,11 +388,32 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
       }
     }
   };
-  process_tile(tile_a, lo, groups_of(lo), owns_new && lo + TILE >= hi);   // straight-line from the loads to their uses
-  for (int t0 = lo + TILE; t0 < hi; t0 += TILE) {
-    issue_keys(tile_a, t0);
-    issue_values(tile_a, t0);
-    process_tile(tile_a, t0, groups_of(t0), owns_new && t0 + TILE >= hi);
+  // the tile after which the owning split scores the appended row: the one that holds its last cached row
+  const int last_row = max(hi - 1, lo);
+  auto with_new = [&](int t0) { return owns_new && t0 <= last_row && last_row < t0 + TILE; };
+  if (!PIPE) {
+    process_tile(tile_a, lo, groups_of(lo), with_new(lo));   // straight-line from the loads to their uses
+    for (int t0 = lo + TILE; t0 < hi; t0 += TILE) {          // (longer chunks normally run the PIPE instantiation)
+      issue_keys(tile_a, t0);
+      issue_values(tile_a, t0);
+      __builtin_amdgcn_sched_barrier(0);
+      process_tile(tile_a, t0, groups_of(t0), with_new(t0));
+    }
+  } else {
+    // Long chunks (N / S above one single-shot tile): smaller tiles, double buffered — the next tile's loads are in
+    // flight while this one is scored and multiplied (in-order returns: waiting for tile A never waits for tile B
+    // behind it), so the memory pipe never drains between tiles.  Tiles past the end re-read the last row (cache
+    // hits) and process nothing.
+    for (int t0 = lo; t0 < hi; t0 += 2 * TILE) {
+      issue_keys(tile_b, t0 + TILE);
+      issue_values(tile_b, t0 + TILE);
+      __builtin_amdgcn_sched_barrier(0);
+      process_tile(tile_a, t0, groups_of(t0), with_new(t0));
+      issue_keys(tile_a, t0 + 2 * TILE);
+      issue_values(tile_a, t0 + 2 * TILE);
+      __builtin_amdgcn_sched_barrier(0);
+      process_tile(tile_b, t0 + TILE, groups_of(t0 + TILE), with_new(t0 + TILE));
+    }
   }
 
 #ifdef SPATTEN_EXP_NOREDUCE   // A/B harness only: what does everything after the streaming loop cost?
@@ -599,16 +622,17 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   SPATTEN_TSTAMP(4);
 }
 
-template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0, bool NT = LEAN, bool CASC = false>
+template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0, bool NT = LEAN, bool CASC = false,
+          bool PIPE = false>
 __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const DecodeParams<T> p) {
-  decode_body<T, D, UNR, MODE, LEAN, KSRC, NT, CASC>(p);
+  decode_body<T, D, UNR, MODE, LEAN, KSRC, NT, CASC, PIPE>(p);
 }
 
 // The plain decode step with its launch-critical arguments FIRST and 32-bit strides: built with
 // -amdgpu-kernarg-preload-count=16 (Makefile) the first 16 kernel-argument dwords — everything the query and the K/V
 // tile loads need (q is dense [B,H,D] here) — arrive in SGPRs with the wave, so those loads are issued without waiting
 // for a scalar load of the argument block (the other arguments are fetched while they are in flight).
-template <typename T, int D, int UNR, bool CASC>
+template <typename T, int D, int UNR, bool CASC, bool PIPE>
 __global__ __launch_bounds__(kDecodeThreads) void decode_lean_kernel(T* krc, T* vc, const T* q, const T* cos, const T* sin,
                                                                      int kv_sb, int kv_sh, int N, int chunk, int H, int pos_q,
                                                                      const DecodeParams<T> rest) {
@@ -616,14 +640,16 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_lean_kernel(T* krc, T* 
   p.krc = krc; p.vc = vc; p.q = q; p.cos = cos; p.sin = sin;
   p.kv_sb = kv_sb; p.kv_sh = kv_sh; p.q_sb = (int64_t)H * D; p.q_sh = D;
   p.N = N; p.chunk = chunk; p.H = H; p.pos_q = pos_q;
-  decode_body<T, D, UNR, 0, true, 0, true, CASC>(p);
+  decode_body<T, D, UNR, 0, true, 0, true, CASC, PIPE>(p);
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-// row-groups per tile: 16-bit dtypes 10 (d = 128: 320 rows — a whole Llama-2-7B split — in flight per workgroup)
+// row-groups per tile.  Single-shot instantiation: 16-bit dtypes 10 (d = 128: 320 rows — a whole Llama-2-7B split — in
+// flight per workgroup).  Pipelined instantiation (chunks longer than that): two tiles of 4 (fp32: 2) row-groups.
 template <typename T, int D> constexpr int decode_unr() { return sizeof(T) == 4 ? (D == 256 ? 2 : 4) : (D == 256 ? 4 : 10); }
+template <typename T, int D> constexpr int decode_unr_pipe() { return sizeof(T) == 4 ? 2 : 4; }
 static inline int decode_group_rows(int d) { return kDecodeThreads / (d / 16); }
 
 static int auto_splits(int units, int d, int kv_len) {
@@ -643,36 +669,47 @@ static int auto_splits(int units, int d, int kv_len) {
 template <typename T, int D>
 static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_only, hipStream_t stream) {
   constexpr int U = decode_unr<T, D>();
+  constexpr int UP = decode_unr_pipe<T, D>();
   const dim3 grid((unsigned)p.S, (unsigned)n_active, (unsigned)(p.B * p.n_q));
   const dim3 blk(kDecodeThreads);
+  // a chunk that fits one single-shot tile: everything in flight at once; longer: the double-buffered loop
+  const bool pipe = p.chunk > U * (kDecodeThreads / (D / 16)) && p.n_q == 1 && !scores_only;
+  const bool casc = p.acc != nullptr;
+#define SPATTEN_LAUNCH(...) hipLaunchKernelGGL((decode_attn_kernel<T, D, __VA_ARGS__>), grid, blk, 0, stream, p)
   if (scores_only) {
-    hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 1>), grid, blk, 0, stream, p);
+    SPATTEN_LAUNCH(U, 1);
   } else if (p.pq_msb != nullptr) {   // progressive-quant keys: pass 1 on the MSB plane, then the refetch pass (same grid)
     if constexpr (D == 256) return SPATTEN_ERR_UNSUPPORTED;
     else {
       // the fused cascade accumulation rides on pass 1 only (pass 2 re-streams the flagged heads: no double count)
-      if (p.acc != nullptr) hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, false, 1, true, true>), grid, blk, 0, stream, p);
-      else hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, false, 1, true>), grid, blk, 0, stream, p);
-      hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, false, 2, true>), grid, blk, 0, stream, p);
+      if (pipe) {
+        if (casc) SPATTEN_LAUNCH(UP, 0, false, 1, true, true, true); else SPATTEN_LAUNCH(UP, 0, false, 1, true, false, true);
+        SPATTEN_LAUNCH(UP, 0, false, 2, true, false, true);
+      } else {
+        if (casc) SPATTEN_LAUNCH(U, 0, false, 1, true, true); else SPATTEN_LAUNCH(U, 0, false, 1, true);
+        SPATTEN_LAUNCH(U, 0, false, 2, true);
+      }
     }
   } else {
     const bool lean = p.n_q == 1 && p.Hkv == p.H && !p.mask && !p.pos_ids && !p.head_ids && !p.causal &&
                       p.q_sh == D && p.q_sb == (int64_t)p.H * D;
     const int64_t lim = 0x7FFFFFFF;
     const bool small = p.kv_sb <= lim && p.kv_sh <= lim;
-    const bool casc = p.acc != nullptr;
     if (lean && small) {
-      if (casc) hipLaunchKernelGGL((decode_lean_kernel<T, D, U, true>), grid, blk, 0, stream, p.krc, p.vc, p.q, p.cos, p.sin,
-                                   (int)p.kv_sb, (int)p.kv_sh, p.N, p.chunk, p.H, p.pos_q, p);
-      else hipLaunchKernelGGL((decode_lean_kernel<T, D, U, false>), grid, blk, 0, stream, p.krc, p.vc, p.q, p.cos, p.sin,
-                              (int)p.kv_sb, (int)p.kv_sh, p.N, p.chunk, p.H, p.pos_q, p);
+#define SPATTEN_LEAN(UU, CC, PP)                                                                                        \
+  hipLaunchKernelGGL((decode_lean_kernel<T, D, UU, CC, PP>), grid, blk, 0, stream, p.krc, p.vc, p.q, p.cos, p.sin,       \
+                     (int)p.kv_sb, (int)p.kv_sh, p.N, p.chunk, p.H, p.pos_q, p)
+      if (pipe) { if (casc) SPATTEN_LEAN(UP, true, true); else SPATTEN_LEAN(UP, false, true); }
+      else { if (casc) SPATTEN_LEAN(U, true, false); else SPATTEN_LEAN(U, false, false); }
+#undef SPATTEN_LEAN
     } else if (p.n_q == 1) {
-      if (casc) hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, false, 0, true, true>), grid, blk, 0, stream, p);
-      else hipLaunchKernelGGL((decode_attn_kernel<T, D, U, 0, false, 0, true>), grid, blk, 0, stream, p);
+      if (pipe) { if (casc) SPATTEN_LAUNCH(UP, 0, false, 0, true, true, true); else SPATTEN_LAUNCH(UP, 0, false, 0, true, false, true); }
+      else { if (casc) SPATTEN_LAUNCH(U, 0, false, 0, true, true); else SPATTEN_LAUNCH(U, 0, false, 0, true); }
     } else {
-      hipLaunchKernelGGL((decode_attn_kernel<T, D, U>), grid, blk, 0, stream, p);
+      SPATTEN_LAUNCH(UP);      // the rows leg of prefill: several query rows re-read K/V through L2, short tiles
     }
   }
+#undef SPATTEN_LAUNCH
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }
 

@@ -49,6 +49,53 @@ __global__ __launch_bounds__(256) void pq_pack_kernel(const T* __restrict__ kr, 
   if (c == 0) scale[b * sc_sb + hkv * sc_sh + row] = sc;
 }
 
+// ---- expand: planes -> integer-valued keys for the matrix cores (progressive-quant prefill) ----------------------------
+// k_msb[row][e] = 16 * sext(msb nibble), k_full[row][e] = that + lsb nibble — exact in bf16 / f16 (|value| <= 128) —
+// contiguous [B,Hkv,rows,D]; kscale[row] = scale / sqrt(D).  One lane per 8 elements.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void pq_expand_kernel(const uint8_t* __restrict__ msb, const uint8_t* __restrict__ lsb,
+                                                        const float* __restrict__ scale, int64_t pl_sb, int64_t pl_sh,
+                                                        int64_t sc_sb, int64_t sc_sh, T* __restrict__ k_msb,
+                                                        T* __restrict__ k_full, float* __restrict__ kscale, int Hkv, int rows) {
+  constexpr int LPR = D / 8;
+  constexpr int RPB = 256 / LPR;
+  const int tid = threadIdx.x, c = tid % LPR, r = tid / LPR;
+  const int row = blockIdx.x * RPB + r;
+  const int hkv = blockIdx.y, b = blockIdx.z;
+  if (row >= rows) return;
+  const int64_t po = b * pl_sb + hkv * pl_sh + (int64_t)row * (D / 2) + 4 * c;
+  const uint32_t m4 = *reinterpret_cast<const uint32_t*>(msb + po);
+  const uint32_t l4 = *reinterpret_cast<const uint32_t*>(lsb + po);
+  float a[8], f[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int m = (int)((m4 >> (4 * e)) & 15u), l = (int)((l4 >> (4 * e)) & 15u);
+    const int ms = (m ^ 8) - 8;                       // sign-extend the 4-bit field
+    a[e] = (float)(ms * 16);
+    f[e] = (float)(ms * 16 + l);
+  }
+  const int64_t o = ((int64_t)(b * Hkv + hkv) * rows + row) * D + 8 * c;
+  Vec8<T>::stg(k_msb + o, Vec8<T>::pack(a));
+  Vec8<T>::stg(k_full + o, Vec8<T>::pack(f));
+  if (c == 0) kscale[(int64_t)(b * Hkv + hkv) * rows + row] = scale[b * sc_sb + hkv * sc_sh + row] / sqrtf((float)D);
+}
+
+int pq_expand(int dtype, const void* msb, const void* lsb, const float* scale, int64_t pl_sb, int64_t pl_sh, int64_t sc_sb,
+              int64_t sc_sh, void* k_msb, void* k_full, float* kscale, int batch, int kv_heads, int head_dim, int rows,
+              hipStream_t stream) {
+  if (head_dim != 64 && head_dim != 128) return SPATTEN_ERR_UNSUPPORTED;
+  const int rpb = 256 / (head_dim / 8);
+  const dim3 grid((unsigned)ceil_div(rows, rpb), (unsigned)kv_heads, (unsigned)batch);
+#define SPATTEN_EXPAND(T, DD)                                                                                          \
+  hipLaunchKernelGGL((pq_expand_kernel<T, DD>), grid, dim3(256), 0, stream, (const uint8_t*)msb, (const uint8_t*)lsb,   \
+                     scale, pl_sb, pl_sh, sc_sb, sc_sh, (T*)k_msb, (T*)k_full, kscale, kv_heads, rows)
+  if (dtype == SPATTEN_BF16) { if (head_dim == 128) SPATTEN_EXPAND(bf16_t, 128); else SPATTEN_EXPAND(bf16_t, 64); }
+  else if (dtype == SPATTEN_F16) { if (head_dim == 128) SPATTEN_EXPAND(f16_t, 128); else SPATTEN_EXPAND(f16_t, 64); }
+  else return SPATTEN_ERR_UNSUPPORTED;
+#undef SPATTEN_EXPAND
+  return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+}
+
 }  // namespace spatten
 
 using namespace spatten;

@@ -104,6 +104,11 @@ struct FlashParams {
   T* out; int64_t out_sb, out_sq;
   T* scores; int64_t sc_sb, sc_sh, sc_sq;
   float* col_imp;     // [B,H,N]
+  // progressive-quant keys (prefill_pp128_kernel<.., PQK>): kr holds INTEGER-valued keys (msb*16 or the full q8, exact in
+  // the 16-bit dtype), kscale the per-key factor scale / sqrt(d) applied to the fp32 score
+  const float* kscale; int64_t ks_sb, ks_sh;   // [B,Hkv,N] fp32
+  int32_t* need;      // [B,H,q_len]: pass 1 writes max prob < thr, pass 2 recomputes the flagged rows
+  float pq_thr;
   int B, H, Hkv, q_len, N, Npad, causal, nqb;
   float sqrt_d;
 };
@@ -545,14 +550,17 @@ template <int ROWB> __device__ inline int swz_slot(int row, int p) {   // logica
   return ROWB == 256 ? (p ^ (row & 15)) : (p ^ ((row >> 1) & 7));
 }
 
-template <typename T, int D, bool MASK>
+template <typename T, int D, bool MASK, int PQK = 0>
 __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams<T> p) {
   constexpr int KT = 128, NKB = KT / 32;                      // keys per tile, 32-key blocks per tile
   constexpr int KK = D / 16, DB = D / 32, KROWB = D * 2;
   constexpr int KBYTES = KT * KROWB, VBYTES = D * 256, BUF = KBYTES + VBYTES;   // Vt row = 128 keys = 256 B
   constexpr int KINST = KBYTES / 1024 / 8, VINST = VBYTES / 1024 / 8;           // DMA instructions per wave per tile
   using frag = typename Mfma<T>::frag;
-  __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
+  // PQK: + a 4-deep ring of per-key scale vectors (128 fp32 per key tile; tile T in slot T & 3: written by the DMA
+  // that brings K(T) in, read by the softmax of tile T one phase later, overwritten four tiles on)
+  constexpr int SCALE_OFF = 2 * BUF;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * BUF + (PQK ? 4 * KT * 4 : 0)];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, qi = lane & 31, hi = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -579,6 +587,23 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   const bool qvalid = myq < p.q_len;
   const int P = p.N - p.q_len;
   const float rsqrt_d = 1.0f / p.sqrt_d;
+  // PQK == 2 (the LSB-refetch pass, RequantDecision.scala:44-72 / SpAttenController.scala:402): only the rows pass 1
+  // flagged are recomputed, ONCE, from the 8-bit keys.  A block without a flagged row leaves at once (every wave reads
+  // the block's 256 flags itself, so the decision is uniform without a barrier); a wave without one keeps serving the
+  // tile DMA and the barriers but computes nothing.
+  int my_flag = 1;
+  if (PQK == 2) {
+    const int32_t* nf = p.need + (int64_t)(b * p.H + h) * p.q_len;
+    int any = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = qblk * 256 + lane + 64 * i;
+      any |= idx < p.q_len ? nf[idx] : 0;
+    }
+    if (__builtin_amdgcn_ballot_w64(any != 0) == 0) return;
+    my_flag = qvalid ? nf[myq] : 0;
+  }
+  const bool wave_live = PQK != 2 || __builtin_amdgcn_ballot_w64(my_flag != 0) != 0;
 
   // Q fragments, rotated here (modify_llama.py:92, the reference's three rounded ops): fragment kk holds elements
   // [16kk + 8hi, +8) of the row, so kk and kk + KK/2 are exactly the (x[i], x[i + d/2]) pairs RoPE combines
@@ -608,6 +633,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  float m_true = -INFINITY;   // PQK == 1: the row's TRUE running maximum (m_run may lag it: deferred rescale)
 
   const int wg_q_end = min(p.q_len, qblk * 256 + 256);
   const int att_keys = p.causal ? min(p.N, P + wg_q_end) : p.N;
@@ -615,7 +641,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   const int n_tiles = n_att_tiles;
   const int my_vis = p.causal ? min(p.N, P + myq + 1) : p.N;
   const int wave_full_keys = p.causal ? min(p.N, P + q0 + 1) : p.N;
-  const int wave_att_tiles = p.causal ? min(n_att_tiles, (max(min(p.N, P + min(q0 + 32, p.q_len)), 0) + KT - 1) / KT) : n_att_tiles;
+  const int wave_att_tiles = !wave_live ? 0 : (p.causal ? min(n_att_tiles, (max(min(p.N, P + min(q0 + 32, p.q_len)), 0) + KT - 1) / KT) : n_att_tiles);
   const int wave_tiles = wave_att_tiles;
 
   const T* krb = p.kr + b * p.kv_sb + hkv * p.kv_sh;
@@ -626,6 +652,8 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   auto v_area = [&](int stage) -> char* { return lds + (stage & 1) * BUF + KBYTES; };   // holds Vt(stage)
   // buffer descriptors (wave-uniform): rows past N read as zeros (out of range), no clamping arithmetic per lane
   const int64_t k_bytes = (int64_t)p.N * D * 2, v_bytes = (int64_t)D * p.Npad * 2;
+  const float* ksb = PQK ? p.kscale + b * p.ks_sb + hkv * p.ks_sh : nullptr;
+  const int64_t ks_bytes = (int64_t)p.N * 4 < 0x7FFFFFFF ? (int64_t)p.N * 4 : 0x7FFFFFFF;
   // This wave's 1-KiB pieces of a tile.  Lane (row-in-piece lr, physical slot ps) fetches logical slot ps ^ f(row); with
   // f(row) = f(first row of the piece) ^ g(lr) (disjoint bits) the per-lane byte offset is ONE xor away from a value
   // computed once per call, and everything wave-uniform (tile, piece) rides in the scalar offset.
@@ -641,6 +669,14 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
       const int piece = wave_u * KINST + i;                                  // 1-KiB piece index within the tile
       const int fp = KROWB == 256 ? ((piece * 4) & 15) : ((piece * 4) & 7);  // swizzle key of the piece's first row
       dma16(krb, k_bytes, area + piece * 1024, base ^ (fp << 4), tile * (KT * D * 2) + piece * 1024);
+    }
+    if (PQK && wave_u == 0) {     // the tile's 128 scale factors: 2 x (64 lanes x 4 bytes), keys past N read as 0
+      const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ksb), 0, (int)ks_bytes, 0x00020000);
+      char* dst = lds + SCALE_OFF + (tile & 3) * (KT * 4);
+#pragma unroll
+      for (int i = 0; i < KT / 64; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst + i * 256), 4, ln * 4,
+                                                 (tile * KT + i * 64) * 4, 0, 0);
     }
   };
   // Vt tile: D rows (dv) of 256 B (128 keys); this wave's rows [wave*D/8, +D/8), 4 rows per piece
@@ -714,6 +750,20 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 
   auto softmax_tile = [&](int tile) {
     const bool edge = tile * KT + KT > wave_full_keys;
+    if (PQK) {
+      // quantised keys: s holds q . q8 (exact integers times the query); the logit is that times the key's scale / sqrt(d)
+      // in fp32 — no 16-bit rounding of logits here (the reference has no quantised path; oracle: pq_prefill_attention).
+      // Register r of block kb is key (r & 3) + 8 (r >> 2) + 4 hi: four consecutive scales per ds_read_b128
+      const float* sl = reinterpret_cast<const float*>(lds + SCALE_OFF + (tile & 3) * (KT * 4)) + 4 * hi;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(sl + kb * 32 + 8 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[kb][4 * g + e] *= sv[e];
+        }
+    } else {
     // both reference roundings of every logit (matmul -> dtype, "/ sqrt(d)" -> dtype, modify_llama.py:111-113), two
     // scores at a time: at large logits a 16-bit ulp is a visible change of P
 #pragma unroll
@@ -725,6 +775,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
         s[kb][r] = v[0];
         s[kb][r + 1] = v[1];
       }
+    }
     float m_new, m_base;                            // new running max; the max the exponentials are taken against
     if (!MASK && !edge) {
       // fully visible tile.  Deferred rescale: the running maximum only moves (and O is only rescaled: 64 multiplies
@@ -742,6 +793,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
       const float m_tile = xor32_max(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3])));
       const bool move = __builtin_amdgcn_ballot_w64(m_tile - m_run > kDeferMax) != 0;   // -inf start: inf > thr
       m_new = move ? fmaxf(m_run, m_tile) : m_run;
+      if (PQK == 1) m_true = fmaxf(m_true, m_tile);
       m_base = m_new;
     } else {
       // explicit mask and / or a tile that straddles the causal diagonal: per-element visibility
@@ -758,6 +810,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
           m_tile = fmaxf(m_tile, v);
         }
       m_tile = xor32_max(m_tile);
+      if (PQK == 1) m_true = fmaxf(m_true, m_tile);
       m_new = fmaxf(m_run, m_tile);
       m_base = (m_new == -INFINITY) ? 0.f : m_new;  // a fully masked row: exp2(-inf) = 0 for every key
     }
@@ -821,7 +874,11 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   // ---- epilogue: O = O^T / l, 4 consecutive dv per 8-byte store ---------------------------------
   const float l_tot = xor32_sum(l_run);
   const float inv = 1.f / l_tot;
-  if (qvalid) {
+  if (PQK == 1) {   // need_lsb = max_j prob_j < threshold (RequantDecision.scala:44-72): exp(max - reference max) / sum
+    const float pmax = __expf(m_true - m_run) * inv;
+    if (qvalid && hi == 0) p.need[(int64_t)(b * p.H + h) * p.q_len + myq] = pmax < p.pq_thr ? 1 : 0;
+  }
+  if (qvalid && my_flag) {
     T* orow = p.out + b * p.out_sb + (int64_t)myq * p.out_sq + h * D;
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
@@ -858,6 +915,16 @@ template <typename T, int D, bool ST, bool CI>
 static void launch_flash_m(const FlashParams<T>& p, hipStream_t st) {
   const dim3 grid((unsigned)(p.nqb * p.H * p.B));
   if constexpr (!ST && !CI) {
+    if (p.kscale != nullptr) {          // progressive-quant keys: pass 1 (MSB logits + need flags) or pass 2 (flagged rows)
+      if (p.pq_thr >= 0.f) {
+        if (p.mask) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, true, 1>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, 1>), grid, dim3(512), 0, st, p);
+      } else {
+        if (p.mask) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, true, 2>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, 2>), grid, dim3(512), 0, st, p);
+      }
+      return;
+    }
     if (prefill_variant() == 0) {
       if (p.mask) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, true>), grid, dim3(512), 0, st, p);
       else hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false>), grid, dim3(512), 0, st, p);
@@ -967,7 +1034,7 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
     p.vt = (const T*)vt; p.mask = (const T*)mask; p.mask_sb = mask_sb; p.mask_sq = mask_sq;            \
     p.out = (T*)out; p.out_sb = out_sb; p.out_sq = out_sq;                                             \
     p.scores = (T*)scores; p.sc_sb = sc_sb; p.sc_sh = sc_sh; p.sc_sq = sc_sq;                          \
-    p.col_imp = col_importance;                                                                        \
+    p.col_imp = col_importance; p.kscale = nullptr; p.ks_sb = p.ks_sh = 0; p.need = nullptr; p.pq_thr = 0.f; \
     p.B = batch; p.H = heads; p.Hkv = kv_heads; p.q_len = q_len; p.N = kv_len; p.Npad = npad;          \
     p.causal = causal; p.sqrt_d = sqrtf((float)head_dim); p.nqb = ceil_div(q_len, 256);                \
     return launch_flash<T, DD>(p, st);                                                                 \
@@ -975,6 +1042,79 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
   if (dtype == SPATTEN_BF16) { if (head_dim == 128) SPATTEN_FLASH(bf16_t, 128) else SPATTEN_FLASH(bf16_t, 64) }
   else { if (head_dim == 128) SPATTEN_FLASH(f16_t, 128) else SPATTEN_FLASH(f16_t, 64) }
 #undef SPATTEN_FLASH
+}
+
+extern "C" size_t spatten_prefill_pq_workspace_bytes(int dtype, int batch, int heads, int kv_heads, int head_dim,
+                                                     int q_len, int kv_len) {
+  if (batch <= 0 || heads <= 0 || kv_heads <= 0 || head_dim <= 0 || q_len <= 0 || kv_len <= 0) return 0;
+  const size_t npad = (size_t)ceil_div(kv_len, 128) * 128, rows = (size_t)batch * kv_heads * kv_len;
+  return 256 + align256((size_t)batch * kv_heads * head_dim * npad * 2) + 2 * align256(rows * head_dim * 2) + align256(rows * 4);
+}
+
+// Prefill over progressively quantised keys (BASELINE.json configs[3]): MSB-first fetch, max-probability decision PER
+// QUERY ROW, LSB refetch + ONE recompute of the flagged rows (RequantDecision.scala:44-72; SpAttenController.scala:402
+// applies the rule to every query row, not only to single-token steps).  Three launches + the V transpose:
+//   expand   planes -> integer-valued keys in the model dtype (exact) + scale / sqrt(d) per key        (pq.hip)
+//   pass 1   the 128-key-tile flash kernel over the MSB keys: logits = (q . 16 msb) * scale / sqrt(d) in fp32, softmax, P.V,
+//            need_lsb[b,h,i] = max_j prob_ij < threshold
+//   pass 2   the same kernel over the 8-bit keys, only for blocks / waves that hold a flagged row; flagged rows overwrite
+//            their output
+extern "C" int spatten_attn_prefill_pq(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sq, const void* msb,
+                                       const void* lsb, const float* scale, int64_t pl_sb, int64_t pl_sh, int64_t sc_sb,
+                                       int64_t sc_sh, const void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* cos,
+                                       const void* sin, int table_rows, const int64_t* position_ids, int64_t pos_sb,
+                                       const void* mask, int64_t mask_sb, int64_t mask_sq, void* out, int64_t out_sb,
+                                       int64_t out_sq, int32_t* need_lsb, float threshold, void* workspace, int batch,
+                                       int heads, int kv_heads, int head_dim, int q_len, int kv_len, int pos_q0,
+                                       int causal, void* stream) {
+  if (!q || !msb || !lsb || !scale || !v_cache || !cos || !sin || !out || !need_lsb || !workspace) return SPATTEN_ERR_INVALID;
+  if (batch <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads != 0 || q_len <= 0 || kv_len < q_len || pos_q0 < 0)
+    return SPATTEN_ERR_INVALID;
+  if (threshold < 0.f) return SPATTEN_ERR_INVALID;
+  if (table_rows < kv_len || (!position_ids && pos_q0 + q_len > table_rows)) return SPATTEN_ERR_INVALID;
+  if ((dtype != SPATTEN_F16 && dtype != SPATTEN_BF16) || (head_dim != 64 && head_dim != 128)) return SPATTEN_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)(((uintptr_t)workspace + 255) / 256 * 256);
+  const int npad = ceil_div(kv_len, 128) * 128;
+  const size_t rows = (size_t)batch * kv_heads * kv_len;
+  void* vt = ws;
+  char* k_msb = ws + align256((size_t)batch * kv_heads * head_dim * npad * 2);
+  char* k_full = k_msb + align256(rows * head_dim * 2);
+  float* kscale = (float*)(k_full + align256(rows * head_dim * 2));
+  {
+    const dim3 grid((unsigned)(npad / 64), (unsigned)kv_heads, (unsigned)batch);
+    if (head_dim == 128)
+      hipLaunchKernelGGL((vt_kernel<128>), grid, dim3(256), 0, st, (const uint16_t*)v_cache, kv_sb, kv_sh, (uint16_t*)vt, kv_len, npad, kv_heads);
+    else
+      hipLaunchKernelGGL((vt_kernel<64>), grid, dim3(256), 0, st, (const uint16_t*)v_cache, kv_sb, kv_sh, (uint16_t*)vt, kv_len, npad, kv_heads);
+    if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
+  }
+  int rc = pq_expand(dtype, msb, lsb, scale, pl_sb, pl_sh, sc_sb, sc_sh, k_msb, k_full, kscale, batch, kv_heads, head_dim, kv_len, st);
+  if (rc != SPATTEN_OK) return rc;
+#define SPATTEN_FLASH_PQ(T, DD, KPTR, THR)                                                              \
+  {                                                                                                    \
+    FlashParams<T> p;                                                                                  \
+    p.q = (const T*)q; p.q_sb = q_sb; p.q_sh = q_sh; p.q_sq = q_sq;                                    \
+    p.cos = (const T*)cos; p.sin = (const T*)sin; p.table_rows = table_rows;                           \
+    p.pos_ids = position_ids; p.pos_sb = pos_sb; p.pos_q0 = pos_q0;                                    \
+    p.kr = (const T*)(KPTR); p.kv_sb = (int64_t)kv_heads * kv_len * head_dim; p.kv_sh = (int64_t)kv_len * head_dim; \
+    p.vt = (const T*)vt; p.mask = (const T*)mask; p.mask_sb = mask_sb; p.mask_sq = mask_sq;            \
+    p.out = (T*)out; p.out_sb = out_sb; p.out_sq = out_sq;                                             \
+    p.scores = nullptr; p.sc_sb = p.sc_sh = p.sc_sq = 0; p.col_imp = nullptr;                          \
+    p.kscale = kscale; p.ks_sb = (int64_t)kv_heads * kv_len; p.ks_sh = kv_len; p.need = need_lsb; p.pq_thr = (THR); \
+    p.B = batch; p.H = heads; p.Hkv = kv_heads; p.q_len = q_len; p.N = kv_len; p.Npad = npad;          \
+    p.causal = causal; p.sqrt_d = sqrtf((float)head_dim); p.nqb = ceil_div(q_len, 256);                \
+    rc = launch_flash<T, DD>(p, st);                                                                   \
+  }
+#define SPATTEN_FLASH_PQ_ANY(KPTR, THR)                                                                                  \
+  if (dtype == SPATTEN_BF16) { if (head_dim == 128) SPATTEN_FLASH_PQ(bf16_t, 128, KPTR, THR) else SPATTEN_FLASH_PQ(bf16_t, 64, KPTR, THR) } \
+  else { if (head_dim == 128) SPATTEN_FLASH_PQ(f16_t, 128, KPTR, THR) else SPATTEN_FLASH_PQ(f16_t, 64, KPTR, THR) }
+  SPATTEN_FLASH_PQ_ANY(k_msb, threshold)          // pass 1 (pq_thr >= 0 selects it)
+  if (rc != SPATTEN_OK) return rc;
+  SPATTEN_FLASH_PQ_ANY(k_full, -1.0f)              // pass 2: flagged rows from the 8-bit keys
+#undef SPATTEN_FLASH_PQ_ANY
+#undef SPATTEN_FLASH_PQ
+  return rc;
 }
 
 #ifdef SPATTEN_PF_TRACE
