@@ -190,6 +190,8 @@ int spatten_kv_append(int dtype, const void* k_new, const void* v_new, int64_t n
  *   col_importance optional [B,H,kv_len] fp32, ZERO-FILLED by the caller: += sum over query rows of the
  *                stash column = the reference importance (kv_cache_token_pruning.py:51) without the stash
  *                (MFMA leg only; fp32 atomics, so the summation order is not reproducible run to run)
+ *   lse          optional [B,H,q_len,2] fp32 (contiguous): per query row (reference max m, sum_j exp(logit_ij - m)) of the
+ *                masked logits — the softmax statistics; input of spatten_importance_accumulate_prefill
  *   workspace    spatten_prefill_workspace_bytes(...) bytes of device scratch
  * ---------------------------------------------------------------------------------------------- */
 size_t spatten_prefill_workspace_bytes(int dtype, int batch, int heads, int kv_heads, int head_dim,
@@ -202,7 +204,7 @@ int spatten_attn_prefill(int dtype,
                          const void* mask, int64_t mask_sb, int64_t mask_sq,
                          void* out, int64_t out_sb, int64_t out_sq,
                          void* scores, int64_t sc_sb, int64_t sc_sh, int64_t sc_sq,
-                         float* col_importance,
+                         float* col_importance, float* lse,
                          void* workspace,
                          int batch, int heads, int kv_heads, int head_dim,
                          int q_len, int kv_len, int pos_q0, int causal,
@@ -274,6 +276,19 @@ int spatten_importance_accumulate(int dtype, const void* stash, int64_t sb, int6
                                   const float* lse, const void* mask, int64_t mask_sb, int64_t mask_sq,
                                   float* acc, int64_t acc_sh, int batch, int heads, int q_len, int kv_len,
                                   int causal, void* stream);
+/* The same accumulation for a multi-token forward WITHOUT the [B,H,q,N] stash (4 GiB per layer at q = N = 8192): the
+ * logits are recomputed on the matrix cores from q (un-rotated, rotated here like spatten_attn_prefill does) and the
+ * rotated shadow, with the flash kernel's roundings, and turned into probabilities with the row statistics `lse`
+ * [B,H,q_len,2] that spatten_attn_prefill wrote for the same inputs; causal != 0: the HF rule.  bf16 / f16, head_dim
+ * 64 / 128.  workspace: spatten_importance_prefill_workspace_bytes (the rotated queries). */
+size_t spatten_importance_prefill_workspace_bytes(int batch, int heads, int head_dim, int q_len);
+int spatten_importance_accumulate_prefill(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sq,
+                                          const void* kr_cache, int64_t kv_sb, int64_t kv_sh,
+                                          const void* cos, const void* sin, int table_rows,
+                                          const int64_t* position_ids, int64_t pos_sb,
+                                          const float* lse, float* acc, int64_t acc_sh, void* workspace,
+                                          int batch, int heads, int kv_heads, int head_dim,
+                                          int q_len, int kv_len, int pos_q0, int causal, void* stream);
 /* (row max, sum exp) of every masked logit row: lse [B,H,q,2] fp32 — for stashes that did not come with one. */
 int spatten_row_lse(int dtype, const void* stash, int64_t sb, int64_t sh, int64_t sq, const void* mask,
                     int64_t mask_sb, int64_t mask_sq, float* lse, int batch, int heads, int q_len, int kv_len,

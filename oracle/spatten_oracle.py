@@ -325,6 +325,33 @@ def pq_logits(qr: np.ndarray, msb, lsb, scale, threshold: float, lsb_bits: int =
     return np.where(need[..., None], s2, s1).astype(np.float32), need
 
 
+def pq_prefill_attention(qr: np.ndarray, msb, lsb, scale, V: np.ndarray, threshold: float, past_len: int,
+                         rows: Optional[Sequence[int]] = None, lsb_bits: int = 4):
+    """Progressive quantisation applied to a BLOCK of query rows (BASELINE.json configs[3]; the RTL takes the
+    max-probability decision and the one refetch per QUERY ROW: RequantDecision.scala:44-72, SpAttenController.scala:402).
+    qr [B,H,q,d] rotated queries; planes [B,H,N,d] of the rotated keys, N = past_len + q; V [B,H,N,d]; HF causal rule
+    (row i sees keys j <= past_len + i).  ``rows`` restricts the computation to some query rows (large shapes).
+    Returns (out [B,len(rows),H*d] fp32, need [B,H,len(rows)] bool, pmax [B,H,len(rows)])."""
+    B, H, ql, d = qr.shape
+    rows = list(range(ql)) if rows is None else list(rows)
+    k1 = pq_dequant(msb, None, scale, lsb_bits)
+    k2 = pq_dequant(msb, lsb, scale, lsb_bits)
+    out = np.zeros((B, len(rows), H, V.shape[-1]), np.float32)
+    need = np.zeros((B, H, len(rows)), bool)
+    pmax = np.zeros((B, H, len(rows)), np.float32)
+    for n, i in enumerate(rows):
+        vis = past_len + i + 1
+        qi = qr[:, :, i].astype(np.float32)
+        s1 = np.einsum("bhd,bhld->bhl", qi, k1[:, :, :vis]) / np.float32(math.sqrt(d))
+        p1 = softmax_probs(s1)
+        pmax[:, :, n] = p1.max(axis=-1)
+        need[:, :, n] = pmax[:, :, n] < np.float32(threshold)
+        s2 = np.einsum("bhd,bhld->bhl", qi, k2[:, :, :vis]) / np.float32(math.sqrt(d))
+        p = np.where(need[:, :, n, None], softmax_probs(s2), p1)
+        out[:, n] = np.einsum("bhl,bhld->bhd", p, V[:, :, :vis].astype(np.float32))
+    return out.reshape(B, len(rows), -1), need, pmax
+
+
 def pq_quantize(K: np.ndarray, bits: int = 8, lsb_bits: int = 4):
     """Progressive-quantisation storage (MatrixFetcher.scala:48-51,341-348;
     SpAttenController.scala:35-39): symmetric per-row linear quantiser to ``bits``

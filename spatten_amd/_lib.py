@@ -91,7 +91,18 @@ def _declare(lib):
     lib.spatten_attn_prefill.restype = c_int
     lib.spatten_attn_prefill.argtypes = [
         i, p, i64, i64, i64, p, p, i64, i64, p, p, i, p, i64, p, i64, i64, p, i64, i64,
-        p, i64, i64, i64, p, p, i, i, i, i, i, i, i, i, p]
+        p, i64, i64, i64, p, p, p, i, i, i, i, i, i, i, i, p]
+    lib.spatten_importance_prefill_workspace_bytes.restype = c_size_t
+    lib.spatten_importance_prefill_workspace_bytes.argtypes = [i, i, i, i]
+    lib.spatten_importance_accumulate_prefill.restype = c_int
+    lib.spatten_importance_accumulate_prefill.argtypes = [i, p, i64, i64, i64, p, i64, i64, p, p, i, p, i64, p, p, i64, p,
+                                                          i, i, i, i, i, i, i, i, p]
+    lib.spatten_prefill_pq_workspace_bytes.restype = c_size_t
+    lib.spatten_prefill_pq_workspace_bytes.argtypes = [i, i, i, i, i, i, i]
+    lib.spatten_attn_prefill_pq.restype = c_int
+    lib.spatten_attn_prefill_pq.argtypes = [
+        i, p, i64, i64, i64, p, p, p, i64, i64, i64, i64, p, i64, i64, p, p, i, p, i64, p, i64, i64, p, i64, i64,
+        p, c_float, p, i, i, i, i, i, i, i, i, p]
     lib.spatten_rope_single.restype = c_int
     lib.spatten_rope_single.argtypes = [i, p, i64, i64, i64, p, i64, i64, i64, p, p, i, p, i64, i,
                                         i, i, i, i, p]

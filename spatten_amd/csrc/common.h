@@ -415,7 +415,7 @@ struct DecodeCall {
   const void* mask = nullptr; int64_t mask_sb = 0, mask_sq = 0;
   void* out = nullptr; int64_t out_sb = 0, out_sq = 0;
   void* scores = nullptr; int64_t sc_sb = 0, sc_sh = 0, sc_sq = 0;
-  float* lse = nullptr;
+  float* lse = nullptr; int lse_q = 0;   // lse rows per (b, h) (0 = n_q)
   // split-N workspace: [256 B header: word 0 = error flag][units x {counter, generation}][units x ws_splits x (D+2) granules]
   void* workspace = nullptr; size_t ws_units = 0; int ws_splits = 0;
   int batch = 0, heads = 0, kv_heads = 0, head_dim = 0, kv_len = 0, pos_q = 0, n_q = 1, causal = 0, n_splits = 0;

@@ -59,7 +59,7 @@ struct DecodeParams {
   const T* mask; int64_t mask_sb, mask_sq;
   T* out; int64_t out_sb, out_sq;
   T* scores; int64_t sc_sb, sc_sh, sc_sq;
-  float* lse;
+  float* lse; int lse_q;   // (max, sum) per softmax row at [((b*H + h) * lse_q + qi) * 2]; lse_q = rows per (b, h)
   const int32_t* head_ids;   // optional: blockIdx.y -> query head (head pruning: only the kept heads are launched)
   // progressive-quant key planes (KSRC != 0, pq.hip): 4-bit MSB / LSB planes [B,Hkv,cap,D/2] + per-row scale
   const uint8_t* pq_msb; const uint8_t* pq_lsb; const float* pq_scale; int64_t pl_sb, pl_sh, ps_sb, ps_sh;
@@ -487,7 +487,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   };
   if (p.S == 1) {
     if (!SCORES_ONLY && tid < D) outp[tid] = DT<T>::from_f32(o_tot / l_tot);
-    if (p.lse != nullptr && tid == 0) { p.lse[unit * 2] = m_run; p.lse[unit * 2 + 1] = l_tot; }
+    if (p.lse != nullptr && tid == 0) { float* ls = p.lse + ((int64_t)(b * p.H + h) * p.lse_q + qi) * 2; ls[0] = m_run; ls[1] = l_tot; }
     const bool need1 = KSRC == 1 && (1.0f / l_tot) < p.pq_thr;                          // max prob = exp(0) / sum
     if (KSRC == 1 && tid == 0) p.pq_need[unit] = need1 ? 1 : 0;
     if (!SCORES_ONLY && p.head_abs != nullptr) add_head_abs(o_tot / l_tot, tid < D, !need1);
@@ -614,7 +614,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
     add_head_abs(og / lg, g == 0, !(KSRC == 1 && s_ticket != 0u));
   }
   if (tid == 0) {
-    if (p.lse != nullptr) { p.lse[unit * 2] = mg; p.lse[unit * 2 + 1] = lg; }
+    if (p.lse != nullptr) { float* ls = p.lse + ((int64_t)(b * p.H + h) * p.lse_q + qi) * 2; ls[0] = mg; ls[1] = lg; }
     if (KSRC == 1) p.pq_need[unit] = (1.0f / lg) < p.pq_thr ? 1 : 0;
     p.ws_cnt[2 * unit + 1] = gen + 1u;                                                         // next launch: new tag
     if (!p.poll_merge) __hip_atomic_store(p.ws_cnt + 2 * unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm the counter
@@ -771,7 +771,7 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   p.mask = (const T*)c.mask; p.mask_sb = c.mask_sb; p.mask_sq = c.mask_sq;                               \
   p.out = (T*)c.out; p.out_sb = c.out_sb; p.out_sq = c.out_sq;                                           \
   p.scores = (T*)c.scores; p.sc_sb = c.sc_sb; p.sc_sh = c.sc_sh; p.sc_sq = c.sc_sq;                      \
-  p.lse = c.lse; p.head_ids = c.head_ids;                                                                \
+  p.lse = c.lse; p.lse_q = c.lse_q > 0 ? c.lse_q : c.n_q; p.head_ids = c.head_ids;                        \
   p.pq_msb = pq ? pq->msb : nullptr; p.pq_lsb = pq ? pq->lsb : nullptr; p.pq_scale = pq ? pq->scale : nullptr; \
   p.pl_sb = pq ? pq->pl_sb : 0; p.pl_sh = pq ? pq->pl_sh : 0; p.ps_sb = pq ? pq->sc_sb : 0; p.ps_sh = pq ? pq->sc_sh : 0; \
   p.pq_thr = pq ? pq->threshold : 0.f; p.pq_need = pq ? pq->need : nullptr;                              \

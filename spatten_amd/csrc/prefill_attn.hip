@@ -104,6 +104,8 @@ struct FlashParams {
   T* out; int64_t out_sb, out_sq;
   T* scores; int64_t sc_sb, sc_sh, sc_sq;
   float* col_imp;     // [B,H,N]
+  float* lse;         // optional [B,H,q_len,2]: (reference max m, sum exp(s - m)) of every query row — what
+                      // spatten_importance_accumulate_prefill turns into softmax probabilities without a stash
   // progressive-quant keys (prefill_pp128_kernel<.., PQK>): kr holds INTEGER-valued keys (msb*16 or the full q8, exact in
   // the 16-bit dtype), kscale the per-key factor scale / sqrt(d) applied to the fp32 score
   const float* kscale; int64_t ks_sb, ks_sh;   // [B,Hkv,N] fp32
@@ -508,6 +510,10 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
   // ---- epilogue: O = O^T / l, 4 consecutive dv per 8-byte store ---------------------------------
   const float l_tot = xor32_sum(l_run);
   const float inv = 1.f / l_tot;
+  if (p.lse != nullptr && qvalid && hi == 0) {
+    float* ls = p.lse + ((int64_t)(b * p.H + h) * p.q_len + myq) * 2;
+    ls[0] = m_run; ls[1] = l_tot;
+  }
   if (qvalid) {
     T* orow = p.out + b * p.out_sb + (int64_t)myq * p.out_sq + h * D;
 #pragma unroll
@@ -874,6 +880,10 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   // ---- epilogue: O = O^T / l, 4 consecutive dv per 8-byte store ---------------------------------
   const float l_tot = xor32_sum(l_run);
   const float inv = 1.f / l_tot;
+  if (p.lse != nullptr && qvalid && hi == 0) {
+    float* ls = p.lse + ((int64_t)(b * p.H + h) * p.q_len + myq) * 2;
+    ls[0] = m_run; ls[1] = l_tot;
+  }
   if (PQK == 1) {   // need_lsb = max_j prob_j < threshold (RequantDecision.scala:44-72): exp(max - reference max) / sum
     const float pmax = __expf(m_true - m_run) * inv;
     if (qvalid && hi == 0) p.need[(int64_t)(b * p.H + h) * p.q_len + myq] = pmax < p.pq_thr ? 1 : 0;
@@ -892,6 +902,132 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
       }
     }
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Cascade importance of a multi-token forward WITHOUT the [B,H,q,N] stash:
+//   acc[h, j] += sum over b and the query rows i that see key j of  exp(s_ij - m_i) / l_i
+// with s_ij recomputed on the matrix cores (same operands, same two roundings as the flash kernel) and (m_i, l_i) the
+// row statistics the flash kernel wrote.  Operand roles are swapped relative to the flash kernel — S = Q K^T with the
+// keys as the B operand — so a lane owns ONE KEY (its 32-key block's fragments stay in registers for the whole
+// launch) and its accumulator registers enumerate 16 queries: the sum over queries is 16 in-lane adds per block and
+// one lane <-> lane+32 exchange at the very end; no atomics inside the loop, no cross-lane traffic per score.
+// Workgroup = 256 keys (8 waves x 32), looping over 128-query tiles staged through LDS (XOR-swizzled 16-byte slots).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct ColProbParams {
+  const T* qrot; int64_t q_sb, q_sh;      // rotated queries [B,H,q_len,D], rows contiguous
+  const T* kr; int64_t kv_sb, kv_sh;      // rotated shadow
+  const float* lse;                       // [B,H,q_len,2]
+  float* acc; int64_t acc_sh;             // [H, >=N]
+  int H, Hkv, q_len, N, causal;
+  float sqrt_d;
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(512, 1) void prefill_colprob_kernel(const ColProbParams<T> p) {
+  constexpr int KK = D / 16, QT = 128, ROWB = D * 2;
+  constexpr int QBYTES = QT * ROWB, PIECES = QT * (D / 8) / 512;     // 16-byte pieces per thread per query tile
+  using frag = typename Mfma<T>::frag;
+  __shared__ __attribute__((aligned(16))) char lds[2 * QBYTES + 2 * QT * 8];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ki = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int hkv = p.Hkv == p.H ? h : h / (p.H / p.Hkv);
+  const int key = blockIdx.x * 256 + wave * 32 + ki;
+  const int P = p.N - p.q_len;
+  const float rsqrt_d = 1.0f / p.sqrt_d;
+  // this lane's key as the B operand: fragment kk = elements [16kk + 8hi, +8) of the key row (zeros past N)
+  frag kf[KK];
+  {
+    const T* krow = p.kr + b * p.kv_sb + hkv * p.kv_sh + (int64_t)min(key, p.N - 1) * D;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(krow + 16 * kk + 8 * hi);
+      kf[kk] = *reinterpret_cast<const frag*>(&raw);
+    }
+  }
+  const T* qb = p.qrot + b * p.q_sb + h * p.q_sh;
+  const float* lb = p.lse + (int64_t)(b * p.H + h) * p.q_len * 2;
+  // query tiles that can see any key of this workgroup (causal: row i sees keys j <= P + i)
+  const int first_q = p.causal ? max(0, blockIdx.x * 256 - P) : 0;
+  const int t_lo = first_q / QT, t_hi = (p.q_len + QT - 1) / QT;
+  u32x4 qreg[PIECES];
+  f32x2 sreg;
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int id = tid + 512 * i, row = id / (D / 8), slot = id % (D / 8);
+      const int qi = min(t * QT + row, p.q_len - 1);
+      qreg[i] = *reinterpret_cast<const u32x4*>(qb + (int64_t)qi * D + slot * 8);
+    }
+    if (tid < QT) {
+      const int qi = min(t * QT + tid, p.q_len - 1);
+      sreg = *reinterpret_cast<const f32x2*>(lb + (int64_t)qi * 2);
+    }
+  };
+  auto write_tile = [&](int buf) {
+    char* base = lds + buf * QBYTES;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int id = tid + 512 * i, row = id / (D / 8), slot = id % (D / 8);
+      *reinterpret_cast<u32x4*>(base + lds_off<ROWB>(row, slot)) = qreg[i];
+    }
+    if (tid < QT) {   // (m * log2e, 1 / l) per query of the tile
+      float* st = reinterpret_cast<float*>(lds + 2 * QBYTES + buf * QT * 8);
+      st[tid] = sreg[0] * kLog2e;
+      st[QT + tid] = 1.0f / sreg[1];
+    }
+  };
+  float colsum = 0.f;
+  if (t_lo < t_hi) {
+    load_tile(t_lo);
+    write_tile(0);
+  }
+  __syncthreads();
+  for (int t = t_lo; t < t_hi; ++t) {
+    const int buf = (t - t_lo) & 1;
+    if (t + 1 < t_hi) load_tile(t + 1);
+    const char* qt = lds + buf * QBYTES;
+    const float* st = reinterpret_cast<const float*>(lds + 2 * QBYTES + buf * QT * 8);
+#pragma unroll
+    for (int blk = 0; blk < QT / 32; ++blk) {
+      const int q0 = t * QT + blk * 32;
+      if (q0 >= p.q_len) break;
+      if (p.causal && P + q0 + 31 < blockIdx.x * 256 + wave * 32) continue;      // none of these rows sees this wave's keys
+      f32x16 c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const frag a = *reinterpret_cast<const frag*>(qt + lds_off<ROWB>(blk * 32 + ki, 2 * kk + hi));
+        c = Mfma<T>::mma(a, kf[kk], c);
+      }
+      // register r <-> query q0 + (r & 3) + 8 (r >> 2) + 4 hi; the two reference roundings of the logit, then its probability
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(st + blk * 32 + 8 * g + 4 * hi);
+        const f32x4 r4 = *reinterpret_cast<const f32x4*>(st + QT + blk * 32 + 8 * g + 4 * hi);
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          const f32x2 x = round2<T>(f32x2{c[4 * g + e], c[4 * g + e + 1]});
+          const f32x2 v = round2<T>(f32x2{logit_scale<T>(x[0], p.sqrt_d, rsqrt_d), logit_scale<T>(x[1], p.sqrt_d, rsqrt_d)});
+#pragma unroll
+          for (int z = 0; z < 2; ++z) {
+            const int qi = q0 + e + z + 8 * g + 4 * hi;
+            const bool vis = qi < p.q_len && key < p.N && (!p.causal || key <= P + qi);
+            const float pr = __builtin_amdgcn_exp2f(fmaf(v[z], kLog2e, -m4[e + z])) * r4[e + z];
+            colsum += vis ? pr : 0.f;
+          }
+        }
+      }
+    }
+    __syncthreads();                       // everyone is done with the other buffer's previous tenant
+    if (t + 1 < t_hi) write_tile(buf ^ 1);
+    __syncthreads();
+  }
+  colsum = xor32_sum(colsum);
+  if (hi == 0 && key < p.N && colsum != 0.f) atomicAdd(p.acc + h * p.acc_sh + key, colsum);
 }
 
 constexpr int kRowsPerLaunch = 4096;   // query rows per launch of the rows leg
@@ -966,7 +1102,7 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
                                     const void* cos, const void* sin, int table_rows, const int64_t* position_ids,
                                     int64_t pos_sb, const void* mask, int64_t mask_sb, int64_t mask_sq, void* out,
                                     int64_t out_sb, int64_t out_sq, void* scores, int64_t sc_sb, int64_t sc_sh,
-                                    int64_t sc_sq, float* col_importance, void* workspace, int batch, int heads,
+                                    int64_t sc_sq, float* col_importance, float* lse, void* workspace, int batch, int heads,
                                     int kv_heads, int head_dim, int q_len, int kv_len, int pos_q0, int causal,
                                     void* stream) {
   if (!q || !kr_cache || !v_cache || !cos || !sin || !out || !workspace) return SPATTEN_ERR_INVALID;
@@ -1001,6 +1137,7 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
       c.mask = mask ? (const char*)mask + (int64_t)i0 * mask_sq * es : nullptr; c.mask_sb = mask_sb; c.mask_sq = mask_sq;
       c.out = (char*)out + (int64_t)i0 * out_sq * es; c.out_sb = out_sb; c.out_sq = out_sq;
       c.scores = scores ? (char*)scores + (int64_t)i0 * sc_sq * es : nullptr; c.sc_sb = sc_sb; c.sc_sh = sc_sh; c.sc_sq = sc_sq;
+      c.lse = lse ? lse + (int64_t)i0 * 2 : nullptr; c.lse_q = q_len;
       c.workspace = ws; c.ws_units = units; c.ws_splits = S;
       c.batch = batch; c.heads = heads; c.kv_heads = kv_heads; c.head_dim = head_dim;
       c.kv_len = kv_len; c.pos_q = pos_q0 + i0; c.n_q = nq; c.causal = causal; c.n_splits = S;
@@ -1034,7 +1171,7 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
     p.vt = (const T*)vt; p.mask = (const T*)mask; p.mask_sb = mask_sb; p.mask_sq = mask_sq;            \
     p.out = (T*)out; p.out_sb = out_sb; p.out_sq = out_sq;                                             \
     p.scores = (T*)scores; p.sc_sb = sc_sb; p.sc_sh = sc_sh; p.sc_sq = sc_sq;                          \
-    p.col_imp = col_importance; p.kscale = nullptr; p.ks_sb = p.ks_sh = 0; p.need = nullptr; p.pq_thr = 0.f; \
+    p.col_imp = col_importance; p.lse = lse; p.kscale = nullptr; p.ks_sb = p.ks_sh = 0; p.need = nullptr; p.pq_thr = 0.f; \
     p.B = batch; p.H = heads; p.Hkv = kv_heads; p.q_len = q_len; p.N = kv_len; p.Npad = npad;          \
     p.causal = causal; p.sqrt_d = sqrtf((float)head_dim); p.nqb = ceil_div(q_len, 256);                \
     return launch_flash<T, DD>(p, st);                                                                 \
@@ -1042,6 +1179,48 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
   if (dtype == SPATTEN_BF16) { if (head_dim == 128) SPATTEN_FLASH(bf16_t, 128) else SPATTEN_FLASH(bf16_t, 64) }
   else { if (head_dim == 128) SPATTEN_FLASH(f16_t, 128) else SPATTEN_FLASH(f16_t, 64) }
 #undef SPATTEN_FLASH
+}
+
+extern "C" size_t spatten_importance_prefill_workspace_bytes(int batch, int heads, int head_dim, int q_len) {
+  if (batch <= 0 || heads <= 0 || head_dim <= 0 || q_len <= 0) return 0;
+  return 256 + align256((size_t)batch * heads * q_len * head_dim * 2);
+}
+
+// Cascade (cumulative) importance of a multi-token forward, stash-free (README.md:11): acc[h, j] += sum_{b, i} softmax
+// probability of key j for query row i, from the row statistics `lse` that spatten_attn_prefill wrote for the SAME
+// inputs.  Two launches: rotate the queries into the workspace (spatten_rope_single's kernel), then the colprob kernel.
+int rope_rows(int dtype, const void* x, int64_t x_sb, int64_t x_sh, int64_t x_sn, void* y, int64_t y_sb, int64_t y_sh,
+              int64_t y_sn, const void* cos, const void* sin, int table_rows, const int64_t* position_ids, int64_t pos_sb,
+              int pos0, int batch, int heads, int n, int head_dim, void* stream);
+
+extern "C" int spatten_importance_accumulate_prefill(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sq,
+                                                     const void* kr_cache, int64_t kv_sb, int64_t kv_sh, const void* cos,
+                                                     const void* sin, int table_rows, const int64_t* position_ids,
+                                                     int64_t pos_sb, const float* lse, float* acc, int64_t acc_sh,
+                                                     void* workspace, int batch, int heads, int kv_heads, int head_dim,
+                                                     int q_len, int kv_len, int pos_q0, int causal, void* stream) {
+  if (!q || !kr_cache || !cos || !sin || !lse || !acc || !workspace) return SPATTEN_ERR_INVALID;
+  if (batch <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads != 0 || q_len <= 0 || kv_len < q_len || pos_q0 < 0)
+    return SPATTEN_ERR_INVALID;
+  if ((dtype != SPATTEN_F16 && dtype != SPATTEN_BF16) || (head_dim != 64 && head_dim != 128)) return SPATTEN_ERR_UNSUPPORTED;
+  char* ws = (char*)(((uintptr_t)workspace + 255) / 256 * 256);
+  const int64_t qr_sh = (int64_t)q_len * head_dim, qr_sb = (int64_t)heads * qr_sh;
+  int rc = rope_rows(dtype, q, q_sb, q_sh, q_sq, ws, qr_sb, qr_sh, head_dim, cos, sin, table_rows, position_ids, pos_sb, pos_q0,
+                     batch, heads, q_len, head_dim, stream);
+  if (rc != SPATTEN_OK) return rc;
+  const dim3 grid((unsigned)ceil_div(kv_len, 256), (unsigned)heads, (unsigned)batch);
+#define SPATTEN_COLPROB(T, DD)                                                                              \
+  {                                                                                                         \
+    ColProbParams<T> p;                                                                                     \
+    p.qrot = (const T*)ws; p.q_sb = qr_sb; p.q_sh = qr_sh; p.kr = (const T*)kr_cache; p.kv_sb = kv_sb; p.kv_sh = kv_sh; \
+    p.lse = lse; p.acc = acc; p.acc_sh = acc_sh; p.H = heads; p.Hkv = kv_heads; p.q_len = q_len; p.N = kv_len; \
+    p.causal = causal; p.sqrt_d = sqrtf((float)head_dim);                                                   \
+    hipLaunchKernelGGL((prefill_colprob_kernel<T, DD>), grid, dim3(512), 0, (hipStream_t)stream, p);         \
+  }
+  if (dtype == SPATTEN_BF16) { if (head_dim == 128) SPATTEN_COLPROB(bf16_t, 128) else SPATTEN_COLPROB(bf16_t, 64) }
+  else { if (head_dim == 128) SPATTEN_COLPROB(f16_t, 128) else SPATTEN_COLPROB(f16_t, 64) }
+#undef SPATTEN_COLPROB
+  return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }
 
 extern "C" size_t spatten_prefill_pq_workspace_bytes(int dtype, int batch, int heads, int kv_heads, int head_dim,
@@ -1100,7 +1279,7 @@ extern "C" int spatten_attn_prefill_pq(int dtype, const void* q, int64_t q_sb, i
     p.kr = (const T*)(KPTR); p.kv_sb = (int64_t)kv_heads * kv_len * head_dim; p.kv_sh = (int64_t)kv_len * head_dim; \
     p.vt = (const T*)vt; p.mask = (const T*)mask; p.mask_sb = mask_sb; p.mask_sq = mask_sq;            \
     p.out = (T*)out; p.out_sb = out_sb; p.out_sq = out_sq;                                             \
-    p.scores = nullptr; p.sc_sb = p.sc_sh = p.sc_sq = 0; p.col_imp = nullptr;                          \
+    p.scores = nullptr; p.sc_sb = p.sc_sh = p.sc_sq = 0; p.col_imp = nullptr; p.lse = nullptr;         \
     p.kscale = kscale; p.ks_sb = (int64_t)kv_heads * kv_len; p.ks_sh = kv_len; p.need = need_lsb; p.pq_thr = (THR); \
     p.B = batch; p.H = heads; p.Hkv = kv_heads; p.q_len = q_len; p.N = kv_len; p.Npad = npad;          \
     p.causal = causal; p.sqrt_d = sqrtf((float)head_dim); p.nqb = ceil_div(q_len, 256);                \

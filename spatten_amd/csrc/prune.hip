@@ -513,6 +513,14 @@ extern "C" int spatten_kv_append(int dtype, const void* k_new, const void* v_new
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }
 
+// C++-linkage name for the other translation units (prefill_attn.hip rotates queries into a workspace with it)
+int rope_rows(int dtype, const void* x, int64_t x_sb, int64_t x_sh, int64_t x_sn, void* y, int64_t y_sb, int64_t y_sh,
+              int64_t y_sn, const void* cos, const void* sin, int table_rows, const int64_t* position_ids, int64_t pos_sb,
+              int pos0, int batch, int heads, int n, int head_dim, void* stream) {
+  return spatten_rope_single(dtype, x, x_sb, x_sh, x_sn, y, y_sb, y_sh, y_sn, cos, sin, table_rows, position_ids, pos_sb, pos0,
+                             batch, heads, n, head_dim, stream);
+}
+
 extern "C" int spatten_abi_version(void) { return SPATTEN_ABI_VERSION; }
 
 extern "C" const char* spatten_status_string(int status) {

@@ -28,7 +28,8 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     """The reference's four positional arguments (enable_spatten_llm.py:5) plus opt-in extensions:
 
     ``prefill_stash=False``: forwards with ``q_len > 1`` do not materialise ``self.attn_scores`` ([B,H,q,N]: 4 GiB per
-    layer at q = N = 8192; the reference writes it on every forward, modify_llama.py:116-119) — it is ``None`` there.  The
+    layer at q = N = 8192; the reference writes it on every forward, modify_llama.py:116-119) — it is ``None`` there
+    (cascade mode then accumulates from the flash kernel's row statistics; fp32 / short blocks still need the stash).  The
     caller protocol (run_spatten_llama.py:71-79) prunes from the LAST DECODE step's stash, which is still written.
     ``assume_causal=True``: the HF mask / position_ids of a forward are taken to be what transformers 4.33 builds
     (causal mask, positions arange(past, past+q)) and are not read: tiles above the diagonal are skipped and a
@@ -50,8 +51,6 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
 
     mods = attention_modules(model)                                # model.modules() order = layer order (:74-77)
     extended = importance_mode == "cascade" or head_keep is not None or pq_threshold is not None or local_v_keep is not None
-    if importance_mode == "cascade" and not prefill_stash:
-        raise ValueError("importance_mode='cascade' accumulates from the prefill stash: prefill_stash must stay True")
     for m in mods:
         m.spatten_prefill_stash = bool(prefill_stash)
         m.spatten_assume_causal = bool(assume_causal)

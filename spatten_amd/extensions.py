@@ -142,21 +142,40 @@ class SpattenExtensions:
             st.pending_len = kv_len
         return st.out, stash[:, :, None, :kv_len]
 
+    def prefill_uses_pq(self, dtype, head_dim: int, q_len: int) -> bool:
+        """The PQ-keyed flash kernel covers 16-bit dtypes at head_dim 64 / 128 and blocks of more than 8 rows (shorter
+        blocks / fp32 run the exact rows leg on the un-quantised shadow)."""
+        return (self.pq_threshold is not None and not self.cascade and dtype in (torch.float16, torch.bfloat16)
+                and head_dim in (64, 128) and q_len > 8)
+
     # ------------------------------------------------------------------------------------------------
     # attention forward, q_len > 1: by-products of the flash path
     # ------------------------------------------------------------------------------------------------
-    def after_prefill(self, layer: int, attn_output, stash, mask, num_heads: int, causal: bool = True):
-        """attn_output [B,q,H*d]; stash [B,H,q,N] or None; mask additive [B,q,N] or None (then ``causal``)."""
+    def prefill_wants_lse(self, dtype, head_dim: int, q_len: int, explicit_mask: bool) -> bool:
+        """Cascade mode: the stash-free accumulation (row statistics + recomputed logits on the matrix cores) covers what
+        the flash kernel covers under the causal / no mask; fp32, short blocks and explicit masks accumulate from the stash."""
+        return (self.cascade and not explicit_mask and dtype in (torch.float16, torch.bfloat16) and head_dim in (64, 128)
+                and q_len > 8)
+
+    def after_prefill(self, layer: int, attn_output, stash, mask, num_heads: int, causal: bool = True, q4=None, slab=None,
+                      kv_len: int = 0, cos=None, sin=None, past_len: int = 0, position_ids=None, lse=None):
+        """attn_output [B,q,H*d]; stash [B,H,q,N] or None; mask additive [B,q,N] or None (then ``causal``); lse [B,H,q,2]
+        when the forward ran the stash-free route (then q4 / slab / tables describe the same launch)."""
         st = self.layers[layer]
         B, q_len = attn_output.shape[0], attn_output.shape[1]
         d = attn_output.shape[2] // num_heads
         if self.cascade:
-            if stash is None:
-                raise RuntimeError("importance_mode='cascade' needs the multi-token stash (prefill_stash=True)")
-            n = stash.shape[-1]
+            n = kv_len if stash is None else stash.shape[-1]
             st.ensure(B, num_heads, d, n, attn_output.dtype, attn_output.device, True)
             self.flush(layer)
-            ops.importance_accumulate(st.acc, stash, None, mask, causal=causal)
+            if lse is not None:
+                ops.importance_accumulate_prefill(st.acc, q4, slab.kr, kv_len, cos, sin, past_len, lse, causal=causal,
+                                                  position_ids=position_ids)
+            elif stash is not None:
+                ops.importance_accumulate(st.acc, stash, None, mask, causal=causal)
+            else:
+                raise RuntimeError("importance_mode='cascade': this forward (fp32 / short block / explicit mask) accumulates "
+                                   "from the stash — enable it (prefill_stash=True)")
         if self.head_keep is not None:
             st.ensure(B, num_heads, d, 1, attn_output.dtype, attn_output.device, False)
             if st.pruned_ids is not None:

@@ -248,11 +248,14 @@ def attn_prefill(q: torch.Tensor, kr_cache: torch.Tensor, v_cache: torch.Tensor,
                  cos: torch.Tensor, sin: torch.Tensor, pos_q0: int, causal: bool = True,
                  position_ids: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
                  out: Optional[torch.Tensor] = None, scores: Optional[torch.Tensor] = None,
-                 col_importance: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 col_importance: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Flash-style prefill (modify_llama.py:86-147 at q_len>1).  q [B,H,q,d] un-rotated (any strides with d
     contiguous); kr_cache = ROTATED shadow of the keys, v_cache values, both already holding the q new rows
-    at [kv_len-q, kv_len); mask additive [B,q,kv_len]; position_ids int64 [B,q].  Returns out [B, q, H*d]."""
-    _dev(q, kr_cache, v_cache, cos, sin, out, scores, col_importance, position_ids, mask)
+    at [kv_len-q, kv_len); mask additive [B,q,kv_len]; position_ids int64 [B,q]; lse optional fp32 [B,H,q,2] output
+    (row reference max, sum exp): the softmax statistics.  Returns out [B, q, H*d]."""
+    _dev(q, kr_cache, v_cache, cos, sin, out, scores, col_importance, position_ids, mask, lse)
+    if lse is not None and (lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != q.shape[0] * q.shape[1] * q.shape[2] * 2):
+        raise ValueError("lse must be a contiguous fp32 [B,H,q,2] tensor")
     lib = _lib.load()
     B, H, ql, d = q.shape
     Hkv = kr_cache.shape[1]
@@ -275,10 +278,53 @@ def attn_prefill(q: torch.Tensor, kr_cache: torch.Tensor, v_cache: torch.Tensor,
         _ptr(mask), *((0, 0) if mask is None else (mask.stride(0), mask.stride(1))),
         out.data_ptr(), out.stride(0), out.stride(1),
         _ptr(scores), *((0, 0, 0) if scores is None else (scores.stride(0), scores.stride(1), scores.stride(2))),
-        _ptr(col_importance), ws.data_ptr(),
+        _ptr(col_importance), _ptr(lse), ws.data_ptr(),
         B, H, Hkv, d, ql, kv_len, pos_q0, int(causal), _stream())
     _lib.check(rc, "spatten_attn_prefill")
     return out
+
+
+def attn_prefill_pq(q: torch.Tensor, planes: "PQPlanes", v_cache: torch.Tensor, kv_len: int, cos: torch.Tensor,
+                    sin: torch.Tensor, pos_q0: int, threshold: float, causal: bool = True,
+                    position_ids: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                    out: Optional[torch.Tensor] = None, need_lsb: Optional[torch.Tensor] = None):
+    """Prefill over progressively quantised keys (BASELINE.json configs[3]): MSB pass for every query row,
+    ``need_lsb[b,h,i] = max_j prob_ij < threshold``, LSB refetch + one recompute of the flagged rows.  q [B,H,q,d]
+    un-rotated; planes of the ROTATED keys rows [0, kv_len) (ops.pq_pack); bf16 / f16, d 64 / 128.
+    Returns (out [B,q,H*d], need_lsb int32 [B,H,q])."""
+    _dev(q, planes.msb, v_cache, cos, sin, out, need_lsb, position_ids, mask)
+    lib = _lib.load()
+    B, H, ql, d = q.shape
+    Hkv = v_cache.shape[1]
+    if q.stride(3) != 1 or v_cache.stride(3) != 1 or v_cache.stride(2) != d:
+        raise ValueError("q needs contiguous d; v_cache needs contiguous rows (pitch d)")
+    if max(kv_len, pos_q0 + ql) > cos.shape[0] and position_ids is None:
+        raise ValueError("rotary table too short")
+    if kv_len > planes.msb.shape[2]:
+        raise ValueError("kv_len exceeds the planes")
+    if position_ids is not None and (position_ids.dtype != torch.int64 or position_ids.stride(-1) != 1):
+        raise TypeError("position_ids must be int64 with contiguous rows")
+    if mask is not None and (mask.stride(-1) != 1 or mask.dtype != q.dtype):
+        raise ValueError("mask must be in the model dtype with contiguous rows")
+    if out is None:
+        out = torch.empty(B, ql, H * d, dtype=q.dtype, device=q.device)
+    if need_lsb is None:
+        need_lsb = torch.empty(B, H, ql, dtype=torch.int32, device=q.device)
+    if need_lsb.dtype != torch.int32 or not need_lsb.is_contiguous() or need_lsb.numel() != B * H * ql:
+        raise ValueError("need_lsb must be a contiguous int32 [B,H,q] tensor")
+    ws = _prefill_workspace(lib.spatten_prefill_pq_workspace_bytes(_dt(q), B, H, Hkv, d, ql, kv_len), q.device)
+    rc = lib.spatten_attn_prefill_pq(
+        _dt(q), q.data_ptr(), q.stride(0), q.stride(1), q.stride(2),
+        planes.msb.data_ptr(), planes.lsb.data_ptr(), planes.scale.data_ptr(), planes.msb.stride(0), planes.msb.stride(1),
+        planes.scale.stride(0), planes.scale.stride(1),
+        v_cache.data_ptr(), v_cache.stride(0), v_cache.stride(1),
+        cos.data_ptr(), sin.data_ptr(), cos.shape[0],
+        _ptr(position_ids), 0 if position_ids is None else (position_ids.stride(0) if position_ids.shape[0] > 1 else 0),
+        _ptr(mask), *((0, 0) if mask is None else (mask.stride(0), mask.stride(1))),
+        out.data_ptr(), out.stride(0), out.stride(1), need_lsb.data_ptr(), float(threshold), ws.data_ptr(),
+        B, H, Hkv, d, ql, kv_len, pos_q0, int(causal), _stream())
+    _lib.check(rc, "spatten_attn_prefill_pq")
+    return out, need_lsb
 
 
 def build_shadow(k_cache: torch.Tensor, kr_cache: torch.Tensor, lo: int, hi: int, cos: torch.Tensor, sin: torch.Tensor):
@@ -470,6 +516,30 @@ def importance_accumulate(acc: torch.Tensor, stash: torch.Tensor, lse: Optional[
         _ptr(mask), *((0, 0) if mask is None else (mask.stride(0), mask.stride(1))),
         acc.data_ptr(), acc.stride(0), B, H, Q, L, int(causal), _stream())
     _lib.check(rc, "spatten_importance_accumulate")
+    return acc
+
+
+def importance_accumulate_prefill(acc: torch.Tensor, q: torch.Tensor, kr_cache: torch.Tensor, kv_len: int,
+                                  cos: torch.Tensor, sin: torch.Tensor, pos_q0: int, lse: torch.Tensor,
+                                  causal: bool = True, position_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Cascade importance of a multi-token forward without the stash: acc[h, j] += sum over batch and query rows of the
+    softmax probability of key j, recomputed from q [B,H,q,d] (un-rotated), the rotated shadow and the row statistics
+    ``lse`` [B,H,q,2] that ``attn_prefill(..., lse=lse)`` wrote for the same inputs.  bf16 / f16, d 64 / 128."""
+    _dev(acc, q, kr_cache, cos, sin, lse, position_ids)
+    lib = _lib.load()
+    B, H, ql, d = q.shape
+    Hkv = kr_cache.shape[1]
+    if acc.dtype != torch.float32 or acc.stride(1) != 1 or acc.shape[0] != H or acc.shape[1] < kv_len:
+        raise ValueError("acc must be fp32 [H, >=kv_len] with contiguous rows")
+    if q.stride(3) != 1 or kr_cache.stride(3) != 1 or kr_cache.stride(2) != d:
+        raise ValueError("q needs contiguous d; kr_cache needs contiguous rows (pitch d)")
+    ws = _prefill_workspace(lib.spatten_importance_prefill_workspace_bytes(B, H, d, ql), q.device)
+    rc = lib.spatten_importance_accumulate_prefill(
+        _dt(q), q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), kr_cache.data_ptr(), kr_cache.stride(0), kr_cache.stride(1),
+        cos.data_ptr(), sin.data_ptr(), cos.shape[0],
+        _ptr(position_ids), 0 if position_ids is None else (position_ids.stride(0) if position_ids.shape[0] > 1 else 0),
+        lse.data_ptr(), acc.data_ptr(), acc.stride(0), ws.data_ptr(), B, H, Hkv, d, ql, kv_len, pos_q0, int(causal), _stream())
+    _lib.check(rc, "spatten_importance_accumulate_prefill")
     return acc
 
 

@@ -165,14 +165,27 @@ def llama_pos_shift_attention_forward(
         slab.length = slab.rot_len = kv_seq_len
         # a mask that IS the HF causal mask lets the kernel skip the tiles above the diagonal and never read the mask
         causal = attention_mask is not None and (assume_causal or _mask_is_causal(attention_mask, past_len))
-        attn_output = ops.attn_prefill(
-            query_states.view(bsz, q_len, num_heads, head_dim).transpose(1, 2), slab.kr, slab.v, kv_seq_len,
-            cos, sin, past_len, causal=causal, position_ids=position_ids,
-            mask=None if (attention_mask is None or causal) else attention_mask[:, 0],
-            scores=stash)
+        q4 = query_states.view(bsz, q_len, num_heads, head_dim).transpose(1, 2)
+        pmask = None if (attention_mask is None or causal) else attention_mask[:, 0]
+        lse_pf = None
+        if ext is not None and ext[0].prefill_uses_pq(dtype, head_dim, q_len):
+            # progressive quantisation also at multi-token forwards (BASELINE.json configs[3]): MSB-first keys, per-row
+            # max-probability decision, LSB refetch of the flagged rows; the logits are never materialised here
+            slab.ensure_pq(kv_seq_len)
+            stash = None
+            attn_output, _ = ops.attn_prefill_pq(q4, slab.pq, slab.v, kv_seq_len, cos, sin, past_len, ext[0].pq_threshold,
+                                                 causal=causal, position_ids=position_ids, mask=pmask)
+        else:
+            if ext is not None and ext[0].prefill_wants_lse(dtype, head_dim, q_len, pmask is not None):
+                lse_pf = torch.empty(bsz, num_heads, q_len, 2, dtype=torch.float32, device=device)
+                if not (output_attentions or bool(getattr(self, "spatten_prefill_stash", True))):
+                    stash = None
+            attn_output = ops.attn_prefill(q4, slab.kr, slab.v, kv_seq_len, cos, sin, past_len, causal=causal,
+                                           position_ids=position_ids, mask=pmask, scores=stash, lse=lse_pf)
         if ext is not None:
-            ext[0].after_prefill(ext[1], attn_output, stash, None if (attention_mask is None or causal) else attention_mask[:, 0],
-                                 num_heads, causal)
+            ext[0].after_prefill(ext[1], attn_output, stash, pmask, num_heads, causal, q4=q4, slab=slab, kv_len=kv_seq_len,
+                                 cos=cos, sin=sin, past_len=past_len, position_ids=position_ids,
+                                 lse=lse_pf)
 
     # store attention scores for deciding which token to prune (:116-119) — raw scaled logits, pre-mask
     self.attn_scores = stash

@@ -100,6 +100,69 @@ def test_cascade_accumulation_fused_into_the_decode_step(dt, B):
     assert float(host(acc)[:, n:].max()) == 0.0
 
 
+@pytest.mark.parametrize("dt,d,Hkv,P,ql", [("bf16", 128, 4, 100, 600), ("f16", 64, 2, 0, 333), ("bf16", 128, 4, 900, 130)])
+def test_cascade_importance_of_a_prefill_without_the_stash(dt, d, Hkv, P, ql):
+    """Multi-token forwards in cascade mode: the flash kernel writes its row statistics, a second matrix-core pass
+    recomputes the logits and sums the probabilities per key — no [B,H,q,N] stash.  vs the oracle's restatement (and vs
+    the stash-based accumulation of the same launch)."""
+    from spatten_amd import ops
+    B, H, N = 2, 4, P + ql
+    q, k, v, past = attn_inputs(B, H, Hkv, d, P, ql, dt, seed=23)
+    kc = k if past is None else np.concatenate([past[0], k], 2)
+    vc = v if past is None else np.concatenate([past[1], v], 2)
+    c, s = orc.rope_table(N, d, dt)
+    cos, sin = dev(c[:, : d // 2], dt), dev(s[:, : d // 2], dt)
+    kd, vd, qd = dev(kc, dt), dev(vc, dt), dev(q, dt)
+    krd = ops.rope_single(kd, cos, sin)
+    lse = torch.empty(B, H, ql, 2, dtype=torch.float32, device="cuda")
+    stash = torch.empty(B, H, ql, N, dtype=TORCH_DT[dt], device="cuda")
+    out = ops.attn_prefill(qd, krd, vd, N, cos, sin, P, causal=True, lse=lse, scores=stash)
+    out2 = ops.attn_prefill(qd, krd, vd, N, cos, sin, P, causal=True, lse=torch.empty_like(lse))      # 128-key-tile kernel
+    assert torch.allclose(out.float(), out2.float(), atol=1e-2, rtol=2e-2)
+    acc = torch.zeros(H, N + 7, dtype=torch.float32, device="cuda")
+    ops.importance_accumulate_prefill(acc, qd, krd, N, cos, sin, P, lse, causal=True)
+    torch.cuda.synchronize()
+    mask = np.where(orc.causal_mask(B, ql, N, "f32") < 0, -np.inf, 0).astype(np.float32)
+    want = orc.cascade_importance_accumulate(np.zeros((H, N), np.float32), host(stash), mask)     # from the kernel's own stash
+    np.testing.assert_allclose(host(acc)[:, :N], want, rtol=1e-2, atol=2e-3)
+    assert float(host(acc)[:, N:].max()) == 0.0
+    np.testing.assert_allclose(host(acc)[:, :N].sum(1), np.full(H, B * ql), rtol=1e-3)        # every row's probabilities sum to 1
+    # the row statistics are what the accumulation needs: softmax of the stash row == exp(s - m) / l
+    pm = np.exp(host(stash)[0, 1, 5, :P + 6] - host(lse)[0, 1, 5, 0]) / host(lse)[0, 1, 5, 1]
+    np.testing.assert_allclose(pm, orc.softmax_probs(host(stash)[0, 1, 5, :P + 6]), rtol=2e-3, atol=1e-6)
+    # and the stash-based kernel agrees
+    acc2 = torch.zeros(H, N, dtype=torch.float32, device="cuda")
+    ops.importance_accumulate(acc2, stash, None, None, causal=True)
+    np.testing.assert_allclose(host(acc)[:, :N], host(acc2), rtol=1e-2, atol=2e-3)
+
+
+def test_cascade_prefill_8192_llama7b_without_the_stash():
+    """configs[3] geometry (H = 32, q = N = 8192, bf16) in cascade mode: no 4 GiB stash; every query row's probabilities
+    sum to 1, so each head's importance sums to the number of rows; spot columns against a direct evaluation."""
+    from spatten_amd import ops
+    dt, B, H, d, N = "bf16", 1, 32, 128, 8192
+    tdt = TORCH_DT[dt]
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    K = torch.randn(B, H, N, d, device="cuda", generator=gen).to(tdt)
+    V = torch.randn(B, H, N, d, device="cuda", generator=gen).to(tdt)
+    Q = torch.randn(B, H, N, d, device="cuda", generator=gen).to(tdt)
+    cos, sin = ops.rope_table(N, d, tdt, "cuda")
+    Kr = ops.rope_single(K, cos, sin)
+    lse = torch.empty(B, H, N, 2, dtype=torch.float32, device="cuda")
+    ops.attn_prefill(Q, Kr, V, N, cos, sin, 0, causal=True, lse=lse)
+    acc = torch.zeros(H, N, dtype=torch.float32, device="cuda")
+    ops.importance_accumulate_prefill(acc, Q, Kr, N, cos, sin, 0, lse, causal=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(host(acc).sum(1), np.full(H, N), rtol=2e-3)
+    # column j of head h, directly: sum_i>=j softmax_i[j]  (torch fp32 on the device, two heads)
+    Qr = ops.rope_single(Q, cos, sin)
+    for h in (0, 17):
+        sc = (Qr[0, h].float() @ Kr[0, h].float().T) / d ** 0.5
+        sc = sc.masked_fill(torch.ones(N, N, dtype=torch.bool, device="cuda").triu(1), float("-inf"))
+        want = torch.softmax(sc, dim=-1).sum(0)
+        np.testing.assert_allclose(host(acc[h]), host(want), rtol=3e-2, atol=3e-3)
+
+
 @pytest.mark.parametrize("dt,Hkv", [("bf16", 8), ("f16", 2), ("f32", 8)])
 def test_local_value_pruning_vs_oracle(dt, Hkv):
     from spatten_amd.cascade import local_v_decode

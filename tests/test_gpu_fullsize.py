@@ -90,6 +90,200 @@ def test_c4_prefill_8192_properties_and_pq_planes():
     assert e8 < 0.03 and e8 <= e4 + 1e-3, (e8, e4)
 
 
+def _pq_setup(B, H, d, N, dt, seed, peaky_rows=()):
+    """Un-rotated Q (queries over rows [P, N)), rotated shadow Kr, V on the device + the planes; `peaky_rows` get a query
+    aligned with one key so that their attention is confident (max prob above any small threshold)."""
+    from spatten_amd import ops
+    tdt = TORCH_DT[dt]
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    K = torch.randn(B, H, N, d, device="cuda", generator=gen).to(tdt)
+    V = torch.randn(B, H, N, d, device="cuda", generator=gen).to(tdt)
+    cos, sin = ops.rope_table(N, d, tdt, "cuda")
+    Kr = ops.rope_single(K, cos, sin)
+    planes = ops.PQPlanes(B, H, N, d, "cuda")
+    ops.pq_pack(Kr, planes, 0, N)
+    return K, V, Kr, planes, cos, sin, gen
+
+
+@pytest.mark.parametrize("dt,d,P,ql", [("bf16", 128, 0, 700), ("f16", 64, 333, 300), ("bf16", 128, 1000, 260)])
+def test_prefill_pq_vs_oracle(dt, d, P, ql):
+    """PQ-keyed prefill (configs[3] semantics) vs the oracle's restatement, every row: MSB-pass flags per query row,
+    refetched rows recomputed from the 8-bit keys, P.V with the un-quantised V."""
+    from spatten_amd import ops
+    B, H, N = 2, 4, P + ql
+    tdt = TORCH_DT[dt]
+    K, V, Kr, planes, cos, sin, gen = _pq_setup(B, H, d, N, dt, 11)
+    Q = (torch.randn(B, H, ql, d, device="cuda", generator=gen) * 1.5).to(tdt)
+    msb, lsb, scale = planes.unpack(N)
+    c, s = host(cos), host(sin)
+    cs, sn = np.concatenate([c, c], -1), np.concatenate([s, s], -1)
+    qr = orc.apply_rotary_pos_emb_single(host(Q), cs, sn, np.arange(P, N)[None], dt)
+    _, _, pmax = orc.pq_prefill_attention(qr, msb, lsb, scale, host(V), 0.0, P)
+    for thr in (0.0, 2.0, float(np.median(pmax))):
+        want, need, _ = orc.pq_prefill_attention(qr, msb, lsb, scale, host(V), thr, P)
+        out, need_g = ops.attn_prefill_pq(Q, planes, V, N, cos, sin, P, thr, causal=True)
+        torch.cuda.synchronize()
+        ng = need_g.cpu().numpy().astype(bool)
+        clear = np.abs(pmax - thr) > 1e-4 * max(thr, 1e-3)          # rows whose decision is not a rounding coin-flip
+        assert np.array_equal(ng[clear], need[clear]), thr
+        assert 0 < clear.mean()
+        ok_rows = clear.all(axis=1)                                  # [B, q]: compare rows decided alike in every head
+        got = host(out).reshape(B, ql, H, d)
+        np.testing.assert_allclose(got[ok_rows], orc.round_dt(want, dt).reshape(B, ql, H, d)[ok_rows], **OUT_TOL[dt])
+    # threshold 0 = MSB keys only, threshold 2 = every row refetched = plain 8-bit keys: the refetch brings the result
+    # closer to the un-quantised attention
+    o4, _ = ops.attn_prefill_pq(Q, planes, V, N, cos, sin, P, 0.0)
+    o8, n8 = ops.attn_prefill_pq(Q, planes, V, N, cos, sin, P, 2.0)
+    of = ops.attn_prefill(Q, Kr, V, N, cos, sin, P, causal=True)
+    assert bool(n8.all())
+    e4, e8 = float((o4.float() - of.float()).abs().max()), float((o8.float() - of.float()).abs().max())
+    assert e8 < 0.05 and e8 <= e4 + 1e-3, (e4, e8)
+
+
+def test_c4_prefill_8192_pq_keyed_full_size():
+    """configs[3] AS WRITTEN: Llama-2-7B geometry (H = 32, d = 128), q = N = 8192 causal prefill over progressively
+    quantised keys, bf16.  Sampled query rows against the oracle (every head), refetch flags for all of them; full-size
+    properties: a row of the PQ prefill equals the PQ decode step on the same prefix, pass 2 only touches flagged rows."""
+    from spatten_amd import ops
+    dt, B, H, d, N = "bf16", 1, 32, 128, 8192
+    K, V, Kr, planes, cos, sin, gen = _pq_setup(B, H, d, N, dt, 44)
+    Q = torch.randn(B, H, N, d, device="cuda", generator=gen).to(TORCH_DT[dt])
+    # make a band of rows confident: query row i of the band points at key i (its own position) with a large norm
+    band = torch.arange(4000, 4400, device="cuda")
+    Q[:, :, band] = (K[:, :, band].float() * 6.0).to(Q.dtype)
+    thr = 0.05                                                      # the traces' auto_requant_thres
+    out, need = ops.attn_prefill_pq(Q, planes, V, N, cos, sin, 0, thr, causal=True)
+    torch.cuda.synchronize()
+    need_h = need.cpu().numpy().astype(bool)
+    assert 0.02 < need_h.mean() < 0.999 and not need_h[:, :, 4100:4300].all()      # a mix: both passes matter
+    rows = [0, 1, 127, 128, 2047, 4000, 4100, 4200, 4399, 4400, 6000, N - 1]
+    msb, lsb, scale = planes.unpack(N)
+    c, s = host(cos), host(sin)
+    cs, sn = np.concatenate([c, c], -1), np.concatenate([s, s], -1)
+    qr = orc.apply_rotary_pos_emb_single(host(Q[:, :, rows]), cs, sn, np.asarray(rows)[None], dt)
+    want = np.zeros((B, len(rows), H * d), np.float32)
+    for n, i in enumerate(rows):                                    # oracle row by row (the prefix of row i only)
+        w, nd, pm = orc.pq_prefill_attention(qr[:, :, n:n + 1], msb[:, :, :i + 1], lsb[:, :, :i + 1], scale[:, :, :i + 1],
+                                             host(V[:, :, :i + 1]), thr, i)
+        want[:, n] = w[:, 0]
+        clear = np.abs(pm[:, :, 0] - thr) > 1e-4
+        assert np.array_equal(need_h[:, :, i][clear], nd[:, :, 0][clear]), i
+        if clear.all():
+            np.testing.assert_allclose(host(out[:, i]), orc.round_dt(want[:, n], dt), err_msg=f"row {i}", **OUT_TOL[dt])
+    # the same row through the decode kernel's PQ path (per-HEAD decision there: compare heads that agree)
+    for i in (2047, 4200, N - 1):
+        nd = torch.empty(B * H, dtype=torch.int32, device="cuda")
+        o1 = ops.attn_decode_pq(Q[:, :, i].contiguous(), planes, V, i + 1, cos, sin, i, thr, need_lsb=nd)
+        assert torch.equal(nd.view(B, H) != 0, need[:, :, i] != 0)
+        np.testing.assert_allclose(host(out[:, i]), host(o1), atol=1e-2, rtol=2e-2)
+    # rows that were not flagged carry exactly the MSB-pass result (pass 2 left them alone)
+    o_msb, _ = ops.attn_prefill_pq(Q, planes, V, N, cos, sin, 0, 0.0, causal=True)
+    keep = (need == 0).permute(0, 2, 1)                              # [B, q, H]
+    assert torch.equal(out.view(B, N, H, d)[keep], o_msb.view(B, N, H, d)[keep])
+
+
+def test_c3_head_pruned_decode_full_size():
+    """configs[2] at full size: Llama-2-7B geometry, 4096 -> 2048 token prune, head importance -> keep 24 of 32 heads ->
+    decode launched on the kept heads only; everything against the oracle."""
+    from spatten_amd import SpAttenKVCache, ops
+    from spatten_amd.cascade import HeadPruner
+    dt, B, H, d, N = "bf16", 1, 32, 128, 4096
+    tdt = TORCH_DT[dt]
+    gen = torch.Generator(device="cuda").manual_seed(33)
+    K = torch.randn(B, H, N, d, device="cuda", generator=gen).to(tdt)
+    V = (torch.randn(B, H, N, d, device="cuda", generator=gen) *
+         torch.linspace(0.5, 2.0, H, device="cuda")[None, :, None, None]).to(tdt)       # heads of different weight
+    q = torch.randn(B, H, d, device="cuda", generator=gen).to(tdt)
+    c, s = orc.rope_table(N + 64, d, dt)
+    cos, sin = dev(c[:, : d // 2], dt), dev(s[:, : d // 2], dt)
+    Kr = ops.rope_single(K, cos, sin)
+    stash = torch.empty(B, H, N, dtype=tdt, device="cuda")
+    head_abs = torch.zeros(B * H, dtype=torch.float32, device="cuda")
+    out = ops.attn_decode(q, None, Kr, V, N, cos, sin, N - 1, scores=stash, head_abs=head_abs)
+    torch.cuda.synchronize()
+    # head importance fused into the decode launch == the oracle's sum |attn_out_h| == the separate kernel
+    want_abs = orc.head_scores(host(out)[:, None, :], H)
+    np.testing.assert_allclose(host(head_abs), want_abs, rtol=1e-5)
+    hp = HeadPruner(H, "cuda")
+    hp.observe(out[:, None, :])
+    np.testing.assert_allclose(host(hp.scores), want_abs, rtol=1e-5)
+    keep = hp.select(24)
+    assert np.array_equal(keep.cpu().numpy(), orc.head_prune_select(want_abs, 24))
+    # token prune 4096 -> 1984 (+ room for the 64 coming tokens; indices bit exact vs the oracle on the kernel's stash)
+    cache = SpAttenKVCache(4, 1024, 1020)
+    new = cache.apply_token_pruning([(K, V)], 64, [stash[:, :, None, :]])
+    idx = cache.keep_indices.cpu().numpy()[0]
+    assert np.array_equal(idx, orc.topk_window(host(stash)[0], 4, N - 1024 + 64, 1020))
+    Kn, Vn = new[0]
+    n = Kn.shape[2]
+    assert n == 4 + 1020 + 960
+    slab = Kn._spatten_slab
+    # decode over the pruned cache, kept heads only, appending a token: vs the oracle on the pruned cache
+    qn = torch.randn(B, H, d, device="cuda", generator=gen).to(tdt)
+    kn = torch.randn(B, H, d, device="cuda", generator=gen).to(tdt)
+    vn = torch.randn(B, H, d, device="cuda", generator=gen).to(tdt)
+    Kh, Vh = host(Kn), host(Vn)
+    o, st, _ = orc.attention_core(host(qn)[:, :, None], host(kn)[:, :, None], host(vn)[:, :, None], Kh, Vh,
+                                  np.full((B, 1), n), None, dt)
+    o2 = torch.zeros(B, H * d, dtype=tdt, device="cuda")
+    st2 = torch.zeros(B, H, n + 1, dtype=tdt, device="cuda")
+    tc, ts = slab.tables(n + 1)
+    # (the product path's torch-built table; the oracle's numpy table differs in a few 16-bit entries -> tolerance only)
+    ops.attn_decode(qn, slab.k, slab.kr, slab.v, n + 1, tc, ts, n, k_new=kn, v_new=vn, out=o2, scores=st2, head_ids=keep)
+    torch.cuda.synchronize()
+    kept = keep.cpu().numpy()
+    dead = np.setdiff1d(np.arange(H), kept)
+    np.testing.assert_allclose(host(o2).reshape(B, H, d)[:, kept], o.reshape(B, H, d)[:, kept], **OUT_TOL[dt])
+    assert not host(o2).reshape(B, H, d)[:, dead].any() and not host(st2)[:, dead].any()     # pruned heads: untouched
+    assert float(np.mean(host(st2)[:, kept] != st[:, kept, 0])) < 0.03
+
+
+def test_c5_combined_token_head_prune_and_pq_decode_full_size():
+    """configs[4] at full size: Llama-2-13B geometry (H = 40), 16384 -> 8192 token prune, head prune to 30 of 40,
+    progressive-quant decode over the kept rows of the kept heads — vs the oracle."""
+    from spatten_amd import SpAttenKVCache, ops
+    dt, B, H, d, N = "bf16", 1, 40, 128, 16384
+    tdt = TORCH_DT[dt]
+    gen = torch.Generator(device="cuda").manual_seed(55)
+    K = torch.randn(B, H, N, d, device="cuda", generator=gen).to(tdt)
+    V = torch.randn(B, H, N, d, device="cuda", generator=gen).to(tdt)
+    q = torch.randn(B, H, d, device="cuda", generator=gen).to(tdt)
+    cos, sin = ops.rope_table(N, d, tdt, "cuda")
+    Kr = ops.rope_single(K, cos, sin)
+    stash = torch.empty(B, H, N, dtype=tdt, device="cuda")
+    head_abs = torch.zeros(B * H, dtype=torch.float32, device="cuda")
+    out = ops.attn_decode(q, None, Kr, V, N, cos, sin, N - 1, scores=stash, head_abs=head_abs)
+    keep = ops.topk_select(head_abs[None, :], 0, H, 30)[0].contiguous()
+    assert np.array_equal(keep.cpu().numpy(), orc.head_prune_select(orc.head_scores(host(out)[:, None, :], H), 30))
+    cache = SpAttenKVCache(4, 4096, 4092)
+    new = cache.apply_token_pruning([(K, V)], 0, [stash[:, :, None, :]])
+    assert np.array_equal(cache.keep_indices.cpu().numpy()[0], orc.topk_window(host(stash)[0], 4, N - 4096, 4092))
+    Kn, Vn = new[0]
+    slab = Kn._spatten_slab
+    n = 8192
+    slab.ensure_pq(n)
+    msb, lsb, scale = slab.pq.unpack(n)
+    gm, gl, gs = orc.pq_quantize(host(slab.kr[:, :, :n]))
+    assert np.array_equal(msb, gm) and np.array_equal(lsb, gl) and np.array_equal(scale, gs)
+    tc, ts = slab.tables(n)
+    c2, s2 = host(tc), host(ts)
+    qn = (torch.randn(B, H, d, device="cuda", generator=gen) * 2).to(tdt)
+    qr = orc.apply_rotary_pos_emb_single(host(qn)[:, :, None], np.concatenate([c2, c2], -1), np.concatenate([s2, s2], -1),
+                                         np.full((B, 1), n - 1), dt)[:, :, 0]
+    logits, _ = orc.pq_logits(qr, msb, lsb, scale, 0.0)
+    thr = float(np.median(orc.softmax_probs(logits).max(-1)))
+    want, need = orc.pq_decode_attention(qr, msb, lsb, scale, host(Vn), thr)
+    o2 = torch.zeros(B, H * d, dtype=tdt, device="cuda")
+    nd = torch.zeros(B * H, dtype=torch.int32, device="cuda")
+    ops.attn_decode_pq(qn, slab.pq, slab.v, n, tc, ts, n - 1, thr, out=o2, need_lsb=nd, head_ids=keep)
+    torch.cuda.synchronize()
+    kept = keep.cpu().numpy()
+    dead = np.setdiff1d(np.arange(H), kept)
+    assert np.array_equal(nd.cpu().numpy().reshape(B, H).astype(bool)[:, kept], need[:, kept])
+    np.testing.assert_allclose(host(o2).reshape(B, H, d)[:, kept], orc.round_dt(want, dt)[:, kept], **OUT_TOL[dt])
+    assert not host(o2).reshape(B, H, d)[:, dead].any()
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_topk_random_shapes_vs_oracle(seed):
     from spatten_amd import ops
