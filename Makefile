@@ -25,7 +25,7 @@ FLAGS_decode_attn := -mllvm -amdgpu-kernarg-preload-count=16
 
 $(LIB): $(OBJS)
 	@mkdir -p spatten_amd/lib
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl
 
 oracle: oracle/liboracle.so
 

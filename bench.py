@@ -51,10 +51,11 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the dense / eager comparison legs")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL path even with one rank (testing)")
-    ap.add_argument("--gather", choices=["flat", "grouped", "per-layer"], default="flat",
-                    help="N>1, after a token's attention graph: ONE all-gather of the 32 layers' output slices, which "
-                         "live in one flat buffer (default); the 32 per-layer all-gathers as one RCCL group; or one "
-                         "eager collective per layer")
+    ap.add_argument("--gather", choices=["native", "flat", "grouped", "per-layer"], default="native",
+                    help="N>1, the exchange of a token's attention outputs: 'native' = ONE all-gather of the 32 layers' "
+                         "slices on the library-owned RCCL communicator (spatten_comm_*), captured INSIDE the token's HIP "
+                         "graph; the others go through torch.distributed eagerly after the graph: one flat all-gather, the "
+                         "32 per-layer all-gathers as one RCCL group, or one collective per layer")
     return ap.parse_args()
 
 
@@ -384,10 +385,22 @@ def main():
                     w.wait()
         return _All()
 
+    native = False
+    if dist_on and args.gather == "native":
+        try:
+            hp.init_native()
+            native = True
+        except Exception as e:
+            if rank == 0:
+                print(f"native RCCL communicator unavailable ({type(e).__name__}: {e}); using torch.distributed", file=sys.stderr)
+            args.gather = "flat"
+
     def run_slot(slot):
         if slot == 0:
             prune()
         decode_token(new_len + slot + 1, slot & 1)
+        if native:      # the exchange is part of the token: same stream, same graph
+            hp.allgather_native(outs_flat[slot & 1].view(-1), staging_flat[slot & 1])
 
     # ---- HIP graphs: one per position in the turn (kv_len is a launch parameter) -------------------------
     graphs = None
@@ -421,14 +434,14 @@ def main():
         for i in range(first, first + n):
             slot = (base_slot + i) % TURN
             par = slot & 1
-            if dist_on and pending[par] is not None:
+            if dist_on and not native and pending[par] is not None:
                 pending[par].wait()            # the gather that still reads this parity's outputs (token i-2)
                 pending[par] = None
             if graphs is not None:
                 graphs[slot].replay()
             else:
                 run_slot(slot)
-            if dist_on:
+            if dist_on and not native:
                 pending[par] = gather_token(par)    # overlaps the next token's attention graph
         for par in (0, 1):                     # the timed region ends with every exchange complete
             if pending[par] is not None:
@@ -669,6 +682,8 @@ def main():
             result["cpu_baseline"] = cpu_baseline(L, new_len, lo, hi)
     if dist_on:
         import torch.distributed as dist
+        if native:
+            hp.close_native()
         dist.destroy_process_group()
     if rank == 0:
         # RCCL prints its banner through C stdio: flush it first so the JSON line is the LAST line of stdout

@@ -296,6 +296,13 @@ int spatten_row_lse(int dtype, const void* stash, int64_t sb, int64_t sh, int64_
 /* The accumulator follows the cache through a prune: dst[h, :] = cat(src[h, :start], src[h, idx[h, :]], src[h, tail_lo:tail_lo+tail_len]) */
 int spatten_importance_compact(const float* src, int64_t src_sh, float* dst, int64_t dst_sh, const int32_t* idx,
                                int64_t idx_sh, int heads, int start, int k, int tail_lo, int tail_len, void* stream);
+/* Layer-to-layer cascade (README.md:11; trace columns if_topk / topk; the survivors of a layer's top-k feed the next
+ * layer): rank[h, j] = score[h, j] if the token held by slot j of THIS layer (ids[h, j]) is among the tokens the previous
+ * layer kept for head h (prev_ids[h, 0..n_prev), ascending), else -inf.  spatten_topk_select over `rank` (fp32) then
+ * prefers the previous layer's survivors.  score [H, >=len] model dtype; ids / prev_ids int32; rank fp32 [H, >=len]. */
+int spatten_cascade_rank(int dtype, const void* score, int64_t score_sh, const int32_t* ids, int64_t ids_sh,
+                         const int32_t* prev_ids, int64_t prev_sh, int n_prev, float* rank, int64_t rank_sh,
+                         int heads, int len, void* stream);
 /* Head importance (head pruning, README.md:21): scores[h] += sum over b, i, d of |out[b, i, h*d : (h+1)*d]|; out [B,q,H*d]. */
 int spatten_head_scores(int dtype, const void* out, int64_t out_sb, int64_t out_sq, float* scores,
                         int batch, int q_len, int heads, int head_dim, void* stream);
@@ -340,6 +347,22 @@ int spatten_attn_prefill_pq(int dtype,
                             int batch, int heads, int kv_heads, int head_dim,
                             int q_len, int kv_len, int pos_q0, int causal,
                             void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Head-parallel exchange: rank r of G owns heads [r*H/G, (r+1)*H/G) and their KV planes; token pruning
+ * needs no communication; the one exchange on the path is the all-gather of the attention outputs [B, q, H/G*d] in
+ * front of o_proj (and, for head pruning, of H/G fp32 head scores).  The library owns an RCCL communicator so that the
+ * collective is a plain stream operation — capturable into the per-token HIP graph — and usable from any host language:
+ *   rank 0: spatten_comm_unique_id(id) ; ship the 128 bytes to every rank out of band (torch.distributed, MPI, a file)
+ *   every rank, after hipSetDevice: spatten_comm_init(&comm, rank, nranks, id)          (collective, blocks)
+ *   per step: spatten_allgather(comm, send, recv, bytes_per_rank, stream)  -> recv[r*bytes .. ) = rank r's send buffer
+ * RCCL is dlopen-ed on first use; SPATTEN_ERR_UNSUPPORTED when librccl is not installed.
+ * ---------------------------------------------------------------------------------------------- */
+#define SPATTEN_COMM_ID_BYTES 128
+int spatten_comm_unique_id(void* id_out /* SPATTEN_COMM_ID_BYTES */);
+int spatten_comm_init(void** comm_out, int rank, int nranks, const void* unique_id);
+int spatten_comm_destroy(void* comm);
+int spatten_allgather(void* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
 
 #ifdef __cplusplus
 }

@@ -314,6 +314,37 @@ def head_prune_cascade(layer_scores: Sequence[np.ndarray], keep: Sequence[int],
     return out
 
 
+def layer_cascade_prune(past, ids, scores, num_coming: int, start: int, recent: int, keeps: Sequence[int]):
+    """Layer-to-layer cascade token pruning at one prune event (README.md:11 "cascade"; the traces' per-layer
+    key_fetch_num shrinks layer by layer, workloads/*.csv columns if_topk / topk; TopK.scala:113-224 ranks, the
+    survivors feed the NEXT layer).  Restated rule, per head:
+      * every layer keeps its first ``start`` rows and its tail ``[L_l - recent + num_coming, L_l)`` like the
+        reference prune (kv_cache_token_pruning.py:72-96);
+      * layer l keeps ``keeps[l]`` rows of its window ``[start, L_l - recent + num_coming)``, ranked by its own
+        importance — but among the tokens layer l-1 just kept (a token pruned by a layer is gone for the layers after
+        it); only when fewer than keeps[l] such tokens are in the window is it filled with the lowest-index others.
+    past[l] = (K, V) [B,H,L_l,d]; ids[l] int [H, L_l] = token id held by each slot (ascending per head);
+    scores[l] [H, L_l].  Returns (new_past, new_ids, idx_per_layer)."""
+    new_past, new_ids, idxs = [], [], []
+    prev = None
+    for l, ((K, V), tid, sc) in enumerate(zip(past, ids, scores)):
+        H, L = sc.shape
+        lo, hi = start, min(L - recent + num_coming, L)
+        rank = sc.astype(np.float32).copy()
+        if prev is not None:
+            for h in range(H):
+                member = np.isin(tid[h], prev[h])
+                rank[h] = np.where(member, rank[h], -np.inf)
+        idx = topk_window(rank, lo, hi, int(keeps[l]))
+        Kn, Vn = kv_compact(K, V, idx, start, hi)
+        nid = np.stack([np.concatenate([tid[h, :start], tid[h, idx[h]], tid[h, hi:L]]) for h in range(H)])
+        new_past.append([Kn, Vn])
+        new_ids.append(nid)
+        idxs.append(idx)
+        prev = nid
+    return new_past, new_ids, idxs
+
+
 def pq_logits(qr: np.ndarray, msb, lsb, scale, threshold: float, lsb_bits: int = 4):
     """The logits a progressive-quant decode step actually uses (pass-1 MSB logits, or the refetched 8-bit logits for
     the rows whose pass-1 max probability is below ``threshold``) and the refetch flags.  qr [B,H,d]; planes [B,H,L,d].

@@ -80,6 +80,8 @@ def _declare(lib):
     lib.spatten_row_lse.argtypes = [i, p, i64, i64, i64, p, i64, i64, p, i, i, i, i, i, p]
     lib.spatten_importance_compact.restype = c_int
     lib.spatten_importance_compact.argtypes = [p, i64, p, i64, p, i64, i, i, i, i, i, p]
+    lib.spatten_cascade_rank.restype = c_int
+    lib.spatten_cascade_rank.argtypes = [i, p, i64, p, i64, p, i64, i, p, i64, i, i, p]
     lib.spatten_head_scores.restype = c_int
     lib.spatten_head_scores.argtypes = [i, p, i64, i64, p, i, i, i, i, p]
     lib.spatten_pv_gather.restype = c_int
@@ -103,6 +105,14 @@ def _declare(lib):
     lib.spatten_attn_prefill_pq.argtypes = [
         i, p, i64, i64, i64, p, p, p, i64, i64, i64, i64, p, i64, i64, p, p, i, p, i64, p, i64, i64, p, i64, i64,
         p, c_float, p, i, i, i, i, i, i, i, i, p]
+    lib.spatten_comm_unique_id.restype = c_int
+    lib.spatten_comm_unique_id.argtypes = [p]
+    lib.spatten_comm_init.restype = c_int
+    lib.spatten_comm_init.argtypes = [POINTER(c_void_p), i, i, p]
+    lib.spatten_comm_destroy.restype = c_int
+    lib.spatten_comm_destroy.argtypes = [p]
+    lib.spatten_allgather.restype = c_int
+    lib.spatten_allgather.argtypes = [p, p, p, c_size_t, p]
     lib.spatten_rope_single.restype = c_int
     lib.spatten_rope_single.argtypes = [i, p, i64, i64, i64, p, i64, i64, i64, p, p, i, p, i64, i,
                                         i, i, i, i, p]

@@ -146,6 +146,27 @@ __global__ __launch_bounds__(256) void pv_gather_kernel(const T* __restrict__ st
   if (tid < D) out[b * out_sb + (int64_t)h * D + tid] = DT<T>::from_f32((s_o[0][tid] + s_o[1][tid]) + (s_o[2][tid] + s_o[3][tid]));
 }
 
+// Layer-to-layer cascade (README.md:11; trace columns if_topk / topk): rank[h, j] = score[h, j] if the token in slot j of
+// this layer is among the tokens the PREVIOUS layer kept for head h, else -inf — the window top-k then picks survivors
+// of the previous layer first.  ids / prev_ids hold token ids, ascending per head: membership = binary search.
+template <typename T>
+__global__ __launch_bounds__(256) void cascade_rank_kernel(const T* __restrict__ score, int64_t score_sh,
+                                                           const int32_t* __restrict__ ids, int64_t ids_sh,
+                                                           const int32_t* __restrict__ prev_ids, int64_t prev_sh, int n_prev,
+                                                           float* __restrict__ rank, int64_t rank_sh, int L) {
+  const int j = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
+  if (j >= L) return;
+  const int32_t want = ids[h * ids_sh + j];
+  const int32_t* pv = prev_ids + h * prev_sh;
+  int lo = 0, hi = n_prev;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (pv[mid] < want) lo = mid + 1; else hi = mid;
+  }
+  const bool member = lo < n_prev && pv[lo] == want;
+  rank[h * rank_sh + j] = member ? DT<T>::to_f32(score[h * score_sh + j]) : -INFINITY;
+}
+
 static inline bool ok_dtype(int dt) { return dt == SPATTEN_F32 || dt == SPATTEN_F16 || dt == SPATTEN_BF16; }
 
 }  // namespace spatten
@@ -192,6 +213,16 @@ extern "C" int spatten_importance_compact(const float* src, int64_t src_sh, floa
   if (Lp == 0) return SPATTEN_OK;
   hipLaunchKernelGGL(importance_compact_kernel, dim3((unsigned)ceil_div(Lp, 256), (unsigned)heads), dim3(256), 0,
                      (hipStream_t)stream, src, src_sh, dst, dst_sh, idx, idx_sh, start, k, tail_lo, Lp);
+  return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+}
+
+extern "C" int spatten_cascade_rank(int dtype, const void* score, int64_t score_sh, const int32_t* ids, int64_t ids_sh,
+                                    const int32_t* prev_ids, int64_t prev_sh, int n_prev, float* rank, int64_t rank_sh,
+                                    int heads, int len, void* stream) {
+  if (!ok_dtype(dtype) || !score || !ids || !prev_ids || !rank || heads <= 0 || len <= 0 || n_prev < 0) return SPATTEN_ERR_INVALID;
+  const dim3 grid((unsigned)ceil_div(len, 256), (unsigned)heads);
+  SPATTEN_BY_DTYPE(dtype, hipLaunchKernelGGL((cascade_rank_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)score,
+                                             score_sh, ids, ids_sh, prev_ids, prev_sh, n_prev, rank, rank_sh, len));
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }
 

@@ -934,7 +934,8 @@ __global__ __launch_bounds__(512, 1) void prefill_colprob_kernel(const ColProbPa
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ki = lane & 31, hi = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z;
   const int hkv = p.Hkv == p.H ? h : h / (p.H / p.Hkv);
-  const int key = blockIdx.x * 256 + wave * 32 + ki;
+  const int kblk = (int)blockIdx.x * 256;          // (int: blockIdx is unsigned, and kblk - P below may be negative)
+  const int key = kblk + wave * 32 + ki;
   const int P = p.N - p.q_len;
   const float rsqrt_d = 1.0f / p.sqrt_d;
   // this lane's key as the B operand: fragment kk = elements [16kk + 8hi, +8) of the key row (zeros past N)
@@ -950,7 +951,7 @@ __global__ __launch_bounds__(512, 1) void prefill_colprob_kernel(const ColProbPa
   const T* qb = p.qrot + b * p.q_sb + h * p.q_sh;
   const float* lb = p.lse + (int64_t)(b * p.H + h) * p.q_len * 2;
   // query tiles that can see any key of this workgroup (causal: row i sees keys j <= P + i)
-  const int first_q = p.causal ? max(0, blockIdx.x * 256 - P) : 0;
+  const int first_q = p.causal ? max(0, kblk - P) : 0;
   const int t_lo = first_q / QT, t_hi = (p.q_len + QT - 1) / QT;
   u32x4 qreg[PIECES];
   f32x2 sreg;
@@ -994,7 +995,7 @@ __global__ __launch_bounds__(512, 1) void prefill_colprob_kernel(const ColProbPa
     for (int blk = 0; blk < QT / 32; ++blk) {
       const int q0 = t * QT + blk * 32;
       if (q0 >= p.q_len) break;
-      if (p.causal && P + q0 + 31 < blockIdx.x * 256 + wave * 32) continue;      // none of these rows sees this wave's keys
+      if (p.causal && P + q0 + 31 < kblk + wave * 32) continue;      // none of these rows sees this wave's keys
       f32x16 c;
 #pragma unroll
       for (int r = 0; r < 16; ++r) c[r] = 0.f;

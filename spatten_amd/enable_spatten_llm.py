@@ -24,7 +24,8 @@ _FAMILIES: Dict[str, Callable] = {"llama": _patch_llama}
 
 
 def enable_spatten_llm(model, start_size, important_size, recent_size, importance_mode="reference",
-                       prefill_stash=True, assume_causal=False, head_keep=None, pq_threshold=None, local_v_keep=None):
+                       prefill_stash=True, assume_causal=False, head_keep=None, pq_threshold=None, local_v_keep=None,
+                       layer_keep=None):
     """The reference's four positional arguments (enable_spatten_llm.py:5) plus opt-in extensions:
 
     ``prefill_stash=False``: forwards with ``q_len > 1`` do not materialise ``self.attn_scores`` ([B,H,q,N]: 4 GiB per
@@ -39,7 +40,8 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     ``importance_mode="cascade"`` (cumulative importance = running sum of softmax probabilities, accumulated inside the
     decode launch), ``head_keep`` (cascade head pruning: int or one int per layer), ``pq_threshold`` (progressive
     quantisation of the keys at decode: MSB plane first, LSB refetch below this max-probability), ``local_v_keep``
-    (local V pruning at decode: fraction of the keys whose V row is fetched)."""
+    (local V pruning at decode: fraction of the keys whose V row is fetched), ``layer_keep`` (layer-to-layer cascade token
+    pruning: one important-token count per layer, non-increasing — the surviving set shrinks through the layers)."""
     model_type = model.config.model_type
     patch = next((fn for key, fn in _FAMILIES.items() if key in model_type), None)
     if patch is None:
@@ -50,7 +52,8 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     from .pos_shift.modify_llama import attention_modules
 
     mods = attention_modules(model)                                # model.modules() order = layer order (:74-77)
-    extended = importance_mode == "cascade" or head_keep is not None or pq_threshold is not None or local_v_keep is not None
+    extended = (importance_mode == "cascade" or head_keep is not None or pq_threshold is not None or local_v_keep is not None
+                or layer_keep is not None)
     for m in mods:
         m.spatten_prefill_stash = bool(prefill_stash)
         m.spatten_assume_causal = bool(assume_causal)
@@ -60,7 +63,7 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
         from .extensions import SpattenExtensions
 
         cache.ext = SpattenExtensions(cache, len(mods), cascade=importance_mode == "cascade", head_keep=head_keep,
-                                      pq_threshold=pq_threshold, local_v_keep=local_v_keep)
+                                      pq_threshold=pq_threshold, local_v_keep=local_v_keep, layer_keep=layer_keep)
         for layer, m in enumerate(mods):
             m._spatten_ext = (cache.ext, layer)
     return cache

@@ -19,6 +19,11 @@ against those restatements.
                                 is below t.
     local_v_keep=f              local V pruning at decode (SpAttenController.scala:546-558,591-612): only the
                                 ceil(f * kv_len) most probable keys of a head fetch their V row.
+    layer_keep=[k_0..k_L-1]     layer-to-layer cascade token pruning (README.md:11; the traces' key_fetch_num shrinks layer
+                                by layer): at a prune event layer l keeps k_l tokens of its window, chosen among the
+                                tokens layer l-1 just kept — the surviving set shrinks through the layers.  Caches of
+                                different layers then have different lengths; every layer rotates with its own
+                                cache-relative positions.
 All modes assume the HF causal mask (a single-token step sees every key), like ``assume_causal=True``.
 """
 from __future__ import annotations
@@ -87,7 +92,7 @@ def _per_layer(x, n_layers: int, name: str):
 class SpattenExtensions:
     def __init__(self, cache, n_layers: int, cascade: bool = False,
                  head_keep: Union[None, int, Sequence[int]] = None, pq_threshold: Optional[float] = None,
-                 local_v_keep: Optional[float] = None):
+                 local_v_keep: Optional[float] = None, layer_keep: Optional[Sequence[int]] = None):
         if pq_threshold is not None and local_v_keep is not None:
             raise ValueError("pq_threshold and local_v_keep cannot be combined (the local-V pass scores from the bf16 shadow)")
         if local_v_keep is not None and not (0.0 < float(local_v_keep) <= 1.0):
@@ -100,8 +105,16 @@ class SpattenExtensions:
             raise ValueError("head_keep must not grow from layer to layer (a pruned head stays pruned in later layers)")
         self.pq_threshold = None if pq_threshold is None else float(pq_threshold)
         self.local_v_keep = None if local_v_keep is None else float(local_v_keep)
+        self.layer_keep = None if layer_keep is None else [int(x) for x in _per_layer(list(layer_keep), n_layers, "layer_keep")]
+        if self.layer_keep is not None:
+            if any(b > a for a, b in zip(self.layer_keep, self.layer_keep[1:])) or min(self.layer_keep) <= 0:
+                raise ValueError("layer_keep must be positive and must not grow from layer to layer")
+            if self.layer_keep[0] > cache.important_size:
+                raise ValueError("layer_keep[0] exceeds important_size")
         self.layers = [LayerState() for _ in range(n_layers)]
-        self.n_lsb_refetch = 0          # diagnostics: filled by stats()
+        # layer cascade: token id held by every cache slot, per layer and head (int32 [H, len]); ids grow with time
+        self.tok_ids: List[Optional[torch.Tensor]] = [None] * n_layers
+        self.next_token_id = 0
 
     # ------------------------------------------------------------------------------------------------
     # attention forward, q_len == 1
@@ -237,6 +250,25 @@ class SpattenExtensions:
         if st.acc is not None:
             st.acc = ops.importance_compact(st.acc, idx, start, tail_lo, seq_len, st.acc.shape[1])
         st.pending_len = 0
+
+    # ------------------------------------------------------------------------------------------------
+    # layer-to-layer cascade: token ids follow the rows through prunes
+    # ------------------------------------------------------------------------------------------------
+    def token_ids(self, layer: int, heads: int, length: int, device) -> torch.Tensor:
+        """int32 [H, length]: the ids of the slots already known (after the last prune) + fresh ids for the rows
+        appended since (the same tokens in every layer, so the same ids)."""
+        known = self.tok_ids[layer]
+        n_known = 0 if known is None else known.shape[1]
+        if layer == 0:
+            self._append_base = self.next_token_id          # ids of the rows appended since the last prune start here
+            self._append_count = length - n_known
+        n_new = length - n_known
+        fresh = (torch.arange(n_new, dtype=torch.int32, device=device) + self._append_base)[None, :].expand(heads, n_new)
+        return fresh.contiguous() if known is None else torch.cat([known, fresh], dim=1)
+
+    def after_layer_cascade(self, new_ids: List[torch.Tensor]):
+        self.tok_ids = list(new_ids)
+        self.next_token_id = self._append_base + self._append_count
 
     def stats(self):
         """Host-readable summary (synchronises): kept heads per layer, LSB refetches of the last step."""

@@ -94,6 +94,8 @@ class SpAttenKVCache:
         ops.check_workspaces()              # a natural sync point: surface a device-side merge timeout, if any
         if self.ext is not None:
             self.ext.before_prune()         # fold the pending decode step, pick the heads that survive
+        if self.ext is not None and self.ext.layer_keep is not None:
+            return self._prune_layer_cascade(past_key_values, num_coming, attn_score_all)
         if self.importance_mode == "cascade":
             return self._prune_cascade(past_key_values, seq_len, num_coming, lo, hi, new_len)
         if len(attn_score_all) != n_layers:
@@ -152,6 +154,55 @@ class SpAttenKVCache:
             idxs.append(idx)
         self.keep_indices = torch.stack(idxs)
         self.n_pruned_last = seq_len - new_len
+        self.n_pruned_total += self.n_pruned_last
+        return out
+
+
+    def _prune_layer_cascade(self, past_key_values, num_coming, attn_score_all):
+        """Layer-to-layer cascade (extension, parity unpinned; oracle: layer_cascade_prune): layer l keeps layer_keep[l]
+        window tokens, chosen among the tokens layer l-1 just kept; layers end up with different cache lengths."""
+        ext = self.ext
+        out, idxs = [], []
+        self.importance_score = []
+        prev_ids = None
+        new_ids = []
+        pruned = 0
+        for layer, (K, V) in enumerate(past_key_values):
+            K, V = _rows(K), _rows(V)
+            if V.stride() != K.stride():
+                K, V = K.contiguous(), V.contiguous()
+            B, H, L, d = K.shape
+            k_l = ext.layer_keep[layer]
+            hi = min(L - self.recent_size + num_coming, L)
+            if hi - self.start_size < k_l:
+                raise ValueError(f"layer {layer}: top-k window [{self.start_size},{hi}) holds fewer than {k_l} candidates")
+            new_len = self.start_size + k_l + (L - hi)
+            if self.importance_mode == "cascade":
+                score = ext.layers[layer].acc[:, :L]
+            else:
+                score = ops.importance(attn_score_all[layer])[:, :L]
+            if score.stride(1) != 1:
+                score = score.contiguous()
+            self.importance_score.append(score)
+            ids = ext.token_ids(layer, H, L, K.device)
+            rank = score if prev_ids is None else ops.cascade_rank(score, ids, prev_ids)
+            idx = ops.topk_select(rank, self.start_size, hi, k_l)
+            base, scaling = _rope_of(past_key_values[layer:layer + 1])
+            cap = kv_slab.round_capacity(new_len + max(int(num_coming), 0))
+            rope = kv_slab.rope_tables(cap, d, K.dtype, K.device, base, scaling)
+            k, v, kr = ops.kv_compact(K, V, idx, self.start_size, hi, L=L, capacity=cap, rope=rope)
+            if self.importance_mode == "cascade":
+                ext.compact_importance(layer, idx, self.start_size, hi, L)
+            ext.layers[layer].pending_len = 0
+            prev_ids = ops.gather_rows_i32(ids, idx, self.start_size, hi, L)
+            new_ids.append(prev_ids)
+            kv_slab.attach(k, v, kr, new_len, base, scaling)
+            out.append([k, v])
+            idxs.append(idx)
+            pruned += L - new_len
+        ext.after_layer_cascade(new_ids)
+        self.keep_indices = idxs                      # a list: the layers keep different numbers of tokens
+        self.n_pruned_last = pruned // max(len(out), 1)
         self.n_pruned_total += self.n_pruned_last
         return out
 

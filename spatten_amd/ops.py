@@ -559,6 +559,37 @@ def importance_compact(acc: torch.Tensor, idx: torch.Tensor, start: int, tail_lo
     return dst
 
 
+def cascade_rank(score: torch.Tensor, ids: torch.Tensor, prev_ids: torch.Tensor) -> torch.Tensor:
+    """rank [H, L] fp32 = score where the slot's token id is among ``prev_ids`` [H, n_prev] (ascending), else -inf —
+    the layer-to-layer cascade's candidate filter (include/spatten.h: spatten_cascade_rank)."""
+    _dev(score, ids, prev_ids)
+    H, L = score.shape
+    if score.stride(1) != 1 or ids.stride(1) != 1 or prev_ids.stride(1) != 1 or ids.dtype != torch.int32 or prev_ids.dtype != torch.int32:
+        raise ValueError("score / ids / prev_ids need contiguous rows; ids are int32")
+    rank = torch.empty(H, L, dtype=torch.float32, device=score.device)
+    rc = _lib.load().spatten_cascade_rank(_dt(score), score.data_ptr(), score.stride(0), ids.data_ptr(), ids.stride(0),
+                                          prev_ids.data_ptr(), prev_ids.stride(0), prev_ids.shape[1], rank.data_ptr(),
+                                          rank.stride(0), H, L, _stream())
+    _lib.check(rc, "spatten_cascade_rank")
+    return rank
+
+
+def gather_rows_i32(src: torch.Tensor, idx: torch.Tensor, start: int, tail_lo: int, L: int) -> torch.Tensor:
+    """int32 [H, L] -> [H, L'] with the prune's row map (start | idx | tail): the token ids follow the cache."""
+    H = src.shape[0]
+    k = idx.shape[1]
+    tail_lo = min(max(tail_lo, 0), L)
+    Lp = start + k + (L - tail_lo)
+    dst = torch.empty(H, Lp, dtype=torch.int32, device=src.device)
+    if src.stride(1) != 1:
+        src = src.contiguous()
+    # a pure 4-byte row gather: the fp32 accumulator's compaction kernel moves the bits unchanged
+    rc = _lib.load().spatten_importance_compact(src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0),
+                                                idx.data_ptr(), idx.stride(0), H, start, k, tail_lo, L - tail_lo, _stream())
+    _lib.check(rc, "spatten_importance_compact")
+    return dst
+
+
 def head_scores(out: torch.Tensor, heads: int, scores: Optional[torch.Tensor] = None) -> torch.Tensor:
     """scores[h] += sum |out[b, i, h*d:(h+1)*d]|; out [B,q,H*d] (or [B,H*d]); scores fp32 [H] (zeros when None)."""
     _dev(out, scores)

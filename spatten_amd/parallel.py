@@ -82,6 +82,45 @@ class HeadParallel:
             return None, _Pending(work, merge)
         return merge(), None
 
+    # ---- the library-owned RCCL communicator (include/spatten.h: spatten_comm_*) -----------------------------------
+    def init_native(self):
+        """Create the C-ABI communicator for this rank's CURRENT device.  The 128-byte id is made on rank 0 and shipped
+        through torch.distributed (any backend); with a single rank no process group is needed.  Collective."""
+        import ctypes
+
+        from . import _lib
+        lib = _lib.load()
+        ident = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.check(lib.spatten_comm_unique_id(ident), "spatten_comm_unique_id")
+        if self.world > 1:
+            box = [ident.raw if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=self.group)
+            ident = ctypes.create_string_buffer(box[0], 128)
+        comm = ctypes.c_void_p()
+        _lib.check(lib.spatten_comm_init(ctypes.byref(comm), self.rank, self.world, ident), "spatten_comm_init")
+        self._comm = comm
+        return self
+
+    def allgather_native(self, send: torch.Tensor, recv: torch.Tensor):
+        """recv[r * n : (r + 1) * n] = rank r's ``send`` (n = send.numel()), on the current stream: an ordinary stream
+        operation, so it may be captured into a HIP graph with the attention launches around it."""
+        from . import _lib
+        if getattr(self, "_comm", None) is None:
+            raise RuntimeError("init_native() first")
+        if not (send.is_contiguous() and recv.is_contiguous()) or recv.numel() != self.world * send.numel() or recv.dtype != send.dtype:
+            raise ValueError("send / recv must be contiguous, recv = world x send")
+        rc = _lib.load().spatten_allgather(self._comm, send.data_ptr(), recv.data_ptr(), send.numel() * send.element_size(),
+                                           torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "spatten_allgather")
+        return recv
+
+    def close_native(self):
+        from . import _lib
+        if getattr(self, "_comm", None) is not None:
+            _lib.load().spatten_comm_destroy(self._comm)
+            self._comm = None
+
     def gather_head_scores(self, local_scores: torch.Tensor) -> torch.Tensor:
         """[H/G] fp32 -> [H] on every rank (head pruning: every rank then runs the same top-k)."""
         if self.world == 1:

@@ -111,7 +111,12 @@ def llama_pos_shift_attention_forward(
     kv_seq_len = past_len + q_len
     ext = getattr(self, "_spatten_ext", None)         # (SpattenExtensions, layer index) — opt-in SpAtten semantics
     assume_causal = bool(getattr(self, "spatten_assume_causal", False)) or ext is not None
-    if attention_mask is not None and attention_mask.size() != (bsz, 1, q_len, kv_seq_len):   # :127-131
+    if ext is not None and ext[0].layer_keep is not None:
+        # layer-to-layer cascade: the layers' caches have different lengths, HF sizes its mask / positions for layer 0 —
+        # every layer uses the causal rule and its own cache-relative positions instead
+        attention_mask = None if q_len == 1 else attention_mask[..., :0]
+        position_ids = None
+    if attention_mask is not None and attention_mask.numel() and attention_mask.size() != (bsz, 1, q_len, kv_seq_len):   # :127-131
         raise ValueError(
             f"Attention mask should be of size {(bsz, 1, q_len, kv_seq_len)}, but is {attention_mask.size()}")
 

@@ -316,3 +316,68 @@ def test_multi_turn_protocol_extension_modes(mode):
     assert kv_cache.n_pruned_total > 0
     if "head" in mode:
         assert all(k is not None and len(k) == 3 for k in ref.kept)
+
+
+def test_multi_turn_protocol_layer_cascade():
+    """Layer-to-layer cascade token pruning through the plugin (enable_spatten_llm(layer_keep=[...])): the token set
+    shrinks from layer to layer, the caches of the layers get different lengths, every layer rotates with its own
+    cache-relative positions.  GPU vs the oracle's restatement (PARITY UNPINNED), multi-turn, fp32."""
+    from spatten_amd import enable_spatten_llm
+    torch.manual_seed(5)
+    model = TinyLlama().cuda().float()
+    for p in model.parameters():
+        p.data.mul_(0.6)
+    keeps = [IMPORTANT, IMPORTANT - 8]
+    ref = NumpyReplica(model)
+    kv_cache = enable_spatten_llm(model, START, IMPORTANT, RECENT, layer_keep=keeps)
+    attn_modules = [m for m in model.modules() if type(m).__name__ == "LlamaAttention"]
+
+    def ref_forward(ids, past):
+        """The replica with PER-LAYER cache lengths (positions / causal mask relative to each layer's own cache)."""
+        B, q = ids.shape
+        x = ref.emb[ids]
+        new_past = []
+        sp = lambda t: np.swapaxes(t.reshape(B, q, H, D), 1, 2)
+        for i, w in enumerate(ref.w):
+            P = 0 if past is None else past[i][0].shape[2]
+            pos = np.tile(np.arange(P, P + q)[None], (B, 1))
+            o, stash, kv = orc.attention_core(sp(x @ w["q_proj"].T), sp(x @ w["k_proj"].T), sp(x @ w["v_proj"].T),
+                                              None if past is None else past[i][0], None if past is None else past[i][1],
+                                              pos, orc.causal_mask(B, q, P + q, "f32"), "f32")
+            ref.stash[i] = stash
+            x = x + o @ w["o_proj"].T
+            new_past.append(kv)
+        return x @ ref.lm.T, new_past
+
+    rng = np.random.default_rng(6)
+    prompts = [rng.integers(0, VOCAB, size=n)[None] for n in (40, 24, 28, 16)]
+    past_g = past_r = None
+    ids_r, next_id = None, 0
+    for turn, prompt in enumerate(prompts):
+        if turn > 0:
+            space_needed = prompt.shape[1] + MAX_GEN
+            scores = [m.attn_scores for m in attn_modules]
+            lens_before = [kv[0].shape[2] for kv in past_r]
+            past_g = kv_cache.apply_token_pruning(past_g, space_needed, scores)
+            # token ids on the replica side: known ids + fresh ones for the rows appended since the last prune
+            n_new = lens_before[0] - (0 if ids_r is None else ids_r[0].shape[1])
+            fresh = np.tile(np.arange(next_id, next_id + n_new, dtype=np.int32)[None], (H, 1))
+            ids_now = [fresh if ids_r is None else np.concatenate([ids_r[i], fresh], 1) for i in range(L)]
+            next_id += n_new
+            imp = [orc.importance(ref.stash[i], "f32") for i in range(L)]
+            past_r, ids_r, idxs = orc.layer_cascade_prune(past_r, ids_now, imp, space_needed, START, RECENT, keeps)
+            for i in range(L):
+                assert np.array_equal(kv_cache.keep_indices[i].cpu().numpy(), idxs[i]), f"turn {turn} layer {i}"
+                assert past_g[i][0].shape[2] == past_r[i][0].shape[2] == START + keeps[i] + (lens_before[i] - min(lens_before[i] - RECENT + space_needed, lens_before[i]))
+                np.testing.assert_allclose(past_g[i][0].cpu().numpy(), past_r[i][0], atol=1e-5, rtol=1e-5)
+                assert np.array_equal(kv_cache.ext.tok_ids[i].cpu().numpy(), ids_r[i])
+            # nesting: what layer 1 kept of its window is a subset of what layer 0 kept (per head)
+            for h in range(H):
+                assert set(ids_r[1][h].tolist()) <= set(ids_r[0][h].tolist())
+            assert past_g[1][0].shape[2] < past_g[0][0].shape[2]
+        tg, past_g, lg_ = greedy(lambda i, p: model(i, p), torch.from_numpy(prompt).cuda(), past_g,
+                                 lambda a: torch.tensor(a, device="cuda"))
+        tr, past_r, lr_ = greedy(ref_forward, prompt, past_r, lambda a: np.asarray(a))
+        assert tg == tr, f"turn {turn}: generated tokens differ {tg} vs {tr}"
+        np.testing.assert_allclose(lg_.cpu().numpy(), lr_, atol=5e-4, rtol=5e-4)
+    assert kv_cache.n_pruned_total > 0
