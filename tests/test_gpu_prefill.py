@@ -298,3 +298,46 @@ def test_enable_patches_every_llama_attention_and_rejects_others():
         assert layer.self_attn.forward.__func__ is llama_pos_shift_attention_forward
     with pytest.raises(ValueError, match="got gpt2"):
         enable_spatten_llm(Model("gpt2"), 4, 10, 12)
+
+
+def test_rope_base_of_the_module_survives_the_prune():
+    """Round-1 advisor finding: the prune rebuilt the rotated shadow with base 10000 whatever the model's rotary base is
+    (CodeLlama: rope_theta 1e6).  prefill -> decode -> prune -> decode on a module with base 1e6, every step vs the oracle
+    run with the same base; and a cache that lost its slab is re-rotated (counted, warned about), not mis-rotated."""
+    import warnings
+    from spatten_amd import SpAttenKVCache, kv_slab
+    dt, B, H, d, ql = "f32", 1, 4, 64, 40
+    base = 1.0e6
+    m = StubAttn(H, H, d)
+    m.rotary_emb = SimpleNamespace(base=base)
+    q, k, v, _ = attn_inputs(B, H, H, d, 0, ql, dt, 71)
+    pos = torch.arange(0, ql, device="cuda")[None]
+    mask = dev(orc.causal_mask(B, ql, ql, dt), dt)
+    out, _, past = fwd(m, q, k, v, None, pos, mask, dt)
+    o_ref, st_ref, (pk, pv) = orc.attention_core(q, k, v, None, None, np.arange(ql)[None], orc.causal_mask(B, ql, ql, dt), dt, base=base)
+    np.testing.assert_allclose(host(out), o_ref, **OUT_TOL[dt])
+    assert past[0]._spatten_slab.base == base
+
+    def step(past_g, past_r, seed):
+        P = past_r[0].shape[2]
+        q1, k1, v1, _ = attn_inputs(B, H, H, d, 0, 1, dt, seed)
+        og, _, new_g = fwd(m, q1, k1, v1, past_g, torch.full((B, 1), P, device="cuda"), torch.zeros(B, 1, 1, P + 1, device="cuda"), dt)
+        orf, st, new_r = orc.attention_core(q1, k1, v1, past_r[0], past_r[1], np.full((B, 1), P), None, dt, base=base)
+        np.testing.assert_allclose(host(og), orf, **OUT_TOL[dt])
+        check_stash(host(m.attn_scores), st, dt)
+        return new_g, new_r, st
+
+    past_g, past_r, st = step(past, (pk, pv), 72)
+    cache = SpAttenKVCache(4, 8, 12)
+    past_g = cache.apply_token_pruning([past_g], 6, [m.attn_scores])[0]
+    new_r, _ = orc.apply_token_pruning([past_r], 6, [st], 4, 8, 12, dt)
+    assert past_g[0]._spatten_slab.base == base                     # the table parameters travel with the slab
+    assert np.array_equal(host(past_g[0]), new_r[0][0])
+    past_g, past_r, _ = step(tuple(past_g), tuple(new_r[0]), 73)     # wrong tables in the shadow would show here
+    # a cache that lost its slab: correct result, one counted re-copy, one warning
+    before = kv_slab.recopy_events
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        step((past_g[0].clone(), past_g[1].clone()), past_r, 74)
+    assert kv_slab.recopy_events == before + 1
+    assert before > 0 or any("without their KV slab" in str(x.message) for x in w)
