@@ -115,6 +115,12 @@ struct FlashParams {
   float sqrt_d;
 };
 
+// A/B switch (tools/mb/pf_exp.sh): row sums of P on the matrix pipe instead of 64 VALU adds per lane and tile.
+// MEASURED SLOWER (713 vs 768 TFLOP/s at q = N = 8192): the 8 extra MFMAs per tile cost more than the adds they
+// replace — the matrix pipe has less slack than its 50 % busy counter suggests.  Off.
+#ifndef SPATTEN_PF_ROWSUM_MFMA
+#define SPATTEN_PF_ROWSUM_MFMA 0
+#endif
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kDeferMax = 8.0f;   // natural-log units of the scaled logits
 
@@ -639,6 +645,16 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  // Row sums on the MATRIX pipe (SPATTEN_PF_ROWSUM_MFMA): O^T = Vt . P^T gets one more 32-row block whose row 0 is all
+  // ones — an A operand that lives in registers — so accumulator register 0 of lanes 0-31 IS sum_keys P for the lane's
+  // query.  8 extra MFMAs per 128-key tile (the matrix pipe has the slack) replace 64 VALU adds per lane (the vector
+  // phase is the pole), and the sum is taken over the SAME rounded P that multiplies V.
+  f32x16 osum;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) osum[r] = 0.f;
+  frag ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = DT<T>::from_f32(qi == 0 ? 1.f : 0.f);
   float m_true = -INFINITY;   // PQK == 1: the row's TRUE running maximum (m_run may lag it: deferred rescale)
 
   const int wg_q_end = min(p.q_len, qblk * 256 + 256);
@@ -744,6 +760,9 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
       const int db = i % DB, kt = i / DB;
       o[db] = Mfma<T>::mma(a[i % RING], pf[kt >> 1][kt & 1], o[db]);
       if (i + RING < 2 * NKB * DB) a[i % RING] = vfrag(i + RING);
+#if SPATTEN_PF_ROWSUM_MFMA
+      if (db == DB - 1) osum = Mfma<T>::mma(ones, pf[kt >> 1][kt & 1], osum);
+#endif
     }
     __builtin_amdgcn_sched_group_barrier(0x100, RING, 0);
 #pragma unroll
@@ -751,7 +770,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, RING, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, RING + (SPATTEN_PF_ROWSUM_MFMA ? 2 * NKB : 0), 0);
   };
 
   auto softmax_tile = [&](int tile) {
@@ -829,12 +848,15 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], kLog2e, -m2));
+#if !SPATTEN_PF_ROWSUM_MFMA
           ls[e & 3] += pvv;
+#endif
           pf[kb][t][e] = DT<T>::from_f32(pvv);
         }
     if (m_new != m_run) {
       const float alpha = __expf(m_run - m_base);
       l_run *= alpha;
+      osum[0] *= alpha;
 #pragma unroll
       for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -878,7 +900,11 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   if (grp == 0) __syncthreads();
 
   // ---- epilogue: O = O^T / l, 4 consecutive dv per 8-byte store ---------------------------------
+#if SPATTEN_PF_ROWSUM_MFMA
+  const float l_tot = xor32_sum(hi == 0 ? osum[0] : 0.f);     // register 0 of lanes 0-31 = row 0 of the ones block
+#else
   const float l_tot = xor32_sum(l_run);
+#endif
   const float inv = 1.f / l_tot;
   if (p.lse != nullptr && qvalid && hi == 0) {
     float* ls = p.lse + ((int64_t)(b * p.H + h) * p.q_len + myq) * 2;

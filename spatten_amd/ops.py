@@ -99,8 +99,8 @@ class DecodeWorkspace:
 _ws_cache = _LRU(16)
 
 
-def _workspace(batch, heads, head_dim, device) -> DecodeWorkspace:
-    key = (batch, heads, head_dim, str(device), torch.cuda.current_stream().cuda_stream)
+def _workspace(batch, heads, head_dim, device, stream: Optional[int] = None) -> DecodeWorkspace:
+    key = (batch, heads, head_dim, device, _stream() if stream is None else stream)
     ws = _ws_cache.get(key)
     if ws is None:
         ws = _ws_cache.put(key, DecodeWorkspace(batch, heads, head_dim, device))
@@ -162,7 +162,8 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: Opti
         raise ValueError("k_new/v_new need contiguous rows")
     if mask is not None and mask.stride(-1) != 1:
         raise ValueError("mask rows must be contiguous")
-    ws = workspace or _workspace(B, H, d, q.device)
+    stream = _stream()
+    ws = workspace or _workspace(B, H, d, q.device, stream)
     if n_splits > ws.max_splits:
         raise ValueError("n_splits exceeds workspace")
     if head_ids is not None and (head_ids.dtype != torch.int32 or not head_ids.is_cuda or head_ids.dim() != 1):
@@ -209,7 +210,7 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: Opti
         a.pq_pl_sb, a.pq_pl_sh = planes.msb.stride(0), planes.msb.stride(1)
         a.pq_sc_sb, a.pq_sc_sh = planes.scale.stride(0), planes.scale.stride(1)
         a.pq_threshold, a.pq_need_lsb = float(threshold), need_lsb.data_ptr()
-    _lib.check(lib.spatten_attn_decode_args(ctypes.byref(a), _stream()), "spatten_attn_decode")
+    _lib.check(lib.spatten_attn_decode_args(ctypes.byref(a), stream), "spatten_attn_decode")
     return out
 
 
