@@ -7,7 +7,10 @@ step's stashed scores, prefill the prompt, greedy-decode ``max_gen_len`` tokens}
 "N pruned token this round" counters.
 
     python run_spatten_synthetic.py --layers 8 --turns 5
-    python run_spatten_synthetic.py --trace tests/golden/trace_synthetic.csv --kv-len 4096     # cascade schedule demo
+    python run_spatten_synthetic.py --layers 8 --cascade --head-keep 24 --pq-threshold 0.05     # SpAtten modes, through the plugin
+    python run_spatten_synthetic.py --layers 12 --schedule tests/golden/trace_synthetic.csv      # per-layer keeps from a trace
+    python run_spatten_synthetic.py --prompts tests/golden/mt_bench_sample.jsonl                 # MT-Bench turn structure
+    python run_spatten_synthetic.py --trace tests/golden/trace_synthetic.csv --kv-len 4096     # cascade schedule demo, one K/V pair
 
 ``--trace`` reads a schedule in the format of the reference's ``spatten_hardware/hardware/workloads/*.csv``
 (spatten_amd/traces.py) and applies its per-layer token / local-V / head keep ratios and requant threshold to one
@@ -90,13 +93,48 @@ def chat(args):
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     torch.manual_seed(0)
     model = SyntheticLlama(args.layers, args.heads, args.head_dim, args.vocab, dt).cuda()
-    kv_cache = enable_spatten_llm(model, args.start_size, args.important_size, args.recent_size)     # :110-115
+    ext = {}
+    if args.cascade:
+        ext["importance_mode"] = "cascade"
+    if args.head_keep:
+        ext["head_keep"] = args.head_keep
+    if args.pq_threshold is not None:
+        ext["pq_threshold"] = args.pq_threshold
+    if args.local_v_keep is not None:
+        ext["local_v_keep"] = args.local_v_keep
+    if args.schedule:
+        # per-layer schedule in the reference's workloads/*.csv format (spatten_amd/traces.py): the token keep ratios
+        # become layer_keep (layer-to-layer cascade), the head ratios head_keep, the requant threshold pq_threshold
+        from spatten_amd.traces import read_trace
+        fr = read_trace(args.schedule).fractions(0)
+        fr = [fr[min(i * len(fr) // args.layers, len(fr) - 1)] for i in range(args.layers)]      # stretch to our depth
+        top = max(f["token_keep"] for f in fr)
+        keeps, heads = [], []
+        for f in fr:
+            keeps.append(max(8, min(args.important_size, int(round(args.important_size * f["token_keep"] / top)))))
+            heads.append(max(1, int(round(args.heads * f["head_keep"]))))
+        ext["layer_keep"] = [min(keeps[:i + 1]) for i in range(len(keeps))]
+        if min(heads) < args.heads:
+            ext["head_keep"] = [min(heads[:i + 1]) for i in range(len(heads))]
+        thr = [f["requant_threshold"] for f in fr if f["requant_threshold"] is not None]
+        if thr and args.pq_threshold is None and args.local_v_keep is None:
+            ext["pq_threshold"] = float(thr[0])
+        print("schedule:", {k: v for k, v in ext.items()})
+    kv_cache = enable_spatten_llm(model, args.start_size, args.important_size, args.recent_size, **ext)     # :110-115
     attn = [m for m in model.modules() if type(m).__name__ == "LlamaAttention"]
     gen = torch.Generator(device="cuda").manual_seed(1)
+    prompts = None
+    if args.prompts:                       # MT-Bench question.jsonl: the turn structure of the reference's demo (:104-107);
+        from spatten_amd.utils import load_mt_bench_prompts       # no tokenizer here: one id per whitespace token
+        prompts = [[hash(w) % args.vocab for w in t.split()] or [0] for t in load_mt_bench_prompts(args.prompts)]
     past, cumulative = None, 0
-    for idx in range(args.turns):
-        plen = int(torch.randint(args.prompt_len // 2, args.prompt_len + 1, (1,)).item())
-        input_ids = torch.randint(0, args.vocab, (1, plen), device="cuda", generator=gen)
+    for idx in range(len(prompts) if prompts else args.turns):
+        if prompts:
+            input_ids = torch.tensor([prompts[idx]], device="cuda")
+            plen = input_ids.shape[1]
+        else:
+            plen = int(torch.randint(args.prompt_len // 2, args.prompt_len + 1, (1,)).item())
+            input_ids = torch.randint(0, args.vocab, (1, plen), device="cuda", generator=gen)
         print(f"\nUSER: <{plen} synthetic tokens>\n\nASSISTANT: ", end="")
         if past is not None:                                                                          # :71-83
             space_needed = plen + args.max_gen_len
@@ -111,7 +149,10 @@ def chat(args):
         past, n = greedy_generate(model, input_ids, past, args.max_gen_len)
         torch.cuda.synchronize()
         dtm = time.perf_counter() - t0
-        print(f"<{n} tokens> kv_len={past[0][0].size(2)}  ({(plen + n) / dtm:.0f} tok/s incl. prefill, {args.layers} layers)")
+        lens = sorted({kv[0].size(2) for kv in past})
+        print(f"<{n} tokens> kv_len={lens[0] if len(lens) == 1 else lens}  ({(plen + n) / dtm:.0f} tok/s incl. prefill, {args.layers} layers)")
+    if kv_cache.ext is not None:
+        print("extensions:", kv_cache.ext.stats())
 
 
 def cascade(args):
@@ -178,6 +219,12 @@ def main():
     ap.add_argument("--start_size", type=int, default=0)            # the reference's demo defaults, :134-136
     ap.add_argument("--important_size", type=int, default=150)
     ap.add_argument("--recent_size", type=int, default=150)
+    ap.add_argument("--cascade", action="store_true", help="importance_mode='cascade' (cumulative softmax probabilities)")
+    ap.add_argument("--head-keep", type=int, default=0, help="cascade head pruning: heads kept per layer")
+    ap.add_argument("--pq-threshold", type=float, default=None, help="progressive quantisation: LSB refetch below this max prob")
+    ap.add_argument("--local-v-keep", type=float, default=None, help="local V pruning: fraction of V rows fetched at decode")
+    ap.add_argument("--schedule", default=None, help="per-layer keeps (layer cascade / heads / requant) from a trace CSV")
+    ap.add_argument("--prompts", default=None, help="MT-Bench style question.jsonl: its turns drive the chat loop")
     ap.add_argument("--trace", default=None, help="cascade schedule CSV (format of the reference's workloads/*.csv)")
     ap.add_argument("--kv-len", type=int, default=4096)
     ap.add_argument("--pq", action="store_true", help="--trace: use progressive-quant keys where the trace requants")

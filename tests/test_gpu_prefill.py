@@ -341,3 +341,30 @@ def test_rope_base_of_the_module_survives_the_prune():
         step((past_g[0].clone(), past_g[1].clone()), past_r, 74)
     assert kv_slab.recopy_events == before + 1
     assert before > 0 or any("without their KV slab" in str(x.message) for x in w)
+
+
+def test_fp32_rows_leg_slices_long_blocks():
+    """Round-1 advisor finding: the exact fp32 leg launched one grid-z entry per query row and failed beyond 65535 rows
+    (B * q_len).  It now runs in slices of <= 4096 rows; a block longer than one slice (stash, row statistics and causal
+    visibility of the later slices included) vs a direct fp32 evaluation on the device."""
+    from spatten_amd import ops
+    B, H, d, P, ql = 1, 2, 64, 300, 4200
+    N = P + ql
+    g = torch.Generator(device="cuda").manual_seed(3)
+    Q = torch.randn(B, H, ql, d, device="cuda", generator=g)
+    K = torch.randn(B, H, N, d, device="cuda", generator=g)
+    V = torch.randn(B, H, N, d, device="cuda", generator=g)
+    cos, sin = ops.rope_table(N, d, torch.float32, "cuda")
+    Kr = ops.rope_single(K, cos, sin)
+    Qr = ops.rope_single(Q, cos, sin, pos0=P)
+    stash = torch.empty(B, H, ql, N, device="cuda")
+    lse = torch.empty(B, H, ql, 2, device="cuda")
+    out = ops.attn_prefill(Q, Kr, V, N, cos, sin, P, causal=True, scores=stash, lse=lse)
+    s = (Qr @ Kr.transpose(2, 3)) / d ** 0.5
+    assert torch.allclose(stash, s, atol=2e-5, rtol=1e-5)                       # the stash is pre-mask: all N columns
+    vis = torch.arange(N, device="cuda")[None, :] <= (P + torch.arange(ql, device="cuda"))[:, None]
+    sm = s.masked_fill(~vis, float("-inf"))
+    want = (torch.softmax(sm, -1) @ V).transpose(1, 2).reshape(B, ql, H * d)
+    assert torch.allclose(out, want, atol=2e-5, rtol=1e-4)
+    p_from_lse = torch.exp(sm[0, 1, 4150] - lse[0, 1, 4150, 0]) / lse[0, 1, 4150, 1]     # a row of the second slice
+    assert torch.allclose(p_from_lse, torch.softmax(sm[0, 1, 4150], -1), atol=1e-6, rtol=1e-4)
