@@ -150,10 +150,6 @@ __global__ __launch_bounds__(kSelThreads) void topk_select_kernel(const SelectPa
 // fused gather + concat of K and V, all layers
 // ================================================================================================
 constexpr int kCompThreads = 256;
-#ifndef SPATTEN_COMP_UNROLL
-#define SPATTEN_COMP_UNROLL 4
-#endif
-constexpr int kCompUnroll = SPATTEN_COMP_UNROLL;
 
 struct CompactParams {
   const void* k_src; const void* v_src; void* k_dst; void* v_dst; void* kr_dst;   // single layer, or
@@ -166,96 +162,78 @@ struct CompactParams {
   int start, k, tail_lo, Lp;                // Lp = start + k + tail_len
   int ppr;                                  // 16-byte pieces per row
   int row_bytes;
-  long long pieces_per_tensor;              // work items per plane: B*H*Lp*(ppr/2) piece pairs
-  long long total;                          // pieces_per_tensor * n_tensors * layers
+  int hp_shift;                             // log2(ppr / 2) when that is a power of two, else -1
+  int rows_per_block;                       // kCompThreads / (ppr / 2)
 };
 
 // One work item = the PAIR of 16-byte pieces (pc, pc + ppr/2) of one destination row — the two halves RoPE
 // pairs up — so the optional rotated-shadow output (row r of the new cache rotated at its NEW slot index r,
 // modify_llama.py:103-104) is produced in registers by the lane that moves the row: the shadow is rebuilt by
 // the same pass that moves the rows, and every lane of a wave does the same amount of work.
+// Grid = (row blocks, B*H, layers * planes): everything a lane needs beyond its row and piece is wave-uniform (scalar
+// ALU), and row / piece come out of the thread index by shift and mask — r02: the first version decoded a flat work
+// index with four integer divisions per 32 bytes moved and was bound by that arithmetic, not by HBM; one item per lane
+// (no unrolling: the registers buy occupancy, which a pure gather needs more than ILP) measured 500 vs 542 us.
 template <typename T>
 __global__ __launch_bounds__(kCompThreads) void kv_compact_kernel(const CompactParams p) {
-  const long long g0 = (long long)blockIdx.x * (kCompThreads * kCompUnroll) + threadIdx.x;
-  const int half_ppr = p.ppr / 2;
-  const int half_bytes = p.row_bytes / 2;
-  const bool want_kr = (p.kr_dst != nullptr) || (p.kr_dst_ptrs != nullptr);
-  u32x4 lo_v[kCompUnroll], hi_v[kCompUnroll], cs[kCompUnroll], sn[kCompUnroll];
-  char* dptr[kCompUnroll];
-  char* rptr[kCompUnroll];
-#pragma unroll
-  for (int u = 0; u < kCompUnroll; ++u) {
-    const long long g = g0 + (long long)u * kCompThreads;
-    dptr[u] = nullptr;
-    rptr[u] = nullptr;
-    if (g < p.total) {
-      const int tl = (int)(g / p.pieces_per_tensor);
-      const unsigned rem = (unsigned)(g - (long long)tl * p.pieces_per_tensor);   // < 2^32 (checked on host)
-      const int layer = tl / p.n_tensors;
-      const int t = tl - layer * p.n_tensors;
-      const unsigned per_bh = (unsigned)p.Lp * (unsigned)half_ppr;
-      const unsigned bh = rem / per_bh;
-      const unsigned rr = rem - bh * per_bh;
-      const unsigned r = rr / (unsigned)half_ppr;
-      const unsigned piece = rr - r * (unsigned)half_ppr;
-      const int b = bh / p.H;
-      const int h = bh - b * p.H;
-      int src_row;
-      if ((int)r < p.start) src_row = (int)r;
-      else if ((int)r < p.start + p.k) src_row = p.idx[layer * p.idx_sl + h * p.idx_sh + ((int)r - p.start)];
-      else src_row = p.tail_lo + ((int)r - p.start - p.k);
-      const char* sbase;
-      char* dbase;
-      if (p.k_src_ptrs) {
-        sbase = (const char*)(t == 0 ? p.k_src_ptrs[layer] : p.v_src_ptrs[layer]);
-        dbase = (char*)(t == 0 ? p.k_dst_ptrs[layer] : p.v_dst_ptrs[layer]);
-      } else {
-        sbase = (const char*)(t == 0 ? p.k_src : p.v_src);
-        dbase = (char*)(t == 0 ? p.k_dst : p.v_dst);
-      }
-      const char* sp = sbase + b * p.src_sb + h * p.src_sh + (int64_t)src_row * p.row_bytes + piece * 16;
-      const int64_t doff = b * p.dst_sb + h * p.dst_sh + (int64_t)r * p.row_bytes + piece * 16;
-      dptr[u] = dbase + doff;
-      lo_v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp));
-      hi_v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp + half_bytes));
-      if (want_kr && t == 0) {
-        char* rbase = (char*)(p.kr_dst_ptrs ? p.kr_dst_ptrs[layer] : p.kr_dst);
-        rptr[u] = rbase + doff;
-        const int pos = min((int)r, p.table_rows - 1);
-        const int64_t toff = (int64_t)pos * half_bytes + piece * 16;
-        cs[u] = *reinterpret_cast<const u32x4*>((const char*)p.cos + toff);
-        sn[u] = *reinterpret_cast<const u32x4*>((const char*)p.sin + toff);
-      }
-    }
+  const int half_ppr = p.ppr >> 1;
+  const int half_bytes = p.row_bytes >> 1;
+  int piece, rloc;
+  if (p.hp_shift >= 0) { piece = threadIdx.x & (half_ppr - 1); rloc = threadIdx.x >> p.hp_shift; }
+  else { rloc = threadIdx.x / half_ppr; piece = threadIdx.x - rloc * half_ppr; }
+  const int r = blockIdx.x * p.rows_per_block + rloc;
+  if (rloc >= p.rows_per_block || r >= p.Lp) return;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;                      // wave-uniform
+  const int layer = blockIdx.z / p.n_tensors, t = blockIdx.z - layer * p.n_tensors;
+  const bool want_kr = t == 0 && ((p.kr_dst != nullptr) || (p.kr_dst_ptrs != nullptr));
+  int src_row;
+  if (r < p.start) src_row = r;
+  else if (r < p.start + p.k) src_row = p.idx[layer * p.idx_sl + h * p.idx_sh + (r - p.start)];
+  else src_row = p.tail_lo + (r - p.start - p.k);
+  const char* sbase;
+  char* dbase;
+  if (p.k_src_ptrs) {
+    sbase = (const char*)(t == 0 ? p.k_src_ptrs[layer] : p.v_src_ptrs[layer]);
+    dbase = (char*)(t == 0 ? p.k_dst_ptrs[layer] : p.v_dst_ptrs[layer]);
+  } else {
+    sbase = (const char*)(t == 0 ? p.k_src : p.v_src);
+    dbase = (char*)(t == 0 ? p.k_dst : p.v_dst);
   }
-#pragma unroll
-  for (int u = 0; u < kCompUnroll; ++u) {
-    if (dptr[u]) {
-      __builtin_nontemporal_store(lo_v[u], reinterpret_cast<u32x4*>(dptr[u]));
-      __builtin_nontemporal_store(hi_v[u], reinterpret_cast<u32x4*>(dptr[u] + half_bytes));
-    }
-    if (rptr[u]) {
-      constexpr int E = 16 / sizeof(T);              // elements per 16-byte piece (8, or 4 for fp32)
-      const T* xl = reinterpret_cast<const T*>(&lo_v[u]);
-      const T* xh = reinterpret_cast<const T*>(&hi_v[u]);
-      const T* cc = reinterpret_cast<const T*>(&cs[u]);
-      const T* ss = reinterpret_cast<const T*>(&sn[u]);
-      u32x4 olo, ohi;
-      T* yl = reinterpret_cast<T*>(&olo);
-      T* yh = reinterpret_cast<T*>(&ohi);
-      {
+  const char* sp = sbase + b * p.src_sb + h * p.src_sh + (int64_t)src_row * p.row_bytes + piece * 16;
+  const int64_t doff = b * p.dst_sb + h * p.dst_sh + (int64_t)r * p.row_bytes + piece * 16;
+  const u32x4 lo_v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp));
+  const u32x4 hi_v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp + half_bytes));
+  u32x4 cs, sn;
+  if (want_kr) {
+    const int pos = min(r, p.table_rows - 1);
+    const int64_t toff = (int64_t)pos * half_bytes + piece * 16;
+    cs = *reinterpret_cast<const u32x4*>((const char*)p.cos + toff);
+    sn = *reinterpret_cast<const u32x4*>((const char*)p.sin + toff);
+  }
+  __builtin_nontemporal_store(lo_v, reinterpret_cast<u32x4*>(dbase + doff));
+  __builtin_nontemporal_store(hi_v, reinterpret_cast<u32x4*>(dbase + doff + half_bytes));
+  if (want_kr) {
+    char* rbase = (char*)(p.kr_dst_ptrs ? p.kr_dst_ptrs[layer] : p.kr_dst);
+    constexpr int E = 16 / sizeof(T);              // elements per 16-byte piece (8, or 4 for fp32)
+    const T* xl = reinterpret_cast<const T*>(&lo_v);
+    const T* xh = reinterpret_cast<const T*>(&hi_v);
+    const T* cc = reinterpret_cast<const T*>(&cs);
+    const T* ss = reinterpret_cast<const T*>(&sn);
+    u32x4 olo, ohi;
+    T* yl = reinterpret_cast<T*>(&olo);
+    T* yh = reinterpret_cast<T*>(&ohi);
+    {
 #pragma clang fp contract(off)
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-          const float a = DT<T>::to_f32(xl[e]), bb = DT<T>::to_f32(xh[e]);
-          const float c = DT<T>::to_f32(cc[e]), s_ = DT<T>::to_f32(ss[e]);
-          yl[e] = DT<T>::from_f32(DT<T>::round(a * c) + DT<T>::round(-bb * s_));
-          yh[e] = DT<T>::from_f32(DT<T>::round(bb * c) + DT<T>::round(a * s_));
-        }
+      for (int e = 0; e < E; ++e) {
+        const float a = DT<T>::to_f32(xl[e]), bb = DT<T>::to_f32(xh[e]);
+        const float c = DT<T>::to_f32(cc[e]), s_ = DT<T>::to_f32(ss[e]);
+        yl[e] = DT<T>::from_f32(DT<T>::round(a * c) + DT<T>::round(-bb * s_));
+        yh[e] = DT<T>::from_f32(DT<T>::round(bb * c) + DT<T>::round(a * s_));
       }
-      __builtin_nontemporal_store(olo, reinterpret_cast<u32x4*>(rptr[u]));
-      __builtin_nontemporal_store(ohi, reinterpret_cast<u32x4*>(rptr[u] + half_bytes));
     }
+    __builtin_nontemporal_store(olo, reinterpret_cast<u32x4*>(rbase + doff));
+    __builtin_nontemporal_store(ohi, reinterpret_cast<u32x4*>(rbase + doff + half_bytes));
   }
 }
 
@@ -382,19 +360,22 @@ static int compact_any(int dtype, CompactParams& p, int head_dim, int tail_len, 
   p.Lp = p.start + p.k + tail_len;
   p.src_sb *= es; p.src_sh *= es; p.dst_sb *= es; p.dst_sh *= es;
   if (p.ppr % 2 != 0) return SPATTEN_ERR_UNSUPPORTED;      // rows are moved as (first half, second half) piece pairs
-  p.pieces_per_tensor = (long long)p.B * p.H * p.Lp * (p.ppr / 2);   // work items (piece pairs) per plane
-  if (p.pieces_per_tensor >= (1ll << 32)) return SPATTEN_ERR_UNSUPPORTED;
-  p.total = p.pieces_per_tensor * p.n_tensors * p.layers;
-  if (p.total == 0) return SPATTEN_OK;
-  const long long per_block = kCompThreads * kCompUnroll;
-  const long long blocks = (p.total + per_block - 1) / per_block;
-  if (blocks >= (1ll << 31)) return SPATTEN_ERR_UNSUPPORTED;
+  const int half_ppr = p.ppr / 2;
+  if (half_ppr > kCompThreads) return SPATTEN_ERR_UNSUPPORTED;
+  p.hp_shift = -1;
+  for (int sft = 0; sft < 9; ++sft) if ((1 << sft) == half_ppr) p.hp_shift = sft;
+  p.rows_per_block = kCompThreads / half_ppr;
+  if (p.Lp == 0) return SPATTEN_OK;
+  const long long blocks_x = ((long long)p.Lp + p.rows_per_block - 1) / p.rows_per_block;
+  const long long grid_y = (long long)p.B * p.H, grid_z = (long long)p.layers * p.n_tensors;
+  if (blocks_x >= (1ll << 31) || grid_y > 65535 || grid_z > 65535) return SPATTEN_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)blocks_x, (unsigned)grid_y, (unsigned)grid_z);
   const bool want_kr = p.kr_dst || p.kr_dst_ptrs;
   if (want_kr && (!p.cos || !p.sin || p.table_rows < p.Lp)) return SPATTEN_ERR_INVALID;
   switch (dtype) {
-    case SPATTEN_F32: hipLaunchKernelGGL((kv_compact_kernel<float>), dim3((unsigned)blocks), dim3(kCompThreads), 0, st, p); break;
-    case SPATTEN_F16: hipLaunchKernelGGL((kv_compact_kernel<f16_t>), dim3((unsigned)blocks), dim3(kCompThreads), 0, st, p); break;
-    default: hipLaunchKernelGGL((kv_compact_kernel<bf16_t>), dim3((unsigned)blocks), dim3(kCompThreads), 0, st, p);
+    case SPATTEN_F32: hipLaunchKernelGGL((kv_compact_kernel<float>), grid, dim3(kCompThreads), 0, st, p); break;
+    case SPATTEN_F16: hipLaunchKernelGGL((kv_compact_kernel<f16_t>), grid, dim3(kCompThreads), 0, st, p); break;
+    default: hipLaunchKernelGGL((kv_compact_kernel<bf16_t>), grid, dim3(kCompThreads), 0, st, p);
   }
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }
