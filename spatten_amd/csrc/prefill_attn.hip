@@ -118,6 +118,12 @@ struct FlashParams {
 // A/B switch (tools/mb/pf_exp.sh): row sums of P on the matrix pipe instead of 64 VALU adds per lane and tile.
 // MEASURED SLOWER (713 vs 768 TFLOP/s at q = N = 8192): the 8 extra MFMAs per tile cost more than the adds they
 // replace — the matrix pipe has less slack than its 50 % busy counter suggests.  Off.
+#ifndef SPATTEN_PF_PRIO
+#define SPATTEN_PF_PRIO 0
+#endif
+#ifndef SPATTEN_PF_SYM_DMA
+#define SPATTEN_PF_SYM_DMA 1
+#endif
 #ifndef SPATTEN_PF_ROWSUM_MFMA
 #define SPATTEN_PF_ROWSUM_MFMA 0
 #endif
@@ -879,23 +885,44 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   __syncthreads();
   if (grp == 1) __syncthreads();                     // hold half 1 one phase behind
 
-  // global phase 2t+2 is half 0's matrix phase of iteration t+1 and half 1's vector phase of iteration t: both issue
-  // stage t+2 there
+#if SPATTEN_PF_PRIO == 1
+  if (grp == 1) __builtin_amdgcn_s_setprio(1);   // static priority for the later-dispatched half (A/B knob)
+#elif SPATTEN_PF_PRIO == 2
+  if (grp == 0) __builtin_amdgcn_s_setprio(1);
+#endif
   for (int t = 0; t < n_tiles; ++t) {
     // ---- matrix phase of iteration t -----------------------------------------------------------------------
+    PF_STAMP(0);
+#if SPATTEN_PF_SYM_DMA
+    // BOTH halves bring their pieces of stage t+1 in at the top of their own matrix phase, where the ~115 cycles each DMA
+    // instruction takes to issue hide under the MFMAs (phase stamps, r02: issued from the vector phase, half 1's 16 DMA
+    // instructions cost 1.8k cycles on top of its 3.5k-cycle softmax, and half 0 idled 1.8k cycles at the barrier every
+    // tile).  Half 0 issues in global phase 2t and has the whole following vector phase for them to land; half 1 issues
+    // in phase 2t+1 and waits for them at the end of that same phase (stage t+1 is first read in phase 2t+2).  The
+    // slot's previous tenant, stage t-1, was last read in phase 2t-1.
+    if (t >= 1 && t + 1 < n_tiles) dma_stage(t + 1);
+#else
     if (grp == 0 && t >= 1 && t + 1 < n_tiles) dma_stage(t + 1);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if (t < wave_att_tiles) pv(v_area(t));
     __builtin_amdgcn_sched_barrier(0);                   // P is dead from here on: keep S(t+1) out of its live range
     if (t + 1 < wave_tiles) qk(k_area(t));
+    PF_STAMP(1);
 
     if (grp == 1) __builtin_amdgcn_s_waitcnt(0x0F70);    // half 1's pieces (issued one phase ago) have landed
     __syncthreads();
+    PF_STAMP(2);
     // ---- vector phase ----------------------------------------------------------------------------------------
+#if !SPATTEN_PF_SYM_DMA
     if (grp == 1 && t + 2 < n_tiles) dma_stage(t + 2);
+#endif
+    PF_STAMP(3);
     if (t + 1 < wave_tiles) softmax_tile(t + 1);
+    PF_STAMP(4);
     if (grp == 0) __builtin_amdgcn_s_waitcnt(0x0F70);    // half 0's pieces (issued at the top of this iteration)
     __syncthreads();
+    PF_STAMP(5);
   }
   if (grp == 0) __syncthreads();
 

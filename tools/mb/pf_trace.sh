@@ -2,9 +2,11 @@
 cd $GRAFT_REPO_ROOT
 cp spatten_amd/lib/libspatten_hip.so /tmp/lib_orig.so
 mkdir -p /tmp/pft; rm -f /tmp/pft/*.o
-for f in decode_attn prefill_attn prune cascade pq; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -DSPATTEN_PF_TRACE $EXTRA -c spatten_amd/csrc/$f.hip -o /tmp/pft/$f.o &
-done; wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o spatten_amd/lib/libspatten_hip.so /tmp/pft/*.o
+for f in decode_attn prune cascade pq comm; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -c spatten_amd/csrc/$f.hip -o /tmp/pft/$f.o &
+done
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -fno-slp-vectorize -DSPATTEN_PF_TRACE $EXTRA -c spatten_amd/csrc/prefill_attn.hip -o /tmp/pft/prefill_attn.o &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o spatten_amd/lib/libspatten_hip.so /tmp/pft/*.o -ldl
 python tools/probe_pf_trace.py 2>&1 | grep -v amdgpu.ids
 cp /tmp/lib_orig.so spatten_amd/lib/libspatten_hip.so
