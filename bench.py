@@ -153,20 +153,27 @@ def cpu_baseline(L, new_len, lo, hi):
     phys = _physical_cores()
     legs = {}
     old_threads = torch.get_num_threads()
+    # torch's intra-op threading is bistable on a big shared host (the same op measured 3.4 ms and 48 ms per layer at 128
+    # threads in two runs of this bench): several thread counts are timed and the BEST one is the baseline `value`
+    # (the comparison least favourable to the GPU); all of them are listed
+    counts = sorted({phys, min(32, phys), min(8, phys), 1}, reverse=True)
     with torch.no_grad():
-        for threads, budget in ((phys, 8.0), (1, 3.0)):
+        for threads in counts:
             torch.set_num_threads(threads)
-            t_dec, n_dec = med(lambda: tm.decode_core(q4, q4, q4, pk, pv, cos, sin), budget)
-            t_pr, n_pr = med(lambda: tm.prune_layer(K4, V4, st4, START, RECENT, IMPORTANT, 0), budget / 4, warm=1, min_reps=3)
+            t_dec, n_dec = med(lambda: tm.decode_core(q4, q4, q4, pk, pv, cos, sin), 3.0)
+            t_pr, n_pr = med(lambda: tm.prune_layer(K4, V4, st4, START, RECENT, IMPORTANT, 0), 0.8, warm=1, min_reps=3)
             legs[threads] = (t_dec, t_pr, n_dec, n_pr)
     torch.set_num_threads(old_threads)
     tps = lambda t_dec, t_pr: 1.0 / (L * t_dec + L * t_pr / TURN)
-    t_dec, t_pr, n_dec, n_pr = legs[phys]
-    out = {"value": round(tps(t_dec, t_pr), 4), "unit": "tokens/s", "cores": phys, "kind": "port",
+    best = max(counts, key=lambda c_: tps(*legs[c_][:2]))
+    t_dec, t_pr, n_dec, n_pr = legs[best]
+    out = {"value": round(tps(t_dec, t_pr), 4), "unit": "tokens/s", "cores": best, "kind": "port",
            "sample": f"{n_dec} decode-attention layer steps at kv_len {n} + {n_pr} one-layer prune events (4096 -> 2048), median, "
                      f"torch-CPU mirror of the reference's op sequence (oracle/torch_mirror.py), extrapolated to {L} layers per "
-                     f"token and one prune per {TURN} tokens",
+                     f"token and one prune per {TURN} tokens; best of the thread counts {counts}",
            "ms_per_layer_decode": round(t_dec * 1e3, 3), "ms_per_layer_prune": round(t_pr * 1e3, 3),
+           "by_threads": {str(c_): {"value": round(tps(*legs[c_][:2]), 4), "ms_per_layer_decode": round(legs[c_][0] * 1e3, 3),
+                                    "ms_per_layer_prune": round(legs[c_][1] * 1e3, 3)} for c_ in counts},
            "one_thread": {"value": round(tps(*legs[1][:2]), 4), "ms_per_layer_decode": round(legs[1][0] * 1e3, 3),
                           "ms_per_layer_prune": round(legs[1][1] * 1e3, 3)},
            "cpu_model": _cpu_model(), "logical_cpus": os.cpu_count(), "physical_cores": phys,

@@ -94,6 +94,21 @@ def test_decode_vs_oracle_ragged_lengths(dt, d, P):
         np.testing.assert_allclose(1.0 / lse[:, :, 1], p[:, :, 0].max(-1), rtol=2e-2)
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("P", [0, 129, 600, 2100])
+def test_decode_head_dim_256_vs_oracle(dt, P):
+    """head_dim 256 (16 lanes per row, 4 row-groups per tile, the merge's one-thread-per-element layout wraps): every
+    split count incl. the long-chunk pipelined variant."""
+    B, H, Hkv, d = 2, 2, 1, 256
+    q, k, v, past = attn_inputs(B, H, Hkv, d, P, 1, dt, seed=300 + P)
+    o, stash, _ = orc.attention_core(q, k, v, None if past is None else past[0], None if past is None else past[1],
+                                     np.full((B, 1), P), None, dt)
+    for ns in (0, 1, 3, 9):
+        out, st, _, _, lse = run_decode(q, k, v, past, dt, n_splits=ns)
+        np.testing.assert_allclose(out, o, err_msg=f"ns={ns}", **OUT_TOL[dt])
+        check_stash(st, stash, dt, f"ns={ns}")
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_decode_mask_gqa_positions(dt):
     B, H, Hkv, d, P = 2, 8, 2, 128, 333
