@@ -308,11 +308,16 @@ int spatten_head_scores(int dtype, const void* out, int64_t out_sb, int64_t out_
                         int batch, int q_len, int heads, int head_dim, void* stream);
 /* Local V pruning, pass 2 (SpAttenController.scala:546-558,591-612): out[b, h*d:(h+1)*d] = sum over the kept keys
  * j = idx[b*H+h, i] of exp(stash[b,h,j] (+mask[b,j]) - lse_max) / lse_sum * V[b, hkv, j, :]   (no renormalisation).
- * idx int32 [B*H, k] (stride idx_sr) from spatten_topk_select over the stash rows. */
+ * idx int32 [B*H, k] (stride idx_sr) from spatten_topk_select over the stash rows.
+ * workspace (zero-filled once, spatten_pv_gather_workspace_bytes; re-armed by the kernel; one per stream): the kept
+ * list is split over up to 64 workgroups per (b, h) whose partial sums the last arriver adds in split order; NULL =
+ * one workgroup per (b, h). */
+size_t spatten_pv_gather_workspace_bytes(int batch, int heads, int head_dim);
 int spatten_pv_gather(int dtype, const void* stash, int64_t sc_sb, int64_t sc_sh, const float* lse,
                       const void* mask, int64_t mask_sb, const void* v_cache, int64_t kv_sb, int64_t kv_sh,
                       const int32_t* idx, int64_t idx_sr, int k, void* out, int64_t out_sb,
-                      int batch, int heads, int kv_heads, int head_dim, void* stream);
+                      int batch, int heads, int kv_heads, int head_dim, void* workspace, size_t workspace_bytes,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Progressive quantisation of the (rotated) key cache — MSB-first fetch with LSB refetch on low confidence

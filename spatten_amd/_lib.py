@@ -85,7 +85,9 @@ def _declare(lib):
     lib.spatten_head_scores.restype = c_int
     lib.spatten_head_scores.argtypes = [i, p, i64, i64, p, i, i, i, i, p]
     lib.spatten_pv_gather.restype = c_int
-    lib.spatten_pv_gather.argtypes = [i, p, i64, i64, p, p, i64, p, i64, i64, p, i64, i, p, i64, i, i, i, i, p]
+    lib.spatten_pv_gather.argtypes = [i, p, i64, i64, p, p, i64, p, i64, i64, p, i64, i, p, i64, i, i, i, i, p, c_size_t, p]
+    lib.spatten_pv_gather_workspace_bytes.restype = c_size_t
+    lib.spatten_pv_gather_workspace_bytes.argtypes = [i, i, i]
     lib.spatten_pq_pack.restype = c_int
     lib.spatten_pq_pack.argtypes = [i, p, i64, i64, p, p, p, i64, i64, i64, i64, i, i, i, i, i, p]
     lib.spatten_prefill_workspace_bytes.restype = c_size_t

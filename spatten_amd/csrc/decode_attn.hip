@@ -677,7 +677,10 @@ static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_onl
   const bool casc = p.acc != nullptr;
 #define SPATTEN_LAUNCH(...) hipLaunchKernelGGL((decode_attn_kernel<T, D, __VA_ARGS__>), grid, blk, 0, stream, p)
   if (scores_only) {
-    SPATTEN_LAUNCH(U, 1);
+    // no V tile: the pipelined instantiation affords twice the key rows per tile (first pass of local V pruning at long
+    // context, where a split is many tiles long)
+    if (p.chunk > U * (kDecodeThreads / (D / 16)) && p.n_q == 1 && sizeof(T) == 2 && D <= 128) SPATTEN_LAUNCH(2 * UP, 1, false, 0, true, false, true);
+    else SPATTEN_LAUNCH(U, 1);
   } else if (p.pq_msb != nullptr) {   // progressive-quant keys: pass 1 on the MSB plane, then the refetch pass (same grid)
     if constexpr (D == 256) return SPATTEN_ERR_UNSUPPORTED;
     else {

@@ -146,6 +146,129 @@ __global__ __launch_bounds__(kSelThreads) void topk_select_kernel(const SelectPa
   }
 }
 
+// The same selection with the whole window in REGISTERS (windows up to 32768 scores): one workgroup of NT threads per
+// (layer, head), VPT consecutive scores per thread, read once.  The k-th largest key is found two bits at a time: per
+// pass every key is classed 0..3 against the prefix found so far (saturating subtract, shift, min) and counted in a
+// byte field of one register — five VALU operations per key, no shuffles and no same-address LDS atomics (real score
+// windows concentrate in a handful of exponent bins, which serialises a histogram) — then one DPP wave reduction and
+// two LDS adds per wave.  The compaction is ONE packed (greater, equal) block scan.  Same result as
+// topk_select_kernel bit for bit (same keys, same tie rule).
+template <int CTRL>
+__device__ inline unsigned dpp_u32(unsigned x) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
+}
+__device__ inline unsigned wave_sum_u32(unsigned v) {
+  v += dpp_u32<kDppXor1>(v);
+  v += dpp_u32<kDppXor2>(v);
+  v += dpp_u32<kDppHalfMirror>(v);
+  v += dpp_u32<kDppMirror>(v);
+  auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = r[0] + r[1];
+  r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return r[0] + r[1];
+}
+
+template <typename T, int NT, int VPT>
+__global__ __launch_bounds__(NT) void topk_select_reg_kernel(const SelectParams<T> p) {
+  constexpr int NW = NT / kWave;
+  constexpr int NE = VPT * NW;                 // (slab, wave) cells of 64 consecutive scores, in window order
+  constexpr int EPL = (NE + kWave - 1) / kWave;
+  __shared__ unsigned s_tot[3][2];
+  __shared__ unsigned s_cell[NE + 1];
+  const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+  const int h = blockIdx.x % p.H, layer = blockIdx.x / p.H;
+  const T* row = (p.score_ptrs ? (const T*)p.score_ptrs[layer] : p.score) + h * p.score_sh + p.lo;
+  int32_t* out = p.idx + layer * p.idx_sl + h * p.idx_sh;
+  const int W = p.hi - p.lo;
+  constexpr int kBits = sizeof(T) == 4 ? 32 : (DT<T>::kId == SPATTEN_BF16 ? 16 : 24);
+  constexpr unsigned kKeyMask = kBits == 32 ? 0xFFFFFFFFu : (kBits == 24 ? 0xFFFFFF00u : 0xFFFF0000u);
+  const unsigned k = (unsigned)p.k;
+
+  // score j * NT + tid in register j: every load instruction of a wave reads 64 consecutive scores (r02: consecutive
+  // scores per THREAD cost 7 us of address-divergent 2-byte loads at 16384 scores)
+  unsigned key[VPT];
+  {
+    float f[VPT];                          // unconditional (clamped) loads, all VPT in flight at once: left to itself
+#pragma unroll                             // the compiler sinks each load into its `i < W` branch, one round trip each
+    for (int j = 0; j < VPT; ++j) f[j] = DT<T>::to_f32(row[min(j * NT + tid, W - 1)]);
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      asm volatile("" : "+v"(f[j]));
+      key[j] = j * NT + tid < W ? (ordered_key(f[j]) & kKeyMask) : 0u;   // 0: below every real key
+    }
+  }
+  if (tid < 6) (&s_tot[0][0])[tid] = 0u;
+  __syncthreads();
+#if defined(SPATTEN_SEL_EXP) && SPATTEN_SEL_EXP == 1
+  { unsigned x = 0; for (int j = 0; j < VPT; ++j) x ^= key[j]; if (x == 0x12345u) out[0] = 1; return; }
+#endif
+
+  unsigned t = 0;
+  int pass = 0;
+#pragma unroll 1
+  for (int s = 30; s >= 32 - kBits; s -= 2, ++pass) {
+    const int slot = pass % 3;
+    unsigned acc = 0;                  // four byte counters: how many of my keys fall in class 0..3
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const unsigned x = __builtin_elementwise_sub_sat(key[j], t);
+      const unsigned d = min(x >> s, 3u);
+      acc += 1u << (8u * d);
+    }
+    const unsigned f3 = acc >> 24, f2 = (acc >> 16) & 255u, f1 = (acc >> 8) & 255u;
+    const unsigned ge3 = f3, ge2 = f3 + f2, ge1 = ge2 + f1;
+    const unsigned a = wave_sum_u32(ge1 | (ge2 << 16)), b3 = wave_sum_u32(ge3);
+    if (lane == 0) { atomicAdd(&s_tot[slot][0], a); atomicAdd(&s_tot[slot][1], b3); }
+    if (tid < 2) s_tot[(pass + 1) % 3][tid] = 0u;     // last read two barriers ago
+    __syncthreads();
+    const unsigned t0 = s_tot[slot][0], n3 = s_tot[slot][1], n1 = t0 & 0xFFFFu, n2 = t0 >> 16;
+    t |= (n3 >= k ? 3u : (n2 >= k ? 2u : (n1 >= k ? 1u : 0u))) << s;
+  }
+#if defined(SPATTEN_SEL_EXP) && SPATTEN_SEL_EXP == 2
+  { if (t == 0x12345u) out[0] = 1; return; }
+#endif
+  // t = key of the k-th largest.  Order-preserving compaction: packed (greater, equal) counts per cell, one scan over
+  // the cells, lane offsets from the ballots.
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const unsigned long long m_gt = __ballot(key[j] > t);
+    const unsigned long long m_eq = __ballot(key[j] == t && j * NT + tid < W);
+    if (lane == 0) s_cell[j * NW + wave] = ((unsigned)__popcll(m_gt) << 16) | (unsigned)__popcll(m_eq);   // <= 32768 each
+  }
+  __syncthreads();
+  if (wave == 0) {
+    unsigned c[EPL], tot = 0;
+#pragma unroll
+    for (int u = 0; u < EPL; ++u) { c[u] = (lane * EPL + u < NE) ? s_cell[lane * EPL + u] : 0u; tot += c[u]; }
+    unsigned inc = tot;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const unsigned v = __shfl_up(inc, off, kWave);
+      if (lane >= off) inc += v;
+    }
+    unsigned ex = inc - tot;
+#pragma unroll
+    for (int u = 0; u < EPL; ++u) { if (lane * EPL + u < NE) s_cell[lane * EPL + u] = ex; ex += c[u]; }
+    if (lane == kWave - 1) s_cell[NE] = inc;
+  }
+  __syncthreads();
+  const unsigned need_eq = k - (s_cell[NE] >> 16);      // >= 1: that many keys equal to t are kept, lowest index first
+#if defined(SPATTEN_SEL_EXP) && SPATTEN_SEL_EXP == 3
+  { if (need_eq == 0x12345u) out[0] = 1; return; }
+#endif
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int i = j * NT + tid;
+    const bool gt = key[j] > t, eq = key[j] == t && i < W;
+    const unsigned long long m_gt = __ballot(gt), m_eq = __ballot(eq);
+    const unsigned ex = s_cell[j * NW + wave];
+    const unsigned g = (ex >> 16) + __builtin_amdgcn_mbcnt_hi((unsigned)(m_gt >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_gt, 0u));
+    const unsigned e = (ex & 0xFFFFu) + __builtin_amdgcn_mbcnt_hi((unsigned)(m_eq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_eq, 0u));
+    if (gt) out[g + (e < need_eq ? e : need_eq)] = p.lo + i;
+    else if (eq && e < need_eq) out[g + e] = p.lo + i;
+  }
+}
+
 // ================================================================================================
 // fused gather + concat of K and V, all layers
 // ================================================================================================
@@ -334,7 +457,15 @@ static int launch_select(const void* score, const void* const* score_ptrs, int64
   p.score = (const T*)score; p.score_ptrs = score_ptrs; p.score_sh = score_sh;
   p.idx = idx; p.idx_sl = idx_sl; p.idx_sh = idx_sh;
   p.H = H; p.lo = lo; p.hi = hi; p.k = k;
-  hipLaunchKernelGGL((topk_select_kernel<T>), dim3((unsigned)(layers * H)), dim3(kSelThreads), 0, st, p);
+  static int env_fast = -1;
+  if (env_fast < 0) { const char* e = getenv("SPATTEN_SELECT_REG"); env_fast = e ? atoi(e) : 1; }
+  const int W = hi - lo;
+  const dim3 grid((unsigned)(layers * H));
+  if (env_fast && W <= 1024) hipLaunchKernelGGL((topk_select_reg_kernel<T, 256, 4>), grid, dim3(256), 0, st, p);
+  else if (env_fast && W <= 4096) hipLaunchKernelGGL((topk_select_reg_kernel<T, 1024, 4>), grid, dim3(1024), 0, st, p);
+  else if (env_fast && W <= 16384) hipLaunchKernelGGL((topk_select_reg_kernel<T, 1024, 16>), grid, dim3(1024), 0, st, p);
+  else if (env_fast && W <= 32768) hipLaunchKernelGGL((topk_select_reg_kernel<T, 1024, 32>), grid, dim3(1024), 0, st, p);
+  else hipLaunchKernelGGL((topk_select_kernel<T>), grid, dim3(kSelThreads), 0, st, p);
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }
 

@@ -607,19 +607,34 @@ def head_scores(out: torch.Tensor, heads: int, scores: Optional[torch.Tensor] = 
     return scores
 
 
+_pv_ws_cache = _LRU(16)
+
+
+def _pv_workspace(batch, heads, head_dim, device) -> torch.Tensor:
+    key = (batch, heads, head_dim, device, _stream())
+    ws = _pv_ws_cache.get(key)
+    if ws is None:
+        n = _lib.load().spatten_pv_gather_workspace_bytes(batch, heads, head_dim)
+        ws = _pv_ws_cache.put(key, torch.zeros(n, dtype=torch.uint8, device=device))
+    return ws
+
+
 def pv_gather(stash: torch.Tensor, lse: torch.Tensor, v_cache: torch.Tensor, idx: torch.Tensor,
-              mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+              workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Local V pruning, pass 2: out[b,h] = sum_{j in idx[b*H+h]} softmax_full(stash[b,h] + mask[b])[j] * V[b,hkv,j].
-    stash [B,H,>=L]; lse [B,H,2]; v_cache [B,Hkv,cap,d]; idx int32 [B*H, k]."""
+    stash [B,H,>=L]; lse [B,H,2]; v_cache [B,Hkv,cap,d]; idx int32 [B*H, k].  ``workspace``: zero-filled uint8 tensor
+    of spatten_pv_gather_workspace_bytes (default: one cached per (shape, stream))."""
     _dev(stash, lse, v_cache, idx, mask, out)
     B, H = stash.shape[0], stash.shape[1]
     Hkv, d = v_cache.shape[1], v_cache.shape[3]
     if out is None:
         out = torch.empty(B, H * d, dtype=v_cache.dtype, device=v_cache.device)
+    ws = workspace if workspace is not None else _pv_workspace(B, H, d, v_cache.device)
     rc = _lib.load().spatten_pv_gather(_dt(v_cache), stash.data_ptr(), stash.stride(0), stash.stride(1), lse.data_ptr(),
                                        _ptr(mask), 0 if mask is None else mask.stride(0), v_cache.data_ptr(),
                                        v_cache.stride(0), v_cache.stride(1), idx.data_ptr(), idx.stride(0), idx.shape[1],
-                                       out.data_ptr(), out.stride(0), B, H, Hkv, d, _stream())
+                                       out.data_ptr(), out.stride(0), B, H, Hkv, d, ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "spatten_pv_gather")
     return out
 
