@@ -176,6 +176,22 @@ def test_local_value_pruning_vs_oracle(dt, Hkv):
         np.testing.assert_allclose(host(st), stash[:, :, 0] if stash.ndim == 4 else stash, rtol=2 ** -6, atol=1e-4)
 
 
+def test_local_value_pruning_long_context_vs_oracle():
+    """20000 rows: the pipelined scores-only pass, the 32-scores-per-thread select and a P.V gather split over ~20
+    workgroups per head"""
+    from spatten_amd.cascade import local_v_decode
+    dt, B, H, d, P = "bf16", 1, 8, 128, 19999
+    q, kc, vc, stash, (qd, krd, vd, cos, sin, N) = setup_decode(B, H, H, d, P, dt, 23)
+    for keep in (6000, 1500):
+        out, st = local_v_decode(qd, krd, vd, N, cos, sin, N - 1, keep)
+        probs = orc.softmax_probs(host(st))
+        want = orc.local_value_prune(probs, vc, keep).reshape(B, H * d)
+        np.testing.assert_allclose(host(out), orc.round_dt(want, dt), **OUT_TOL[dt])
+        np.testing.assert_allclose(host(st), stash[:, :, 0] if stash.ndim == 4 else stash, rtol=2 ** -6, atol=1e-4)
+        out2, _ = local_v_decode(qd, krd, vd, N, cos, sin, N - 1, keep)          # workspace re-armed: same bits again
+        assert torch.equal(out, out2)
+
+
 def test_head_scores_and_pruned_decode():
     from spatten_amd import ops
     from spatten_amd.cascade import HeadPruner

@@ -101,6 +101,26 @@ def test_topk_large_window_and_bf16_threshold_ties():
         ops.topk_select(dev(s, "f32"), 5, 10, 6)
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+def test_topk_register_resident_windows_vs_oracle(dt):
+    """windows of 4k..32k scores (the 16- and 32-scores-per-thread instantiations) and one beyond (the histogram
+    kernel), with ties at the threshold, infinities and NaN"""
+    from spatten_amd import ops
+    rng = np.random.default_rng(11)
+    H, L = 5, 40000
+    s = orc.round_dt(rng.standard_normal((H, L)).astype(np.float32), dt)
+    s[1] = np.round(s[1] * 4) / 4                  # heavy duplicates: the threshold value repeats ~thousands of times
+    s[2, ::9] = np.inf
+    s[2, 4::17] = -np.inf
+    s[3, 3::1001] = np.nan
+    s[4] = 0.0
+    sd = dev(s, dt)
+    for lo, hi, k in ((0, 16384, 4915), (5, 12005, 1), (7, 12007, 12000), (0, 20000, 6000), (100, 32868, 32768),
+                      (100, 32868, 9000), (3, 5003, 2500), (0, 40000, 20000)):
+        want = orc.topk_window(s, lo, hi, k)
+        assert np.array_equal(ops.topk_select(sd, lo, hi, k).cpu().numpy(), want), (dt, lo, hi, k)
+
+
 @pytest.mark.parametrize("dt,d", [("bf16", 128), ("f32", 64), ("f16", 80), ("f32", 8)])
 def test_kv_compact_batch_heads_vs_oracle(dt, d):
     from spatten_amd import ops
