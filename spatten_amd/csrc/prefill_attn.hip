@@ -22,6 +22,8 @@
 //     diagonal are still scored (but skip softmax / P·V).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace spatten {
@@ -115,17 +117,21 @@ struct FlashParams {
   float sqrt_d;
 };
 
-// A/B switch (tools/mb/pf_exp.sh): row sums of P on the matrix pipe instead of 64 VALU adds per lane and tile.
-// MEASURED SLOWER (713 vs 768 TFLOP/s at q = N = 8192): the 8 extra MFMAs per tile cost more than the adds they
-// replace — the matrix pipe has less slack than its 50 % busy counter suggests.  Off.
-#ifndef SPATTEN_PF_PRIO
+// A/B switches (tools/mb/pf_exp.sh rebuilds with -D<macro>=<v>; findings in DESIGN §3.4).
+#ifndef SPATTEN_PF_PRIO         // static s_setprio for one half: MEASURED SLOWER (775-789 vs 812 TFLOP/s).  Off.
 #define SPATTEN_PF_PRIO 0
 #endif
-#ifndef SPATTEN_PF_SYM_DMA
-#define SPATTEN_PF_SYM_DMA 1
+#ifndef SPATTEN_PF_EXPMODE      // harness bits: 1 = FASTNUM; 2 = no DMA in the tile loop and 8 = no softmax (both give WRONG
+#define SPATTEN_PF_EXPMODE 0    // results: anatomy only); 4 = DMA_MODE 2
 #endif
-#ifndef SPATTEN_PF_ROWSUM_MFMA
-#define SPATTEN_PF_ROWSUM_MFMA 0
+#ifndef SPATTEN_PF_DMA_MODE     // who issues a stage's LDS-DMA: 0 half 0 in its matrix / half 1 in its vector phase (r01, 762);
+#define SPATTEN_PF_DMA_MODE ((SPATTEN_PF_EXPMODE & 4) ? 2 : 1)   // 1 both in their matrix phase (r02, 810); 2 both in their vector phase (743)
+#endif
+#ifndef SPATTEN_PF_FASTNUM      // logits kept in fp32 (no reference roundings), scale folded into the exponent: +6-8 %, NOT the
+#define SPATTEN_PF_FASTNUM (SPATTEN_PF_EXPMODE & 1)   // default — the flash kernel's logits stay the reference's
+#endif
+#ifndef SPATTEN_PF_ROWSUM_MFMA  // row sums of P on the matrix pipe instead of 64 VALU adds per lane and tile: MEASURED SLOWER
+#define SPATTEN_PF_ROWSUM_MFMA 0   // (713 vs 768): the 8 extra MFMAs per tile cost more than the adds they replace.  Off.
 #endif
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kDeferMax = 8.0f;   // natural-log units of the scaled logits
@@ -512,7 +518,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
       if (next_stage < n_tiles) load_stage(next_stage);
     }
     PF_STAMP(3);
-    if (t + 1 < wave_tiles) softmax_tile(t + 1);
+    if (!(SPATTEN_PF_EXPMODE & 8) && t + 1 < wave_tiles) softmax_tile(t + 1);
     PF_STAMP(4);
     __syncthreads();
     PF_STAMP(5);
@@ -725,7 +731,10 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 
   f32x16 s[NKB];
   frag pf[NKB][2];
-  constexpr int RING = 4;
+#ifndef SPATTEN_PF_RING
+#define SPATTEN_PF_RING 4
+#endif
+  constexpr int RING = SPATTEN_PF_RING;
   auto qk = [&](const char* kbuf) {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
@@ -797,15 +806,21 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     } else {
     // both reference roundings of every logit (matmul -> dtype, "/ sqrt(d)" -> dtype, modify_llama.py:111-113), two
     // scores at a time: at large logits a 16-bit ulp is a visible change of P
+    if (!(SPATTEN_PF_FASTNUM && !MASK && !edge)) {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
+#if SPATTEN_PF_FASTNUM
+        s[kb][r] *= rsqrt_d; s[kb][r + 1] *= rsqrt_d;
+#else
         const f32x2 x = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
         const f32x2 v = round2<T>(f32x2{logit_scale<T>(x[0], p.sqrt_d, rsqrt_d), logit_scale<T>(x[1], p.sqrt_d, rsqrt_d)});
         s[kb][r] = v[0];
         s[kb][r + 1] = v[1];
+#endif
       }
+    }
     }
     float m_new, m_base;                            // new running max; the max the exponentials are taken against
     if (!MASK && !edge) {
@@ -821,7 +836,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 #pragma unroll
         for (int r = 0; r < 16; r += 2) mt[kb] = max3_raw(mt[kb], s[kb][r], s[kb][r + 1]);
       }
-      const float m_tile = xor32_max(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3])));
+      const float m_tile = xor32_max(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3]))) * (SPATTEN_PF_FASTNUM && !PQK ? rsqrt_d : 1.0f);
       const bool move = __builtin_amdgcn_ballot_w64(m_tile - m_run > kDeferMax) != 0;   // -inf start: inf > thr
       m_new = move ? fmaxf(m_run, m_tile) : m_run;
       if (PQK == 1) m_true = fmaxf(m_true, m_tile);
@@ -846,6 +861,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
       m_base = (m_new == -INFINITY) ? 0.f : m_new;  // a fully masked row: exp2(-inf) = 0 for every key
     }
     const float m2 = m_base * kLog2e;
+    const float sc2 = (SPATTEN_PF_FASTNUM && !PQK && !MASK && !edge) ? kLog2e * rsqrt_d : kLog2e;
     float ls[4] = {0.f, 0.f, 0.f, 0.f};             // independent partial sums
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
@@ -853,7 +869,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], kLog2e, -m2));
+          const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], sc2, -m2));
 #if !SPATTEN_PF_ROWSUM_MFMA
           ls[e & 3] += pvv;
 #endif
@@ -893,15 +909,15 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   for (int t = 0; t < n_tiles; ++t) {
     // ---- matrix phase of iteration t -----------------------------------------------------------------------
     PF_STAMP(0);
-#if SPATTEN_PF_SYM_DMA
+#if SPATTEN_PF_DMA_MODE == 1
     // BOTH halves bring their pieces of stage t+1 in at the top of their own matrix phase, where the ~115 cycles each DMA
     // instruction takes to issue hide under the MFMAs (phase stamps, r02: issued from the vector phase, half 1's 16 DMA
     // instructions cost 1.8k cycles on top of its 3.5k-cycle softmax, and half 0 idled 1.8k cycles at the barrier every
     // tile).  Half 0 issues in global phase 2t and has the whole following vector phase for them to land; half 1 issues
     // in phase 2t+1 and waits for them at the end of that same phase (stage t+1 is first read in phase 2t+2).  The
     // slot's previous tenant, stage t-1, was last read in phase 2t-1.
-    if (t >= 1 && t + 1 < n_tiles) dma_stage(t + 1);
-#else
+    if (!(SPATTEN_PF_EXPMODE & 2) && t >= 1 && t + 1 < n_tiles) dma_stage(t + 1);
+#elif SPATTEN_PF_DMA_MODE == 0
     if (grp == 0 && t >= 1 && t + 1 < n_tiles) dma_stage(t + 1);
 #endif
     __builtin_amdgcn_sched_barrier(0);
@@ -914,11 +930,16 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     __syncthreads();
     PF_STAMP(2);
     // ---- vector phase ----------------------------------------------------------------------------------------
-#if !SPATTEN_PF_SYM_DMA
+#if SPATTEN_PF_DMA_MODE == 0
+    if (grp == 1 && t + 2 < n_tiles) dma_stage(t + 2);
+#elif SPATTEN_PF_DMA_MODE == 2
+    // both halves issue from their VECTOR phase (stage t+1 may be written during global phases 2t and 2t+1: half 1 is in
+    // its vector phase of iteration t-1 during 2t, half 0 in its vector phase of iteration t during 2t+1)
+    if (grp == 0 && t >= 1 && t + 1 < n_tiles) dma_stage(t + 1);
     if (grp == 1 && t + 2 < n_tiles) dma_stage(t + 2);
 #endif
     PF_STAMP(3);
-    if (t + 1 < wave_tiles) softmax_tile(t + 1);
+    if (!(SPATTEN_PF_EXPMODE & 8) && t + 1 < wave_tiles) softmax_tile(t + 1);
     PF_STAMP(4);
     if (grp == 0) __builtin_amdgcn_s_waitcnt(0x0F70);    // half 0's pieces (issued at the top of this iteration)
     __syncthreads();
