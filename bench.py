@@ -208,7 +208,7 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48):
     """The DROP-IN number: tokens/s through the patched HF forward itself (`llama_pos_shift_attention_forward`, called per
     layer with the arguments transformers 4.33 passes — hidden states, a zero mask, position_ids, the layer's (K, V)
     pair — including the module's q/k/v/o projections and every per-call host step), eager launches, Llama-2-7B geometry,
-    2048-row pruned cache.  Next to it the same with enable_spatten_llm(assume_causal=True)."""
+    2048-row pruned cache.  Next to it the same with enable_spatten_llm(assume_causal=True) and with fuse_qkv=True on top."""
     from types import SimpleNamespace
 
     from torch import nn
@@ -237,11 +237,11 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48):
     P = START + IMPORTANT + RECENT
     with torch.no_grad():
         model = Stack()
-        for flag in (False, True):
+        for flag, fuse in ((False, False), (True, False), (True, True)):
             import contextlib
             import io
             with contextlib.redirect_stdout(io.StringIO()):       # the constructor prints the reference's banner
-                enable_spatten_llm(model, START, IMPORTANT, RECENT, prefill_stash=False, assume_causal=flag)
+                enable_spatten_llm(model, START, IMPORTANT, RECENT, prefill_stash=False, assume_causal=flag, fuse_qkv=fuse)
             hid = HEADS * HEAD_DIM
             x = torch.randn(1, P, hid, device=dev, dtype=torch.float32).to(dt)
             mask = torch.zeros(1, 1, P, P, dtype=dt, device=dev).masked_fill_(
@@ -267,8 +267,9 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48):
             for t in range(n_tokens):
                 token(t)
             torch.cuda.synchronize()
-            out["plugin_path_assume_causal_tokens_per_s" if flag else "plugin_path_tokens_per_s"] = round(
-                n_tokens / (time.perf_counter() - t0), 2)
+            key = "plugin_path_assume_causal_fused_qkv_tokens_per_s" if fuse else (
+                "plugin_path_assume_causal_tokens_per_s" if flag else "plugin_path_tokens_per_s")
+            out[key] = round(n_tokens / (time.perf_counter() - t0), 2)
             del past
     return out
 
@@ -394,12 +395,22 @@ def main():
 
     native = False
     if dist_on and args.gather == "native":
+        err = None
         try:
             hp.init_native()
             native = True
-        except Exception as e:
+        except Exception as e:      # noqa: BLE001 - any failure here means "use torch.distributed instead"
+            err = e
+        # every rank must take the same branch: one that fell back while the others entered the native collective would hang
+        ok = torch.tensor([1 if native else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if native:
+                hp.close_native()
+            native = False
             if rank == 0:
-                print(f"native RCCL communicator unavailable ({type(e).__name__}: {e}); using torch.distributed", file=sys.stderr)
+                print(f"native RCCL communicator unavailable ({type(err).__name__ if err else 'on another rank'}: {err}); "
+                      "using torch.distributed", file=sys.stderr)
             args.gather = "flat"
 
     def run_slot(slot):

@@ -25,7 +25,7 @@ _FAMILIES: Dict[str, Callable] = {"llama": _patch_llama}
 
 def enable_spatten_llm(model, start_size, important_size, recent_size, importance_mode="reference",
                        prefill_stash=True, assume_causal=False, head_keep=None, pq_threshold=None, local_v_keep=None,
-                       layer_keep=None):
+                       layer_keep=None, fuse_qkv=False):
     """The reference's four positional arguments (enable_spatten_llm.py:5) plus opt-in extensions:
 
     ``prefill_stash=False``: forwards with ``q_len > 1`` do not materialise ``self.attn_scores`` ([B,H,q,N]: 4 GiB per
@@ -35,6 +35,9 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     ``assume_causal=True``: the HF mask / position_ids of a forward are taken to be what transformers 4.33 builds
     (causal mask, positions arange(past, past+q)) and are not read: tiles above the diagonal are skipped and a
     single-token step runs the lean decode kernel.
+    ``fuse_qkv=True``: the q / k / v projections of every patched module run as ONE torch GEMM over the stacked weights
+    (host-bound decode: two launches fewer per layer; a different GEMM shape, so results can differ from three separate
+    ``nn.Linear`` calls in the last bit).
 
     SpAtten semantics the reference's Python does not implement (PARITY UNPINNED; spatten_amd/extensions.py):
     ``importance_mode="cascade"`` (cumulative importance = running sum of softmax probabilities, accumulated inside the
@@ -59,6 +62,11 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
         m.spatten_assume_causal = bool(assume_causal)
         m._spatten_ext = None
         m._spatten_rope = None
+        m._spatten_qkv = None
+        if fuse_qkv:
+            from .pos_shift.modify_llama import fuse_qkv_projections
+
+            fuse_qkv_projections(m)
     if extended:
         from .extensions import SpattenExtensions
 

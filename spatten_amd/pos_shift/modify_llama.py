@@ -101,6 +101,12 @@ def llama_pos_shift_attention_forward(
         query_states = torch.cat([F.linear(hidden_states, q_slices[i]) for i in range(tp)], dim=-1)
         key_states = torch.cat([F.linear(hidden_states, k_slices[i]) for i in range(tp)], dim=-1)
         value_states = torch.cat([F.linear(hidden_states, v_slices[i]) for i in range(tp)], dim=-1)
+    elif getattr(self, "_spatten_qkv", None) is not None:
+        # opt-in (enable_spatten_llm(..., fuse_qkv=True)): ONE GEMM over the stacked q/k/v weights — a single-token step
+        # is host-bound and each torch linear costs ~20 us of launch path; the three results are slices of one row
+        w, bias, nq, nk = self._spatten_qkv
+        qkv = F.linear(hidden_states, w, bias)
+        query_states, key_states, value_states = qkv[..., :nq], qkv[..., nq:nq + nk], qkv[..., nq + nk:]
     else:                                                                         # :72-74
         query_states = self.q_proj(hidden_states)
         key_states = self.k_proj(hidden_states)
@@ -213,6 +219,32 @@ def llama_pos_shift_attention_forward(
 
     new_past = slab.views() if use_cache else None                                # :100
     return attn_output, attn_weights, new_past
+
+
+def fuse_qkv_projections(module) -> bool:
+    """Stack q_proj / k_proj / v_proj of one attention module into ONE weight [nq + 2 nk, hidden] (and bias) for the
+    patched forward; the three modules keep working — their ``weight`` / ``bias`` become views of the stacked tensors, so
+    no memory is duplicated.  Not applied (returns False) with ``pretraining_tp > 1`` or mixed bias / dtype / device."""
+    tp = getattr(getattr(module, "config", None), "pretraining_tp", 1) or 1
+    projs = [getattr(module, n, None) for n in ("q_proj", "k_proj", "v_proj")]
+    if tp > 1 or any(p is None or not hasattr(p, "weight") for p in projs):
+        return False
+    ws = [p.weight for p in projs]
+    bs = [getattr(p, "bias", None) for p in projs]
+    if len({(w.dtype, w.device, w.shape[1]) for w in ws}) != 1 or len({b is None for b in bs}) != 1:
+        return False
+    with torch.no_grad():
+        w = torch.cat([x.detach() for x in ws], dim=0).contiguous()
+        bias = None if bs[0] is None else torch.cat([x.detach() for x in bs], dim=0).contiguous()
+        off = 0
+        for p_, x in zip(projs, ws):
+            n = x.shape[0]
+            p_.weight.data = w[off:off + n]
+            if bias is not None:
+                p_.bias.data = bias[off:off + n]
+            off += n
+    module._spatten_qkv = (w, bias, ws[0].shape[0], ws[1].shape[0])
+    return True
 
 
 def _mask_is_causal(mask: torch.Tensor, past_len: int) -> bool:

@@ -300,6 +300,63 @@ def test_enable_patches_every_llama_attention_and_rejects_others():
         enable_spatten_llm(Model("gpt2"), 4, 10, 12)
 
 
+@pytest.mark.parametrize("Hkv,bias", [(4, False), (2, True)])
+def test_fused_qkv_projection_matches_the_three_linears(Hkv, bias):
+    """enable_spatten_llm(..., fuse_qkv=True): one GEMM over the stacked weights; prefill, then decode steps whose query /
+    key / value rows are SLICES of one row — against the same module run with its three nn.Linear projections."""
+    import copy
+    from spatten_amd import enable_spatten_llm
+    dt, tdt, B, H, d, P = "bf16", torch.bfloat16, 1, 4, 64, 300
+    torch.manual_seed(5)
+
+    class Attn(nn.Module):
+        _spatten_llama_attention = True
+
+        def __init__(self):
+            super().__init__()
+            hid = H * d
+            self.config = SimpleNamespace(pretraining_tp=1, model_type="llama")
+            self.num_heads, self.num_key_value_heads, self.head_dim, self.hidden_size = H, Hkv, d, hid
+            self.num_key_value_groups = H // Hkv
+            self.q_proj = nn.Linear(hid, H * d, bias=bias, dtype=tdt, device="cuda")
+            self.k_proj = nn.Linear(hid, Hkv * d, bias=bias, dtype=tdt, device="cuda")
+            self.v_proj = nn.Linear(hid, Hkv * d, bias=bias, dtype=tdt, device="cuda")
+            self.o_proj = nn.Linear(H * d, hid, bias=False, dtype=tdt, device="cuda")
+
+    class Model(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.config = SimpleNamespace(model_type="llama")
+            self.layers = nn.ModuleList([Attn()])
+
+    ref = Model()
+    fused = copy.deepcopy(ref)
+    enable_spatten_llm(ref, 4, 100, 100)
+    enable_spatten_llm(fused, 4, 100, 100, fuse_qkv=True)
+    mf = fused.layers[0]
+    assert mf._spatten_qkv is not None and mf.q_proj.weight.data_ptr() == mf._spatten_qkv[0].data_ptr()   # views, no copy
+    assert torch.equal(mf.k_proj.weight, ref.layers[0].k_proj.weight)
+    x = torch.randn(B, P, H * d, device="cuda").to(tdt)
+    mask = dev(orc.causal_mask(B, P, P, dt), dt)
+    pos = torch.arange(P, device="cuda")[None]
+    with torch.no_grad():
+        outs = []
+        for model in (ref, fused):
+            m = model.layers[0]
+            o, _, past = m(x, attention_mask=mask, position_ids=pos, past_key_value=None, use_cache=True)
+            steps = [o]
+            for t in range(3):
+                n = past[0].shape[2]
+                xt = x[:, t:t + 1] * 0.5
+                o1, _, past = m(xt, attention_mask=torch.zeros(B, 1, 1, n + 1, dtype=tdt, device="cuda"),
+                                position_ids=torch.full((B, 1), n, device="cuda"), past_key_value=past, use_cache=True)
+                steps += [o1, m.attn_scores]
+            outs.append((steps, past))
+    for a_, b_ in zip(outs[0][0], outs[1][0]):
+        np.testing.assert_allclose(host(b_), host(a_), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(host(outs[1][1][0]), host(outs[0][1][0]), rtol=2e-2, atol=2e-2)   # the K cache
+
+
 def test_rope_base_of_the_module_survives_the_prune():
     """Round-1 advisor finding: the prune rebuilt the rotated shadow with base 10000 whatever the model's rotary base is
     (CodeLlama: rope_theta 1e6).  prefill -> decode -> prune -> decode on a module with base 1e6, every step vs the oracle

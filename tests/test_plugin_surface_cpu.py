@@ -112,3 +112,32 @@ def test_bounded_caches():
     assert c.get(0) is None and c.get(1) is None and c.get(2) == 4
     c.put(9, 81)                                    # 3 is now the oldest (2 was just touched)
     assert c.get(3) is None and sorted(c.values()) == [4, 16, 81]
+
+
+def test_fuse_qkv_projections_stacks_weights_as_views():
+    import torch
+    from torch import nn
+    from types import SimpleNamespace
+    from spatten_amd.pos_shift.modify_llama import fuse_qkv_projections
+
+    class M(nn.Module):
+        def __init__(self, tp=1, bias=True):
+            super().__init__()
+            self.config = SimpleNamespace(pretraining_tp=tp)
+            self.q_proj, self.k_proj, self.v_proj = nn.Linear(16, 16, bias=bias), nn.Linear(16, 8, bias=bias), nn.Linear(16, 8, bias=bias)
+
+    m = M()
+    x = torch.randn(3, 16)
+    want = [m.q_proj(x), m.k_proj(x), m.v_proj(x)]
+    assert fuse_qkv_projections(m)
+    w, b, nq, nk = m._spatten_qkv
+    assert w.shape == (32, 16) and b.shape == (32,) and (nq, nk) == (16, 8)
+    assert m.k_proj.weight.data_ptr() == w[16:].data_ptr()                 # a view of the stacked weight
+    qkv = torch.nn.functional.linear(x, w, b)
+    for got, ref in zip((qkv[:, :16], qkv[:, 16:24], qkv[:, 24:]), want):
+        torch.testing.assert_close(got, ref)
+    torch.testing.assert_close(m.v_proj(x), want[2])                       # the modules themselves still work
+    assert not fuse_qkv_projections(M(tp=2))                               # pretraining_tp > 1: left alone
+    mixed = M()
+    mixed.k_proj = nn.Linear(16, 8, bias=False)
+    assert not fuse_qkv_projections(mixed)
