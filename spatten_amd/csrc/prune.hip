@@ -461,11 +461,18 @@ static int launch_select(const void* score, const void* const* score_ptrs, int64
   if (env_fast < 0) { const char* e = getenv("SPATTEN_SELECT_REG"); env_fast = e ? atoi(e) : 1; }
   const int W = hi - lo;
   const dim3 grid((unsigned)(layers * H));
-  if (env_fast && W <= 1024) hipLaunchKernelGGL((topk_select_reg_kernel<T, 256, 4>), grid, dim3(256), 0, st, p);
-  else if (env_fast && W <= 4096) hipLaunchKernelGGL((topk_select_reg_kernel<T, 1024, 4>), grid, dim3(1024), 0, st, p);
-  else if (env_fast && W <= 16384) hipLaunchKernelGGL((topk_select_reg_kernel<T, 1024, 16>), grid, dim3(1024), 0, st, p);
-  else if (env_fast && W <= 32768) hipLaunchKernelGGL((topk_select_reg_kernel<T, 1024, 32>), grid, dim3(1024), 0, st, p);
-  else hipLaunchKernelGGL((topk_select_kernel<T>), grid, dim3(kSelThreads), 0, st, p);
+  // Many windows (the prune event: layers x heads of them): 4-wave workgroups, several resident per CU, cheap barriers.
+  // Few long windows (local V pruning: one per head): 16 waves on one window.
+  const bool many = layers * H >= 128;
+#define SPATTEN_SEL(NT_, VPT_) hipLaunchKernelGGL((topk_select_reg_kernel<T, NT_, VPT_>), grid, dim3(NT_), 0, st, p)
+  if (!env_fast || W > 32768) hipLaunchKernelGGL((topk_select_kernel<T>), grid, dim3(kSelThreads), 0, st, p);
+  else if (W <= 1024) SPATTEN_SEL(256, 4);
+  else if (many && W <= 4096) SPATTEN_SEL(256, 16);
+  else if (many && W <= 8192) SPATTEN_SEL(256, 32);
+  else if (W <= 4096) SPATTEN_SEL(1024, 4);
+  else if (W <= 16384) SPATTEN_SEL(1024, 16);
+  else SPATTEN_SEL(1024, 32);
+#undef SPATTEN_SEL
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }
 
