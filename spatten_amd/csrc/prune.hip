@@ -197,6 +197,7 @@ __global__ __launch_bounds__(NT) void topk_select_reg_kernel(const SelectParams<
       key[j] = j * NT + tid < W ? (ordered_key(f[j]) & kKeyMask) : 0u;   // 0: below every real key
     }
   }
+  const int jmax = (W + NT - 1) / NT;    // registers j >= jmax are padding in every thread: skipped below
   if (tid < 6) (&s_tot[0][0])[tid] = 0u;
   __syncthreads();
 #if defined(SPATTEN_SEL_EXP) && SPATTEN_SEL_EXP == 1
@@ -209,11 +210,21 @@ __global__ __launch_bounds__(NT) void topk_select_reg_kernel(const SelectParams<
   for (int s = 30; s >= 32 - kBits; s -= 2, ++pass) {
     const int slot = pass % 3;
     unsigned acc = 0;                  // four byte counters: how many of my keys fall in class 0..3
+    if (jmax == VPT) {
 #pragma unroll
-    for (int j = 0; j < VPT; ++j) {
-      const unsigned x = __builtin_elementwise_sub_sat(key[j], t);
-      const unsigned d = min(x >> s, 3u);
-      acc += 1u << (8u * d);
+      for (int j = 0; j < VPT; ++j) {
+        const unsigned x = __builtin_elementwise_sub_sat(key[j], t);
+        const unsigned d = min(x >> s, 3u);
+        acc += 1u << (8u * d);
+      }
+    } else {                           // a window that fills only part of the registers: the all-padding ones are skipped
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) {
+        if (j >= jmax) break;
+        const unsigned x = __builtin_elementwise_sub_sat(key[j], t);
+        const unsigned d = min(x >> s, 3u);
+        acc += 1u << (8u * d);
+      }
     }
     const unsigned f3 = acc >> 24, f2 = (acc >> 16) & 255u, f1 = (acc >> 8) & 255u;
     const unsigned ge3 = f3, ge2 = f3 + f2, ge1 = ge2 + f1;

@@ -13,6 +13,6 @@ for var in "$@"; do
     fi
   done; wait
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o spatten_amd/lib/libspatten_hip.so /tmp/pfl/*.o -ldl
-  echo "== $M=$var"; python tools/mb/localv_exp.py ${ARGS:-16384 40 0.3} 2>&1 | tail -1
+  echo "== $M=$var"; ${SCRIPT:-python tools/mb/localv_exp.py ${ARGS:-16384 40 0.3}} 2>&1 | tail -1
 done
 cp /tmp/lib_orig.so spatten_amd/lib/libspatten_hip.so
