@@ -192,6 +192,32 @@ def test_local_value_pruning_long_context_vs_oracle():
         assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_pv_gather_split_counts_and_mask_vs_torch(dt):
+    """spatten_pv_gather over kept lists from 1 to 9000 rows (one slice, a few, the 64-slice cap), GQA, with a mask,
+    repeated on one workspace — against the same sum in torch fp32"""
+    from spatten_amd import ops
+    tdt = TORCH_DT[dt]
+    B, H, Hkv, d, N = 2, 8, 4, 128, 12000
+    g = torch.Generator(device="cuda").manual_seed(3)
+    stash = (torch.randn(B, H, N, device="cuda", generator=g) * 2).to(tdt)
+    V = torch.randn(B, Hkv, N, d, device="cuda", generator=g).to(tdt)
+    mask = torch.zeros(B, N, device="cuda", dtype=tdt)
+    mask[:, ::7] = -3.0
+    lg = (stash.float() + mask[:, None, :].float()).to(tdt).float()
+    m = lg.max(-1).values
+    lse = torch.stack([m, torch.exp(lg - m[..., None]).sum(-1)], -1).contiguous()
+    for k in (1, 17, 64, 65, 700, 4097, 9000):
+        idx = torch.stack([torch.randperm(N, device="cuda", generator=g)[:k].sort().values for _ in range(B * H)]).to(torch.int32)
+        for rep in range(2):
+            out = ops.pv_gather(stash, lse, V, idx, mask=mask)
+        p = torch.exp(torch.gather(lg.reshape(B * H, N), 1, idx.long()) - m.reshape(B * H, 1)) / lse[..., 1].reshape(B * H, 1)
+        Vh = V.repeat_interleave(H // Hkv, dim=1).reshape(B * H, N, d).float()
+        want = torch.einsum("uk,ukd->ud", p, torch.gather(Vh, 1, idx.long()[..., None].expand(-1, -1, d))).reshape(B, H * d)
+        tol = dict(rtol=2e-2, atol=2e-2) if dt == "bf16" else dict(rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(out.float(), want, **tol)
+
+
 def test_head_scores_and_pruned_decode():
     from spatten_amd import ops
     from spatten_amd.cascade import HeadPruner

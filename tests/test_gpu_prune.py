@@ -121,6 +121,22 @@ def test_topk_register_resident_windows_vs_oracle(dt):
         assert np.array_equal(ops.topk_select(sd, lo, hi, k).cpu().numpy(), want), (dt, lo, hi, k)
 
 
+@pytest.mark.parametrize("rows", [3, 130])
+def test_topk_every_dispatch_boundary_vs_oracle(rows):
+    """window widths on both sides of every instantiation boundary of the select dispatch (1024 / 4096 / 8192 / 16384 /
+    32768 scores; few windows -> 16-wave workgroups, many windows -> 4-wave ones), random k, bf16 scores with ties"""
+    from spatten_amd import ops
+    rng = np.random.default_rng(100 + rows)
+    L = 33000
+    s = orc.round_dt(np.round(rng.standard_normal((rows, L)).astype(np.float32) * 8) / 8, "bf16")
+    sd = dev(s, "bf16")
+    for W in (1, 2, 63, 64, 65, 1023, 1024, 1025, 4095, 4096, 4097, 8192, 8193, 16384, 16385, 32767, 32768, 32769):
+        lo = int(rng.integers(0, L - W + 1))
+        for k in sorted({1, W, int(rng.integers(1, W + 1)), max(1, W // 2)}):
+            got = ops.topk_select(sd, lo, lo + W, k).cpu().numpy()
+            assert np.array_equal(got, orc.topk_window(s, lo, lo + W, k)), (rows, W, lo, k)
+
+
 @pytest.mark.parametrize("dt,d", [("bf16", 128), ("f32", 64), ("f16", 80), ("f32", 8)])
 def test_kv_compact_batch_heads_vs_oracle(dt, d):
     from spatten_amd import ops
