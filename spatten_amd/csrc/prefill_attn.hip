@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(512, 1) void prefill_colprob_kernel(const ColProbPa
   constexpr int KK = D / 16, QT = 128, ROWB = D * 2;
   constexpr int QBYTES = QT * ROWB, PIECES = QT * (D / 8) / 512;     // 16-byte pieces per thread per query tile
   using frag = typename Mfma<T>::frag;
-  __shared__ __attribute__((aligned(16))) char lds[2 * QBYTES + 2 * QT * 8];
+  __shared__ __attribute__((aligned(16))) char lds[2 * QBYTES + 2 * QT * 8];   // (2 x QT x 4 B of statistics are used)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ki = lane & 31, hi = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z;
   const int hkv = p.Hkv == p.H ? h : h / (p.H / p.Hkv);
@@ -1048,10 +1048,9 @@ __global__ __launch_bounds__(512, 1) void prefill_colprob_kernel(const ColProbPa
       const int id = tid + 512 * i, row = id / (D / 8), slot = id % (D / 8);
       *reinterpret_cast<u32x4*>(base + lds_off<ROWB>(row, slot)) = qreg[i];
     }
-    if (tid < QT) {   // (m * log2e, 1 / l) per query of the tile
+    if (tid < QT) {   // per query of the tile: m * log2e + log2(l), so that exp2(s * log2e - it) IS the probability
       float* st = reinterpret_cast<float*>(lds + 2 * QBYTES + buf * QT * 8);
-      st[tid] = sreg[0] * kLog2e;
-      st[QT + tid] = 1.0f / sreg[1];
+      st[tid] = sreg[1] > 0.f ? fmaf(sreg[0], kLog2e, __log2f(sreg[1])) : INFINITY;   // a row without keys: probability 0
     }
   };
   float colsum = 0.f;
@@ -1078,22 +1077,33 @@ __global__ __launch_bounds__(512, 1) void prefill_colprob_kernel(const ColProbPa
         const frag a = *reinterpret_cast<const frag*>(qt + lds_off<ROWB>(blk * 32 + ki, 2 * kk + hi));
         c = Mfma<T>::mma(a, kf[kk], c);
       }
-      // register r <-> query q0 + (r & 3) + 8 (r >> 2) + 4 hi; the two reference roundings of the logit, then its probability
+      // register r <-> query q0 + (r & 3) + 8 (r >> 2) + 4 hi; the two reference roundings of the logit, then its
+      // probability.  Blocks every row of which sees every key of this wave (all but the ones on the diagonal and at
+      // the ragged ends) skip the per-element visibility test: this kernel is VALU-bound (8 MFMAs per 16 scores a lane)
+      const bool all_vis = q0 + 31 < p.q_len && kblk + wave * 32 + 31 < p.N && (!p.causal || kblk + wave * 32 + 31 <= P + q0);
+      float pr[16];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 m4 = *reinterpret_cast<const f32x4*>(st + blk * 32 + 8 * g + 4 * hi);
-        const f32x4 r4 = *reinterpret_cast<const f32x4*>(st + QT + blk * 32 + 8 * g + 4 * hi);
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
           const f32x2 x = round2<T>(f32x2{c[4 * g + e], c[4 * g + e + 1]});
           const f32x2 v = round2<T>(f32x2{logit_scale<T>(x[0], p.sqrt_d, rsqrt_d), logit_scale<T>(x[1], p.sqrt_d, rsqrt_d)});
+          pr[4 * g + e] = __builtin_amdgcn_exp2f(fmaf(v[0], kLog2e, -m4[e]));
+          pr[4 * g + e + 1] = __builtin_amdgcn_exp2f(fmaf(v[1], kLog2e, -m4[e + 1]));
+        }
+      }
+      if (all_vis) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-          for (int z = 0; z < 2; ++z) {
-            const int qi = q0 + e + z + 8 * g + 4 * hi;
-            const bool vis = qi < p.q_len && key < p.N && (!p.causal || key <= P + qi);
-            const float pr = __builtin_amdgcn_exp2f(fmaf(v[z], kLog2e, -m4[e + z])) * r4[e + z];
-            colsum += vis ? pr : 0.f;
-          }
+        for (int r = 0; r < 16; r += 4) { a0 += pr[r]; a1 += pr[r + 1]; a2 += pr[r + 2]; a3 += pr[r + 3]; }
+        colsum += (a0 + a1) + (a2 + a3);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const bool vis = qi < p.q_len && key < p.N && (!p.causal || key <= P + qi);
+          colsum += vis ? pr[r] : 0.f;
         }
       }
     }
