@@ -665,6 +665,13 @@ def main():
                     q[i % L], None, Krd[i % L], Vd[i % L], new_len, cos, sin, new_len - 1, out=outs[i % L], workspace=ws, head_ids=hid), n=L), 2)
                 extras["c2_decode_2048_32_heads_us"] = round(_time(lambda i: ops.attn_decode(
                     q[i % L], None, Krd[i % L], Vd[i % L], new_len, cos, sin, new_len - 1, out=outs[i % L], workspace=ws), n=L), 2)
+                # the turn prefill of the multi-turn protocol: 64 new tokens on the 2048-row pruned cache of one layer
+                # (key-split flash kernel + merge; run_spatten_llama.py:71-86 feeds every new prompt this way)
+                qt = rnd(1, HEADS, 64, d)
+                ot = torch.empty(1, 64, HEADS * d, dtype=dt, device=dev)
+                extras["turn_prefill_64_on_2048_us_per_layer"] = round(_time(lambda i: ops.attn_prefill(
+                    qt, Krd[i % L][:, :, :new_len + 64], Vd[i % L][:, :, :new_len + 64], new_len + 64, cos, sin, new_len,
+                    causal=True, out=ot), n=L), 2)
                 del planes, Krp2, Vp2, Qp, Krc, Vc, plc
                 # configs[4] (C5): Llama-2-13B geometry (H = 40), 16384-token cache pruned to 8192 rows
                 # (start 4 / important 4092 / recent 4096), one layer: decode over bf16 keys and over PQ planes

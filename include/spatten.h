@@ -192,7 +192,9 @@ int spatten_kv_append(int dtype, const void* k_new, const void* v_new, int64_t n
  *                (MFMA leg only; fp32 atomics, so the summation order is not reproducible run to run)
  *   lse          optional [B,H,q_len,2] fp32 (contiguous): per query row (reference max m, sum_j exp(logit_ij - m)) of the
  *                masked logits — the softmax statistics; input of spatten_importance_accumulate_prefill
- *   workspace    spatten_prefill_workspace_bytes(...) bytes of device scratch
+ *   workspace    spatten_prefill_workspace_bytes(...) bytes of device scratch (the key-contiguous copy of V; for short
+ *                query blocks on a long cache — few query blocks x heads — also the fp32 partials of the KEY SPLIT:
+ *                up to 8 workgroups per (b, h, 256-query block), each over a range of key tiles, folded by a merge launch)
  * ---------------------------------------------------------------------------------------------- */
 size_t spatten_prefill_workspace_bytes(int dtype, int batch, int heads, int kv_heads, int head_dim,
                                        int q_len, int kv_len);

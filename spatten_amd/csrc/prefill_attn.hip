@@ -115,6 +115,13 @@ struct FlashParams {
   float pq_thr;
   int B, H, Hkv, q_len, N, Npad, causal, nqb;
   float sqrt_d;
+  // key split (prefill_pp128_kernel, plain keys): a (b, h, query block) is served by ksplit workgroups, each over a
+  // contiguous range of key tiles; they leave un-normalised partial outputs + (m, l) here and prefill_merge_kernel
+  // folds them.  Short query blocks on a long cache (the turn prefill of the multi-turn protocol: 64-500 new tokens on
+  // 2048 cached rows) otherwise run on H workgroups of a 256-CU chip.
+  int ksplit;
+  float* part_o;      // [B*H*nqb][ksplit][256][D] fp32
+  float* part_ml;     // [B*H*nqb][ksplit][256][2]
 };
 
 // A/B switches (tools/mb/pf_exp.sh rebuilds with -D<macro>=<v>; findings in DESIGN §3.4).
@@ -591,8 +598,11 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   const int grp = wave_u >> 2;
   const int nqb = p.nqb;
   int h, qblk, b;
+  const int ksplit = PQK ? 1 : p.ksplit;
+  const int ks = ksplit > 1 ? (int)blockIdx.x % ksplit : 0;          // which range of key tiles
+  const int item = ksplit > 1 ? (int)blockIdx.x / ksplit : (int)blockIdx.x;
   {
-    const int i = blockIdx.x;
+    const int i = item;
     const int per_b = p.H * nqb;
     b = i / per_b;
     const int j = i - b * per_b;
@@ -671,8 +681,12 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 
   const int wg_q_end = min(p.q_len, qblk * 256 + 256);
   const int att_keys = p.causal ? min(p.N, P + wg_q_end) : p.N;
-  const int n_att_tiles = (att_keys + KT - 1) / KT;
-  const int n_tiles = n_att_tiles;
+  const int all_tiles = (att_keys + KT - 1) / KT;
+  // this workgroup's tiles [T0, T1) (all of them without a key split); an empty range leaves an empty partial
+  const int per_split = (all_tiles + ksplit - 1) / ksplit;
+  const int T0 = min(ks * per_split, all_tiles), T1 = min(T0 + per_split, all_tiles);
+  const int n_att_tiles = T1;
+  const int n_tiles = T1;
   const int my_vis = p.causal ? min(p.N, P + myq + 1) : p.N;
   const int wave_full_keys = p.causal ? min(p.N, P + q0 + 1) : p.N;
   const int wave_att_tiles = !wave_live ? 0 : (p.causal ? min(n_att_tiles, (max(min(p.N, P + min(q0 + 32, p.q_len)), 0) + KT - 1) / KT) : n_att_tiles);
@@ -889,14 +903,14 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   };
 
   // ---- prologue (all 8 waves together): K(0) parked in stage 1's K area, stage 0 = { K(1), Vt(0) } --------------
-  dma_k(0, k_area(1));
-  dma_stage(0);
+  dma_k(T0, k_area(T0 + 1));
+  dma_stage(T0);
   __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0) (gfx9 encoding: vmcnt in bits 3:0 and 15:14)
   __syncthreads();
-  if (wave_tiles > 0) qk(k_area(1));
-  __syncthreads();                                   // everyone is done with K(0): stage 1 may be filled
-  if (1 < n_tiles) dma_stage(1);
-  if (wave_tiles > 0) softmax_tile(0);
+  if (wave_tiles > T0) qk(k_area(T0 + 1));
+  __syncthreads();                                   // everyone is done with K(T0): stage T0+1 may be filled
+  if (T0 + 1 < n_tiles) dma_stage(T0 + 1);
+  if (wave_tiles > T0) softmax_tile(T0);
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
   if (grp == 1) __syncthreads();                     // hold half 1 one phase behind
@@ -906,7 +920,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 #elif SPATTEN_PF_PRIO == 2
   if (grp == 0) __builtin_amdgcn_s_setprio(1);
 #endif
-  for (int t = 0; t < n_tiles; ++t) {
+  for (int t = T0; t < n_tiles; ++t) {
     // ---- matrix phase of iteration t -----------------------------------------------------------------------
     PF_STAMP(0);
 #if SPATTEN_PF_DMA_MODE == 1
@@ -916,9 +930,9 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     // tile).  Half 0 issues in global phase 2t and has the whole following vector phase for them to land; half 1 issues
     // in phase 2t+1 and waits for them at the end of that same phase (stage t+1 is first read in phase 2t+2).  The
     // slot's previous tenant, stage t-1, was last read in phase 2t-1.
-    if (!(SPATTEN_PF_EXPMODE & 2) && t >= 1 && t + 1 < n_tiles) dma_stage(t + 1);
+    if (!(SPATTEN_PF_EXPMODE & 2) && t >= T0 + 1 && t + 1 < n_tiles) dma_stage(t + 1);
 #elif SPATTEN_PF_DMA_MODE == 0
-    if (grp == 0 && t >= 1 && t + 1 < n_tiles) dma_stage(t + 1);
+    if (grp == 0 && t >= T0 + 1 && t + 1 < n_tiles) dma_stage(t + 1);
 #endif
     __builtin_amdgcn_sched_barrier(0);
     if (t < wave_att_tiles) pv(v_area(t));
@@ -935,7 +949,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 #elif SPATTEN_PF_DMA_MODE == 2
     // both halves issue from their VECTOR phase (stage t+1 may be written during global phases 2t and 2t+1: half 1 is in
     // its vector phase of iteration t-1 during 2t, half 0 in its vector phase of iteration t during 2t+1)
-    if (grp == 0 && t >= 1 && t + 1 < n_tiles) dma_stage(t + 1);
+    if (grp == 0 && t >= T0 + 1 && t + 1 < n_tiles) dma_stage(t + 1);
     if (grp == 1 && t + 2 < n_tiles) dma_stage(t + 2);
 #endif
     PF_STAMP(3);
@@ -953,6 +967,21 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 #else
   const float l_tot = xor32_sum(l_run);
 #endif
+  if (ksplit > 1) {       // partial result of this key range: un-normalised O^T, (m, l) — folded by prefill_merge_kernel
+    const int64_t slot = ((int64_t)item * ksplit + ks) * 256 + wave * 32 + qi;
+    float* po = p.part_o + slot * D;
+    if (qvalid) {           // rows past q_len are never read back
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dv = db * 32 + 8 * g + 4 * hi;
+          *reinterpret_cast<f32x4*>(po + dv) = f32x4{o[db][4 * g], o[db][4 * g + 1], o[db][4 * g + 2], o[db][4 * g + 3]};
+        }
+      if (hi == 0) { p.part_ml[slot * 2] = m_run; p.part_ml[slot * 2 + 1] = l_tot; }
+    }
+    return;
+  }
   const float inv = 1.f / l_tot;
   if (p.lse != nullptr && qvalid && hi == 0) {
     float* ls = p.lse + ((int64_t)(b * p.H + h) * p.q_len + myq) * 2;
@@ -978,6 +1007,42 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   }
 }
 
+
+// Fold the key-split partials of prefill_pp128_kernel: one wave per query row (D/64 output elements per lane).
+// out = sum_s O_s e^(m_s - m) / sum_s l_s e^(m_s - m),  m = max_s m_s   (a split without keys has m = -inf, l = 0)
+template <typename T, int D>
+__global__ __launch_bounds__(256) void prefill_merge_kernel(const FlashParams<T> p) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;                 // over B * H * q_len
+  if (row >= (int64_t)p.B * p.H * p.q_len) return;
+  const int qi = (int)(row % p.q_len);
+  const int bh = (int)(row / p.q_len), h = bh % p.H, b = bh / p.H;
+  // the flash kernel's work order: item = b * H * nqb + j with j as decoded there
+  const int qblk = qi / 256, qin = qi % 256, nqb = p.nqb;
+  int j;
+  if ((p.H & 7) == 0) j = (h & 7) + 8 * ((h >> 3) * nqb + (nqb - 1 - qblk));
+  else j = h * nqb + (nqb - 1 - qblk);
+  const int64_t item = (int64_t)b * p.H * nqb + j;
+  const int S = p.ksplit;
+  float m = -INFINITY;
+  for (int s = 0; s < S; ++s) m = fmaxf(m, p.part_ml[((item * S + s) * 256 + qin) * 2]);
+  const float mu = (m == -INFINITY) ? 0.f : m;
+  float l = 0.f, acc[D / 64];
+#pragma unroll
+  for (int e = 0; e < D / 64; ++e) acc[e] = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const int64_t slot = (item * S + s) * 256 + qin;
+    const float w = __expf(p.part_ml[slot * 2] - mu);               // exp(-inf) = 0
+    l = fmaf(p.part_ml[slot * 2 + 1], w, l);
+#pragma unroll
+    for (int e = 0; e < D / 64; ++e) acc[e] = fmaf(p.part_o[slot * D + lane + 64 * e], w, acc[e]);
+  }
+  const float inv = 1.f / l;
+  T* orow = p.out + b * p.out_sb + (int64_t)qi * p.out_sq + h * D;
+#pragma unroll
+  for (int e = 0; e < D / 64; ++e) orow[lane + 64 * e] = DT<T>::from_f32(acc[e] * inv);
+  if (p.lse != nullptr && lane == 0) { float* ls = p.lse + row * 2; ls[0] = m; ls[1] = l; }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Cascade importance of a multi-token forward WITHOUT the [B,H,q,N] stash:
@@ -1132,6 +1197,24 @@ static int prefill_variant() {
   return v;
 }
 
+// Key split of the plain flash kernel: only when the launch would leave most of the chip idle (few query blocks x heads)
+// and every range still has >= 2 key tiles.  The same rule sizes the workspace.
+static inline int flash_ksplit(int batch, int heads, int q_len, int kv_len) {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("SPATTEN_PREFILL_KSPLIT"); env = e ? atoi(e) : 0; }   // 1 = off, n = forced (A/B)
+  const long long items = (long long)batch * heads * ceil_div(q_len, 256);
+  const int tiles = ceil_div(kv_len, 128);
+  int ks = items >= 128 ? 1 : (int)(256 / items);
+  if (env > 0) ks = env;
+  if (ks > 8) ks = 8;
+  if (ks > tiles / 2) ks = tiles / 2;
+  return ks < 1 ? 1 : ks;
+}
+static inline size_t flash_partial_bytes(int batch, int heads, int head_dim, int q_len, int ks) {
+  if (ks <= 1) return 0;
+  return (size_t)batch * heads * ceil_div(q_len, 256) * ks * 256 * (head_dim + 2) * sizeof(float);
+}
+
 template <typename T, int D, bool ST, bool CI>
 static void launch_flash_m(const FlashParams<T>& p, hipStream_t st) {
   const dim3 grid((unsigned)(p.nqb * p.H * p.B));
@@ -1147,8 +1230,13 @@ static void launch_flash_m(const FlashParams<T>& p, hipStream_t st) {
       return;
     }
     if (prefill_variant() == 0) {
-      if (p.mask) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, true>), grid, dim3(512), 0, st, p);
-      else hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false>), grid, dim3(512), 0, st, p);
+      const dim3 gridk((unsigned)(p.nqb * p.H * p.B * (p.ksplit > 1 ? p.ksplit : 1)));
+      if (p.mask) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, true>), gridk, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false>), gridk, dim3(512), 0, st, p);
+      if (p.ksplit > 1) {
+        const long long rows = (long long)p.B * p.H * p.q_len;
+        hipLaunchKernelGGL((prefill_merge_kernel<T, D>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+      }
       return;
     }
   }
@@ -1179,7 +1267,8 @@ extern "C" size_t spatten_prefill_workspace_bytes(int dtype, int batch, int head
     return 256 + kDecodeWsHeader + decode_cnt_bytes(units) + (S > 1 ? units * S * (head_dim + 2) * sizeof(unsigned long long) : 0);
   }
   const size_t es = 2, npad = (size_t)ceil_div(kv_len, 128) * 128;
-  return 256 + align256((size_t)batch * kv_heads * head_dim * npad * es);      // the key-contiguous copy of V
+  return 256 + align256((size_t)batch * kv_heads * head_dim * npad * es)      // the key-contiguous copy of V
+         + align256(flash_partial_bytes(batch, heads, head_dim, q_len, flash_ksplit(batch, heads, q_len, kv_len)));   // key-split partials
 }
 
 extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sq,
@@ -1259,6 +1348,9 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
     p.col_imp = col_importance; p.lse = lse; p.kscale = nullptr; p.ks_sb = p.ks_sh = 0; p.need = nullptr; p.pq_thr = 0.f; \
     p.B = batch; p.H = heads; p.Hkv = kv_heads; p.q_len = q_len; p.N = kv_len; p.Npad = npad;          \
     p.causal = causal; p.sqrt_d = sqrtf((float)head_dim); p.nqb = ceil_div(q_len, 256);                \
+    p.ksplit = (!scores && !col_importance && prefill_variant() == 0) ? flash_ksplit(batch, heads, q_len, kv_len) : 1; \
+    p.part_o = (float*)(ws + align256((size_t)batch * kv_heads * head_dim * npad * 2));                \
+    p.part_ml = p.part_o + (size_t)batch * heads * p.nqb * p.ksplit * 256 * head_dim;                   \
     return launch_flash<T, DD>(p, st);                                                                 \
   }
   if (dtype == SPATTEN_BF16) { if (head_dim == 128) SPATTEN_FLASH(bf16_t, 128) else SPATTEN_FLASH(bf16_t, 64) }
@@ -1368,6 +1460,7 @@ extern "C" int spatten_attn_prefill_pq(int dtype, const void* q, int64_t q_sb, i
     p.kscale = kscale; p.ks_sb = (int64_t)kv_heads * kv_len; p.ks_sh = kv_len; p.need = need_lsb; p.pq_thr = (THR); \
     p.B = batch; p.H = heads; p.Hkv = kv_heads; p.q_len = q_len; p.N = kv_len; p.Npad = npad;          \
     p.causal = causal; p.sqrt_d = sqrtf((float)head_dim); p.nqb = ceil_div(q_len, 256);                \
+    p.ksplit = 1; p.part_o = nullptr; p.part_ml = nullptr;                                             \
     rc = launch_flash<T, DD>(p, st);                                                                   \
   }
 #define SPATTEN_FLASH_PQ_ANY(KPTR, THR)                                                                                  \

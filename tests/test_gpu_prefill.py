@@ -120,6 +120,46 @@ def test_prefill_multi_block_shapes_vs_oracle(case):
     np.testing.assert_allclose(out2, o2, **OUT_TOL[dt])
 
 
+@pytest.mark.parametrize("case", [("bf16", 128, 1, 8, 8, 2000, 40), ("bf16", 128, 1, 8, 2, 1500, 300), ("f16", 64, 2, 4, 4, 900, 17),
+                                  ("bf16", 128, 1, 4, 4, 0, 700)])
+def test_turn_prefill_key_split_vs_oracle(case, monkeypatch):
+    """A short block of new tokens on a long cache (the turn prefill of the multi-turn protocol): the flash kernel splits
+    the KEY tiles of a query block over several workgroups and a merge kernel folds the partials — outputs and the row
+    statistics vs the oracle, causal flag and explicit mask, and the same call with the split forced off."""
+    from spatten_amd import ops
+    dt, d, B, H, Hkv, P, ql = case
+    q, k, v, past = attn_inputs(B, H, Hkv, d, P, ql, dt, seed=1300 + P + ql)
+    N = P + ql
+    pos = np.tile(np.arange(P, N)[None], (B, 1))
+    pk, pv = (None, None) if past is None else past
+    o, stash, _ = orc.attention_core(q, k, v, pk, pv, pos, orc.causal_mask(B, ql, N, dt), dt)
+    out, _, _ = run_prefill(q, k, v, past, dt, causal=True, stash=False)
+    np.testing.assert_allclose(out, o, **OUT_TOL[dt])
+    # row statistics through the split: (m, l) of every row = max / sum-exp of the oracle's masked logits
+    kc = k if past is None else np.concatenate([pk, k], 2)
+    vc = v if past is None else np.concatenate([pv, v], 2)
+    cos, sin = ops.rope_table(N + 3, d, TORCH_DT[dt], "cuda")
+    kd, vd = dev(kc, dt), dev(vc, dt)
+    krd = ops.rope_single(kd, cos, sin)
+    qd = dev(q, dt)
+    lse = torch.empty(B, H, ql, 2, dtype=torch.float32, device="cuda")
+    out2 = ops.attn_prefill(qd, krd, vd, N, cos, sin, P, causal=True, lse=lse)
+    logits = stash.astype(np.float32) + orc.causal_mask(B, ql, N, dt).astype(np.float32)
+    m_ref = logits.max(-1)
+    l_ref = np.exp(logits - m_ref[..., None]).sum(-1)
+    got = host(lse)
+    # the kernel's m may lag the true maximum (deferred rescale): compare the invariant m + log l
+    np.testing.assert_allclose(got[..., 0] + np.log(got[..., 1]), m_ref + np.log(l_ref), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(host(out2), o, **OUT_TOL[dt])
+    # explicit (non-causal) mask through the same split
+    rng = np.random.default_rng(5)
+    am = np.where(rng.random((B, 1, ql, N)) < 0.3, np.float32(orc.finfo_min(dt)), np.float32(0)).astype(np.float32)
+    am[..., 0] = 0
+    o3, _, _ = orc.attention_core(q, k, v, pk, pv, pos, am, dt)
+    out3, _, _ = run_prefill(q, k, v, past, dt, mask=am[:, 0], stash=False)
+    np.testing.assert_allclose(out3, o3, **OUT_TOL[dt])
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 def test_prefill_deferred_rescale_spikes(dt):
     """The no-stash flash path only moves its running maximum when a row outgrows it by more than a threshold.  Rare
