@@ -62,6 +62,7 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
         m.spatten_assume_causal = bool(assume_causal)
         m._spatten_ext = None
         m._spatten_rope = None
+        m.__dict__.pop("_spatten_geom", None)       # geometry cache of the patched forward: re-read on the next call
         m._spatten_qkv = None
         if fuse_qkv:
             from .pos_shift.modify_llama import fuse_qkv_projections

@@ -49,7 +49,7 @@ def rope_tables(n: int, d: int, dtype: torch.dtype, device, base: float = 10000.
 
 
 class KVSlab:
-    __slots__ = ("k", "kr", "v", "length", "rot_len", "base", "scaling", "pq", "pq_len", "__weakref__")
+    __slots__ = ("k", "kr", "v", "length", "rot_len", "base", "scaling", "pq", "pq_len", "dec", "_tab", "__weakref__")
 
     def __init__(self, k, kr, v, length, rot_len, base=10000.0, scaling=None):
         self.k, self.kr, self.v = k, kr, v          # full-capacity planes [B,Hkv,cap,d]
@@ -58,14 +58,26 @@ class KVSlab:
         self.base, self.scaling = float(base), scaling
         self.pq = None                              # ops.PQPlanes of kr (progressive quantisation), built on demand
         self.pq_len = 0                             # rows of the planes that are valid
+        self.dec = None                             # ops.SlabDecodeCall: the prefilled argument block of the decode step
+        self._tab = None                            # this slab's rotary tables (rows >= capacity), looked up once
 
     @property
     def capacity(self) -> int:
         return self.k.shape[2]
 
     def tables(self, rows: Optional[int] = None):
-        B, H, cap, d = self.k.shape
-        return rope_tables(max(cap, rows or 0), d, self.k.dtype, self.k.device, self.base, self.scaling)
+        t = self._tab
+        if t is None or t[0].shape[0] < (rows or 0):
+            B, H, cap, d = self.k.shape
+            t = self._tab = rope_tables(max(cap, rows or 0), d, self.k.dtype, self.k.device, self.base, self.scaling)
+        return t
+
+    def decode_step(self, q, k_new, v_new, kv_len: int, pos_q: int, cos, sin, scores):
+        """The plain fused decode step on this slab through its prefilled argument block (ops.SlabDecodeCall)."""
+        dec = self.dec
+        if dec is None or dec.key != (tuple(q.shape), q.dtype, cos.data_ptr()):
+            dec = self.dec = ops.SlabDecodeCall(self.k, self.kr, self.v, cos, sin, q)
+        return dec.run(q, k_new, v_new, kv_len, pos_q, scores)
 
     def views(self):
         kv = self.k[:, :, :self.length]

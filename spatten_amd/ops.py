@@ -223,6 +223,54 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: Opti
     return out
 
 
+class SlabDecodeCall:
+    """A prefilled argument block for the plain decode step on ONE KV slab (host-path fast lane of the patched forward:
+    a single-token step is host-bound, and filling ~35 ctypes fields + re-validating the slab costs more than the launch).
+    Everything that does not change from token to token — the slab planes and their strides, the rotary tables, the
+    workspace, the geometry — is validated and written once; ``run`` sets the per-token fields and launches."""
+
+    def __init__(self, k_cache, kr_cache, v_cache, cos, sin, q: torch.Tensor):
+        _dev(q, k_cache, kr_cache, v_cache, cos, sin)
+        B, H, d = q.shape
+        Hkv, cap = v_cache.shape[1], v_cache.shape[2]
+        if v_cache.stride(3) != 1 or v_cache.stride(2) != d or kr_cache.stride() != v_cache.stride() \
+                or k_cache.stride() != v_cache.stride() or cos.shape[1] * 2 != d:
+            raise ValueError("slab planes need contiguous rows (pitch d) and identical strides")
+        self.key = (tuple(q.shape), q.dtype, cos.data_ptr())
+        self.cap, self.table_rows, self.B, self.H, self.d = cap, cos.shape[0], B, H, d
+        self.keep = (k_cache, kr_cache, v_cache, cos, sin)        # the block holds raw pointers: keep the tensors alive
+        self.stream = _stream()
+        self.ws = _workspace(B, H, d, q.device, self.stream)
+        a = self.a = _lib.DecodeArgs()
+        a.struct_size = ctypes.sizeof(_lib.DecodeArgs)
+        a.dtype = _dt(q)
+        a.k_cache, a.kr_cache, a.v_cache = k_cache.data_ptr(), kr_cache.data_ptr(), v_cache.data_ptr()
+        a.kv_sb, a.kv_sh = v_cache.stride(0), v_cache.stride(1)
+        a.cos, a.sin, a.table_rows = cos.data_ptr(), sin.data_ptr(), cos.shape[0]
+        a.workspace, a.workspace_splits = self.ws.buf.data_ptr(), self.ws.max_splits
+        a.batch, a.heads, a.kv_heads, a.head_dim = B, H, Hkv, d
+        self.lib = _lib.load()
+
+    def run(self, q, k_new, v_new, kv_len: int, pos_q: int, scores: torch.Tensor) -> torch.Tensor:
+        """q [B,H,d], k_new / v_new [B,Hkv,d] (rows contiguous), scores [B,H,>=kv_len]; returns out [B, H*d]."""
+        if kv_len > self.cap or max(kv_len, pos_q + 1) > self.table_rows or q.stride(2) != 1 or k_new.stride(2) != 1 \
+                or v_new.stride() != k_new.stride() or scores.stride(2) != 1:
+            raise ValueError("decode step outside the slab / rotary table, or operands without contiguous rows")
+        stream = _stream()
+        if stream != self.stream:                       # the workspace belongs to a stream
+            self.stream, self.ws = stream, _workspace(self.B, self.H, self.d, q.device, stream)
+            self.a.workspace = self.ws.buf.data_ptr()
+        out = torch.empty(self.B, self.H * self.d, dtype=q.dtype, device=q.device)
+        a = self.a
+        a.q, a.q_sb, a.q_sh = q.data_ptr(), (self.H * self.d if self.B == 1 else q.stride(0)), q.stride(1)
+        a.k_new, a.v_new, a.new_sb, a.new_sh = k_new.data_ptr(), v_new.data_ptr(), k_new.stride(0), k_new.stride(1)
+        a.out, a.out_sb = out.data_ptr(), out.stride(0)
+        a.scores, a.sc_sb, a.sc_sh = scores.data_ptr(), scores.stride(0), scores.stride(1)
+        a.kv_len, a.pos_q = kv_len, pos_q
+        _lib.check(self.lib.spatten_attn_decode_args(ctypes.byref(a), stream), "spatten_attn_decode")
+        return out
+
+
 def kv_append(k_new: torch.Tensor, v_new: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: torch.Tensor,
               v_cache: torch.Tensor, row0: int, cos: torch.Tensor, sin: torch.Tensor):
     """Rows [row0, row0+n) of the slab planes from k_new / v_new [B,Hkv,n,d] (any strides, d contiguous): K un-rotated,

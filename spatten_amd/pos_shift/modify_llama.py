@@ -87,11 +87,15 @@ def llama_pos_shift_attention_forward(
     padding_mask: Optional[torch.Tensor] = None,
 ) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[Tuple[torch.Tensor]]]:
     bsz, q_len, _ = hidden_states.size()
-    num_heads = _cfg(self, "num_heads", "num_attention_heads")
-    num_kv_heads = _cfg(self, "num_key_value_heads", "num_key_value_heads", default=num_heads)
-    head_dim = _cfg(self, "head_dim", "head_dim") or (_cfg(self, "hidden_size", "hidden_size") // num_heads)
-    hidden_size = _cfg(self, "hidden_size", "hidden_size", default=num_heads * head_dim)
-    tp = getattr(getattr(self, "config", None), "pretraining_tp", 1) or 1
+    geom = self.__dict__.get("_spatten_geom")          # the module's geometry, read once (a decode step is host-bound)
+    if geom is None:
+        num_heads = _cfg(self, "num_heads", "num_attention_heads")
+        num_kv_heads = _cfg(self, "num_key_value_heads", "num_key_value_heads", default=num_heads)
+        head_dim = _cfg(self, "head_dim", "head_dim") or (_cfg(self, "hidden_size", "hidden_size") // num_heads)
+        hidden_size = _cfg(self, "hidden_size", "hidden_size", default=num_heads * head_dim)
+        tp = getattr(getattr(self, "config", None), "pretraining_tp", 1) or 1
+        geom = self.__dict__["_spatten_geom"] = (num_heads, num_kv_heads, head_dim, hidden_size, tp)
+    num_heads, num_kv_heads, head_dim, hidden_size, tp = geom
 
     if tp > 1:                                                                    # :43-69
         kv_slicing = (num_kv_heads * head_dim) // tp
@@ -158,6 +162,10 @@ def llama_pos_shift_attention_forward(
         k3, v3 = key_states.view(bsz, num_kv_heads, head_dim), value_states.view(bsz, num_kv_heads, head_dim)
         if ext is not None:
             attn_output, stash = ext[0].decode_step(ext[1], q3, k3, v3, slab, kv_seq_len, past_len, cos, sin)
+        elif position_ids is None and (attention_mask is None or assume_causal):
+            # host-path fast lane (nothing per-token but pointers and two lengths): the slab's prefilled argument block
+            stash = torch.empty(bsz, num_heads, 1, kv_seq_len, dtype=dtype, device=device)
+            attn_output = slab.decode_step(q3, k3, v3, kv_seq_len, past_len, cos, sin, stash.view(bsz, num_heads, kv_seq_len))
         else:
             stash = torch.empty(bsz, num_heads, 1, kv_seq_len, dtype=dtype, device=device)
             attn_output = ops.attn_decode(

@@ -269,13 +269,16 @@ def test_forward_matches_reference_goldens():
                 assert not _mask_is_causal(bad, P)
 
 
+@pytest.mark.parametrize("assume", [False, True])
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
-def test_forward_multi_step_decode_and_prune_roundtrip(dt):
+def test_forward_multi_step_decode_and_prune_roundtrip(dt, assume):
     """prefill -> 5 decode steps (in-place appends into the slab) -> prune -> decode again: every step vs the oracle
-    run on the reference's semantics (cat + re-rotate everything each step)."""
+    run on the reference's semantics (cat + re-rotate everything each step).  ``assume``: the assume_causal extension —
+    single-token steps then go through the slab's prefilled argument block (host-path fast lane, lean decode kernel)."""
     from spatten_amd import SpAttenKVCache
     B, H, d = 1, 4, 128
     m = StubAttn(H, H, d)
+    m.spatten_assume_causal = assume
     rng_seed = 77
     past_np, past_dev = None, None
     L = 0
@@ -293,6 +296,9 @@ def test_forward_multi_step_decode_and_prune_roundtrip(dt):
         # so compare with the output tolerance only
         np.testing.assert_allclose(host(out), o, err_msg=f"step {step}", **OUT_TOL[dt])
         assert np.array_equal(host(past_dev[0]), kc) and np.array_equal(host(past_dev[1]), vc)
+        if ql == 1:
+            check_stash(host(m.attn_scores), stash, dt, f"step {step}")
+            assert (past_dev[0]._spatten_slab.dec is not None) == assume        # the fast lane ran iff assume_causal
         past_np, L = (kc, vc), N
     slab = past_dev[0]._spatten_slab
     assert slab.length == L and slab.rot_len == L and slab.capacity >= L
