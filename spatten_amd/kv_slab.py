@@ -72,12 +72,12 @@ class KVSlab:
             t = self._tab = rope_tables(max(cap, rows or 0), d, self.k.dtype, self.k.device, self.base, self.scaling)
         return t
 
-    def decode_step(self, q, k_new, v_new, kv_len: int, pos_q: int, cos, sin, scores):
+    def decode_step(self, q, k_new, v_new, kv_len: int, pos_q: int, cos, sin, scores, position_ids=None, mask=None):
         """The plain fused decode step on this slab through its prefilled argument block (ops.SlabDecodeCall)."""
         dec = self.dec
         if dec is None or dec.key != (tuple(q.shape), q.dtype, cos.data_ptr()):
             dec = self.dec = ops.SlabDecodeCall(self.k, self.kr, self.v, cos, sin, q)
-        return dec.run(q, k_new, v_new, kv_len, pos_q, scores)
+        return dec.run(q, k_new, v_new, kv_len, pos_q, scores, position_ids, mask)
 
     def views(self):
         kv = self.k[:, :, :self.length]

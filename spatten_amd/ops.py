@@ -251,11 +251,17 @@ class SlabDecodeCall:
         a.batch, a.heads, a.kv_heads, a.head_dim = B, H, Hkv, d
         self.lib = _lib.load()
 
-    def run(self, q, k_new, v_new, kv_len: int, pos_q: int, scores: torch.Tensor) -> torch.Tensor:
-        """q [B,H,d], k_new / v_new [B,Hkv,d] (rows contiguous), scores [B,H,>=kv_len]; returns out [B, H*d]."""
+    def run(self, q, k_new, v_new, kv_len: int, pos_q: int, scores: torch.Tensor,
+            position_ids: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """q [B,H,d], k_new / v_new [B,Hkv,d] (rows contiguous), scores [B,H,>=kv_len]; optional position_ids int64 [B]
+        (device) and additive mask [B,kv_len] as in attn_decode; returns out [B, H*d]."""
         if kv_len > self.cap or max(kv_len, pos_q + 1) > self.table_rows or q.stride(2) != 1 or k_new.stride(2) != 1 \
                 or v_new.stride() != k_new.stride() or scores.stride(2) != 1:
             raise ValueError("decode step outside the slab / rotary table, or operands without contiguous rows")
+        if position_ids is not None and (position_ids.dtype != torch.int64 or not position_ids.is_cuda):
+            raise TypeError("position_ids must be an int64 device tensor")
+        if mask is not None and (mask.stride(-1) != 1 or mask.dtype != q.dtype or not mask.is_cuda):
+            raise ValueError("mask must be a device tensor in the model dtype with contiguous rows")
         stream = _stream()
         if stream != self.stream:                       # the workspace belongs to a stream
             self.stream, self.ws = stream, _workspace(self.B, self.H, self.d, q.device, stream)
@@ -267,6 +273,14 @@ class SlabDecodeCall:
         a.out, a.out_sb = out.data_ptr(), out.stride(0)
         a.scores, a.sc_sb, a.sc_sh = scores.data_ptr(), scores.stride(0), scores.stride(1)
         a.kv_len, a.pos_q = kv_len, pos_q
+        if position_ids is not None:
+            a.position_ids, a.pos_sb = position_ids.data_ptr(), position_ids.stride(0)
+        else:
+            a.position_ids = None
+        if mask is not None:
+            a.mask, a.mask_sb = mask.data_ptr(), mask.stride(0)
+        else:
+            a.mask = None
         _lib.check(self.lib.spatten_attn_decode_args(ctypes.byref(a), stream), "spatten_attn_decode")
         return out
 

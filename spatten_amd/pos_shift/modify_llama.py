@@ -142,7 +142,8 @@ def llama_pos_shift_attention_forward(
         # assume_causal the tensor is not read — the query positions are a launch constant, which is what lets a
         # single-token step run the lean decode kernel (no position tensor, no mask)
         position_ids = None
-    if position_ids is not None:
+    if position_ids is not None and not (position_ids.dtype == torch.int64 and position_ids.device == device
+                                         and position_ids.shape == (bsz, q_len) and position_ids.is_contiguous()):
         position_ids = position_ids.to(device=device, dtype=torch.int64)
         if position_ids.dim() == 1:
             position_ids = position_ids[None]
@@ -162,18 +163,15 @@ def llama_pos_shift_attention_forward(
         k3, v3 = key_states.view(bsz, num_kv_heads, head_dim), value_states.view(bsz, num_kv_heads, head_dim)
         if ext is not None:
             attn_output, stash = ext[0].decode_step(ext[1], q3, k3, v3, slab, kv_seq_len, past_len, cos, sin)
-        elif position_ids is None and (attention_mask is None or assume_causal):
-            # host-path fast lane (nothing per-token but pointers and two lengths): the slab's prefilled argument block
-            stash = torch.empty(bsz, num_heads, 1, kv_seq_len, dtype=dtype, device=device)
-            attn_output = slab.decode_step(q3, k3, v3, kv_seq_len, past_len, cos, sin, stash.view(bsz, num_heads, kv_seq_len))
         else:
+            # the slab's prefilled argument block (host-path fast lane: per token only pointers and two lengths are
+            # written).  With assume_causal the HF mask of a single-token step (all zeros) and its position_ids are not
+            # read: the lean decode kernel.
             stash = torch.empty(bsz, num_heads, 1, kv_seq_len, dtype=dtype, device=device)
-            attn_output = ops.attn_decode(
-                q3, slab.k, slab.kr, slab.v, kv_seq_len, cos, sin, past_len, k_new=k3, v_new=v3,
-                position_ids=None if position_ids is None else position_ids[:, 0],
-                # with assume_causal the HF mask of a single-token step (all zeros) is not read: the lean decode kernel
-                mask=None if (attention_mask is None or assume_causal) else attention_mask[:, 0, 0, :],
-                scores=stash.view(bsz, num_heads, kv_seq_len))
+            attn_output = slab.decode_step(
+                q3, k3, v3, kv_seq_len, past_len, cos, sin, stash.view(bsz, num_heads, kv_seq_len),
+                None if position_ids is None else position_ids[:, 0],
+                None if (attention_mask is None or assume_causal) else attention_mask[:, 0, 0, :])
         slab.length = slab.rot_len = kv_seq_len
         attn_output = attn_output.view(bsz, 1, num_heads * head_dim)
     else:
