@@ -204,7 +204,7 @@ def cpu_baseline(L, new_len, lo, hi):
     return out
 
 
-def plugin_path_tokens_per_s(dev, dt, n_tokens=48):
+def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False), (True, False), (True, True))):
     """The DROP-IN number: tokens/s through the patched HF forward itself (`llama_pos_shift_attention_forward`, called per
     layer with the arguments transformers 4.33 passes — hidden states, a zero mask, position_ids, the layer's (K, V)
     pair — including the module's q/k/v/o projections and every per-call host step), eager launches, Llama-2-7B geometry,
@@ -237,7 +237,7 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48):
     P = START + IMPORTANT + RECENT
     with torch.no_grad():
         model = Stack()
-        for flag, fuse in ((False, False), (True, False), (True, True)):
+        for flag, fuse in variants:
             import contextlib
             import io
             with contextlib.redirect_stdout(io.StringIO()):       # the constructor prints the reference's banner
