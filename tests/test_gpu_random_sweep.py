@@ -1,5 +1,7 @@
 """Seeded random sweeps of the three hot-path pieces against the oracle: shapes, GQA ratios, batch, lengths that do not
 align with any tile or split boundary, dtypes.  Complements the hand-picked cases of the other GPU tests."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -11,8 +13,11 @@ from tests.util import OUT_TOL, attn_inputs, check_stash, dev, host
 
 pytestmark = pytest.mark.gpu
 
+# SPATTEN_SWEEP_SEEDS=n widens every sweep to n seeds (soak runs; the default keeps the suite short)
+SEEDS = int(os.environ.get("SPATTEN_SWEEP_SEEDS", "0"))
 
-@pytest.mark.parametrize("seed", range(10))
+
+@pytest.mark.parametrize("seed", range(max(10, SEEDS)))
 def test_decode_random_configs(seed):
     rng = np.random.default_rng(1000 + seed)
     dt = str(rng.choice(["f32", "bf16", "f16"]))
@@ -31,7 +36,7 @@ def test_decode_random_configs(seed):
     assert np.array_equal(kc_g, kc) and np.array_equal(vc_g, vc)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(max(8, SEEDS)))
 def test_prefill_random_configs(seed):
     rng = np.random.default_rng(2000 + seed)
     dt = str(rng.choice(["bf16", "f16"]))
@@ -39,7 +44,7 @@ def test_prefill_random_configs(seed):
     Hkv = int(rng.choice([1, 2]))
     H = Hkv * int(rng.choice([1, 2, 4]))
     B = int(rng.choice([1, 2]))
-    P = int(rng.integers(0, 700))
+    P = int(rng.integers(0, 700 if seed < 8 else 3000))      # later seeds: long pasts (key-split flash kernel)
     ql = int(rng.integers(9, 600))
     q, k, v, past = attn_inputs(B, H, Hkv, d, P, ql, dt, seed=8000 + seed)
     N = P + ql
@@ -55,7 +60,7 @@ def test_prefill_random_configs(seed):
     np.testing.assert_allclose(ci, st.sum(axis=2, dtype=np.float32), rtol=1e-4, atol=2e-3, err_msg=msg)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(max(8, SEEDS)))
 def test_prune_random_configs(seed):
     from spatten_amd import SpAttenKVCache
     rng = np.random.default_rng(3000 + seed)
