@@ -78,3 +78,22 @@ def test_product_fails_loudly_without_library_or_gpu(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libspatten_hip.so")
     with pytest.raises(_lib.SpattenLibraryError, match="make lib"):
         _lib.load()
+
+
+def test_integration_md_c_snippet_compiles_against_the_header(tmp_path):
+    """The C example of INTEGRATION.md §2 (the decode argument block) is compiled as written against include/spatten.h."""
+    import re
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    body = re.search(r"```c\n(spatten_decode_args_t a = \{0\};.*?)```", text, re.S).group(1)
+    src = tmp_path / "snippet.c"
+    src.write_text('#include <stddef.h>\n#include <stdint.h>\n#include "spatten.h"\n'
+                   "int f(void* q, void* k, void* kr, void* v, void* k_new, void* v_new, void* cos, void* sin, void* out,\n"
+                   "      void* stash, void* ws, const int32_t* kept, void* stream, int H, int Hkv, int d, int cap, int rows,\n"
+                   "      int B, int n) {\n" + body + "  return rc;\n}\n")
+    subprocess.check_call([gcc, "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)])
