@@ -1204,11 +1204,13 @@ static inline int flash_ksplit(int batch, int heads, int q_len, int kv_len) {
   if (env < 0) { const char* e = getenv("SPATTEN_PREFILL_KSPLIT"); env = e ? atoi(e) : 0; }   // 1 = off, n = forced (A/B)
   const long long items = (long long)batch * heads * ceil_div(q_len, 256);
   const int tiles = ceil_div(kv_len, 128);
-  int ks = items >= 128 ? 1 : (int)(256 / items);
+  int ks = (items >= 128 || tiles < 8) ? 1 : (int)(256 / items);    // short key ranges: the partials cost more than they buy
   if (env > 0) ks = env;
   if (ks > 8) ks = 8;
   if (ks > tiles / 2) ks = tiles / 2;
-  return ks < 1 ? 1 : ks;
+  if (ks < 1) ks = 1;
+  const int per = ceil_div(tiles, ks);          // tiles per range ...
+  return ceil_div(tiles, per);                  // ... and no empty ranges (17 tiles: 8 ranges of 3 would leave two empty)
 }
 static inline size_t flash_partial_bytes(int batch, int heads, int head_dim, int q_len, int ks) {
   if (ks <= 1) return 0;
