@@ -270,7 +270,97 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False), (Tr
             key = "plugin_path_assume_causal_fused_qkv_tokens_per_s" if fuse else (
                 "plugin_path_assume_causal_tokens_per_s" if flag else "plugin_path_tokens_per_s")
             out[key] = round(n_tokens / (time.perf_counter() - t0), 2)
+            # ---- the same decode step as ONE captured HIP graph of the whole layer stack (spatten_amd/graph.py): the
+            # device-resident step state (ABI 3) lets a single graph replay for every token of the turn
+            if flag and not fuse:
+                continue                # (assume_causal is implied under capture: graph legs for the plain and the fused form)
+            from spatten_amd.graph import DecodeGraph
+
+            def step_fn(pst, xin):
+                n = pst[0][0].shape[2]
+                zm = torch.zeros(1, 1, 1, n + 1, dtype=dt, device=dev)
+                pid = torch.full((1, 1), n, dtype=torch.long, device=dev)
+                new, o = [], None
+                for i, m in enumerate(model.layers):
+                    o, _, kv = m(xin, attention_mask=zm, position_ids=pid, past_key_value=pst[i], use_cache=True)
+                    new.append(kv)
+                return new, o
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            graph = DecodeGraph(step_fn, past, horizon=TURN)
+            for t in range(TURN):       # one turn as the reference's caller runs it: warm-up step + capture + 62 replays
+                graph.step(xt)
+            torch.cuda.synchronize()
+            t_turn = time.perf_counter() - t0
+            n_rep = 128
+            t0 = time.perf_counter()
+            for t in range(n_rep):
+                graph.step(xt)
+            torch.cuda.synchronize()
+            t_rep = time.perf_counter() - t0
+            sfx = "_fused_qkv" if fuse else ""
+            out[f"plugin_path_graph{sfx}_tokens_per_s"] = round(n_rep / t_rep, 2)
+            out[f"plugin_path_graph{sfx}_turn_incl_capture_tokens_per_s"] = round(TURN / t_turn, 2)
+            del graph
             del past
+    # bytes one token of this path must move at least: the four projection matrices of every layer + the kept K/V rows
+    hid = HEADS * HEAD_DIM
+    out["plugin_path_min_bytes_per_token"] = int(LAYERS * (4 * hid * hid * 2 + 2 * HEADS * (P + TURN) * HEAD_DIM * 2))
+    out["plugin_path_tokens_per_s_at_hbm_peak"] = round(HBM_PEAK_GBS * 1e9 / out["plugin_path_min_bytes_per_token"], 1)
+    return out
+
+
+def dense_with_projections_tokens_per_s(dev, dt, n_tokens=6):
+    """The like-for-like dense leg of the drop-in comparison: the reference forward's op sequence (modify_llama.py:72-163:
+    q/k/v projections, cat, rotation of the whole key cache, QK^T/sqrt(d), stash clone, +mask, fp32 softmax, PV, o_proj) in
+    eager torch on the GPU, Llama-2-7B geometry, dense N = 4096 — eagerly launched, as the reference runs it, and the same
+    op sequence captured into one HIP graph per token (what a caller could do without this package)."""
+    hid = HEADS * HEAD_DIM
+    g = torch.Generator(device=dev).manual_seed(7)
+    W = [[(torch.randn(hid, hid, device=dev, dtype=torch.float32, generator=g) * hid ** -0.5).to(dt) for _ in range(4)]
+         for _ in range(LAYERS)]
+    pk = [torch.randn(1, HEADS, CTX - 1, HEAD_DIM, device=dev, dtype=torch.float32, generator=g).to(dt) for _ in range(LAYERS)]
+    pv = [torch.randn(1, HEADS, CTX - 1, HEAD_DIM, device=dev, dtype=torch.float32, generator=g).to(dt) for _ in range(LAYERS)]
+    x = torch.randn(1, 1, hid, device=dev, dtype=torch.float32, generator=g).to(dt)
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, HEAD_DIM, 2, device=dev).float() / HEAD_DIM))
+    F = torch.nn.functional
+
+    def token():
+        o = None
+        for l in range(LAYERS):
+            wq, wk, wv, wo = W[l]
+            sp = lambda t: t.view(1, 1, HEADS, HEAD_DIM).transpose(1, 2)
+            a, _, _ = eager_pos_shift_layer(sp(F.linear(x, wq)), sp(F.linear(x, wk)), sp(F.linear(x, wv)), pk[l], pv[l], inv_freq)
+            o = F.linear(a, wo)
+        return o
+    out = {}
+    with torch.no_grad():
+        for _ in range(2):
+            token()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_tokens):
+            token()
+        torch.cuda.synchronize()
+        out["dense_eager_with_projections_tokens_per_s"] = round(n_tokens / (time.perf_counter() - t0), 2)
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                token()
+                side.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=side):
+                    token()
+                gr.replay()
+                side.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n_tokens):
+                    gr.replay()
+                side.synchronize()
+            out["dense_eager_with_projections_graphed_tokens_per_s"] = round(n_tokens / (time.perf_counter() - t0), 2)
+        except Exception as e:
+            out["dense_graphed_error"] = f"{type(e).__name__}: {e}"
     return out
 
 
@@ -603,6 +693,14 @@ def main():
                 extras.update(plugin_path_tokens_per_s(dev, dt))
             except Exception as e:
                 extras["plugin_path_error"] = f"{type(e).__name__}: {e}"
+            try:
+                extras.update(dense_with_projections_tokens_per_s(dev, dt))
+                for k_ in ("plugin_path_tokens_per_s", "plugin_path_graph_tokens_per_s", "plugin_path_graph_fused_qkv_tokens_per_s"):
+                    if k_ in extras:
+                        extras[k_.replace("_tokens_per_s", "") + "_speedup_vs_dense_eager_with_projections"] = round(
+                            extras[k_] / extras["dense_eager_with_projections_tokens_per_s"], 2)
+            except Exception as e:
+                extras["dense_with_projections_error"] = f"{type(e).__name__}: {e}"
             # ---- other rows of the scope table, measured on the same box (not part of `value`) -----------------
             try:
                 Np = 8192                                                   # C4: causal prefill, q = N = 8192, one layer

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SPATTEN_ABI_VERSION 2
+#define SPATTEN_ABI_VERSION 3
 
 typedef enum {
   SPATTEN_F32 = 0,
@@ -158,8 +158,41 @@ typedef struct spatten_decode_args {
   int64_t pq_pl_sb, pq_pl_sh, pq_sc_sb, pq_sc_sh;
   float pq_threshold; int32_t pad2_;
   int32_t* pq_need_lsb;
+  const void* step_state;          /* ABI 3: device-resident cache length (see "Device-resident step state" below) */
+  int32_t kv_len_layout;           /* ABI 3: 0 = kv_len.  Otherwise >= kv_len: the split-N decomposition (splits, rows per
+                                      split) is laid out for THIS length, so steps at different lengths share it — a static
+                                      launch and a step_state launch whose bound (its kv_len) is this value add their
+                                      partials in the same order: bit-identical outputs.  Later splits may then be empty. */
+  int32_t pad3_;
 } spatten_decode_args_t;
 int spatten_attn_decode_args(const spatten_decode_args_t* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device-resident step state (ABI 3) — what makes a decode step capturable ONCE and replayable for every token of a
+ * turn.  The reference's caller is a per-token Python loop (run_spatten_llama.py:27-35) in which the cache length is a
+ * host integer that changes every token; with `step_state` set in spatten_decode_args_t the kernel reads it from
+ * device memory instead:
+ *   - args.kv_len becomes a BOUND: the grid, the split chunks and every load address are laid out for it; it must be
+ *     >= the device value at every replay and <= the capacity of the planes and of the stash row.  args.pos_q is ignored.
+ *   - the length AFTER this step's append is state word 0; the query's rotary position is state word 1; the rotary rows
+ *     of those two positions are staged in the state (copied from the tables by spatten_step_set / _advance), so no
+ *     load address in the attention kernel depends on the length.
+ *   - rows [length, bound) of kr_cache and v_cache are read and discarded (weight 0): they must hold FINITE values —
+ *     zero-fill the planes once when they are allocated.  Stash entries [length, bound) are left untouched.
+ *   - admitted for the plain single-token step (mask, position_ids, pq_*, importance_acc, SCORES_ONLY must be unset).
+ * A token of a captured graph = spatten_step_advance(state, ..., 1) followed by the layers' spatten_attn_decode_args
+ * launches sharing the state; before the first replay of a turn: spatten_step_set(state, ..., cache_len, cache_len - 1).
+ * The state is spatten_step_state_bytes(dtype, head_dim) bytes of device memory owned by the caller.
+ * ---------------------------------------------------------------------------------------------- */
+size_t spatten_step_state_bytes(int dtype, int head_dim);
+/* state := (kv_len, pos_q) from HOST values + the rotary rows of positions pos_q and kv_len - 1 (cos / sin: the half tables
+ * [table_rows, d/2]; positions are clamped to the table).  Negative kv_len = "no step yet" is not accepted: kv_len >= 0. */
+int spatten_step_set(void* state, int dtype, int head_dim, const void* cos, const void* sin, int table_rows,
+                     int kv_len, int pos_q, void* stream);
+/* state := (kv_len + delta, pos_q + delta) + the rotary rows of the new positions — a stream operation without host
+ * values of the length, hence capturable. */
+int spatten_step_advance(void* state, int dtype, int head_dim, const void* cos, const void* sin, int table_rows,
+                         int delta, void* stream);
 
 /* KV append without attention (modify_llama.py:95-100 + the shadow row): k_new / v_new [B,Hkv,n,d] (strides new_sb,
  * new_sh, new_sn; d contiguous) are written to rows [row0, row0+n) of k_cache / v_cache, and their rotation at slot

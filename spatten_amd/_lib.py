@@ -9,7 +9,7 @@ import ctypes
 import os
 from ctypes import c_char_p, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p, POINTER, c_float
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 DECODE_MAX_SPLITS = 64
 
 
@@ -38,6 +38,7 @@ class DecodeArgs(ctypes.Structure):
         ("pq_pl_sb", c_int64), ("pq_pl_sh", c_int64), ("pq_sc_sb", c_int64), ("pq_sc_sh", c_int64),
         ("pq_threshold", c_float), ("pad2_", c_int32),
         ("pq_need_lsb", c_void_p),
+        ("step_state", c_void_p), ("kv_len_layout", c_int32), ("pad3_", c_int32),
     ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -72,6 +73,12 @@ def _declare(lib):
     lib.spatten_attn_decode_args.argtypes = [POINTER(DecodeArgs), p]
     lib.spatten_decode_workspace_status.restype = c_int
     lib.spatten_decode_workspace_status.argtypes = [p, p]
+    lib.spatten_step_state_bytes.restype = c_size_t
+    lib.spatten_step_state_bytes.argtypes = [i, i]
+    lib.spatten_step_set.restype = c_int
+    lib.spatten_step_set.argtypes = [p, i, i, p, p, i, i, i, p]
+    lib.spatten_step_advance.restype = c_int
+    lib.spatten_step_advance.argtypes = [p, i, i, p, p, i, i, p]
     lib.spatten_kv_append.restype = c_int
     lib.spatten_kv_append.argtypes = [i, p, p, i64, i64, i64, p, p, p, i64, i64, p, p, i, i, i, i, i, i, p]
     lib.spatten_importance_accumulate.restype = c_int

@@ -272,18 +272,9 @@ __global__ __launch_bounds__(256) void cascade_rank_kernel(const T* __restrict__
   rank[h * rank_sh + j] = member ? DT<T>::to_f32(score[h * score_sh + j]) : -INFINITY;
 }
 
-static inline bool ok_dtype(int dt) { return dt == SPATTEN_F32 || dt == SPATTEN_F16 || dt == SPATTEN_BF16; }
-
 }  // namespace spatten
 
 using namespace spatten;
-
-#define SPATTEN_BY_DTYPE(dt, CALL)                        \
-  switch (dt) {                                           \
-    case SPATTEN_F32: { using T = float; CALL; } break;   \
-    case SPATTEN_F16: { using T = f16_t; CALL; } break;   \
-    default: { using T = bf16_t; CALL; }                  \
-  }
 
 extern "C" int spatten_importance_accumulate(int dtype, const void* stash, int64_t sb, int64_t sh, int64_t sq,
                                              const float* lse, const void* mask, int64_t mask_sb, int64_t mask_sq,
@@ -361,10 +352,12 @@ extern "C" int spatten_pv_gather(int dtype, const void* stash, int64_t sc_sb, in
   // slices of the kept list: about four workgroups per CU over the whole launch, at least 64 rows each
   int per = ceil_div((int)(((long long)k * units + 1023) / 1024), 16) * 16;
   if (per < 64) per = 64;
+  if (per > kPvMaxPer) per = kPvMaxPer;    // the slice lives in LDS: many units (B*H large) just get more workgroups than 4 per CU
   if (per < ceil_div(k, kPvMaxSplits)) per = ceil_div(k, kPvMaxSplits);
   int S = ceil_div(k, per);
   if (!workspace || S == 1 || per > kPvMaxPer) {
-    if (workspace && per > kPvMaxPer) return SPATTEN_ERR_UNSUPPORTED;     // k > 65536 kept rows per head
+    // per > kPvMaxPer only when k > kPvMaxPer * kPvMaxSplits (65536 kept rows per head): the one-workgroup kernel below
+    // has no such bound (it walks the kept list in LDS-sized pieces)
     S = 1;
   } else if (workspace_bytes < spatten_pv_gather_workspace_bytes(batch, heads, head_dim)) {
     return SPATTEN_ERR_INVALID;

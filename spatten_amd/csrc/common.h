@@ -426,6 +426,8 @@ struct DecodeCall {
   const void* prev_scores = nullptr; int64_t pv_sb = 0, pv_sh = 0; const float* prev_lse = nullptr;
   float* acc = nullptr; int64_t acc_sh = 0; int prev_len = 0;
   float* head_abs = nullptr;   // [B*H] head importance accumulators (n_q == 1 only)
+  const void* step = nullptr;  // device-resident step state (step.hip): kv_len above is then a bound
+  int layout_len = 0;          // > kv_len: lay the splits out for this length (spatten_decode_args_t::kv_len_layout)
 };
 int decode_rows(const DecodeCall& c, hipStream_t stream);
 
@@ -436,7 +438,18 @@ int pq_expand(int dtype, const void* msb, const void* lsb, const float* scale, i
               hipStream_t stream);
 
 constexpr int kDecodeMaxSplits = 64;
+constexpr size_t kStepHeader = 64;      // spatten_step_state_t: 16 int32 words, then the staged rotary rows
 constexpr size_t kDecodeWsHeader = 256;
 inline size_t decode_cnt_bytes(size_t units) { return (units * 2 * sizeof(unsigned) + 255) / 256 * 256; }
 
+static inline bool ok_dtype(int dt) { return dt == SPATTEN_F32 || dt == SPATTEN_F16 || dt == SPATTEN_BF16; }
+
 }  // namespace spatten
+
+// CALL with `T` bound to the element type of the dtype enum (inside namespace spatten or after `using namespace`)
+#define SPATTEN_BY_DTYPE(dt, CALL)                                 \
+  switch (dt) {                                                    \
+    case SPATTEN_F32: { using T = float; CALL; } break;            \
+    case SPATTEN_F16: { using T = spatten::f16_t; CALL; } break;   \
+    default: { using T = spatten::bf16_t; CALL; }                  \
+  }

@@ -67,6 +67,10 @@ struct DecodeParams {
   // cascade importance (CASC): the previous step's stash + (max, sum) folded into acc while this step's keys stream
   const T* prev_scores; int64_t pv_sb, pv_sh; const float* prev_lse; float* acc; int64_t acc_sh; int prev_len;
   float* head_abs;      // optional [B*H]: += sum_e |out[b, h, e]| (head importance, README.md:21), by the unit's last writer
+  const int32_t* step;  // DYN: the device-resident step state (step.hip): word 0 = the cache length AFTER this step's append.
+                        // N below is then only a BOUND (grid / chunk / load addresses come from it); cos / sin point at the
+                        // state's two staged rotary rows (row 0: the query's position, row 1: the appended key's slot)
+  int nr_row;           // rotary-table row of the appended key's slot (N - 1; DYN: 1)
   unsigned long long* ws_part;   // [units][ws_unit] {value, tag} granules; split s of a unit at s * (D + 2)
   unsigned* ws_cnt;     // [units][2]: {arrival counter, launch generation}
   unsigned* ws_err;     // device error word (workspace header)
@@ -100,8 +104,14 @@ __device__ inline void store_granule(unsigned long long* g, float v, unsigned ta
 // NT: K/V rows are fetched with the non-temporal cache policy (each row is used once per launch: -0.5 us of 13.7 at
 // C2); off when several query rows (the rows leg of prefill) re-read the same K/V through L2.
 // CASC: cascade (cumulative) importance, deferred by one step — see DecodeParams.
+// DYN: the cache length lives in DEVICE memory (DecodeParams::step) so that ONE captured HIP graph of a decode step
+// replays for every token of a turn.  Everything an ADDRESS of a tile load depends on stays a launch constant — the
+// split's first row, the static chunk, the bound p.N — and the loaded length only gates the arithmetic (which rows are
+// live, where the appended row goes): the loads are issued exactly as in the static kernel, nothing waits for the
+// length.  Rows [length, bound) of the planes are read and discarded (weight 0), so they must hold finite values
+// (include/spatten.h: zero-fill the planes once).
 template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0, bool NT = LEAN, bool CASC = false,
-          bool PIPE = false>
+          bool PIPE = false, bool DYN = false>
 __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   constexpr bool SCORES_ONLY = (MODE == 1);
   constexpr bool PQ = (KSRC != 0);
@@ -133,16 +143,19 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   const int unit = LEAN ? (b * p.H + h) : (b * p.H + h) * p.n_q + qi;   // one softmax row
   if (KSRC == 2 && p.pq_need[unit] == 0) return;   // confident head: the MSB pass already produced its output
 
-  // keys this query may attend to (HF causal: j <= P + i with P = N - n_q); the stash covers all N
-  const int n_vis = (!LEAN && p.causal) ? min(p.N, p.vis0 + qi) : p.N;
-  // rows [lo, hi_all) of this split: chunks are balanced (ceil(N / S), any N) and need not be whole tiles — the last
-  // tile of a chunk runs with fewer live row-groups
+  // DYN: the length is requested FIRST (vector loads return in order: it is back before the query) and read after the
+  // tile loads have been issued
+  int n_dyn = 0;
+  if (DYN) n_dyn = p.step[opaque_lane(0)];
+  // rows [lo, lo + chunk) of this split: chunks are balanced (ceil(N / S), any N) and need not be whole tiles — the last
+  // tile of a chunk runs with fewer live row-groups.  The tile loads touch rows [lo, rl): a launch constant.
   const int lo = split * p.chunk;
-  const int hi_all = min(lo + p.chunk, (p.scores != nullptr) ? p.N : n_vis);
-  // The split that ends at N appends the new token (row N-1): its K/V rows come from k_new / v_new, not from the
-  // cache, so it is scored as ONE EXTRA ROW beside the tile and the tile covers the rows already cached, [lo, hi).
-  const bool owns_new = p.append && lo < p.N && hi_all == p.N;
-  const int hi = owns_new ? hi_all - 1 : hi_all;
+  int rl;
+  {
+    const int n_vis_s = (!LEAN && p.causal) ? min(p.N, p.vis0 + qi) : p.N;
+    const int hi_all_s = min(lo + p.chunk, (p.scores != nullptr) ? p.N : n_vis_s);
+    rl = (!DYN && p.append && lo < p.N && hi_all_s == p.N) ? hi_all_s - 1 : hi_all_s;
+  }
 
   T* krbase = p.krc + b * p.kv_sb + hkv * p.kv_sh;
   T* vbase = p.vc + b * p.kv_sb + hkv * p.kv_sh;
@@ -173,7 +186,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   const uint8_t* pq_l = KSRC == 2 ? p.pq_lsb + b * p.pl_sb + hkv * p.pl_sh : nullptr;
   const float* pq_s = PQ ? p.pq_scale + b * p.ps_sb + hkv * p.ps_sh : nullptr;
   const T* prevp = CASC ? p.prev_scores + b * p.pv_sb + h * p.pv_sh : nullptr;
-  auto row_of = [&](int t0, int u) { return max(min(t0 + u * RPI + r, hi - 1), 0); };   // (an empty split reads row 0)
+  auto row_of = [&](int t0, int u) { return max(min(t0 + u * RPI + r, rl - 1), 0); };   // (an empty split reads row 0)
   auto issue_keys = [&](Tile& tl, int t0) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -205,8 +218,6 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
       }
     }
   };
-  auto groups_of = [&](int t0) { return max(0, min(UNR, (hi - t0 + RPI - 1) / RPI)); };
-
   raw_t q_raw[4], n_raw[2], nk_raw[2], nv_raw[2];
   {
     const T* qp = p.q + b * p.q_sb + h * p.q_sh + (LEAN ? 0 : qi * p.q_sq);
@@ -222,9 +233,8 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
     const T* kp = p.k_new + b * p.new_sb + hkv * p.new_sh;      // (always readable: see `append`)
     nk_raw[0] = V8::ldg(kp + 8 * c);
     nk_raw[1] = V8::ldg(kp + HALF + 8 * c);
-    const int nr = min(p.N, p.table_rows) - 1;
-    n_raw[0] = V8::ldg(p.cos + (int64_t)nr * HALF + 8 * c);
-    n_raw[1] = V8::ldg(p.sin + (int64_t)nr * HALF + 8 * c);
+    n_raw[0] = V8::ldg(p.cos + (int64_t)p.nr_row * HALF + 8 * c);
+    n_raw[1] = V8::ldg(p.sin + (int64_t)p.nr_row * HALF + 8 * c);
   }
   issue_values(tile_a, lo);
   {
@@ -240,6 +250,16 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   // rotation (and the wait for the query) in front of the tile loads, which then leave one memory latency late
   __builtin_amdgcn_sched_barrier(0);
   SPATTEN_TSTAMP(5);
+  // ---- the live rows of this split ------------------------------------------------------------------------------
+  const int N = DYN ? __builtin_amdgcn_readfirstlane(n_dyn) : p.N;
+  // keys this query may attend to (HF causal: j <= P + i with P = N - n_q); the stash covers all N
+  const int n_vis = (!LEAN && p.causal) ? min(N, p.vis0 + qi) : N;
+  const int hi_all = min(lo + p.chunk, (p.scores != nullptr) ? N : n_vis);
+  // The split that ends at N appends the new token (row N-1): its K/V rows come from k_new / v_new, not from the
+  // cache, so it is scored as ONE EXTRA ROW beside the tile and the tile covers the rows already cached, [lo, hi).
+  const bool owns_new = p.append && lo < N && hi_all == N;
+  const int hi = owns_new ? hi_all - 1 : hi_all;
+  auto groups_of = [&](int t0) { return max(0, min(UNR, (hi - t0 + RPI - 1) / RPI)); };
 
   // ---- rotate the query (its data was requested first, so it is here long before the keys) -----------------------
   typename D8::packed q_lo, q_hi;                // rotated query, packed in the model dtype (exact: it IS rounded)
@@ -313,7 +333,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
       V8::unpack(n_raw[1], ss);
       rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
       const raw_t r_lo = V8::pack(ylo), r_hi = V8::pack(yhi);
-      const int jn = p.N - 1;
+      const int jn = N - 1;
       if (r == 0) {
         T* kbase = p.kc ? p.kc + b * p.kv_sb + hkv * p.kv_sh : nullptr;
         if (kbase) {
@@ -382,8 +402,8 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
         PairFma<T>::fma(olo, nv_raw[0], nv_raw[0], pp);
         PairFma<T>::fma(ohi, nv_raw[1], nv_raw[1], pp);
         if (r == 0) {
-          V8::stg(vbase + (int64_t)(p.N - 1) * D + 8 * c, nv_raw[0]);
-          V8::stg(vbase + (int64_t)(p.N - 1) * D + HALF + 8 * c, nv_raw[1]);
+          V8::stg(vbase + (int64_t)(N - 1) * D + 8 * c, nv_raw[0]);
+          V8::stg(vbase + (int64_t)(N - 1) * D + HALF + 8 * c, nv_raw[1]);
         }
       }
     }
@@ -414,6 +434,8 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
       __builtin_amdgcn_sched_barrier(0);
       process_tile(tile_b, t0 + TILE, groups_of(t0 + TILE), with_new(t0 + TILE));
     }
+    // the appended token is the ONLY row of its split (N = lo + 1: the loop above ran zero times): score and store it
+    if (owns_new && hi <= lo) process_tile(tile_a, lo, 0, true);
   }
 
 #ifdef SPATTEN_EXP_NOREDUCE   // A/B harness only: what does everything after the streaming loop cost?
@@ -623,16 +645,16 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
 }
 
 template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0, bool NT = LEAN, bool CASC = false,
-          bool PIPE = false>
+          bool PIPE = false, bool DYN = false>
 __global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const DecodeParams<T> p) {
-  decode_body<T, D, UNR, MODE, LEAN, KSRC, NT, CASC, PIPE>(p);
+  decode_body<T, D, UNR, MODE, LEAN, KSRC, NT, CASC, PIPE, DYN>(p);
 }
 
 // The plain decode step with its launch-critical arguments FIRST and 32-bit strides: built with
 // -amdgpu-kernarg-preload-count=16 (Makefile) the first 16 kernel-argument dwords — everything the query and the K/V
 // tile loads need (q is dense [B,H,D] here) — arrive in SGPRs with the wave, so those loads are issued without waiting
 // for a scalar load of the argument block (the other arguments are fetched while they are in flight).
-template <typename T, int D, int UNR, bool CASC, bool PIPE>
+template <typename T, int D, int UNR, bool CASC, bool PIPE, bool DYN = false>
 __global__ __launch_bounds__(kDecodeThreads) void decode_lean_kernel(T* krc, T* vc, const T* q, const T* cos, const T* sin,
                                                                      int kv_sb, int kv_sh, int N, int chunk, int H, int pos_q,
                                                                      const DecodeParams<T> rest) {
@@ -640,7 +662,7 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_lean_kernel(T* krc, T* 
   p.krc = krc; p.vc = vc; p.q = q; p.cos = cos; p.sin = sin;
   p.kv_sb = kv_sb; p.kv_sh = kv_sh; p.q_sb = (int64_t)H * D; p.q_sh = D;
   p.N = N; p.chunk = chunk; p.H = H; p.pos_q = pos_q;
-  decode_body<T, D, UNR, 0, true, 0, true, CASC, PIPE>(p);
+  decode_body<T, D, UNR, 0, true, 0, true, CASC, PIPE, DYN>(p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -675,6 +697,7 @@ static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_onl
   // a chunk that fits one single-shot tile: everything in flight at once; longer: the double-buffered loop
   const bool pipe = p.chunk > U * (kDecodeThreads / (D / 16)) && p.n_q == 1 && !scores_only;
   const bool casc = p.acc != nullptr;
+  const bool dyn = p.step != nullptr;      // decode_rows admits it for the plain single-row step only
 #define SPATTEN_LAUNCH(...) hipLaunchKernelGGL((decode_attn_kernel<T, D, __VA_ARGS__>), grid, blk, 0, stream, p)
   if (scores_only) {
     // no V tile: the pipelined instantiation affords twice the key rows per tile (first pass of local V pruning at long
@@ -699,14 +722,16 @@ static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_onl
     const int64_t lim = 0x7FFFFFFF;
     const bool small = p.kv_sb <= lim && p.kv_sh <= lim;
     if (lean && small) {
-#define SPATTEN_LEAN(UU, CC, PP)                                                                                        \
-  hipLaunchKernelGGL((decode_lean_kernel<T, D, UU, CC, PP>), grid, blk, 0, stream, p.krc, p.vc, p.q, p.cos, p.sin,       \
+#define SPATTEN_LEAN(UU, CC, PP, DD)                                                                                    \
+  hipLaunchKernelGGL((decode_lean_kernel<T, D, UU, CC, PP, DD>), grid, blk, 0, stream, p.krc, p.vc, p.q, p.cos, p.sin,   \
                      (int)p.kv_sb, (int)p.kv_sh, p.N, p.chunk, p.H, p.pos_q, p)
-      if (pipe) { if (casc) SPATTEN_LEAN(UP, true, true); else SPATTEN_LEAN(UP, false, true); }
-      else { if (casc) SPATTEN_LEAN(U, true, false); else SPATTEN_LEAN(U, false, false); }
+      if (dyn) { if (pipe) SPATTEN_LEAN(UP, false, true, true); else SPATTEN_LEAN(U, false, false, true); }
+      else if (pipe) { if (casc) SPATTEN_LEAN(UP, true, true, false); else SPATTEN_LEAN(UP, false, true, false); }
+      else { if (casc) SPATTEN_LEAN(U, true, false, false); else SPATTEN_LEAN(U, false, false, false); }
 #undef SPATTEN_LEAN
     } else if (p.n_q == 1) {
-      if (pipe) { if (casc) SPATTEN_LAUNCH(UP, 0, false, 0, true, true, true); else SPATTEN_LAUNCH(UP, 0, false, 0, true, false, true); }
+      if (dyn) { if (pipe) SPATTEN_LAUNCH(UP, 0, false, 0, true, false, true, true); else SPATTEN_LAUNCH(U, 0, false, 0, true, false, false, true); }
+      else if (pipe) { if (casc) SPATTEN_LAUNCH(UP, 0, false, 0, true, true, true); else SPATTEN_LAUNCH(UP, 0, false, 0, true, false, true); }
       else { if (casc) SPATTEN_LAUNCH(U, 0, false, 0, true, true); else SPATTEN_LAUNCH(U, 0, false, 0, true); }
     } else {
       SPATTEN_LAUNCH(UP);      // the rows leg of prefill: several query rows re-read K/V through L2, short tiles
@@ -743,16 +768,21 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   if (c.acc && (!c.prev_scores || !c.prev_lse || c.mask || c.n_q != 1 || c.prev_len < 0 || c.prev_len > c.kv_len || scores_only))
     return SPATTEN_ERR_INVALID;
   if (c.table_rows < c.kv_len || (!c.position_ids && c.pos_q + c.n_q > c.table_rows)) return SPATTEN_ERR_INVALID;
+  // device-resident step state: the plain single-row step only (kv_len is then the BOUND the grid is laid out for)
+  if (c.step && (c.n_q != 1 || c.mask || c.position_ids || pq || scores_only || c.acc || c.causal)) return SPATTEN_ERR_INVALID;
   if (c.head_dim != 64 && c.head_dim != 128 && c.head_dim != 256) return SPATTEN_ERR_UNSUPPORTED;
   if (c.dtype != SPATTEN_F32 && c.dtype != SPATTEN_F16 && c.dtype != SPATTEN_BF16) return SPATTEN_ERR_INVALID;
   const int units = c.batch * c.heads * c.n_q;          // workspace is indexed by the FULL head id
   const int ws_splits = c.ws_splits > 0 ? c.ws_splits : kDecodeMaxSplits;
-  int S = c.n_splits > 0 ? c.n_splits : auto_splits(c.batch * n_active * c.n_q, c.head_dim, c.kv_len);
-  if (S > c.kv_len) S = c.kv_len;
+  // the length the splits are laid out for: the step's own, or a common layout length of a whole turn (the device-length
+  // form is laid out for its bound, kv_len)
+  const int lay = (!c.step && c.layout_len > c.kv_len && c.n_q == 1) ? c.layout_len : c.kv_len;
+  int S = c.n_splits > 0 ? c.n_splits : auto_splits(c.batch * n_active * c.n_q, c.head_dim, lay);
+  if (S > lay) S = lay;
   if (S > kDecodeMaxSplits) S = kDecodeMaxSplits;
   // balanced chunks: ceil(N / S) rows per split (rounded up to the 8 rows of a stash line), whatever N is
-  const int chunk = ceil_div(ceil_div(c.kv_len, S), 8) * 8;
-  S = ceil_div(c.kv_len, chunk);
+  const int chunk = ceil_div(ceil_div(lay, S), 8) * 8;
+  S = ceil_div(lay, chunk);
   if (S > 1 && (!c.workspace || (size_t)units > c.ws_units || S > ws_splits)) return SPATTEN_ERR_INVALID;
   const size_t cnt_bytes = decode_cnt_bytes(c.ws_units);
   // single-hop merge (see the kernel): only when the grid cannot outnumber the workgroup slots of the chip.  Causal
@@ -770,6 +800,11 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   p.k_new = (const T*)(c.k_new ? c.k_new : c.q); p.v_new = (const T*)(c.k_new ? c.v_new : c.q);           \
   p.new_sb = c.k_new ? c.new_sb : c.q_sb; p.new_sh = c.k_new ? c.new_sh : c.q_sh;                        \
   p.cos = (const T*)c.cos; p.sin = (const T*)c.sin; p.table_rows = c.table_rows;                         \
+  p.step = (const int32_t*)c.step; p.nr_row = (c.kv_len < c.table_rows ? c.kv_len : c.table_rows) - 1;   \
+  if (c.step) {   /* the state's staged rotary rows stand in for the table: row 0 = query, row 1 = appended key */ \
+    p.cos = (const T*)((const char*)c.step + kStepHeader);                                               \
+    p.sin = p.cos + 2 * (c.head_dim / 2); p.table_rows = 2; p.nr_row = 1;                                \
+  }                                                                                                      \
   p.pos_ids = c.position_ids; p.pos_sb = c.pos_sb;                                                       \
   p.mask = (const T*)c.mask; p.mask_sb = c.mask_sb; p.mask_sq = c.mask_sq;                               \
   p.out = (T*)c.out; p.out_sb = c.out_sb; p.out_sq = c.out_sq;                                           \
@@ -785,7 +820,7 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   p.ws_cnt = c.workspace ? (unsigned*)((char*)c.workspace + kDecodeWsHeader) : (unsigned*)c.cos;         \
   p.ws_part = c.workspace ? (unsigned long long*)((char*)c.workspace + kDecodeWsHeader + cnt_bytes) : nullptr; \
   p.ws_unit = (int64_t)ws_splits * (c.head_dim + 2);                                                     \
-  p.B = c.batch; p.H = c.heads; p.Hkv = c.kv_heads; p.N = c.kv_len; p.pos_q = c.pos_q; p.S = S; p.chunk = chunk; \
+  p.B = c.batch; p.H = c.heads; p.Hkv = c.kv_heads; p.N = c.kv_len; p.pos_q = c.step ? 0 : c.pos_q; p.S = S; p.chunk = chunk; \
   p.n_q = c.n_q; p.causal = c.causal; p.vis0 = c.vis0 > 0 ? c.vis0 : c.kv_len - c.n_q + 1;                \
   p.poll_merge = poll_merge;                                                                             \
   p.sqrt_d = sqrtf((float)c.head_dim);                                                                   \
@@ -846,6 +881,7 @@ extern "C" int spatten_attn_decode_args(const spatten_decode_args_t* a, void* st
   c.prev_scores = a->prev_scores; c.pv_sb = a->prev_sb; c.pv_sh = a->prev_sh; c.prev_lse = a->prev_lse;
   c.acc = a->importance_acc; c.acc_sh = a->acc_sh; c.prev_len = a->prev_len;
   c.head_abs = a->head_abs_acc;
+  c.step = a->step_state; c.layout_len = a->kv_len_layout;
   PQKeys keys;
   if (a->pq_msb) {
     if (!a->pq_lsb || !a->pq_scale || !a->pq_need_lsb) return SPATTEN_ERR_INVALID;

@@ -100,13 +100,6 @@ int pq_expand(int dtype, const void* msb, const void* lsb, const float* scale, i
 
 using namespace spatten;
 
-#define SPATTEN_BY_DTYPE(dt, CALL)                        \
-  switch (dt) {                                           \
-    case SPATTEN_F32: { using T = float; CALL; } break;   \
-    case SPATTEN_F16: { using T = f16_t; CALL; } break;   \
-    default: { using T = bf16_t; CALL; }                  \
-  }
-
 extern "C" int spatten_pq_pack(int dtype, const void* kr_cache, int64_t kv_sb, int64_t kv_sh, void* msb, void* lsb,
                                float* scale, int64_t pl_sb, int64_t pl_sh, int64_t sc_sb, int64_t sc_sh, int batch,
                                int kv_heads, int head_dim, int row_lo, int row_hi, void* stream) {

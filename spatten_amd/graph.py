@@ -1,0 +1,143 @@
+"""DecodeGraph — one captured HIP graph of the WHOLE decode step, replayed for every token of a turn.
+
+The reference's caller is a per-token Python loop (run_spatten_llama.py:27-35: ``model(pred_token, past_key_values)``
+for up to 63 tokens per turn); through the patched forward that loop is host-bound (~30 launches x 32 layers of Python,
+ctypes and torch dispatch per token for ~0.4 ms of GPU work).  What kept the step from being captured once were the
+host integers that change every token: the cache length (it sized the stash, the K/V views, the split-N grid) and the
+query position.  With the device-resident step state (include/spatten.h, ABI 3; ops.StepState) the attention launch of
+every layer reads both from device memory; the stash row lives in the KV slab at capacity; the K/V views HF sees are
+rebuilt on demand.  So:
+
+    graph = DecodeGraph(step_fn, past_key_values)          # step_fn(past, *inputs) -> (new_past, outputs)
+    for t in range(n):
+        logits = graph.step(token)                         # call 1: eager (warm-up), call 2: capture + replay, then replays
+        token = logits.argmax(-1)                          # outputs are STATIC tensors, overwritten by the next step
+    past_key_values = graph.past_key_values                # fresh [K, V] views at the current length; also refreshes
+                                                           # ``module.attn_scores`` of every patched module
+
+``step_fn`` is whatever runs one token through the patched model, e.g.
+``lambda past, tok: (lambda o: (o.past_key_values, o.logits))(model(tok, past_key_values=past, use_cache=True))``.
+Requirements: batch and shapes fixed; the plain plugin path (the SpAtten extension modes run eagerly); the HF mask /
+position_ids of the step are the ones transformers 4.33 builds (zeros / the past length) — they are not read.
+
+Numerics: every step — the warm-up, and a plain eager step through the patched forward on slabs of the same capacity —
+lays its split-N decomposition out for the slab capacity, so graph replays and eager steps agree bit for bit
+(tests/test_gpu_graph_decode.py).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from . import kv_slab, ops
+
+__all__ = ["DecodeGraph"]
+
+
+class DecodeGraph:
+    def __init__(self, step_fn: Callable, past_key_values: Sequence, horizon: int = 128):
+        """``past_key_values``: the per-layer ``(K, V)`` pairs the patched forward (or ``apply_token_pruning``) returned;
+        ``horizon``: tokens the slabs are sized for up front (more are possible: the graph is re-captured on new slabs)."""
+        if past_key_values is None or len(past_key_values) == 0:
+            raise ValueError("DecodeGraph needs the past_key_values of a prefilled / pruned cache")
+        self.step_fn = step_fn
+        self.horizon = int(horizon)
+        self.length = int(past_key_values[0][0].shape[2])
+        if any(int(kv[0].shape[2]) != self.length for kv in past_key_values):
+            raise ValueError("DecodeGraph needs one cache length for all layers (layer_keep caches differ per layer)")
+        self.stream = torch.cuda.Stream(device=past_key_values[0][0].device)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.state: Optional[ops.StepState] = None
+        self.touched: List[tuple] = []          # (module, slab) pairs of the last traced step, in call order
+        self.static_in: Optional[List[torch.Tensor]] = None
+        self.static_out = None
+        self.n_replays = 0
+        self._past = None
+        self._bind(past_key_values)
+
+    # ------------------------------------------------------------------------------------------------
+    def _bind(self, past_key_values):
+        """Size the slabs for the next ``horizon`` tokens, zero their tails, (re)create the step state."""
+        past = kv_slab.reserve(past_key_values, self.length + self.horizon)
+        self._past = past
+        self.bound = min(kv_slab.slab_of(kv[0]).capacity for kv in past)
+        self.graph = None
+        self.state = None
+        self.touched = []
+
+    def state_for(self, slab, cos, sin) -> ops.StepState:
+        """Called by the patched forward while a step is traced: the step state every layer shares."""
+        if self.state is None:
+            self.state = ops.StepState(cos, sin)
+            self.state.set(self.length, self.length - 1)
+            self.state.advance(1)             # the traced step is already under way: its advance, issued late
+        elif self.state.cos.data_ptr() != cos.data_ptr():
+            raise RuntimeError("DecodeGraph: the layers rotate with different rotary tables")
+        if slab.capacity < self.bound:
+            raise RuntimeError("DecodeGraph: a layer's slab is smaller than the graph's bound")
+        return self.state
+
+    def _trace(self, inputs):
+        """Run step_fn once in device-length mode on the current stream (eagerly, or under capture)."""
+        self.touched = []
+        prev = kv_slab.graph_ctx
+        kv_slab.graph_ctx = self
+        try:
+            if self.state is not None:
+                self.state.advance(1)
+            new_past, out = self.step_fn(self._past, *inputs)
+        finally:
+            kv_slab.graph_ctx = prev
+        if not self.touched:
+            raise RuntimeError("DecodeGraph: step_fn did not run a single-token step through the patched forward")
+        self._past = new_past
+        return out
+
+    # ------------------------------------------------------------------------------------------------
+    def step(self, *inputs):
+        """One token.  Returns step_fn's outputs (static tensors from the second call on)."""
+        if self.length + 1 > self.bound:                   # out of room: larger slabs, new graph
+            self._bind(self.past_key_values)
+        cur = torch.cuda.current_stream()
+        if self.graph is None and self.state is None:
+            # call 1 on these slabs: eager, on the capture stream (creates the per-stream workspaces, warms the allocator
+            # and the GEMM heuristics) — the same device-length kernels the graph will replay
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                out = self._trace(inputs)
+            cur.wait_stream(self.stream)
+            self.length += 1
+            return out
+        if self.graph is None:
+            self.static_in = [x.clone() if isinstance(x, torch.Tensor) else x for x in inputs]
+            self.stream.wait_stream(cur)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.stream):
+                self.static_out = self._trace(self.static_in)
+            cur.wait_stream(self.stream)
+            self.graph = g
+        else:
+            for dst, src in zip(self.static_in, inputs):
+                if isinstance(dst, torch.Tensor) and dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
+        self.graph.replay()
+        self.n_replays += 1
+        self.length += 1
+        return self.static_out
+
+    @property
+    def past_key_values(self):
+        """``[K, V]`` views of every layer at the CURRENT length (the tuples a replayed step cannot update), in layer
+        order; also points every patched module's ``attn_scores`` at its stash row of the last step (:116-119)."""
+        slabs = [kv_slab.slab_of(kv[0]) for kv in self._past]
+        out = []
+        for slab in slabs:
+            slab.length = slab.rot_len = self.length
+            k, v = slab.views()
+            out.append([k, v])
+        for module, slab in self.touched:
+            if slab.stash is not None:
+                object.__setattr__(module, "attn_scores", slab.stash[:, :, None, :self.length])
+        self._past = out
+        return out

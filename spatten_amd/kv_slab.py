@@ -48,8 +48,14 @@ def rope_tables(n: int, d: int, dtype: torch.dtype, device, base: float = 10000.
     return t
 
 
+# the DecodeGraph (spatten_amd/graph.py) that is warming up / capturing a decode step right now, or None: the patched
+# forward then runs its single-token step in the device-length form (ops.StepState) on persistent buffers
+graph_ctx = None
+
+
 class KVSlab:
-    __slots__ = ("k", "kr", "v", "length", "rot_len", "base", "scaling", "pq", "pq_len", "dec", "_tab", "__weakref__")
+    __slots__ = ("k", "kr", "v", "length", "rot_len", "base", "scaling", "pq", "pq_len", "dec", "_tab", "stash",
+                 "__weakref__")
 
     def __init__(self, k, kr, v, length, rot_len, base=10000.0, scaling=None):
         self.k, self.kr, self.v = k, kr, v          # full-capacity planes [B,Hkv,cap,d]
@@ -60,6 +66,7 @@ class KVSlab:
         self.pq_len = 0                             # rows of the planes that are valid
         self.dec = None                             # ops.SlabDecodeCall: the prefilled argument block of the decode step
         self._tab = None                            # this slab's rotary tables (rows >= capacity), looked up once
+        self.stash = None                           # [B, H, cap] persistent stash row of the captured decode step
 
     @property
     def capacity(self) -> int:
@@ -72,12 +79,28 @@ class KVSlab:
             t = self._tab = rope_tables(max(cap, rows or 0), d, self.k.dtype, self.k.device, self.base, self.scaling)
         return t
 
-    def decode_step(self, q, k_new, v_new, kv_len: int, pos_q: int, cos, sin, scores, position_ids=None, mask=None):
-        """The plain fused decode step on this slab through its prefilled argument block (ops.SlabDecodeCall)."""
+    def decode_step(self, q, k_new, v_new, kv_len: int, pos_q: int, cos, sin, scores, position_ids=None, mask=None,
+                    step=None):
+        """The plain fused decode step on this slab through its prefilled argument block (ops.SlabDecodeCall).
+        The split-N decomposition is laid out for the slab's CAPACITY, whatever the current length: every step of a turn
+        — launched with a host length, or (``step``: ops.StepState) with the device-resident length inside a captured
+        graph — adds its partials in the same order, so the two forms agree bit for bit."""
         dec = self.dec
         if dec is None or dec.key != (tuple(q.shape), q.dtype, cos.data_ptr()):
             dec = self.dec = ops.SlabDecodeCall(self.k, self.kr, self.v, cos, sin, q)
-        return dec.run(q, k_new, v_new, kv_len, pos_q, scores, position_ids, mask)
+        cap = self.k.shape[2]
+        if step is not None:
+            return dec.run(q, k_new, v_new, cap, 0, scores, step=step)
+        return dec.run(q, k_new, v_new, kv_len, pos_q, scores, position_ids, mask, layout=cap)
+
+    def stash_row(self, heads: int) -> torch.Tensor:
+        """[B, H, cap] in the model dtype, zero-filled once: where a captured decode step leaves its logits (the
+        reference allocates a fresh clone per forward, modify_llama.py:116-119; a replayed graph needs a fixed address)."""
+        st = self.stash
+        if st is None or st.shape[1] != heads:
+            B, _, cap, _ = self.k.shape
+            st = self.stash = torch.zeros(B, heads, cap, dtype=self.k.dtype, device=self.k.device)
+        return st
 
     def views(self):
         kv = self.k[:, :, :self.length]
@@ -130,8 +153,8 @@ def slab_for(k_view: Optional[torch.Tensor], v_view: Optional[torch.Tensor], nee
         return slab
     cap = round_capacity(need + GROW)
     k = torch.empty(batch, kv_heads, cap, d, dtype=dtype, device=device)
-    kr = torch.empty_like(k)
-    v = torch.empty_like(k)
+    kr = torch.zeros_like(k)          # rows past the length are READ by the device-length decode step (weight 0): finite
+    v = torch.zeros_like(k)
     rot = 0
     if P:
         if not ok:
@@ -149,3 +172,23 @@ def slab_for(k_view: Optional[torch.Tensor], v_view: Optional[torch.Tensor], nee
             kr[:, :, :slab.rot_len].copy_(slab.kr[:, :, :slab.rot_len])
             rot = slab.rot_len
     return KVSlab(k, kr, v, P, rot, base, scaling)
+
+
+def reserve(past_key_values, need: int):
+    """Make every layer's slab hold ``need`` rows and give the rows past the current length finite contents (zeros) —
+    what a captured decode step requires (include/spatten.h, "Device-resident step state").  Returns the list of
+    ``[K, V]`` views to continue with (the same tensors when nothing had to grow)."""
+    out = []
+    for K, V in past_key_values:
+        slab = slab_of(K)
+        B, Hkv, P, d = K.shape
+        if slab is None:
+            raise ValueError("reserve() needs the (K, V) pairs the patched forward / apply_token_pruning returned")
+        slab = slab_for(K, V, need, B, Hkv, d, K.dtype, K.device, slab.base, slab.scaling)
+        slab.ensure_shadow(P)
+        if slab.capacity > P:
+            slab.kr[:, :, P:].zero_()
+            slab.v[:, :, P:].zero_()
+        k, v = slab.views()
+        out.append([k, v])
+    return out

@@ -131,7 +131,8 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: Opti
                 n_splits: int = 0, workspace: Optional[DecodeWorkspace] = None,
                 head_ids: Optional[torch.Tensor] = None, scores_only: bool = False,
                 cascade: Optional[tuple] = None, pq: Optional[tuple] = None,
-                head_abs: Optional[torch.Tensor] = None) -> torch.Tensor:
+                head_abs: Optional[torch.Tensor] = None, step: Optional["StepState"] = None,
+                layout: int = 0) -> torch.Tensor:
     """Fused decode attention (modify_llama.py:86-147 at q_len=1).
 
     q [B,H,d]; k_cache (un-rotated, only appended to) / kr_cache (rotated shadow, see build_shadow) /
@@ -146,6 +147,9 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: Opti
     pq = (PQPlanes, threshold, need_lsb int32 [B*H]): keys come from the progressive-quantisation planes (MSB pass,
     LSB refetch for heads whose max probability is below threshold) instead of kr_cache.
     head_abs fp32 [B*H]: += sum |out| per (b, h) (cumulative head importance for head pruning).
+    layout: lay the split-N decomposition out for this length (>= kv_len) instead of kv_len.
+    step (StepState): the device-resident length — ``kv_len`` is then the BOUND of the launch, ``pos_q`` is not read, rows
+    [length, bound) of kr_cache / v_cache must hold finite values.
     Returns out [B, H*d]."""
     _dev(q, k_cache, kr_cache, v_cache, cos, sin, k_new, v_new, mask, out, scores, lse, position_ids, head_abs)
     if position_ids is not None and position_ids.dtype != torch.int64:
@@ -199,6 +203,13 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: Opti
     if head_ids is not None:
         a.head_ids, a.n_active_heads = head_ids.data_ptr(), head_ids.numel()
     a.flags = 1 if scores_only else 0
+    a.kv_len_layout = int(layout)
+    if layout > cap:
+        raise ValueError("layout length exceeds the cache capacity")
+    if step is not None:
+        if scores is not None and scores.shape[2] < kv_len:
+            raise ValueError("device-length step: the stash row must cover the bound")
+        a.step_state = step.data_ptr()
     if cascade is not None:
         acc, prev_scores, prev_lse, prev_len = cascade
         _dev(acc, prev_scores, prev_lse)
@@ -221,6 +232,44 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: Opti
         a.pq_threshold, a.pq_need_lsb = float(threshold), need_lsb.data_ptr()
     _lib.check(lib.spatten_attn_decode_args(ctypes.byref(a), stream), "spatten_attn_decode")
     return out
+
+
+class StepState:
+    """Device-resident step state (include/spatten.h, ABI 3): the cache length after the next append, the query's rotary
+    position and the rotary rows of both.  One per token stream (all layers of a model share it); ``advance`` is a stream
+    operation without host values, so a token's launch sequence — advance, then every layer's decode launch with
+    ``step=state`` — is captured once into a HIP graph and replayed for each token."""
+
+    def __init__(self, cos: torch.Tensor, sin: torch.Tensor):
+        _dev(cos, sin)
+        self.lib = _lib.load()
+        self.cos, self.sin = cos, sin                      # half tables [rows, d/2] in the model dtype (kept alive)
+        self.d = cos.shape[1] * 2
+        self.dt = _dt(cos)
+        nbytes = self.lib.spatten_step_state_bytes(self.dt, self.d)
+        if nbytes == 0:
+            raise ValueError("unsupported head_dim / dtype for a step state")
+        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=cos.device)
+
+    def data_ptr(self) -> int:
+        return self.buf.data_ptr()
+
+    def set(self, kv_len: int, pos_q: int):
+        """Host values -> state (not capturable: the values are launch arguments).  ``kv_len`` = the current cache length;
+        after the next ``advance()`` the state describes the step that appends row ``kv_len``."""
+        if max(kv_len, pos_q + 1) > self.cos.shape[0]:
+            raise ValueError("step state beyond the rotary table")
+        _lib.check(self.lib.spatten_step_set(self.buf.data_ptr(), self.dt, self.d, self.cos.data_ptr(), self.sin.data_ptr(),
+                                             self.cos.shape[0], int(kv_len), int(pos_q), _stream()), "spatten_step_set")
+
+    def advance(self, delta: int = 1):
+        _lib.check(self.lib.spatten_step_advance(self.buf.data_ptr(), self.dt, self.d, self.cos.data_ptr(), self.sin.data_ptr(),
+                                                 self.cos.shape[0], int(delta), _stream()), "spatten_step_advance")
+
+    def read(self):
+        """(kv_len, pos_q) — synchronises; for tests and assertions."""
+        w = self.buf[:8].view(torch.int32).cpu()
+        return int(w[0]), int(w[1])
 
 
 class SlabDecodeCall:
@@ -252,12 +301,17 @@ class SlabDecodeCall:
         self.lib = _lib.load()
 
     def run(self, q, k_new, v_new, kv_len: int, pos_q: int, scores: torch.Tensor,
-            position_ids: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+            position_ids: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+            step: Optional[StepState] = None, layout: int = 0) -> torch.Tensor:
         """q [B,H,d], k_new / v_new [B,Hkv,d] (rows contiguous), scores [B,H,>=kv_len]; optional position_ids int64 [B]
-        (device) and additive mask [B,kv_len] as in attn_decode; returns out [B, H*d]."""
+        (device) and additive mask [B,kv_len] as in attn_decode; returns out [B, H*d].
+        ``layout``: lay the split-N decomposition out for this length (>= kv_len) instead of kv_len.  ``step``: the
+        device-resident length — ``kv_len`` is then the BOUND of the launch (= the layout) and ``pos_q`` is not read."""
         if kv_len > self.cap or max(kv_len, pos_q + 1) > self.table_rows or q.stride(2) != 1 or k_new.stride(2) != 1 \
-                or v_new.stride() != k_new.stride() or scores.stride(2) != 1:
+                or v_new.stride() != k_new.stride() or scores.stride(2) != 1 or layout > self.cap:
             raise ValueError("decode step outside the slab / rotary table, or operands without contiguous rows")
+        if step is not None and (scores.shape[2] < kv_len or position_ids is not None or mask is not None):
+            raise ValueError("device-length step: the stash row must cover the bound; no mask / position tensor")
         if position_ids is not None and (position_ids.dtype != torch.int64 or not position_ids.is_cuda):
             raise TypeError("position_ids must be an int64 device tensor")
         if mask is not None and (mask.stride(-1) != 1 or mask.dtype != q.dtype or not mask.is_cuda):
@@ -273,6 +327,8 @@ class SlabDecodeCall:
         a.out, a.out_sb = out.data_ptr(), out.stride(0)
         a.scores, a.sc_sb, a.sc_sh = scores.data_ptr(), scores.stride(0), scores.stride(1)
         a.kv_len, a.pos_q = kv_len, pos_q
+        a.kv_len_layout = layout
+        a.step_state = None if step is None else step.data_ptr()
         if position_ids is not None:
             a.position_ids, a.pos_sb = position_ids.data_ptr(), position_ids.stride(0)
         else:

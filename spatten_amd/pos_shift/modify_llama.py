@@ -161,8 +161,20 @@ def llama_pos_shift_attention_forward(
     if q_len == 1:
         q3 = query_states.view(bsz, num_heads, head_dim)
         k3, v3 = key_states.view(bsz, num_kv_heads, head_dim), value_states.view(bsz, num_kv_heads, head_dim)
+        gctx = kv_slab.graph_ctx
         if ext is not None:
+            if gctx is not None:
+                raise RuntimeError("DecodeGraph captures the plain decode step; the SpAtten extension modes run eagerly")
             attn_output, stash = ext[0].decode_step(ext[1], q3, k3, v3, slab, kv_seq_len, past_len, cos, sin)
+        elif gctx is not None:
+            # a DecodeGraph is warming up / capturing this step (spatten_amd/graph.py): the cache length is read from the
+            # graph's device-resident step state, the logits go to the slab's persistent stash row — nothing in the
+            # launch depends on a host value that changes from token to token.  The HF mask / position_ids of a
+            # single-token step (zeros / past_len, transformers 4.33) are not read, as with assume_causal.
+            row = slab.stash_row(num_heads)
+            attn_output = slab.decode_step(q3, k3, v3, kv_seq_len, past_len, cos, sin, row, step=gctx.state_for(slab, cos, sin))
+            stash = row[:, :, None, :kv_seq_len]
+            gctx.touched.append((self, slab))
         else:
             # the slab's prefilled argument block (host-path fast lane: per token only pointers and two lengths are
             # written).  With assume_causal the HF mask of a single-token step (all zeros) and its position_ids are not

@@ -1,0 +1,287 @@
+"""The graph-capturable decode step (ABI 3): device-resident step state, the decode kernel's device-length form against
+its static form (bit for bit) and the oracle, and DecodeGraph — one captured HIP graph of the whole patched layer stack
+replayed per token — against the eager per-token loop of the plugin (run_spatten_llama.py:27-35).  Needs an MI355X."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from oracle import spatten_oracle as orc
+from tests.util import OUT_TOL, TORCH_DT, attn_inputs, check_stash, dev, host
+
+pytestmark = pytest.mark.gpu
+
+
+def test_step_state_set_and_advance():
+    from spatten_amd import ops
+    for dt, d in (("bf16", 128), ("f16", 64), ("f32", 128), ("bf16", 256)):
+        cos, sin = ops.rope_table(300, d, TORCH_DT[dt], "cuda")
+        st = ops.StepState(cos, sin)
+        st.set(17, 16)
+        assert st.read() == (17, 16)
+        h = d // 2
+        es = cos.element_size()
+        rows = lambda: st.buf[64:64 + 4 * h * es].view(TORCH_DT[dt]).view(4, h)
+        assert torch.equal(rows()[0], cos[16]) and torch.equal(rows()[1], cos[16])
+        assert torch.equal(rows()[2], sin[16]) and torch.equal(rows()[3], sin[16])
+        st.advance()
+        st.advance(2)
+        assert st.read() == (20, 19)
+        assert torch.equal(rows()[0], cos[19]) and torch.equal(rows()[1], cos[19]) and torch.equal(rows()[3], sin[19])
+        st.set(40, 7)                      # query position and appended slot differ: two distinct staged rows
+        assert torch.equal(rows()[0], cos[7]) and torch.equal(rows()[1], cos[39])
+        with pytest.raises(ValueError):
+            st.set(301, 300)
+
+
+@pytest.mark.parametrize("dt,d,H,Hkv,P,cap", [
+    ("bf16", 128, 32, 32, 2050, 2176),      # the C2 turn: lean kernel, 8 splits laid out for the capacity
+    ("bf16", 128, 4, 4, 700, 1024),         # few heads: 64 splits, most of them short; later ones EMPTY at this length
+    ("f16", 64, 8, 2, 333, 512),            # GQA: the general kernel
+    ("f32", 128, 2, 2, 95, 128),
+    ("bf16", 128, 8, 8, 5000, 5120),        # long chunks: the double-buffered instantiation
+    ("bf16", 256, 2, 2, 130, 256),
+])
+def test_device_length_steps_equal_static_steps_bitwise(dt, d, H, Hkv, P, cap):
+    """Six consecutive tokens: the device-length form (one argument block, the state advanced on the device) against the
+    static form laid out for the same length (kv_len_layout) — outputs, stash, appended rows bit for bit — and the first
+    step against the oracle."""
+    from spatten_amd import ops
+    B, tdt, steps = 1, TORCH_DT[dt], 6
+    q, k, v, past = attn_inputs(B, H, Hkv, d, P, 1, dt, 11)
+    cos_h, sin_h = orc.rope_table(cap + 8, d, dt)
+    cos, sin = dev(cos_h[:, : d // 2], dt), dev(sin_h[:, : d // 2], dt)
+
+    def planes():
+        kc = torch.zeros(B, Hkv, cap, d, dtype=tdt, device="cuda")
+        vc, krc = torch.zeros_like(kc), torch.zeros_like(kc)
+        kc[:, :, :P], vc[:, :, :P] = dev(past[0], dt), dev(past[1], dt)
+        ops.build_shadow(kc, krc, 0, P, cos, sin)
+        # stale but FINITE rows past the length (an older, longer turn): must not leak into the result
+        krc[:, :, P + steps:] = 3.0
+        vc[:, :, P + steps:] = -2.0
+        return kc, krc, vc
+    ka, kra, va = planes()
+    kb, krb, vb = planes()
+    st = ops.StepState(cos, sin)
+    st.set(P, P - 1)
+    stash_a = torch.zeros(B, H, cap, dtype=tdt, device="cuda")
+    stash_b = torch.zeros_like(stash_a)
+    qs = [dev(orc.synth_normal(50 + t, 0, (B, H, d), dt), dt) for t in range(steps)]
+    ks = [dev(orc.synth_normal(50 + t, 1, (B, Hkv, d), dt), dt) for t in range(steps)]
+    vs = [dev(orc.synth_normal(50 + t, 2, (B, Hkv, d), dt), dt) for t in range(steps)]
+    qs[0], ks[0], vs[0] = dev(q[:, :, 0], dt), dev(k[:, :, 0], dt), dev(v[:, :, 0], dt)
+    for t in range(steps):
+        n = P + t + 1
+        st.advance()
+        oa = ops.attn_decode(qs[t], ka, kra, va, cap, cos, sin, 0, k_new=ks[t], v_new=vs[t], scores=stash_a, step=st)
+        ob = ops.attn_decode(qs[t], kb, krb, vb, n, cos, sin, n - 1, k_new=ks[t], v_new=vs[t], scores=stash_b, layout=cap)
+        torch.cuda.synchronize()
+        assert st.read() == (n, n - 1)
+        assert torch.equal(oa, ob), (t, (oa.float() - ob.float()).abs().max().item())
+        assert torch.equal(stash_a[:, :, :n], stash_b[:, :, :n]), t
+        assert (stash_a[:, :, n:] == 0).all(), "stash written past the length"
+        assert torch.equal(ka[:, :, :n], kb[:, :, :n]) and torch.equal(kra[:, :, :n], krb[:, :, :n]) and torch.equal(va[:, :, :n], vb[:, :, :n])
+        if t == 0:
+            o, stash, _ = orc.attention_core(q, k, v, past[0], past[1], np.full((B, 1), P), None, dt)
+            np.testing.assert_allclose(host(oa)[:, None], o, **OUT_TOL[dt])
+            check_stash(host(stash_a[:, :, :n])[:, :, None], stash, dt, "device-length step")
+    assert (kra[:, :, P + steps:] == 3.0).all() and (va[:, :, P + steps:] == -2.0).all(), "rows past the length were written"
+
+
+def test_device_length_step_rejects_what_it_does_not_cover():
+    from spatten_amd import ops
+    cos, sin = ops.rope_table(256, 128, torch.bfloat16, "cuda")
+    st = ops.StepState(cos, sin)
+    st.set(10, 9)
+    z = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device="cuda")
+    q, kc = z(1, 4, 128), z(1, 4, 128, 128)
+    with pytest.raises(RuntimeError):       # a mask needs a host length: the argument check refuses the combination
+        ops.attn_decode(q, kc, kc.clone(), kc.clone(), 128, cos, sin, 0, k_new=z(1, 4, 128), v_new=z(1, 4, 128),
+                        mask=z(1, 128), scores=z(1, 4, 128), step=st)
+    with pytest.raises(ValueError):         # the stash row must cover the bound
+        ops.attn_decode(q, kc, kc.clone(), kc.clone(), 128, cos, sin, 0, k_new=z(1, 4, 128), v_new=z(1, 4, 128),
+                        scores=z(1, 4, 64), step=st)
+
+
+@pytest.mark.parametrize("units,kv_len", [(4, 20665), (5, 16401), (6, 13449)])
+def test_appended_token_alone_in_the_last_split_of_the_pipelined_kernel(units, kv_len):
+    """Round-2 advisor finding: with a chunk above one single-shot tile and N = (S-1)*chunk + 1 the appended token is the
+    only row of the last split; the double-buffered loop ran zero times and the token was never scored or stored."""
+    from spatten_amd import _lib, ops
+    dt, tdt, d, B, H = "bf16", torch.bfloat16, 128, 1, units
+    S = _lib.load().spatten_decode_auto_splits(B, H, d, kv_len)
+    per = -(-kv_len // S)
+    chunk = -(-per // 8) * 8                # decode_rows: balanced chunks, rounded to the 8 rows of a stash line
+    assert (kv_len - 1) % chunk == 0 and chunk > 320, "shape no longer hits the empty owning split"
+    P = kv_len - 1
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, device="cuda", dtype=torch.float32, generator=g).to(tdt)
+    cos, sin = ops.rope_table(kv_len + 8, d, tdt, "cuda")
+    kc = torch.full((B, H, kv_len + 3, d), float("nan"), dtype=tdt, device="cuda")
+    vc, krc = kc.clone(), kc.clone()
+    kc[:, :, :P], vc[:, :, :P] = rnd(B, H, P, d), rnd(B, H, P, d)
+    ops.build_shadow(kc, krc, 0, P, cos, sin)
+    q, kn, vn = rnd(B, H, d) * 2, rnd(B, H, d) * 2, rnd(B, H, d)
+    outs, stashes = [], []
+    for ns in (0, 1):                       # the auto split count (hits the case) against a single workgroup per head
+        k2, kr2, v2 = kc.clone(), krc.clone(), vc.clone()
+        stash = torch.full((B, H, kv_len), float("nan"), dtype=tdt, device="cuda")
+        o = ops.attn_decode(q, k2, kr2, v2, kv_len, cos, sin, P, k_new=kn, v_new=vn, scores=stash, n_splits=ns)
+        torch.cuda.synchronize()
+        assert not torch.isnan(stash.float()).any(), "the appended token's logit is missing from the stash"
+        assert torch.equal(k2[:, :, P], kn) and torch.equal(v2[:, :, P], vn), "appended rows not stored"
+        assert torch.equal(kr2[:, :, P:P + 1], ops.rope_single(kn[:, :, None], cos, sin, pos0=P))
+        outs.append(o)
+        stashes.append(stash)
+    assert torch.equal(stashes[0], stashes[1])
+    np.testing.assert_allclose(host(outs[0]), host(outs[1]), **OUT_TOL[dt])
+
+
+def test_pv_gather_many_units_with_a_workspace():
+    """Round-2 advisor finding: k * B * H above ~1M made the split P.V gather return UNSUPPORTED (B = 8, H = 32, k = 4915)."""
+    from spatten_amd import ops
+    B, H, d, N, k = 8, 32, 128, 8192, 4915
+    tdt = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(5)
+    stash = torch.randn(B, H, N, device="cuda", generator=g).to(tdt)
+    V = torch.randn(B, H, N, d, device="cuda", generator=g).to(tdt)
+    lse = torch.stack([stash.float().amax(-1), torch.exp(stash.float() - stash.float().amax(-1, keepdim=True)).sum(-1)], -1).contiguous()
+    idx = torch.stack([torch.randperm(N, device="cuda", generator=g)[:k].sort().values for _ in range(B * H)]).to(torch.int32)
+    out = ops.pv_gather(stash, lse, V, idx)
+    torch.cuda.synchronize()
+    p = torch.softmax(stash.float(), -1)
+    ix = idx.view(B, H, k).long()
+    want = torch.einsum("bhk,bhkd->bhd", p.gather(2, ix), V.float().gather(2, ix[..., None].expand(B, H, k, d)))
+    np.testing.assert_allclose(host(out).reshape(B, H, d), host(want), atol=2e-3, rtol=2e-2)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# DecodeGraph on the plugin surface
+# ------------------------------------------------------------------------------------------------------------------
+LAYERS, H, D = 3, 8, 128
+HID = H * D
+
+
+class LlamaAttention(nn.Module):          # duck-typed by class name, like HF's module
+    def __init__(self, dt):
+        super().__init__()
+        self.config = SimpleNamespace(pretraining_tp=1)
+        self.num_heads = self.num_key_value_heads = H
+        self.num_key_value_groups, self.head_dim, self.hidden_size = 1, D, HID
+        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            setattr(self, n, nn.Linear(HID, HID, bias=False, dtype=dt, device="cuda"))
+
+
+class Stack(nn.Module):
+    """The attention path of a decoder stack under the transformers 4.33 calling convention (device-built mask and
+    position_ids, legacy (K, V) tuples)."""
+
+    def __init__(self, dt):
+        super().__init__()
+        self.config = SimpleNamespace(model_type="llama")
+        self.layers = nn.ModuleList([LlamaAttention(dt) for _ in range(LAYERS)])
+
+    @torch.no_grad()
+    def forward(self, x, past):
+        B, q, _ = x.shape
+        P = 0 if past is None else past[0][0].shape[2]
+        N = P + q
+        pos = torch.arange(P, N, device=x.device)[None]
+        mask = torch.zeros(B, 1, q, N, dtype=x.dtype, device=x.device)
+        if q > 1:
+            mask.masked_fill_(torch.ones(q, N, dtype=torch.bool, device=x.device).triu(P + 1), torch.finfo(x.dtype).min)
+        new_past = []
+        for i, m in enumerate(self.layers):
+            a, _, kv = m(x, attention_mask=mask, position_ids=pos, past_key_value=None if past is None else past[i], use_cache=True)
+            x = x + a
+            new_past.append(kv)
+        return x, new_past
+
+
+def _models(dt):
+    import contextlib
+    import io
+
+    from spatten_amd import enable_spatten_llm
+    torch.manual_seed(0)
+    a = Stack(dt)
+    for p in a.parameters():
+        p.data.mul_(0.5)
+    b = Stack(dt)
+    b.load_state_dict(a.state_dict())
+    caches = []
+    for m in (a, b):
+        with contextlib.redirect_stdout(io.StringIO()):
+            caches.append(enable_spatten_llm(m, 4, 60, 64))
+    return a, b, caches
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_decode_graph_replays_equal_the_eager_plugin_loop_bitwise(dt):
+    """The same tokens through (a) the eager per-token loop of the patched forward and (b) DecodeGraph: one eager warm-up
+    step, one capture, then replays of ONE graph of the whole layer stack.  Hidden states of every token, the final
+    K / V caches and every module's attn_scores must agree bit for bit; then a prune event on both (bit exact) and a second
+    turn on a NEW graph."""
+    from spatten_amd import kv_slab
+    from spatten_amd.graph import DecodeGraph
+    a, b, (cache_a, cache_b) = _models(dt)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    P, T = 200, 14
+    x0 = torch.randn(1, P, HID, device="cuda", generator=g).to(dt)
+    toks = [torch.randn(1, 1, HID, device="cuda", generator=g).to(dt) for _ in range(2 * T + 8)]
+    _, past_a = a(x0, None)
+    _, past_b = b(x0, None)
+    for turn in range(2):
+        graph = DecodeGraph(lambda past, x: tuple(reversed(b(x, past))), past_b, horizon=T)
+        for t in range(T):
+            x = toks[turn * T + t]
+            ya, past_a = a(x, past_a)
+            yb = graph.step(x)
+            torch.cuda.synchronize()
+            assert torch.equal(ya, yb), (turn, t, (ya.float() - yb.float()).abs().max().item())
+        assert graph.n_replays == T - 1, "every step after the warm-up must be a replay of the one captured graph"
+        past_b = graph.past_key_values
+        n = past_a[0][0].shape[2]
+        assert n == P + (turn + 1) * T - (0 if turn == 0 else pruned)
+        for (ka, va), (kb, vb), ma, mb in zip(past_a, past_b, a.layers, b.layers):
+            assert kb.shape == ka.shape and torch.equal(ka, kb) and torch.equal(va, vb)
+            sa, sb = kv_slab.slab_of(ka), kv_slab.slab_of(kb)
+            assert torch.equal(sa.kr[:, :, :n], sb.kr[:, :, :n])
+            assert mb.attn_scores.shape == ma.attn_scores.shape and torch.equal(ma.attn_scores, mb.attn_scores)
+        if turn == 0:       # the reference's turn boundary (run_spatten_llama.py:71-79): prune from the last step's stash
+            coming = 8 + T
+            new_a = cache_a.apply_token_pruning(past_a, coming, [m.attn_scores for m in a.layers])
+            new_b = cache_b.apply_token_pruning(past_b, coming, [m.attn_scores for m in b.layers])
+            assert new_a is not past_a
+            pruned = n - new_a[0][0].shape[2]
+            for (ka, va), (kb, vb) in zip(new_a, new_b):
+                assert torch.equal(ka, kb) and torch.equal(va, vb)
+            xp = torch.randn(1, 8, HID, device="cuda", generator=g).to(dt)      # the next turn's prompt
+            _, past_a = a(xp, new_a)
+            _, past_b = b(xp, new_b)
+            pruned -= 8
+
+
+def test_decode_graph_outgrows_its_slabs_and_recaptures():
+    from spatten_amd.graph import DecodeGraph
+    dt = torch.bfloat16
+    a, b, _ = _models(dt)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x0 = torch.randn(1, 100, HID, device="cuda", generator=g).to(dt)
+    _, past_a = a(x0, None)
+    _, past_b = b(x0, None)
+    graph = DecodeGraph(lambda past, x: tuple(reversed(b(x, past))), past_b, horizon=8)
+    bound0 = graph.bound
+    T = bound0 - 100 + 5                    # runs past the capacity the slabs had at capture
+    for t in range(T):
+        x = torch.randn(1, 1, HID, device="cuda", generator=g).to(dt)
+        ya, past_a = a(x, past_a)
+        yb = graph.step(x)
+        # slabs of different capacity split the keys differently: same result up to the merge order
+        np.testing.assert_allclose(host(yb), host(ya), atol=2e-2, rtol=2e-2)
+    assert graph.bound > bound0 and graph.length == 100 + T
+    for (ka, va), (kb, vb) in zip(past_a, graph.past_key_values):
+        assert torch.equal(ka, kb) and torch.equal(va, vb)
