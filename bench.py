@@ -204,7 +204,8 @@ def cpu_baseline(L, new_len, lo, hi):
     return out
 
 
-def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False), (True, False), (True, True))):
+def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False, False), (True, False, False), (True, True, False),
+                                                              (True, True, True))):
     """The DROP-IN number: tokens/s through the patched HF forward itself (`llama_pos_shift_attention_forward`, called per
     layer with the arguments transformers 4.33 passes — hidden states, a zero mask, position_ids, the layer's (K, V)
     pair — including the module's q/k/v/o projections and every per-call host step), eager launches, Llama-2-7B geometry,
@@ -237,11 +238,12 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False), (Tr
     P = START + IMPORTANT + RECENT
     with torch.no_grad():
         model = Stack()
-        for flag, fuse in variants:
+        for flag, fuse, gemv in variants:
             import contextlib
             import io
             with contextlib.redirect_stdout(io.StringIO()):       # the constructor prints the reference's banner
-                enable_spatten_llm(model, START, IMPORTANT, RECENT, prefill_stash=False, assume_causal=flag, fuse_qkv=fuse)
+                enable_spatten_llm(model, START, IMPORTANT, RECENT, prefill_stash=False, assume_causal=flag, fuse_qkv=fuse,
+                                   native_gemv=gemv)
             hid = HEADS * HEAD_DIM
             x = torch.randn(1, P, hid, device=dev, dtype=torch.float32).to(dt)
             mask = torch.zeros(1, 1, P, P, dtype=dt, device=dev).masked_fill_(
@@ -267,8 +269,9 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False), (Tr
             for t in range(n_tokens):
                 token(t)
             torch.cuda.synchronize()
-            key = "plugin_path_assume_causal_fused_qkv_tokens_per_s" if fuse else (
-                "plugin_path_assume_causal_tokens_per_s" if flag else "plugin_path_tokens_per_s")
+            key = "plugin_path_assume_causal_fused_qkv_native_gemv_tokens_per_s" if gemv else (
+                "plugin_path_assume_causal_fused_qkv_tokens_per_s" if fuse else (
+                    "plugin_path_assume_causal_tokens_per_s" if flag else "plugin_path_tokens_per_s"))
             out[key] = round(n_tokens / (time.perf_counter() - t0), 2)
             # ---- the same decode step as ONE captured HIP graph of the whole layer stack (spatten_amd/graph.py): the
             # device-resident step state (ABI 3) lets a single graph replay for every token of the turn
@@ -285,6 +288,10 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False), (Tr
                     o, _, kv = m(xin, attention_mask=zm, position_ids=pid, past_key_value=pst[i], use_cache=True)
                     new.append(kv)
                 return new, o
+            graph = DecodeGraph(step_fn, past, horizon=4)        # first use in the process: one-time library set-up costs
+            for t in range(3):
+                graph.step(xt)
+            past = graph.past_key_values
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             graph = DecodeGraph(step_fn, past, horizon=TURN)
@@ -298,7 +305,7 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False), (Tr
                 graph.step(xt)
             torch.cuda.synchronize()
             t_rep = time.perf_counter() - t0
-            sfx = "_fused_qkv" if fuse else ""
+            sfx = "_fused_qkv_native_gemv" if gemv else ("_fused_qkv" if fuse else "")
             out[f"plugin_path_graph{sfx}_tokens_per_s"] = round(n_rep / t_rep, 2)
             out[f"plugin_path_graph{sfx}_turn_incl_capture_tokens_per_s"] = round(TURN / t_turn, 2)
             del graph
@@ -695,7 +702,8 @@ def main():
                 extras["plugin_path_error"] = f"{type(e).__name__}: {e}"
             try:
                 extras.update(dense_with_projections_tokens_per_s(dev, dt))
-                for k_ in ("plugin_path_tokens_per_s", "plugin_path_graph_tokens_per_s", "plugin_path_graph_fused_qkv_tokens_per_s"):
+                for k_ in ("plugin_path_tokens_per_s", "plugin_path_graph_tokens_per_s", "plugin_path_graph_fused_qkv_tokens_per_s",
+                           "plugin_path_graph_fused_qkv_native_gemv_tokens_per_s"):
                     if k_ in extras:
                         extras[k_.replace("_tokens_per_s", "") + "_speedup_vs_dense_eager_with_projections"] = round(
                             extras[k_] / extras["dense_eager_with_projections_tokens_per_s"], 2)

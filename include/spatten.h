@@ -194,6 +194,14 @@ int spatten_step_set(void* state, int dtype, int head_dim, const void* cos, cons
 int spatten_step_advance(void* state, int dtype, int head_dim, const void* cos, const void* sin, int table_rows,
                          int delta, void* stream);
 
+/* The projections of a single-token step (modify_llama.py:72-74 q/k/v_proj, :163 o_proj; nn.Linear semantics):
+ *   y[m, n] = sum_k x[m, k] * W[n, k] (+ bias[n]),  W [N, K] row-major with row stride w_sn (elements), x [M, K] row stride
+ *   x_sm, y [M, N] row stride y_sm, bias optional [N]; fp32 accumulation, one rounding to the dtype.  A weight-streaming
+ *   kernel for M = 1 (a batch of M single-token rows streams W once per row); K, w_sn, x_sm multiples of 8.
+ *   Multi-token forwards keep their GEMM library. */
+int spatten_gemv(int dtype, const void* x, int64_t x_sm, const void* W, int64_t w_sn, const void* bias, void* y,
+                 int64_t y_sm, int M, int N, int K, void* stream);
+
 /* KV append without attention (modify_llama.py:95-100 + the shadow row): k_new / v_new [B,Hkv,n,d] (strides new_sb,
  * new_sh, new_sn; d contiguous) are written to rows [row0, row0+n) of k_cache / v_cache, and their rotation at slot
  * positions row0+i to kr_cache (all three [B,Hkv,cap,d], strides kv_sb, kv_sh, rows contiguous).  Used by the modes

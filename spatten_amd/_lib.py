@@ -79,6 +79,8 @@ def _declare(lib):
     lib.spatten_step_set.argtypes = [p, i, i, p, p, i, i, i, p]
     lib.spatten_step_advance.restype = c_int
     lib.spatten_step_advance.argtypes = [p, i, i, p, p, i, i, p]
+    lib.spatten_gemv.restype = c_int
+    lib.spatten_gemv.argtypes = [i, p, i64, p, i64, p, p, i64, i, i, i, p]
     lib.spatten_kv_append.restype = c_int
     lib.spatten_kv_append.argtypes = [i, p, p, i64, i64, i64, p, p, p, i64, i64, p, p, i, i, i, i, i, i, p]
     lib.spatten_importance_accumulate.restype = c_int

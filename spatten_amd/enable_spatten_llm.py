@@ -25,7 +25,7 @@ _FAMILIES: Dict[str, Callable] = {"llama": _patch_llama}
 
 def enable_spatten_llm(model, start_size, important_size, recent_size, importance_mode="reference",
                        prefill_stash=True, assume_causal=False, head_keep=None, pq_threshold=None, local_v_keep=None,
-                       layer_keep=None, fuse_qkv=False):
+                       layer_keep=None, fuse_qkv=False, native_gemv=False):
     """The reference's four positional arguments (enable_spatten_llm.py:5) plus opt-in extensions:
 
     ``prefill_stash=False``: forwards with ``q_len > 1`` do not materialise ``self.attn_scores`` ([B,H,q,N]: 4 GiB per
@@ -38,6 +38,10 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     ``fuse_qkv=True``: the q / k / v projections of every patched module run as ONE torch GEMM over the stacked weights
     (host-bound decode: two launches fewer per layer; a different GEMM shape, so results can differ from three separate
     ``nn.Linear`` calls in the last bit).
+    ``native_gemv=True``: the q / k / v / o projections of a SINGLE-TOKEN step run on the library's weight-streaming kernel
+    (``spatten_gemv``) instead of torch's GEMM library — at q_len = 1 they are HBM-bound streams that make up four fifths
+    of the decode step's bytes (same fp32 accumulation and single rounding as ``nn.Linear``; a different summation order,
+    so the last bit can differ).  Multi-token forwards keep torch's GEMMs.
 
     SpAtten semantics the reference's Python does not implement (PARITY UNPINNED; spatten_amd/extensions.py):
     ``importance_mode="cascade"`` (cumulative importance = running sum of softmax probabilities, accumulated inside the
@@ -64,6 +68,7 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
         m._spatten_rope = None
         m.__dict__.pop("_spatten_geom", None)       # geometry cache of the patched forward: re-read on the next call
         m._spatten_qkv = None
+        m.__dict__["_spatten_gemv"] = bool(native_gemv)
         if fuse_qkv:
             from .pos_shift.modify_llama import fuse_qkv_projections
 

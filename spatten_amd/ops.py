@@ -341,6 +341,28 @@ class SlabDecodeCall:
         return out
 
 
+def gemv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``torch.nn.functional.linear(x, weight, bias)`` for single-token rows: x [..., K] with few rows (a decode step),
+    weight [N, K] (rows contiguous), as ONE weight-streaming launch per row (modify_llama.py:72-74, :163).
+    Returns [..., N]."""
+    _dev(x, weight, bias, out)
+    N, K = weight.shape
+    if x.shape[-1] != K or weight.stride(1) != 1 or x.stride(-1) != 1 or weight.dtype != x.dtype:
+        raise ValueError("gemv: x [..., K] and weight [N, K] of one dtype with contiguous rows")
+    x2 = x.reshape(-1, K)
+    M = x2.shape[0]
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    y2 = out.view(-1, N)
+    if bias is not None and (bias.dtype != x.dtype or not bias.is_contiguous() or bias.numel() != N):
+        raise ValueError("gemv: bias must be a contiguous [N] tensor of the same dtype")
+    rc = _lib.load().spatten_gemv(_dt(x), x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), _ptr(bias),
+                                  y2.data_ptr(), y2.stride(0), M, N, K, _stream())
+    _lib.check(rc, "spatten_gemv")
+    return out
+
+
 def kv_append(k_new: torch.Tensor, v_new: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: torch.Tensor,
               v_cache: torch.Tensor, row0: int, cos: torch.Tensor, sin: torch.Tensor):
     """Rows [row0, row0+n) of the slab planes from k_new / v_new [B,Hkv,n,d] (any strides, d contiguous): K un-rotated,

@@ -97,6 +97,10 @@ def llama_pos_shift_attention_forward(
         geom = self.__dict__["_spatten_geom"] = (num_heads, num_kv_heads, head_dim, hidden_size, tp)
     num_heads, num_kv_heads, head_dim, hidden_size, tp = geom
 
+    # single-token rows through the library's weight-streaming kernel (opt-in), everything else through torch's GEMMs
+    native_rows = (tp == 1 and bsz * q_len <= 4 and bool(self.__dict__.get("_spatten_gemv", False))
+                   and hidden_states.is_cuda and hidden_states.dtype == self.o_proj.weight.dtype
+                   and type(self.o_proj) is torch.nn.Linear)
     if tp > 1:                                                                    # :43-69
         kv_slicing = (num_kv_heads * head_dim) // tp
         q_slices = self.q_proj.weight.split((num_heads * head_dim) // tp, dim=0)
@@ -109,8 +113,21 @@ def llama_pos_shift_attention_forward(
         # opt-in (enable_spatten_llm(..., fuse_qkv=True)): ONE GEMM over the stacked q/k/v weights — a single-token step
         # is host-bound and each torch linear costs ~20 us of launch path; the three results are slices of one row
         w, bias, nq, nk = self._spatten_qkv
-        qkv = F.linear(hidden_states, w, bias)
+        qw = self.q_proj.weight
+        if qw.data_ptr() != w.data_ptr() or qw.dtype != w.dtype or qw.device != w.device:
+            # the parameters were moved / cast / reassigned after the fusion (model.to(), .half()): stack them again
+            self._spatten_qkv = None
+            if not fuse_qkv_projections(self):
+                raise RuntimeError("fuse_qkv: the q/k/v projections can no longer be stacked (mixed dtype / device / bias)")
+            w, bias, nq, nk = self._spatten_qkv
+        qkv = ops.gemv(hidden_states, w, bias) if native_rows else F.linear(hidden_states, w, bias)
         query_states, key_states, value_states = qkv[..., :nq], qkv[..., nq:nq + nk], qkv[..., nq + nk:]
+    elif native_rows:
+        # opt-in (enable_spatten_llm(..., native_gemv=True)): a single-token projection is a 2-FLOP-per-byte weight
+        # stream, HBM-bound like the attention next to it — the library's streaming kernel instead of the GEMM library
+        query_states = ops.gemv(hidden_states, self.q_proj.weight, self.q_proj.bias)
+        key_states = ops.gemv(hidden_states, self.k_proj.weight, self.k_proj.bias)
+        value_states = ops.gemv(hidden_states, self.v_proj.weight, self.v_proj.bias)
     else:                                                                         # :72-74
         query_states = self.q_proj(hidden_states)
         key_states = self.k_proj(hidden_states)
@@ -227,6 +244,8 @@ def llama_pos_shift_attention_forward(
         attn_output = attn_output.split(hidden_size // tp, dim=2)
         o_slices = self.o_proj.weight.split(hidden_size // tp, dim=1)
         attn_output = sum(F.linear(attn_output[i], o_slices[i]) for i in range(tp))
+    elif native_rows:
+        attn_output = ops.gemv(attn_output, self.o_proj.weight, self.o_proj.bias)
     else:
         attn_output = self.o_proj(attn_output)                                    # :163
 

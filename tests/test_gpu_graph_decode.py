@@ -201,7 +201,7 @@ class Stack(nn.Module):
         return x, new_past
 
 
-def _models(dt):
+def _models(dt, **kw):
     import contextlib
     import io
 
@@ -215,19 +215,20 @@ def _models(dt):
     caches = []
     for m in (a, b):
         with contextlib.redirect_stdout(io.StringIO()):
-            caches.append(enable_spatten_llm(m, 4, 60, 64))
+            caches.append(enable_spatten_llm(m, 4, 60, 64, **kw))
     return a, b, caches
 
 
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
-def test_decode_graph_replays_equal_the_eager_plugin_loop_bitwise(dt):
+@pytest.mark.parametrize("dt,kw", [(torch.bfloat16, {}), (torch.float32, {}),
+                                   (torch.bfloat16, dict(native_gemv=True)), (torch.float16, dict(native_gemv=True, fuse_qkv=True))])
+def test_decode_graph_replays_equal_the_eager_plugin_loop_bitwise(dt, kw):
     """The same tokens through (a) the eager per-token loop of the patched forward and (b) DecodeGraph: one eager warm-up
     step, one capture, then replays of ONE graph of the whole layer stack.  Hidden states of every token, the final
     K / V caches and every module's attn_scores must agree bit for bit; then a prune event on both (bit exact) and a second
     turn on a NEW graph."""
     from spatten_amd import kv_slab
     from spatten_amd.graph import DecodeGraph
-    a, b, (cache_a, cache_b) = _models(dt)
+    a, b, (cache_a, cache_b) = _models(dt, **kw)
     g = torch.Generator(device="cuda").manual_seed(1)
     P, T = 200, 14
     x0 = torch.randn(1, P, HID, device="cuda", generator=g).to(dt)
@@ -285,3 +286,31 @@ def test_decode_graph_outgrows_its_slabs_and_recaptures():
     assert graph.bound > bound0 and graph.length == 100 + T
     for (ka, va), (kb, vb) in zip(past_a, graph.past_key_values):
         assert torch.equal(ka, kb) and torch.equal(va, vb)
+
+
+def test_native_gemv_forward_stays_within_rounding_of_the_torch_projections():
+    """enable_spatten_llm(native_gemv=True): the single-token projections on the streaming kernel — same fp32
+    accumulation and single rounding as nn.Linear, another summation order."""
+    dt = torch.bfloat16
+    a, b, _ = _models(dt)
+    import contextlib
+    import io
+
+    from spatten_amd import enable_spatten_llm
+    with contextlib.redirect_stdout(io.StringIO()):
+        enable_spatten_llm(b, 4, 60, 64, native_gemv=True, fuse_qkv=True)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x0 = torch.randn(1, 150, HID, device="cuda", generator=g).to(dt)
+    ya, past_a = a(x0, None)
+    yb, past_b = b(x0, None)
+    assert torch.equal(ya, yb), "multi-token forwards keep torch's GEMMs"
+    for t in range(5):
+        x = torch.randn(1, 1, HID, device="cuda", generator=g).to(dt)
+        ya, past_a = a(x, past_a)
+        yb, past_b = b(x, past_b)
+        np.testing.assert_allclose(host(yb), host(ya), atol=6e-2, rtol=3e-2)
+    # model.half(): the stacked q/k/v weight is rebuilt from the new parameters instead of going stale
+    b.half()
+    yh, _ = b(x0.half(), None)
+    yh1, _ = b(x.half(), _)
+    assert yh.dtype == torch.float16 and torch.isfinite(yh1.float()).all()
