@@ -404,12 +404,16 @@ int spatten_attn_prefill_pq(int dtype,
  *   rank 0: spatten_comm_unique_id(id) ; ship the 128 bytes to every rank out of band (torch.distributed, MPI, a file)
  *   every rank, after hipSetDevice: spatten_comm_init(&comm, rank, nranks, id)          (collective, blocks)
  *   per step: spatten_allgather(comm, send, recv, bytes_per_rank, stream)  -> recv[r*bytes .. ) = rank r's send buffer
- * RCCL is dlopen-ed on first use; SPATTEN_ERR_UNSUPPORTED when librccl is not installed.
+ * RCCL is dlopen-ed on first use (librccl.so by name, or the path in the environment variable SPATTEN_RCCL_LIB);
+ * SPATTEN_ERR_UNSUPPORTED when it cannot be loaded.  SPATTEN_ERR_INVALID: rank outside [0, nranks), NULL arguments;
+ * SPATTEN_ERR_LAUNCH: RCCL refused (e.g. two ranks of one communicator on the same device).
  * ---------------------------------------------------------------------------------------------- */
 #define SPATTEN_COMM_ID_BYTES 128
 int spatten_comm_unique_id(void* id_out /* SPATTEN_COMM_ID_BYTES */);
 int spatten_comm_init(void** comm_out, int rank, int nranks, const void* unique_id);
 int spatten_comm_destroy(void* comm);
+/* what the communicator itself reports (ncclCommCount / ncclCommUserRank) */
+int spatten_comm_info(void* comm, int* nranks_out, int* rank_out);
 int spatten_allgather(void* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
 
 #ifdef __cplusplus

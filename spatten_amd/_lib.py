@@ -120,6 +120,8 @@ def _declare(lib):
     lib.spatten_comm_unique_id.argtypes = [p]
     lib.spatten_comm_init.restype = c_int
     lib.spatten_comm_init.argtypes = [POINTER(c_void_p), i, i, p]
+    lib.spatten_comm_info.restype = c_int
+    lib.spatten_comm_info.argtypes = [p, POINTER(c_int), POINTER(c_int)]
     lib.spatten_comm_destroy.restype = c_int
     lib.spatten_comm_destroy.argtypes = [p]
     lib.spatten_allgather.restype = c_int

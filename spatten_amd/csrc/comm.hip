@@ -6,6 +6,7 @@
 // RCCL is loaded lazily (dlopen) the first time a communicator is asked for: a single-GPU user of libspatten_hip.so
 // never pays for, or depends on, librccl.
 #include <dlfcn.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -17,6 +18,8 @@ struct RcclApi {
   int (*CommInitRank)(void**, int, const void*, int) = nullptr;   // ncclUniqueId is passed BY VALUE: see init below
   int (*CommDestroy)(void*) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
+  int (*CommUserRank)(void*, int*) = nullptr;
   bool ok = false;
 };
 
@@ -27,16 +30,25 @@ static RcclApi& rccl() {
   static bool tried = false;
   if (!tried) {
     tried = true;
-    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    for (const char* n : names) {
-      api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-      if (api.handle) break;
+    // SPATTEN_RCCL_LIB: an explicit library path (deployment with a private RCCL build; also how the tests reach the
+    // "RCCL not installed" branch)
+    const char* forced = getenv("SPATTEN_RCCL_LIB");
+    if (forced && *forced) {
+      api.handle = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+    } else {
+      const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+      for (const char* n : names) {
+        api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (api.handle) break;
+      }
     }
     if (api.handle) {
       api.GetUniqueId = (int (*)(void*))dlsym(api.handle, "ncclGetUniqueId");
       api.CommInitRank = (int (*)(void**, int, const void*, int))dlsym(api.handle, "ncclCommInitRank");
       api.CommDestroy = (int (*)(void*))dlsym(api.handle, "ncclCommDestroy");
       api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.handle, "ncclAllGather");
+      api.CommCount = (int (*)(void*, int*))dlsym(api.handle, "ncclCommCount");
+      api.CommUserRank = (int (*)(void*, int*))dlsym(api.handle, "ncclCommUserRank");
       api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather;
     }
   }
@@ -75,6 +87,13 @@ extern "C" int spatten_comm_destroy(void* comm) {
   RcclApi& r = rccl();
   if (!r.ok) return SPATTEN_ERR_UNSUPPORTED;
   return r.CommDestroy(comm) == 0 ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+}
+
+extern "C" int spatten_comm_info(void* comm, int* nranks_out, int* rank_out) {
+  if (!comm || !nranks_out || !rank_out) return SPATTEN_ERR_INVALID;
+  RcclApi& r = rccl();
+  if (!r.ok || !r.CommCount || !r.CommUserRank) return SPATTEN_ERR_UNSUPPORTED;
+  return (r.CommCount(comm, nranks_out) == 0 && r.CommUserRank(comm, rank_out) == 0) ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }
 
 extern "C" int spatten_allgather(void* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream) {

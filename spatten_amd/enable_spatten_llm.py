@@ -25,7 +25,7 @@ _FAMILIES: Dict[str, Callable] = {"llama": _patch_llama}
 
 def enable_spatten_llm(model, start_size, important_size, recent_size, importance_mode="reference",
                        prefill_stash=True, assume_causal=False, head_keep=None, pq_threshold=None, local_v_keep=None,
-                       layer_keep=None, fuse_qkv=False, native_gemv=False):
+                       layer_keep=None, fuse_qkv=False, native_gemv=False, head_parallel=None):
     """The reference's four positional arguments (enable_spatten_llm.py:5) plus opt-in extensions:
 
     ``prefill_stash=False``: forwards with ``q_len > 1`` do not materialise ``self.attn_scores`` ([B,H,q,N]: 4 GiB per
@@ -42,6 +42,12 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     (``spatten_gemv``) instead of torch's GEMM library — at q_len = 1 they are HBM-bound streams that make up four fifths
     of the decode step's bytes (same fp32 accumulation and single rounding as ``nn.Linear``; a different summation order,
     so the last bit can differ).  Multi-token forwards keep torch's GEMMs.
+
+    ``head_parallel=HeadParallel(H, Hkv)`` (spatten_amd/parallel.py; one process per GPU): this rank's modules project,
+    cache, attend and prune only its H/G heads (column-sharded q/k/v projections; ``past_key_values`` and ``attn_scores``
+    hold the local heads) and all-gather the attention outputs [B, q, H/G*d] in front of the full ``o_proj``
+    (modify_llama.py:146-163) — the reference's only multi-device story is ``device_map="auto"`` (utils.py:58-63).
+    Token pruning needs no communication; ``head_keep`` ranks the heads of ALL ranks (one all-gather of H/G scores).
 
     SpAtten semantics the reference's Python does not implement (PARITY UNPINNED; spatten_amd/extensions.py):
     ``importance_mode="cascade"`` (cumulative importance = running sum of softmax probabilities, accumulated inside the
@@ -69,7 +75,12 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
         m.__dict__.pop("_spatten_geom", None)       # geometry cache of the patched forward: re-read on the next call
         m._spatten_qkv = None
         m.__dict__["_spatten_gemv"] = bool(native_gemv)
-        if fuse_qkv:
+        m.__dict__.pop("_spatten_hp", None)
+        if head_parallel is not None:
+            from .pos_shift.modify_llama import shard_attention_projections
+
+            shard_attention_projections(m, head_parallel, fuse=bool(fuse_qkv))
+        elif fuse_qkv:
             from .pos_shift.modify_llama import fuse_qkv_projections
 
             fuse_qkv_projections(m)
@@ -77,7 +88,8 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
         from .extensions import SpattenExtensions
 
         cache.ext = SpattenExtensions(cache, len(mods), cascade=importance_mode == "cascade", head_keep=head_keep,
-                                      pq_threshold=pq_threshold, local_v_keep=local_v_keep, layer_keep=layer_keep)
+                                      pq_threshold=pq_threshold, local_v_keep=local_v_keep, layer_keep=layer_keep,
+                                      head_parallel=head_parallel)
         for layer, m in enumerate(mods):
             m._spatten_ext = (cache.ext, layer)
     return cache

@@ -48,7 +48,8 @@ class LayerState:
         self.acc: Optional[torch.Tensor] = None                     # [H, cap] fp32 cumulative importance
         self.head_abs: Optional[torch.Tensor] = None                # [B*H] fp32: sum |attn_out| per (b, h), decode steps
         self.head_abs_prefill: Optional[torch.Tensor] = None        # [H] fp32: the same from multi-token forwards
-        self.head_ids: Optional[torch.Tensor] = None                # int32 ascending kept heads (None = all)
+        self.head_ids: Optional[torch.Tensor] = None                # int32 ascending kept heads of THIS process (None = all)
+        self.kept_global: Optional[torch.Tensor] = None             # int32 kept heads of the whole model (head-parallel: all ranks)
         self.pruned_ids: Optional[torch.Tensor] = None              # int64 pruned heads
         self.need_lsb: Optional[torch.Tensor] = None                # int32 [B*H]
         self.out: Optional[torch.Tensor] = None                     # [B, H*d], zero in the pruned heads' slices
@@ -92,12 +93,13 @@ def _per_layer(x, n_layers: int, name: str):
 class SpattenExtensions:
     def __init__(self, cache, n_layers: int, cascade: bool = False,
                  head_keep: Union[None, int, Sequence[int]] = None, pq_threshold: Optional[float] = None,
-                 local_v_keep: Optional[float] = None, layer_keep: Optional[Sequence[int]] = None):
+                 local_v_keep: Optional[float] = None, layer_keep: Optional[Sequence[int]] = None, head_parallel=None):
         if pq_threshold is not None and local_v_keep is not None:
             raise ValueError("pq_threshold and local_v_keep cannot be combined (the local-V pass scores from the bf16 shadow)")
         if local_v_keep is not None and not (0.0 < float(local_v_keep) <= 1.0):
             raise ValueError("local_v_keep is a fraction in (0, 1]")
         self.cache = cache
+        self.hp = head_parallel                     # spatten_amd.parallel.HeadParallel: the layers hold H/G local heads
         self.n_layers = n_layers
         self.cascade = bool(cascade)
         self.head_keep = _per_layer(head_keep, n_layers, "head_keep")
@@ -218,25 +220,38 @@ class SpattenExtensions:
         if self.head_keep is None or self.layers[0].head_abs is None:
             return
         dev = self.layers[0].head_abs.device
-        H = self.layers[0].head_abs_prefill.numel()
+        Hl = self.layers[0].head_abs_prefill.numel()          # heads this process holds
+        hp = self.hp
+        H = Hl if hp is None else hp.num_heads
+        lo = 0 if hp is None else hp.head_range()[0]
         cum = torch.zeros(H, dtype=torch.float32, device=dev)
         alive = torch.ones(H, dtype=torch.bool, device=dev)
         neg = torch.full((H,), float("-inf"), dtype=torch.float32, device=dev)
         for layer, st in enumerate(self.layers):
             if st.head_abs is None:
                 break
-            cum = cum + self.head_scores(layer)
-            if st.head_ids is not None:
+            local = self.head_scores(layer)
+            # head-parallel: ONE all-gather of the H/G local scores, then the same deterministic top-k on every rank
+            # (head_keep counts heads of the whole model; every rank tracks the global kept set and launches its share)
+            cum = cum + (local if hp is None else hp.gather_head_scores(local))
+            if st.kept_global is not None:
                 mine = torch.zeros(H, dtype=torch.bool, device=dev)
-                mine[st.head_ids.long()] = True
+                mine[st.kept_global.long()] = True
                 alive = alive & mine
             k = min(int(self.head_keep[layer]), H)
             k = min(k, int(alive.sum().item()))
             ids = ops.topk_select(torch.where(alive, cum, neg)[None, :].contiguous(), 0, H, k)[0].contiguous()
             alive = torch.zeros(H, dtype=torch.bool, device=dev)
             alive[ids.long()] = True
-            st.head_ids = ids if k < H else None
-            st.pruned_ids = (~alive).nonzero().flatten() if k < H else None
+            st.kept_global = ids if k < H else None
+            mine_alive = alive[lo:lo + Hl]
+            if k < H:
+                st.head_ids = mine_alive.nonzero().flatten().to(torch.int32).contiguous()     # local ids, ascending
+                st.pruned_ids = (~mine_alive).nonzero().flatten()
+                if st.head_ids.numel() == 0:
+                    raise NotImplementedError("head pruning left this rank without a head in one layer")
+            else:
+                st.head_ids = st.pruned_ids = None
             if st.out is not None:
                 st.out.zero_()
 

@@ -36,10 +36,20 @@ class _Pending:
 
 
 class HeadParallel:
-    def __init__(self, num_heads: int, num_kv_heads: Optional[int] = None, group=None):
+    def __init__(self, num_heads: int, num_kv_heads: Optional[int] = None, group=None, rank: Optional[int] = None,
+                 world: Optional[int] = None, gather_fn=None):
+        """Default: rank / world of the torch.distributed process group.  ``rank`` / ``world`` / ``gather_fn`` given
+        explicitly: a partition WITHOUT a process group — ``gather_fn(local [B,q,H/G*d], rank) -> full [B,q,H*d]`` stands
+        in for the all-gather (tests run every rank's shard in one process, one after the other)."""
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.gather_fn = gather_fn
+        if rank is not None or world is not None:
+            if rank is None or world is None or not (0 <= rank < world) or gather_fn is None:
+                raise ValueError("an explicit partition needs rank, world and gather_fn")
+            self.world, self.rank = int(world), int(rank)
+        else:
+            self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+            self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         num_kv_heads = num_kv_heads or num_heads
         if num_heads % self.world or num_kv_heads % self.world:
             raise ValueError(f"heads ({num_heads}/{num_kv_heads}) must divide evenly over {self.world} ranks")
@@ -70,6 +80,17 @@ class HeadParallel:
         ``async_op=True``: returns (None, handle); ``handle.wait()`` yields the merged tensor (the
         head-major merge reads the staging buffer, so it must not run before the collective finished)."""
         B, ql, hd = out_local.shape
+        if self.gather_fn is not None:
+            full = self.gather_fn(out_local, self.rank)
+            return (None, _Done(full)) if async_op else (full, None)
+        if getattr(self, "_comm", None) is not None and out_local.is_cuda:
+            # the library-owned RCCL communicator (init_native): an ordinary stream operation — the form a captured decode
+            # step (spatten_amd/graph.py) can hold; torch's process-group collectives cannot be captured on this stack
+            if staging is None:
+                staging = torch.empty(self.world, B, ql, hd, dtype=out_local.dtype, device=out_local.device)
+            self.allgather_native(out_local.contiguous(), staging)
+            full = staging.permute(1, 2, 0, 3).reshape(B, ql, self.world * hd)
+            return (None, _Done(full)) if async_op else (full, None)
         if self.world == 1 and not (dist.is_initialized() and staging is not None):
             return (None, _Done(out_local)) if async_op else (out_local, None)
         if staging is None:
@@ -81,6 +102,16 @@ class HeadParallel:
         if async_op:
             return None, _Pending(work, merge)
         return merge(), None
+
+    # ---- the plugin's sharded projections (enable_spatten_llm(..., head_parallel=hp)) --------------------------------
+    def shard_projection(self, weight: torch.Tensor, bias: Optional[torch.Tensor], head_dim: int, kv: bool = False):
+        """Rows of a q / k / v projection that produce this rank's heads: nn.Linear weight [H*d, hidden] (bias [H*d])
+        -> ([H/G*d, hidden], [H/G*d] or None) — the column-sharded projection of SURVEY §8e (output features = rows of
+        the stored weight).  Contiguous copies: the full matrices can then be dropped by the caller."""
+        lo, hi = self.kv_head_range() if kv else self.head_range()
+        w = weight.detach()[lo * head_dim:hi * head_dim].contiguous()
+        b = None if bias is None else bias.detach()[lo * head_dim:hi * head_dim].contiguous()
+        return w, b
 
     # ---- the library-owned RCCL communicator (include/spatten.h: spatten_comm_*) -----------------------------------
     def init_native(self):
@@ -115,6 +146,17 @@ class HeadParallel:
         _lib.check(rc, "spatten_allgather")
         return recv
 
+    def native_info(self):
+        """(ranks, rank) as the RCCL communicator itself reports them (ncclCommCount / ncclCommUserRank)."""
+        import ctypes
+
+        from . import _lib
+        if getattr(self, "_comm", None) is None:
+            raise RuntimeError("init_native() first")
+        n, r = ctypes.c_int(-1), ctypes.c_int(-1)
+        _lib.check(_lib.load().spatten_comm_info(self._comm, ctypes.byref(n), ctypes.byref(r)), "spatten_comm_info")
+        return n.value, r.value
+
     def close_native(self):
         from . import _lib
         if getattr(self, "_comm", None) is not None:
@@ -123,6 +165,8 @@ class HeadParallel:
 
     def gather_head_scores(self, local_scores: torch.Tensor) -> torch.Tensor:
         """[H/G] fp32 -> [H] on every rank (head pruning: every rank then runs the same top-k)."""
+        if self.gather_fn is not None:
+            return self.gather_fn(local_scores.reshape(1, 1, -1), self.rank).reshape(-1)
         if self.world == 1:
             return local_scores
         full = torch.empty(self.world * local_scores.numel(), dtype=local_scores.dtype, device=local_scores.device)

@@ -97,6 +97,14 @@ def llama_pos_shift_attention_forward(
         geom = self.__dict__["_spatten_geom"] = (num_heads, num_kv_heads, head_dim, hidden_size, tp)
     num_heads, num_kv_heads, head_dim, hidden_size, tp = geom
 
+    # head-parallel (enable_spatten_llm(..., head_parallel=hp)): this rank projects, caches, attends and prunes
+    # ONLY its H/G heads — column-sharded q/k/v projections — and the one exchange is the all-gather of the attention
+    # outputs in front of the full o_proj (:146-163)
+    hp = self.__dict__.get("_spatten_hp")
+    if hp is not None:
+        if tp > 1:
+            raise NotImplementedError("head_parallel with config.pretraining_tp > 1")
+        num_heads, num_kv_heads = hp[0].local_heads, hp[0].local_kv_heads
     # single-token rows through the library's weight-streaming kernel (opt-in), everything else through torch's GEMMs
     native_rows = (tp == 1 and bsz * q_len <= 4 and bool(self.__dict__.get("_spatten_gemv", False))
                    and hidden_states.is_cuda and hidden_states.dtype == self.o_proj.weight.dtype
@@ -109,6 +117,15 @@ def llama_pos_shift_attention_forward(
         query_states = torch.cat([F.linear(hidden_states, q_slices[i]) for i in range(tp)], dim=-1)
         key_states = torch.cat([F.linear(hidden_states, k_slices[i]) for i in range(tp)], dim=-1)
         value_states = torch.cat([F.linear(hidden_states, v_slices[i]) for i in range(tp)], dim=-1)
+    elif hp is not None:
+        lin = ops.gemv if native_rows else F.linear
+        if hp[2] is not None:                       # fuse_qkv: the three local slices stacked into one weight
+            w, bias, nq, nk = hp[2]
+            qkv = lin(hidden_states, w, bias)
+            query_states, key_states, value_states = qkv[..., :nq], qkv[..., nq:nq + nk], qkv[..., nq + nk:]
+        else:
+            (qw, qb), (kw, kb), (vw, vb) = hp[1]
+            query_states, key_states, value_states = lin(hidden_states, qw, qb), lin(hidden_states, kw, kb), lin(hidden_states, vw, vb)
     elif getattr(self, "_spatten_qkv", None) is not None:
         # opt-in (enable_spatten_llm(..., fuse_qkv=True)): ONE GEMM over the stacked q/k/v weights — a single-token step
         # is host-bound and each torch linear costs ~20 us of launch path; the three results are slices of one row
@@ -236,6 +253,10 @@ def llama_pos_shift_attention_forward(
     # store attention scores for deciding which token to prune (:116-119) — raw scaled logits, pre-mask
     object.__setattr__(self, "attn_scores", stash)      # (nn.Module.__setattr__ costs ~2.5 us of type checks per call)
 
+    if hp is not None:
+        # [B, q, H/G*d] of every rank -> [B, q, H*d], rank-major = head-major: the reference's transpose(1, 2).reshape
+        # layout (:146-147).  (attn_scores, the KV cache and hence the prune stay local: they are per head.)
+        attn_output, _ = hp[0].gather_heads(attn_output.reshape(bsz, q_len, num_heads * head_dim))
     if attn_output.size() != (bsz, q_len, hidden_size):                           # :140-147
         raise ValueError(
             f"`attn_output` should be of size {(bsz, q_len, hidden_size)}, but is {attn_output.size()}")
@@ -328,3 +349,24 @@ def enable_llama_pos_shift_attention(model):
             enable_llama_pos_shift_attention(module)
         if _is_llama_attention(module):
             model._modules[name].forward = types.MethodType(llama_pos_shift_attention_forward, model._modules[name])
+
+
+def shard_attention_projections(module, hp, fuse: bool = False):
+    """Give one patched attention module its head-parallel form: the rows of q_proj / k_proj / v_proj that produce this
+    rank's heads (``HeadParallel.shard_projection``: column-sharded projections, copies), optionally stacked into one
+    weight; ``o_proj`` stays whole (it consumes the gathered [B, q, H*d]).  The module's own parameters are not touched —
+    a caller that wants the memory back can drop q/k/v_proj afterwards."""
+    heads = _cfg(module, "num_heads", "num_attention_heads")
+    kv_heads = _cfg(module, "num_key_value_heads", "num_key_value_heads", default=heads)
+    head_dim = _cfg(module, "head_dim", "head_dim") or (_cfg(module, "hidden_size", "hidden_size") // heads)
+    if heads != hp.num_heads or kv_heads != hp.num_kv_heads:
+        raise ValueError(f"head_parallel was built for {hp.num_heads}/{hp.num_kv_heads} heads, the module has {heads}/{kv_heads}")
+    parts = [hp.shard_projection(module.q_proj.weight, getattr(module.q_proj, "bias", None), head_dim),
+             hp.shard_projection(module.k_proj.weight, getattr(module.k_proj, "bias", None), head_dim, kv=True),
+             hp.shard_projection(module.v_proj.weight, getattr(module.v_proj, "bias", None), head_dim, kv=True)]
+    stacked = None
+    if fuse and len({b is None for _, b in parts}) == 1:
+        w = torch.cat([w_ for w_, _ in parts], dim=0).contiguous()
+        b = None if parts[0][1] is None else torch.cat([b_ for _, b_ in parts], dim=0).contiguous()
+        stacked = (w, b, parts[0][0].shape[0], parts[1][0].shape[0])
+    module.__dict__["_spatten_hp"] = (hp, parts, stacked)

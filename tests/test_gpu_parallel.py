@@ -66,6 +66,7 @@ def test_native_rccl_allgather_eager_and_graph_captured():
     except RuntimeError as e:                        # librccl missing on the box: the path must say so, not crash
         assert "unsupported" in str(e)
         pytest.skip("librccl not installed")
+    assert hp.native_info() == (1, 0)                # what the RCCL communicator itself reports
     send = torch.randn(32, 1, 512, device="cuda").to(torch.bfloat16)
     recv = torch.zeros_like(send)
     hp.allgather_native(send, recv)
@@ -88,3 +89,174 @@ def test_native_rccl_allgather_eager_and_graph_captured():
         side.synchronize()
     assert torch.equal(recv, want) and torch.equal(send, want)
     hp.close_native()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# head-parallel mode of the PLUGIN: enable_spatten_llm(..., head_parallel=hp)
+# ------------------------------------------------------------------------------------------------------------------
+def _stack(layers, H, Hkv, d, dt, bias=False):
+    from types import SimpleNamespace
+
+    from torch import nn
+
+    class LlamaAttention(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.config = SimpleNamespace(pretraining_tp=1)
+            self.num_heads, self.num_key_value_heads, self.num_key_value_groups = H, Hkv, H // Hkv
+            self.head_dim, self.hidden_size = d, H * d
+            self.q_proj = nn.Linear(H * d, H * d, bias=bias, dtype=dt, device="cuda")
+            self.k_proj = nn.Linear(H * d, Hkv * d, bias=bias, dtype=dt, device="cuda")
+            self.v_proj = nn.Linear(H * d, Hkv * d, bias=bias, dtype=dt, device="cuda")
+            self.o_proj = nn.Linear(H * d, H * d, bias=bias, dtype=dt, device="cuda")
+
+    class Stack(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.config = SimpleNamespace(model_type="llama")
+            self.layers = nn.ModuleList([LlamaAttention() for _ in range(layers)])
+    return Stack()
+
+
+def _hf_args(x, P):
+    B, q, _ = x.shape
+    N = P + q
+    pos = torch.arange(P, N, device=x.device)[None]
+    mask = torch.zeros(B, 1, q, N, dtype=x.dtype, device=x.device)
+    if q > 1:
+        mask.masked_fill_(torch.ones(q, N, dtype=torch.bool, device=x.device).triu(P + 1), torch.finfo(x.dtype).min)
+    return mask, pos
+
+
+@pytest.mark.parametrize("world,Hkv,kw", [(2, 8, {}), (4, 4, dict(fuse_qkv=True)), (2, 8, dict(native_gemv=True, fuse_qkv=True)),
+                                          (2, 8, dict(head_keep=[6, 5]))])
+def test_plugin_head_parallel_shards_run_in_sequence_equal_the_unsharded_plugin(world, Hkv, kw):
+    """Every rank's copy of the patched stack (its column-sharded q/k/v projections, its H/G heads of KV cache) is driven
+    layer by layer in ONE process; the all-gather is a loopback that lays the slices out rank-major.  Prefill, decode
+    steps, a prune event and a second turn must reproduce the unsharded plugin: hidden states of every forward, the local
+    caches = the head slices of the full caches (bit exact: per-head work), kept positions bit exact."""
+    import contextlib
+    import io
+
+    from spatten_amd import enable_spatten_llm
+    from spatten_amd.parallel import HeadParallel
+    torch.manual_seed(7)
+    dt, L, H, d = torch.bfloat16, 2, 8, 64
+    HID = H * d
+    full = _stack(L, H, Hkv, d, dt, bias="fuse_qkv" not in kw)
+    for p in full.parameters():
+        p.data.mul_(0.5)
+    ranks = []
+    shared = {}
+
+    def loopback(local, rank):            # the all-gather: rank r's slice lands at [r*n, (r+1)*n) of the last axis
+        n = local.shape[-1]
+        buf = shared.setdefault((tuple(local.shape), local.dtype), torch.zeros(*local.shape[:-1], n * world, dtype=local.dtype,
+                                                                               device=local.device))
+        buf[..., rank * n:(rank + 1) * n] = local
+        return buf.clone()
+    with contextlib.redirect_stdout(io.StringIO()):
+        cache_full = enable_spatten_llm(full, 4, 40, 48, **kw)
+        for r in range(world):
+            m = _stack(L, H, Hkv, d, dt, bias="fuse_qkv" not in kw)
+            m.load_state_dict(full.state_dict())
+            hp = HeadParallel(H, Hkv, rank=r, world=world, gather_fn=loopback)
+            ranks.append((m, enable_spatten_llm(m, 4, 40, 48, head_parallel=hp, **kw), hp))
+    g = torch.Generator(device="cuda").manual_seed(8)
+    tol = dict(atol=3e-2, rtol=3e-2)
+
+    def forward_all(x, past_full, past_ranks):
+        """one forward of the stack: unsharded, and every rank layer by layer (the LAST rank to run a layer sees the
+        complete gathered tensor: its o_proj output is that layer's output on every rank of a real run)"""
+        P = 0 if past_full is None else past_full[0][0].shape[2]
+        mask, pos = _hf_args(x, P)
+        xf, new_full = x, []
+        xs, new_ranks = x, [[] for _ in range(world)]
+        for i in range(L):
+            a, _, kv = full.layers[i](xf, attention_mask=mask, position_ids=pos, past_key_value=None if past_full is None else past_full[i], use_cache=True)
+            xf = xf + a
+            new_full.append(kv)
+            for r, (m, _, hp) in enumerate(ranks):
+                ar, _, kvr = m.layers[i](xs, attention_mask=mask, position_ids=pos, past_key_value=None if past_ranks is None else past_ranks[r][i], use_cache=True)
+                new_ranks[r].append(kvr)
+            xs = xs + ar
+            np.testing.assert_allclose(host(xs), host(xf), err_msg=f"layer {i}", **tol)
+            xs = xf                       # keep the two runs on identical inputs: differences must not accumulate into the caches
+        return new_full, new_ranks
+    x0 = torch.randn(1, 120, HID, device="cuda", generator=g).to(dt)
+    pf, pr = forward_all(x0, None, None)
+    for turn in range(2):
+        for t in range(6):
+            pf, pr = forward_all(torch.randn(1, 1, HID, device="cuda", generator=g).to(dt), pf, pr)
+        for r, (m, _, hp) in enumerate(ranks):
+            lo, hi = hp.kv_head_range()
+            for i in range(L):
+                assert pr[r][i][0].shape[1] == Hkv // world
+                assert torch.equal(pr[r][i][0], pf[i][0][:, lo:hi]) and torch.equal(pr[r][i][1], pf[i][1][:, lo:hi])
+                hl, hh = hp.head_range()
+                if "head_keep" not in kw:
+                    assert torch.equal(m.layers[i].attn_scores, full.layers[i].attn_scores[:, hl:hh])
+        if turn == 0:
+            coming = 10
+            if "head_keep" in kw and Hkv != H:
+                break
+            new_f = cache_full.apply_token_pruning(pf, coming, [m.attn_scores for m in full.layers])
+            assert new_f is not pf
+            new_r = []
+            for r, (m, cache_r, hp) in enumerate(ranks):
+                nr = cache_r.apply_token_pruning(pr[r], coming, [mm.attn_scores for mm in m.layers])
+                lo, hi = hp.kv_head_range()
+                for i in range(L):
+                    assert torch.equal(nr[i][0], new_f[i][0][:, lo:hi]) and torch.equal(nr[i][1], new_f[i][1][:, lo:hi])
+                if "head_keep" in kw:       # the same global kept set on every rank, its local share launched
+                    for i in range(L):
+                        kg_f = cache_full.ext.layers[i].kept_global
+                        kg_r = cache_r.ext.layers[i].kept_global
+                        assert (kg_f is None and kg_r is None) or torch.equal(kg_f, kg_r)
+                        hl, hh = hp.head_range()
+                        if kg_f is not None:
+                            want = [int(h) - hl for h in kg_f.tolist() if hl <= int(h) < hh]
+                            assert cache_r.ext.layers[i].head_ids.tolist() == want
+                new_r.append(nr)
+            pf, pr = new_f, new_r
+            pf, pr = forward_all(torch.randn(1, coming, HID, device="cuda", generator=g).to(dt), pf, pr)
+
+
+def test_comm_init_refuses_two_ranks_on_one_device():
+    """spatten_comm_init failure mode: both ranks of a 2-rank communicator on the SAME device — RCCL refuses ("duplicate
+    GPU"), the entry point returns SPATTEN_ERR_LAUNCH on both instead of building a broken communicator.  Run in a child
+    process under a timeout (two threads = the two ranks)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import ctypes, sys, threading
+sys.path.insert(0, %r)
+import torch
+torch.cuda.init()
+from spatten_amd import _lib
+lib = _lib.load()
+ident = ctypes.create_string_buffer(128)
+rc = lib.spatten_comm_unique_id(ident)
+if rc == -2:
+    print("norccl"); raise SystemExit(0)
+assert rc == 0
+res = [None, None]
+def run(r):
+    torch.cuda.set_device(0)
+    comm = ctypes.c_void_p()
+    res[r] = lib.spatten_comm_init(ctypes.byref(comm), r, 2, ident)
+ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+[t.start() for t in ts]; [t.join() for t in ts]
+print("rc", res[0], res[1])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=150)
+    except subprocess.TimeoutExpired:
+        pytest.fail("spatten_comm_init with two ranks on one device did not return")
+    if "norccl" in out.stdout:
+        pytest.skip("librccl not installed")
+    last = [ln for ln in out.stdout.splitlines() if ln.startswith("rc ")]
+    assert last, (out.stdout[-500:], out.stderr[-1500:])
+    a, b = (int(x) for x in last[-1].split()[1:])
+    assert a == -4 and b == -4, last[-1]

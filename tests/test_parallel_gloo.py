@@ -66,3 +66,104 @@ def test_head_parallel_world2_gloo():
     ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {0: 1, 1: 1}
+
+
+def _plugin_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+
+        from torch import nn
+
+        from spatten_amd.parallel import HeadParallel
+        from spatten_amd.pos_shift.modify_llama import shard_attention_projections
+        torch.manual_seed(3)                      # the same random Llama-attention stub on every rank
+        B, H, Hkv, d, P, dt = 2, 8, 4, 16, 40, "f32"
+        HID = H * d
+
+        class LlamaAttention(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.config = SimpleNamespace(pretraining_tp=1)
+                self.num_heads, self.num_key_value_heads, self.head_dim, self.hidden_size = H, Hkv, d, HID
+                self.q_proj = nn.Linear(HID, H * d, bias=True)
+                self.k_proj = nn.Linear(HID, Hkv * d, bias=True)
+                self.v_proj = nn.Linear(HID, Hkv * d, bias=True)
+                self.o_proj = nn.Linear(HID, HID, bias=False)
+        m = LlamaAttention()
+        hp = HeadParallel(H, Hkv)
+        x = torch.from_numpy(orc.synth_normal(9, 0, (B, 1, HID), dt))
+        pk = orc.synth_normal(9, 3, (B, Hkv, P, d), dt)
+        pv = orc.synth_normal(9, 4, (B, Hkv, P, d), dt)
+        pos = np.full((B, 1), P)
+        heads = lambda t, n: t.detach().view(B, 1, n, d).transpose(1, 2).numpy()
+        with torch.no_grad():
+            # unsharded: the reference op sequence on all heads (oracle), then o_proj
+            o_full, _, _ = orc.attention_core(heads(m.q_proj(x), H), heads(m.k_proj(x), Hkv), heads(m.v_proj(x), Hkv), pk, pv, pos, None, dt)
+            y_full = m.o_proj(torch.from_numpy(o_full))
+            for fuse in (False, True):
+                shard_attention_projections(m, hp, fuse=fuse)
+                hpo, parts, stacked = m.__dict__["_spatten_hp"]
+                assert hpo is hp and (stacked is not None) == fuse
+                Hl, Hkvl = hp.local_heads, hp.local_kv_heads
+                assert parts[0][0].shape == (Hl * d, HID) and parts[1][0].shape == (Hkvl * d, HID) and parts[0][1].shape == (Hl * d,)
+                if fuse:
+                    qkv = torch.nn.functional.linear(x, stacked[0], stacked[1])
+                    ql, kl, vl = qkv[..., :stacked[2]], qkv[..., stacked[2]:stacked[2] + stacked[3]], qkv[..., stacked[2] + stacked[3]:]
+                else:
+                    ql, kl, vl = (torch.nn.functional.linear(x, w, b) for w, b in parts)
+                lo, hi = hp.kv_head_range()
+                # the rank's column-sharded projections give exactly its heads of the full projections
+                hl, hh = hp.head_range()
+                np.testing.assert_allclose(heads(ql, Hl), heads(m.q_proj(x), H)[:, hl:hh], rtol=1e-5, atol=1e-6)
+                o_loc, _, _ = orc.attention_core(heads(ql, Hl), heads(kl, Hkvl), heads(vl, Hkvl), pk[:, lo:hi], pv[:, lo:hi], pos, None, dt)
+                full, _ = hp.gather_heads(torch.from_numpy(o_loc))          # the exchange in front of o_proj (:146-163)
+                y = m.o_proj(full)
+                np.testing.assert_allclose(y.numpy(), y_full.numpy(), rtol=1e-4, atol=1e-5)
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_plugin_head_parallel_slicing_and_gather_layout_world2_gloo():
+    world, port = 2, _free_port()
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_plugin_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: 1, 1: 1}
+
+
+def test_comm_entry_points_reject_bad_arguments_and_a_missing_rccl():
+    """spatten_comm_* failure modes that need no GPU: argument checks, and SPATTEN_ERR_UNSUPPORTED when RCCL cannot be
+    loaded (SPATTEN_RCCL_LIB points the loader at a path; a fresh process, because the loader runs once)."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes, sys
+sys.path.insert(0, %r)
+from spatten_amd import _lib
+lib = _lib.load()
+ident = ctypes.create_string_buffer(128)
+comm = ctypes.c_void_p()
+assert lib.spatten_comm_unique_id(None) == -1
+assert lib.spatten_comm_init(ctypes.byref(comm), 2, 2, ident) == -1          # rank outside [0, nranks)
+assert lib.spatten_comm_init(ctypes.byref(comm), 0, 0, ident) == -1
+assert lib.spatten_comm_init(None, 0, 1, ident) == -1
+assert lib.spatten_comm_init(ctypes.byref(comm), 0, 1, None) == -1
+assert lib.spatten_allgather(None, ident, ident, 8, None) == -1
+n = ctypes.c_int()
+assert lib.spatten_comm_info(None, ctypes.byref(n), ctypes.byref(n)) == -1
+assert lib.spatten_comm_destroy(None) == 0
+assert lib.spatten_comm_unique_id(ident) == -2, "RCCL must be reported missing"     # SPATTEN_ERR_UNSUPPORTED
+assert lib.spatten_comm_init(ctypes.byref(comm), 0, 1, ident) == -2
+from spatten_amd.parallel import HeadParallel
+try:
+    HeadParallel(8).init_native()
+    raise SystemExit("init_native must raise")
+except RuntimeError as e:
+    assert "unsupported" in str(e), str(e)
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SPATTEN_RCCL_LIB="/nonexistent/librccl.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
