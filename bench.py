@@ -15,10 +15,14 @@ The timed region always STARTS AT A TURN BOUNDARY (slot 0 = the prune event): K 
 prune events, whatever K the caller picks — never fewer than the workload's one-per-64-tokens.
 
 N > 1: head-parallel (spatten_amd/parallel.py); `python bench.py --gpus N` spawns its own N ranks (torch.distributed.run
-on a free local port) when it is not already running under a launcher.  --scaling weak (default): the batch grows with
-N (B = N sequences), every rank owns H/N heads of every sequence — the same KV bytes per rank as the single-GPU run.
---scaling strong: ONE sequence (B = 1) split over the ranks, H/N heads each (BASELINE.json configs[2] / [4]: 4 resp.
-5 heads per GPU at N = 8).  Either way each token all-gathers the layers' [B, H/N*d] output slices over RCCL.
+on a free local port) when it is not already running under a launcher.  --scaling strong (default): ONE sequence
+(B = 1) split over the ranks, H/N heads each (BASELINE.json configs[2] / [4]: 4 resp. 5 heads per GPU at N = 8) — total
+work fixed.  --scaling weak: the batch grows with N (B = N sequences), every rank owns H/N heads of every sequence — the
+same KV bytes per rank as the single-GPU run.  Either way each token all-gathers the layers' [B, H/N*d] output slices
+over RCCL (`config.rccl_ranks` = what the library's communicator reports).
+
+Defaults: --steps 512 --warmup 64 (8 turns timed; ~0.2 s of GPU time + ~25 s of CPU-baseline sampling and side
+measurements); the driver may pass any K / W — the timed region always starts at a turn boundary.
 
 Prints ONE JSON line (rank 0).  `value` = whole-job tokens/s.  `roofline` describes the dominant kernel
 (decode attention, HBM-bound); `cpu_baseline` times the torch-CPU mirror of the reference's op sequence
@@ -39,6 +43,7 @@ sys.path.insert(0, ROOT)
 LAYERS, HEADS, HEAD_DIM, CTX = 32, 32, 128, 4096
 START, IMPORTANT, RECENT, TURN = 4, 1020, 1024, 64
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0    # what a streaming copy reaches on this part (same guide; our gather / long decodes sit at 5.5-6.2)
 
 
 def parse():
@@ -46,7 +51,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N > 1.  strong (default; BASELINE.json configs[2] / [4]): ONE sequence, H/N heads per rank — the "
+                         "north star's head-parallel partition, 4 heads per GPU at N = 8.  weak: B = N sequences, every "
+                         "rank holds H/N heads of each (the 1-GPU KV bytes per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the dense / eager comparison legs")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
@@ -491,6 +499,7 @@ def main():
         return _All()
 
     native = False
+    rccl_ranks = None
     if dist_on and args.gather == "native":
         err = None
         try:
@@ -509,6 +518,11 @@ def main():
                 print(f"native RCCL communicator unavailable ({type(err).__name__ if err else 'on another rank'}: {err}); "
                       "using torch.distributed", file=sys.stderr)
             args.gather = "flat"
+        if native:
+            try:
+                rccl_ranks = hp.native_info()[0]
+            except Exception:
+                rccl_ranks = None
 
     def run_slot(slot):
         if slot == 0:
@@ -579,6 +593,7 @@ def main():
                    "prune_events_in_timed_region": -(-args.steps // TURN),
                    "parallelism": (f"head-parallel x{world}, {args.scaling} scaling (B = {B}, H/{world} heads per rank; RCCL "
                                    f"all-gather of every layer's output, {args.gather})") if dist_on else "single GPU",
+                   "rccl_ranks": rccl_ranks if native else (world if dist_on else None),
                    "launch": "hip-graph" if graphs is not None else "eager"},
     }
 
@@ -612,7 +627,12 @@ def main():
                 traffic = None
             result["roofline"] = {"kernel": "decode_lean_kernel<bf16,128> (decode_attn.hip)", "bound": "hbm", "achieved": round(gbs, 1),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                  "traffic": traffic, "avg_launch_us": round(us, 3),
+                                  "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4), "achievable_GBs": HBM_ACHIEVABLE_GBS,
+                                  "traffic": traffic,
+                                  "traffic_source": ("committed PMC profile profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                                     "of this command, tools/pmc_decode.sh) - not measured in this run" % pm[-1])
+                                  if traffic is not None else None,
+                                  "avg_launch_us": round(us, 3),
                                   "algorithmic_bytes_per_launch": int(algo_bytes)}
             # the prune event (select + fused gather): separate, informative
             torch.cuda.synchronize()

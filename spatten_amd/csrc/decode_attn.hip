@@ -29,8 +29,10 @@
 // Rounding: in the 16-bit dtypes the reference rounds after every torch op; everything that feeds the
 // stash is reproduced (rotations, matmul result -> dtype, /sqrt(d) -> dtype) so stash values — the input
 // of the top-k — match the reference except where fp32 accumulation ORDER moves a value across a
-// rounding boundary.  P is NOT rounded to the model dtype before P·V (it would need the global softmax
-// denominator before the first V row); tolerance stated in tests/util.py.
+// rounding boundary.  P IS rounded to the model dtype before P·V, like the reference's `.to(query_states.dtype)`
+// (:135-138), but UN-NORMALISED: the kernel rounds exp(s - running max) (PairFma::pack_p feeds the packed-dot units),
+// the reference rounds exp(s - max) / sum — the global denominator is not known before the first V row.  fp32 keeps
+// P in fp32.  Tolerance stated in tests/util.py.
 #include <stdlib.h>
 
 #include "common.h"

@@ -328,26 +328,23 @@ def gen_fullsize(out):
     step on a 4095-token cache) and C5 (Llama-2-13B: H = 40, 16383-token cache), bf16 — and the C2 prune event
     (start 4 / important 1020 / recent 1024) driven by the bf16 stash that forward produced.  Outputs and stashes are kept
     as bf16 bit patterns (C5: the stash rows of heads 0, 5, ..., 35); the kept positions are read back from a cache whose
-    row j encodes j.  The seed is bumped until no head has a tie at the 1020-th score (torch.topk's order among equal
-    scores is unspecified; the HIP path keeps the lowest positions)."""
+    row j encodes j.  NOTE on ties: with 3068 bf16 candidates per head about two scores share every bf16 value near the
+    1020-th largest, so a tie AT the threshold is the normal case at this scale (no seed avoids it in all 32 heads);
+    torch.topk's choice among equal scores is unspecified, the HIP path keeps the lowest positions — consumers compare
+    under the tie rule: everything above the threshold value identical, the same COUNT of threshold-valued positions."""
     cases = {}
     dt, d = "bf16", 128
     for name, H, P, seed0 in (("c2", 32, 4095, 61), ("c5", 40, 16383, 62)):
-        bump = 0
-        while True:
-            seed = seed0 + 1000 * bump
-            q = synth_normal(seed, 0, (1, H, 1, d), dt)
-            k = synth_normal(seed, 1, (1, H, 1, d), dt)
-            v = synth_normal(seed, 2, (1, H, 1, d), dt)
-            past = (synth_normal(seed, 3, (1, H, P, d), dt), synth_normal(seed, 4, (1, H, P, d), dt))
-            N = P + 1
-            pos = np.full((1, 1), P, np.int64)
-            mask = torch.zeros(1, 1, 1, N, dtype=TORCH_DT[dt])
-            o, stash, kc, vc = ref_forward(q, k, v, past, pos, mask, dt, H, H, d)
-            if name != "c2" or tie_free(stash[0, :, 0], 4, N - 1024, 1020):
-                break
-            bump += 1
-        cases[f"{name}_meta"] = np.array([H, P, d, seed, bump])
+        seed = seed0
+        q = synth_normal(seed, 0, (1, H, 1, d), dt)
+        k = synth_normal(seed, 1, (1, H, 1, d), dt)
+        v = synth_normal(seed, 2, (1, H, 1, d), dt)
+        past = (synth_normal(seed, 3, (1, H, P, d), dt), synth_normal(seed, 4, (1, H, P, d), dt))
+        N = P + 1
+        pos = np.full((1, 1), P, np.int64)
+        mask = torch.zeros(1, 1, 1, N, dtype=TORCH_DT[dt])
+        o, stash, kc, vc = ref_forward(q, k, v, past, pos, mask, dt, H, H, d)
+        cases[f"{name}_meta"] = np.array([H, P, d, seed])
         cases[f"{name}_out"] = bf16_bits(o)
         cases[f"{name}_stash"] = bf16_bits(stash if name == "c2" else stash[:, ::5])
         cases[f"{name}_inck"] = cksum(q, k, v, *past)
@@ -358,10 +355,7 @@ def gen_fullsize(out):
                 cache = SpAttenKVCache(start_size=4, recent_size=1024, important_size=1020)
             res = cache.apply_token_pruning([(torch.from_numpy(ids), torch.from_numpy(ids))], 0, [tt(stash, dt)])
             cases["c2_kept"] = nn_(res[0][0])[0, :, :, 0].astype(np.uint16)           # [32, 2048] source positions
-            # and the gathered rows of the real bf16 cache the forward returned, as a checksum per head
-            res2 = cache.apply_token_pruning([(tt(kc, dt), tt(vc, dt))], 0, [tt(stash, dt)])
-            cases["c2_Kck"] = nn_(res2[0][0]).astype(np.float64).sum(axis=(0, 2, 3))
-            cases["c2_Vck"] = nn_(res2[0][1]).astype(np.float64).sum(axis=(0, 2, 3))
+            cases["c2_tied_heads"] = np.array([0 if tie_free(stash[0, h:h + 1, 0], 4, N - 1024, 1020) else 1 for h in range(H)])
     np.savez_compressed(os.path.join(out, "g6_fullsize.npz"), **cases)
 
 

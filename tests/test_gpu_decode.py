@@ -317,3 +317,42 @@ def test_bf16_kept_set_agreement_with_the_reference_at_c2_scale():
     assert same.min() >= 1015            # a differing stash entry can only swap tokens that sit AT the threshold
     # ... and given the SAME scores the two selections are identical
     assert np.array_equal(ops.topk_select(dev(orc.importance(stash_ref, dt), dt), 4, N - 1024, 1020).cpu().numpy(), idx_ref)
+
+
+@pytest.mark.parametrize("name", ["c2", "c5"])
+def test_fullsize_decode_matches_the_reference_goldens(name):
+    """BASELINE.json configs[1] / [4] geometry pinned to the REFERENCE forward itself (g6_fullsize.npz:
+    H = 32 on a 4095-token cache, H = 40 on 16383 tokens; bf16) — output and stash of the fused decode launch, then (C2) the
+    prune event driven by the kernel's own stash against the reference's kept positions."""
+    from tests.test_oracle_golden import _bf16, tie_rule_equal
+    from spatten_amd import SpAttenKVCache, ops
+    g = golden("g6_fullsize.npz")
+    H, P, d, seed = (int(x) for x in g[f"{name}_meta"])
+    dt, N = "bf16", P + 1
+    q, k, v, past = attn_inputs(1, H, H, d, P, 1, dt, seed)
+    out, stash, kc, vc, _ = run_decode(q, k, v, past, dt, table="torch")
+    want_stash = _bf16(g[f"{name}_stash"])
+    got = stash if name == "c2" else stash[:, ::5]
+    check_stash(got, want_stash, dt, name)
+    np.testing.assert_allclose(out, _bf16(g[f"{name}_out"]), **OUT_TOL[dt])
+    if name != "c2":
+        return
+    kept_ref = g["c2_kept"].astype(np.int64)
+    score_ref = want_stash[0, :, 0]
+    # (1) the HIP selection on the REFERENCE's stash: the reference's kept set under the tie rule, bit exact where no tie
+    idx = ops.topk_select(dev(score_ref, dt), 4, N - 1024, 1020).cpu().numpy()
+    assert np.array_equal(idx, orc.topk_window(score_ref, 4, N - 1024, 1020))
+    for h in range(H):
+        assert tie_rule_equal(idx[h], kept_ref[h, 4:1024], score_ref[h], 4, 1020), h
+        if not g["c2_tied_heads"][h]:
+            assert np.array_equal(idx[h], kept_ref[h, 4:1024]), h
+    # (2) end to end: the kernel's own stash -> plugin prune -> the reference's kept rows (a stash entry that differs by
+    # an ulp can only swap tokens AT the threshold)
+    cache = SpAttenKVCache(4, 1024, 1020)
+    st_dev = dev(stash, dt)
+    new = cache.apply_token_pruning([(dev(kc, dt), dev(vc, dt))], 0, [st_dev])
+    mine = cache.keep_indices[0].cpu().numpy()
+    overlap = np.array([len(np.intersect1d(mine[h], kept_ref[h, 4:1024])) for h in range(H)])
+    print(f"\nC2 golden: kept-set overlap with the reference min {overlap.min()}/1020, mean {overlap.mean():.1f}")
+    assert overlap.min() >= 1010
+    assert new[0][0].shape == (1, H, 2048, d)

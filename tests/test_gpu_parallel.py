@@ -128,20 +128,25 @@ def _hf_args(x, P):
     return mask, pos
 
 
-@pytest.mark.parametrize("world,Hkv,kw", [(2, 8, {}), (4, 4, dict(fuse_qkv=True)), (2, 8, dict(native_gemv=True, fuse_qkv=True)),
-                                          (2, 8, dict(head_keep=[6, 5]))])
-def test_plugin_head_parallel_shards_run_in_sequence_equal_the_unsharded_plugin(world, Hkv, kw):
+@pytest.mark.parametrize("dt,world,Hkv,kw", [
+    (torch.float32, 2, 8, {}), (torch.float32, 4, 4, dict(fuse_qkv=True)), (torch.float32, 2, 8, dict(native_gemv=True, fuse_qkv=True)),
+    (torch.float32, 2, 8, dict(head_keep=[6, 5])), (torch.bfloat16, 2, 8, dict(native_gemv=True))])
+def test_plugin_head_parallel_shards_run_in_sequence_equal_the_unsharded_plugin(dt, world, Hkv, kw):
     """Every rank's copy of the patched stack (its column-sharded q/k/v projections, its H/G heads of KV cache) is driven
     layer by layer in ONE process; the all-gather is a loopback that lays the slices out rank-major.  Prefill, decode
     steps, a prune event and a second turn must reproduce the unsharded plugin: hidden states of every forward, the local
-    caches = the head slices of the full caches (bit exact: per-head work), kept positions bit exact."""
+    caches = the head slices of the full caches, the same kept positions.  (A sharded projection is another GEMM shape,
+    so its rows can differ from the full GEMM's in the last bits: fp32 runs the whole protocol with exact kept sets and
+    caches to 1e-5; bf16 checks the first turn within rounding and the prune by agreement.)"""
     import contextlib
     import io
 
     from spatten_amd import enable_spatten_llm
     from spatten_amd.parallel import HeadParallel
     torch.manual_seed(7)
-    dt, L, H, d = torch.bfloat16, 2, 8, 64
+    L, H, d = 2, 8, 64
+    exact = dt == torch.float32
+    close = (lambda a, b: torch.allclose(a, b, atol=1e-5, rtol=1e-5)) if exact else (lambda a, b: torch.allclose(a.float(), b.float(), atol=3e-2, rtol=3e-2))
     HID = H * d
     full = _stack(L, H, Hkv, d, dt, bias="fuse_qkv" not in kw)
     for p in full.parameters():
@@ -163,7 +168,7 @@ def test_plugin_head_parallel_shards_run_in_sequence_equal_the_unsharded_plugin(
             hp = HeadParallel(H, Hkv, rank=r, world=world, gather_fn=loopback)
             ranks.append((m, enable_spatten_llm(m, 4, 40, 48, head_parallel=hp, **kw), hp))
     g = torch.Generator(device="cuda").manual_seed(8)
-    tol = dict(atol=3e-2, rtol=3e-2)
+    tol = dict(atol=1e-4, rtol=1e-4) if exact else dict(atol=3e-2, rtol=3e-2)
 
     def forward_all(x, past_full, past_ranks):
         """one forward of the stack: unsharded, and every rank layer by layer (the LAST rank to run a layer sees the
@@ -192,10 +197,10 @@ def test_plugin_head_parallel_shards_run_in_sequence_equal_the_unsharded_plugin(
             lo, hi = hp.kv_head_range()
             for i in range(L):
                 assert pr[r][i][0].shape[1] == Hkv // world
-                assert torch.equal(pr[r][i][0], pf[i][0][:, lo:hi]) and torch.equal(pr[r][i][1], pf[i][1][:, lo:hi])
+                assert close(pr[r][i][0], pf[i][0][:, lo:hi]) and close(pr[r][i][1], pf[i][1][:, lo:hi])
                 hl, hh = hp.head_range()
                 if "head_keep" not in kw:
-                    assert torch.equal(m.layers[i].attn_scores, full.layers[i].attn_scores[:, hl:hh])
+                    assert close(m.layers[i].attn_scores, full.layers[i].attn_scores[:, hl:hh])
         if turn == 0:
             coming = 10
             if "head_keep" in kw and Hkv != H:
@@ -206,8 +211,15 @@ def test_plugin_head_parallel_shards_run_in_sequence_equal_the_unsharded_plugin(
             for r, (m, cache_r, hp) in enumerate(ranks):
                 nr = cache_r.apply_token_pruning(pr[r], coming, [mm.attn_scores for mm in m.layers])
                 lo, hi = hp.kv_head_range()
+                hl, hh = hp.head_range()
                 for i in range(L):
-                    assert torch.equal(nr[i][0], new_f[i][0][:, lo:hi]) and torch.equal(nr[i][1], new_f[i][1][:, lo:hi])
+                    if exact:         # token pruning is per head: the rank keeps exactly the rows the full model keeps for its heads
+                        assert torch.equal(cache_r.keep_indices[i], cache_full.keep_indices[i][hl:hh])
+                        assert close(nr[i][0], new_f[i][0][:, lo:hi]) and close(nr[i][1], new_f[i][1][:, lo:hi])
+                    else:
+                        a_, b_ = cache_r.keep_indices[i].cpu().numpy(), cache_full.keep_indices[i][hl:hh].cpu().numpy()
+                        for ra, rb in zip(a_, b_):      # rounding-level score differences can only swap threshold tokens
+                            assert len(np.intersect1d(ra, rb)) >= 0.9 * len(ra)
                 if "head_keep" in kw:       # the same global kept set on every rank, its local share launched
                     for i in range(L):
                         kg_f = cache_full.ext.layers[i].kept_global
@@ -218,6 +230,8 @@ def test_plugin_head_parallel_shards_run_in_sequence_equal_the_unsharded_plugin(
                             want = [int(h) - hl for h in kg_f.tolist() if hl <= int(h) < hh]
                             assert cache_r.ext.layers[i].head_ids.tolist() == want
                 new_r.append(nr)
+            if not exact:
+                break
             pf, pr = new_f, new_r
             pf, pr = forward_all(torch.randn(1, coming, HID, device="cuda", generator=g).to(dt), pf, pr)
 

@@ -159,3 +159,53 @@ def test_topk_tie_policy_lowest_index_first():
     assert orc.topk_window(s, 0, 6, 3).tolist() == [[2, 3, 5]]      # NaN ranks largest (torch.topk)
     with pytest.raises(ValueError):
         orc.topk_window(np.zeros((1, 10), np.float32), 4, 8, 5)
+
+
+def _bf16(u16):
+    return (np.asarray(u16).astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+def tie_rule_equal(kept_a, kept_b, score, lo, k):
+    """Two selections of the k largest of a head's window agree under the tie rule: identical above the threshold value,
+    and the same NUMBER of threshold-valued positions (which of those is unspecified in torch.topk)."""
+    a, b = np.asarray(kept_a, np.int64), np.asarray(kept_b, np.int64)
+    thr = min(score[a].min(), score[b].min())
+    if score[a].min() != score[b].min():
+        return False
+    above_a, above_b = a[score[a] > thr], b[score[b] > thr]
+    return np.array_equal(np.sort(above_a), np.sort(above_b)) and (score[a] == thr).sum() == (score[b] == thr).sum()
+
+
+@pytest.mark.parametrize("name", ["c2", "c5"])
+def test_fullsize_decode_goldens_of_the_reference(golden_dir, name):
+    """G6: BASELINE.json configs[1] / [4] geometry through the reference forward itself (Llama-2-7B H = 32 on a 4095-token
+    cache; Llama-2-13B H = 40 on 16383 tokens), bf16 — the oracle must reproduce output and stash; C2: also the prune of
+    that stash (start 4 / important 1020 / recent 1024) under the tie rule."""
+    g = _load(golden_dir, "g6_fullsize.npz")
+    H, P, d, seed = (int(x) for x in g[f"{name}_meta"])
+    dt = "bf16"
+    q = orc.synth_normal(seed, 0, (1, H, 1, d), dt)
+    k = orc.synth_normal(seed, 1, (1, H, 1, d), dt)
+    v = orc.synth_normal(seed, 2, (1, H, 1, d), dt)
+    past = (orc.synth_normal(seed, 3, (1, H, P, d), dt), orc.synth_normal(seed, 4, (1, H, P, d), dt))
+    assert abs(_cksum(q, k, v, *past) - float(g[f"{name}_inck"])) < 1e-5
+    o, stash, _ = orc.attention_core(q, k, v, past[0], past[1], np.full((1, 1), P), np.zeros((1, 1, 1, P + 1), np.float32), dt)
+    want_stash = _bf16(g[f"{name}_stash"])
+    got_stash = stash if name == "c2" else stash[:, ::5]
+    np.testing.assert_allclose(got_stash, want_stash, **TOL[dt])
+    assert np.mean(got_stash != want_stash) < 0.02
+    np.testing.assert_allclose(o, _bf16(g[f"{name}_out"]), **TOL[dt])
+    if name == "c2":
+        kept = g["c2_kept"].astype(np.int64)                   # [32, 2048]: start | important (ascending) | recent
+        N = P + 1
+        assert np.array_equal(kept[:, :4], np.tile(np.arange(4), (H, 1))) and np.array_equal(kept[:, 1024:], np.tile(np.arange(N - 1024, N), (H, 1)))
+        score = want_stash[0, :, 0]                            # importance = the stash itself at B = q = 1 (:51)
+        idx = orc.topk_window(score, 4, N - 1024, 1020)
+        tied = g["c2_tied_heads"]
+        assert tied.sum() > 0, "the fixture is expected to contain threshold ties (3068 bf16 candidates per head)"
+        for h in range(H):
+            ref = kept[h, 4:1024]
+            assert np.all(np.diff(ref) > 0)
+            if not tied[h]:
+                assert np.array_equal(idx[h], ref), h       # no tie at the threshold: bit exact
+            assert tie_rule_equal(idx[h], ref, score[h], 4, 1020), h
