@@ -659,6 +659,22 @@ def main():
                 "GBs_moved_incl_select": round(moved / pus / 1e3, 1), "frac_of_hbm_peak": round(moved / pus / 1e3 / HBM_PEAK_GBS, 4),
                 "gather_only_us": round(gus, 1), "gather_only_GBs_incl_select": round(gather_bytes / gus / 1e3, 1),
                 "gather_only_frac_of_hbm_peak": round(gather_bytes / gus / 1e3 / HBM_PEAK_GBS, 4)}
+            # the same event in cascade mode (importance = fp32 accumulators of softmax probabilities, README.md:11):
+            # select over fp32 scores + the fused gather + the accumulators' rows, three launches for all layers
+            accs = [torch.rand(Hl, CTX, device=dev, generator=gen) for _ in range(L)]
+            acc_new = torch.zeros(L, Hl, cap, dtype=torch.float32, device=dev)
+            plan3 = ops.PrunePlan(accs, Kp, Vp, Kd, Vd, Krd, accs, [acc_new[l] for l in range(L)])
+            casc = lambda: ops.prune_layers(accs, Kp, Vp, CTX, lo, hi, IMPORTANT, dst=(Kd, Vd, Krd), plan=plan3, idx=idx,
+                                            rope=(cos, sin), acc=(accs, [acc_new[l] for l in range(L)]))
+            casc()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                casc()
+            e1.record()
+            torch.cuda.synchronize()
+            result["prune_event"]["cascade_prune_event_us"] = round(e0.elapsed_time(e1) * 1e3 / 5, 1)
+            del accs, acc_new, plan3
             prune()   # restore the shadow planes for whatever runs next
 
         # ---- dense comparison legs ---------------------------------------------------------------------

@@ -306,6 +306,22 @@ int spatten_prune_layers(int dtype, int layers,
                          int batch, int heads, int head_dim,
                          int lo, int hi, int k, int tail_lo, int tail_len, void* stream);
 
+/* The same event ranked by scores of their OWN dtype (cascade importance: fp32 accumulators, README.md:11) while the
+ * cache keeps the model dtype, with the accumulators carried through the row map by a third all-layer launch:
+ *   score_ptrs[l] -> [H, >=hi] in score_dtype;  acc_src_ptrs[l] -> fp32 [H, >=L] (stride acc_src_sh), acc_dst_ptrs[l] ->
+ *   fp32 [H, >=L'] (stride acc_dst_sh; rows past L' are left as the caller initialised them) — both NULL to skip.
+ * Everything else as spatten_prune_layers (which is this call with score_dtype == kv_dtype and no accumulators). */
+int spatten_prune_layers_scored(int score_dtype, int kv_dtype, int layers,
+                                const void* const* score_ptrs, int64_t score_sh,
+                                const void* const* k_src_ptrs, const void* const* v_src_ptrs, int64_t src_sb, int64_t src_sh,
+                                void* const* k_dst_ptrs, void* const* v_dst_ptrs, void* const* kr_dst_ptrs /* optional */,
+                                int64_t dst_sb, int64_t dst_sh,
+                                const void* cos, const void* sin, int table_rows, int32_t* idx,
+                                const float* const* acc_src_ptrs, int64_t acc_src_sh,
+                                float* const* acc_dst_ptrs, int64_t acc_dst_sh,
+                                int batch, int heads, int head_dim,
+                                int lo, int hi, int k, int tail_lo, int tail_len, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * SpAtten semantics with no numeric implementation in the reference ("parity unpinned": restated from the RTL
  * control flow / README, checked against oracle/spatten_oracle.py only).

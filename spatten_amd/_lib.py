@@ -140,6 +140,11 @@ def _declare(lib):
                                          i, i, i, i, i, i, i, i, p]
 
 
+    lib.spatten_prune_layers_scored.restype = c_int
+    lib.spatten_prune_layers_scored.argtypes = [i, i, i, p, i64, p, p, i64, i64, p, p, p, i64, i64, p, p, i, p,
+                                                p, i64, p, i64, i, i, i, i, i, i, i, i, p]
+
+
 def load():
     """Load (once) and return the ctypes handle.  Raises SpattenLibraryError if the .so is missing."""
     global _lib

@@ -596,6 +596,50 @@ extern "C" int spatten_prune_layers(int dtype, int layers, const void* const* sc
   return compact_any(dtype, p, head_dim, tail_len, (hipStream_t)stream);
 }
 
+// all layers' fp32 accumulator rows through the prune's row map (start | idx | tail): blockIdx.z = layer
+__global__ __launch_bounds__(256) void acc_compact_layers_kernel(const float* const* __restrict__ src_ptrs, int64_t src_sh,
+                                                                 float* const* __restrict__ dst_ptrs, int64_t dst_sh,
+                                                                 const int32_t* __restrict__ idx, int64_t idx_sl,
+                                                                 int64_t idx_sh, int start, int k, int tail_lo, int Lp) {
+  const int r = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, l = blockIdx.z;
+  if (r >= Lp) return;
+  int j;
+  if (r < start) j = r;
+  else if (r < start + k) j = idx[l * idx_sl + h * idx_sh + (r - start)];
+  else j = tail_lo + (r - start - k);
+  dst_ptrs[l][h * dst_sh + r] = src_ptrs[l][h * src_sh + j];
+}
+
+extern "C" int spatten_prune_layers_scored(int score_dtype, int kv_dtype, int layers, const void* const* score_ptrs,
+                                           int64_t score_sh, const void* const* k_src_ptrs, const void* const* v_src_ptrs,
+                                           int64_t src_sb, int64_t src_sh, void* const* k_dst_ptrs, void* const* v_dst_ptrs,
+                                           void* const* kr_dst_ptrs, int64_t dst_sb, int64_t dst_sh, const void* cos,
+                                           const void* sin, int table_rows, int32_t* idx,
+                                           const float* const* acc_src_ptrs, int64_t acc_src_sh, float* const* acc_dst_ptrs,
+                                           int64_t acc_dst_sh, int batch, int heads, int head_dim, int lo, int hi, int k,
+                                           int tail_lo, int tail_len, void* stream) {
+  if (!score_ptrs || !k_src_ptrs || !v_src_ptrs || !k_dst_ptrs || !v_dst_ptrs || !idx) return SPATTEN_ERR_INVALID;
+  if ((acc_src_ptrs == nullptr) != (acc_dst_ptrs == nullptr)) return SPATTEN_ERR_INVALID;
+  const int rc = select_any(score_dtype, nullptr, score_ptrs, score_sh, layers, heads, lo, hi, k, idx,
+                            (int64_t)heads * k, k, (hipStream_t)stream);
+  if (rc != SPATTEN_OK) return rc;
+  CompactParams p{};
+  p.k_src_ptrs = k_src_ptrs; p.v_src_ptrs = v_src_ptrs; p.k_dst_ptrs = k_dst_ptrs; p.v_dst_ptrs = v_dst_ptrs;
+  p.kr_dst_ptrs = kr_dst_ptrs; p.cos = cos; p.sin = sin; p.table_rows = table_rows;
+  p.src_sb = src_sb; p.src_sh = src_sh; p.dst_sb = dst_sb; p.dst_sh = dst_sh;
+  p.idx = idx; p.idx_sl = (int64_t)heads * k; p.idx_sh = k;
+  p.B = batch; p.H = heads; p.layers = layers; p.n_tensors = 2;
+  p.start = lo; p.k = k; p.tail_lo = tail_lo;
+  const int rc2 = compact_any(kv_dtype, p, head_dim, tail_len, (hipStream_t)stream);
+  if (rc2 != SPATTEN_OK || !acc_src_ptrs) return rc2;
+  const int Lp = lo + k + tail_len;
+  if (heads > 65535 || layers > 65535) return SPATTEN_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(acc_compact_layers_kernel, dim3((unsigned)ceil_div(Lp, 256), (unsigned)heads, (unsigned)layers), dim3(256),
+                     0, (hipStream_t)stream, acc_src_ptrs, acc_src_sh, acc_dst_ptrs, acc_dst_sh, idx, (int64_t)heads * k,
+                     (int64_t)k, lo, k, tail_lo, Lp);
+  return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+}
+
 extern "C" int spatten_rope_single(int dtype, const void* x, int64_t x_sb, int64_t x_sh, int64_t x_sn, void* y,
                                    int64_t y_sb, int64_t y_sh, int64_t y_sn, const void* cos, const void* sin,
                                    int table_rows, const int64_t* position_ids, int64_t pos_sb, int pos0,

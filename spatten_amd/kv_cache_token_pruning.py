@@ -134,25 +134,34 @@ class SpAttenKVCache:
         if self.ext is None or any(st.acc is None for st in self.ext.layers[:len(past_key_values)]):
             raise RuntimeError("cascade importance has not been accumulated: run the patched forward first "
                                "(enable_spatten_llm(..., importance_mode='cascade'))")
-        out, idxs = [], []
-        self.importance_score = []
+        # all layers in three launches (select over the fp32 accumulators, fused K/V gather + shadow, accumulator rows),
+        # like reference mode's two — not a Python loop of per-layer launches
+        n_layers = len(past_key_values)
         base, scaling = _rope_of(past_key_values)
-        for layer, (K, V) in enumerate(past_key_values):
-            K, V = _rows(K), _rows(V)
-            if V.stride() != K.stride():
-                K, V = K.contiguous(), V.contiguous()
-            d = K.shape[3]
-            acc = self.ext.layers[layer].acc
-            self.importance_score.append(acc[:, :seq_len])
-            idx = ops.topk_select(acc[:, :seq_len], lo, hi, self.important_size)
-            cap = kv_slab.round_capacity(new_len + max(int(num_coming), 0))
-            rope = kv_slab.rope_tables(cap, d, K.dtype, K.device, base, scaling)
-            k, v, kr = ops.kv_compact(K, V, idx, self.start_size, hi, L=seq_len, capacity=cap, rope=rope)
-            self.ext.compact_importance(layer, idx, self.start_size, hi, seq_len)
+        Ks = [_rows(kv[0]) for kv in past_key_values]
+        Vs = [_rows(kv[1]) for kv in past_key_values]
+        Ks, Vs = _common_strides(Ks, Vs)
+        B, H, _, d = Ks[0].shape
+        accs = [self.ext.layers[layer].acc for layer in range(n_layers)]
+        if any(a.shape[0] != H or a.shape[1] < seq_len for a in accs):
+            raise RuntimeError("cascade importance accumulators do not cover the cache")
+        if any(a.stride(0) != accs[0].stride(0) for a in accs):
+            width = max(a.shape[1] for a in accs)
+            accs = [torch.nn.functional.pad(a, (0, width - a.shape[1])) for a in accs]
+        self.importance_score = [a[:, :seq_len] for a in accs]
+        cap = kv_slab.round_capacity(new_len + max(int(num_coming), 0))
+        rope = kv_slab.rope_tables(cap, d, Ks[0].dtype, Ks[0].device, base, scaling)
+        new_acc = torch.zeros(n_layers, H, max(cap, accs[0].shape[1]), dtype=torch.float32, device=Ks[0].device)
+        Kn, Vn, Krn, idx = ops.prune_layers(accs, Ks, Vs, seq_len, lo, hi, self.important_size, capacity=cap, rope=rope,
+                                            acc=(accs, [new_acc[layer] for layer in range(n_layers)]))
+        out = []
+        for layer, (k, v, kr) in enumerate(zip(Kn, Vn, Krn)):
+            st = self.ext.layers[layer]
+            st.acc = new_acc[layer]
+            st.pending_len = 0
             kv_slab.attach(k, v, kr, new_len, base, scaling)
             out.append([k, v])
-            idxs.append(idx)
-        self.keep_indices = torch.stack(idxs)
+        self.keep_indices = idx
         self.n_pruned_last = seq_len - new_len
         self.n_pruned_total += self.n_pruned_last
         return out

@@ -576,22 +576,30 @@ def kv_compact(K: torch.Tensor, V: Optional[torch.Tensor], idx: torch.Tensor, st
 class PrunePlan:
     """Device pointer tables for the batched all-layer prune (spatten_prune_layers)."""
 
-    def __init__(self, scores: Sequence[torch.Tensor], Ks, Vs, Kd, Vd, Krd=None):
+    def __init__(self, scores: Sequence[torch.Tensor], Ks, Vs, Kd, Vd, Krd=None, acc_src=None, acc_dst=None):
         dev = Ks[0].device
-        mk = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64).to(dev)
-        self.score_ptrs, self.ks, self.vs, self.kd, self.vd = mk(scores), mk(Ks), mk(Vs), mk(Kd), mk(Vd)
-        self.krd = mk(Krd) if Krd is not None else None
-        self.keep = (list(scores), list(Ks), list(Vs), list(Kd), list(Vd), None if Krd is None else list(Krd))
+        groups = [scores, Ks, Vs, Kd, Vd] + ([Krd] if Krd is not None else []) + ([acc_src, acc_dst] if acc_src is not None else [])
+        # ONE host->device copy for all pointer tables
+        flat = torch.tensor([t.data_ptr() for g in groups for t in g], dtype=torch.int64).to(dev)
+        n = len(Ks)
+        tabs = [flat[i * n:(i + 1) * n] for i in range(len(groups))]
+        self.score_ptrs, self.ks, self.vs, self.kd, self.vd = tabs[:5]
+        self.krd = tabs[5] if Krd is not None else None
+        self.acc_src, self.acc_dst = (tabs[-2], tabs[-1]) if acc_src is not None else (None, None)
+        self.keep = (flat, list(scores), list(Ks), list(Vs), list(Kd), list(Vd), None if Krd is None else list(Krd), acc_src, acc_dst)
 
 
 def prune_layers(scores: Sequence[torch.Tensor], Ks: Sequence[torch.Tensor], Vs: Sequence[torch.Tensor],
                  L: int, lo: int, hi: int, k: int, capacity: Optional[int] = None,
                  dst: Optional[Tuple[List[torch.Tensor], List[torch.Tensor], Optional[List[torch.Tensor]]]] = None,
                  plan: Optional[PrunePlan] = None, idx: Optional[torch.Tensor] = None,
-                 rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+                 rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                 acc: Optional[Tuple[Sequence[torch.Tensor], Sequence[torch.Tensor]]] = None):
     """All layers of apply_token_pruning's loop (kv_cache_token_pruning.py:55-96) in two launches.
-    scores[l] [H, >=hi]; Ks[l]/Vs[l] [B,H,>=L,d].  With ``rope=(cos, sin)`` the rotated shadow of every new
-    cache is produced by the same pass.  Returns (K' list, V' list, Kr' list or None, idx [layers,H,k])."""
+    scores[l] [H, >=hi] (the model dtype, or fp32 cascade accumulators); Ks[l]/Vs[l] [B,H,>=L,d].  With ``rope=(cos, sin)``
+    the rotated shadow of every new cache is produced by the same pass.  ``acc=(src list, dst list)``: fp32 [H, >=L] /
+    [H, >=L'] accumulators that follow the rows (a third all-layer launch).
+    Returns (K' list, V' list, Kr' list or None, idx [layers,H,k])."""
     _dev(*scores, *Ks, *Vs)
     lib = _lib.load()
     nl = len(Ks)
@@ -617,16 +625,26 @@ def prune_layers(scores: Sequence[torch.Tensor], Ks: Sequence[torch.Tensor], Vs:
         raise ValueError("scores need contiguous rows and a common head stride")
     if Krd is not None and rope is None:
         raise ValueError("a shadow destination needs the rotary tables")
+    if acc is not None:
+        a_src, a_dst = acc
+        for t in list(a_src) + list(a_dst):
+            if t.dtype != torch.float32 or t.stride(1) != 1 or t.shape[0] != H:
+                raise ValueError("accumulators must be fp32 [H, len] with contiguous rows")
+        if any(t.stride(0) != a_src[0].stride(0) or t.shape[1] < L for t in a_src) \
+                or any(t.stride(0) != a_dst[0].stride(0) or t.shape[1] < Lp for t in a_dst):
+            raise ValueError("accumulators need a common head stride and room for the rows")
     if plan is None:
-        plan = PrunePlan(scores, Ks, Vs, Kd, Vd, Krd)
+        plan = PrunePlan(scores, Ks, Vs, Kd, Vd, Krd, *(acc if acc is not None else (None, None)))
     if idx is None:
         idx = torch.empty(nl, H, k, dtype=torch.int32, device=Ks[0].device)
     cos, sin = rope if rope is not None else (None, None)
-    rc = lib.spatten_prune_layers(_dt(Ks[0]), nl, plan.score_ptrs.data_ptr(), scores[0].stride(0),
-                                  plan.ks.data_ptr(), plan.vs.data_ptr(), Ks[0].stride(0), Ks[0].stride(1),
-                                  plan.kd.data_ptr(), plan.vd.data_ptr(), _ptr(plan.krd), Kd[0].stride(0), Kd[0].stride(1),
-                                  _ptr(cos), _ptr(sin), 0 if cos is None else cos.shape[0],
-                                  idx.data_ptr(), B, H, d, lo, hi, k, tail_lo, tail_len, _stream())
+    rc = lib.spatten_prune_layers_scored(
+        _dt(scores[0]), _dt(Ks[0]), nl, plan.score_ptrs.data_ptr(), scores[0].stride(0),
+        plan.ks.data_ptr(), plan.vs.data_ptr(), Ks[0].stride(0), Ks[0].stride(1),
+        plan.kd.data_ptr(), plan.vd.data_ptr(), _ptr(plan.krd), Kd[0].stride(0), Kd[0].stride(1),
+        _ptr(cos), _ptr(sin), 0 if cos is None else cos.shape[0], idx.data_ptr(),
+        _ptr(plan.acc_src), 0 if acc is None else acc[0][0].stride(0), _ptr(plan.acc_dst), 0 if acc is None else acc[1][0].stride(0),
+        B, H, d, lo, hi, k, tail_lo, tail_len, _stream())
     _lib.check(rc, "spatten_prune_layers")
     return ([x[:, :, :Lp] for x in Kd], [x[:, :, :Lp] for x in Vd],
             None if Krd is None else [x[:, :, :Lp] for x in Krd], idx)
