@@ -106,6 +106,12 @@ class SpAttenKVCache:
         for s in self.importance_score:
             if s.shape[1] < hi:
                 raise ValueError("attention-score stash is shorter than the KV cache")
+        kv_heads = past_key_values[0][0].shape[1]
+        if self.importance_score[0].shape[0] != kv_heads:
+            # grouped-query attention: one cached K/V head serves a GROUP of query heads.  The reference cannot prune such
+            # a cache at all (its [H, L] mask meets a [Hkv, L, d] tensor: SURVEY A5); here a key's importance is the sum
+            # of its group's rows — the rows of ``importance_score`` are then KV heads
+            self.importance_score = [_group_rows(s, kv_heads) for s in self.importance_score]
         scores = _common_rows(self.importance_score)
         Ks = [_rows(kv[0]) for kv in past_key_values]
         Vs = [_rows(kv[1]) for kv in past_key_values]
@@ -224,6 +230,13 @@ def _rope_of(past_key_values):
     if slab is None:
         return 10000.0, None        # foreign tensors: the next forward re-rotates them with the module's tables anyway
     return slab.base, slab.scaling
+
+
+def _group_rows(score: torch.Tensor, kv_heads: int) -> torch.Tensor:
+    H, L = score.shape
+    if H % kv_heads:
+        raise ValueError(f"{H} score rows cannot be grouped onto {kv_heads} KV heads")
+    return score.reshape(kv_heads, H // kv_heads, L).sum(1)
 
 
 def _rows(t: torch.Tensor) -> torch.Tensor:

@@ -214,10 +214,10 @@ def test_plugin_head_parallel_shards_run_in_sequence_equal_the_unsharded_plugin(
                 hl, hh = hp.head_range()
                 for i in range(L):
                     if exact:         # token pruning is per head: the rank keeps exactly the rows the full model keeps for its heads
-                        assert torch.equal(cache_r.keep_indices[i], cache_full.keep_indices[i][hl:hh])
+                        assert torch.equal(cache_r.keep_indices[i], cache_full.keep_indices[i][lo:hi])   # rows = KV heads
                         assert close(nr[i][0], new_f[i][0][:, lo:hi]) and close(nr[i][1], new_f[i][1][:, lo:hi])
                     else:
-                        a_, b_ = cache_r.keep_indices[i].cpu().numpy(), cache_full.keep_indices[i][hl:hh].cpu().numpy()
+                        a_, b_ = cache_r.keep_indices[i].cpu().numpy(), cache_full.keep_indices[i][lo:hi].cpu().numpy()
                         for ra, rb in zip(a_, b_):      # rounding-level score differences can only swap threshold tokens
                             assert len(np.intersect1d(ra, rb)) >= 0.9 * len(ra)
                 if "head_keep" in kw:       # the same global kept set on every rank, its local share launched

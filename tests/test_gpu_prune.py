@@ -226,3 +226,21 @@ def test_prune_c2_full_size_all_layers_properties():
             assert torch.equal(Vn[0, :, 4:1024], torch.gather(V[0], 1, ii[:, :, None].expand(-1, -1, d)))
         want = orc.topk_window(host(stash[0])[0, :, 0], 4, L - 1024 + c, 1020)
         assert np.array_equal(idx[0], want)
+
+
+def test_grouped_query_cache_is_pruned_by_the_sum_of_its_group():
+    """GQA (H query heads on Hkv cached heads): the reference cannot prune such a cache (its [H, L] mask meets a
+    [Hkv, L, d] tensor); here a cached key's importance is the sum of its group's stash rows."""
+    from spatten_amd import SpAttenKVCache
+    H, Hkv, L, d, dt = 8, 2, 300, 64, "f32"
+    stash = orc.synth_normal(21, 5, (1, H, 1, L), dt)
+    K = orc.synth_normal(21, 6, (1, Hkv, L, d), dt)
+    V = orc.synth_normal(21, 7, (1, Hkv, L, d), dt)
+    cache = SpAttenKVCache(start_size=4, recent_size=64, important_size=50)
+    out = cache.apply_token_pruning([(dev(K, dt), dev(V, dt))], 20, [dev(stash, dt)])
+    score = torch.from_numpy(stash[0, :, 0]).reshape(Hkv, H // Hkv, L).sum(1).numpy()
+    idx = orc.topk_window(score, 4, L - 64 + 20, 50)
+    wk, wv = orc.kv_compact(K, V, idx, 4, L - 64 + 20)
+    assert np.array_equal(cache.keep_indices[0].cpu().numpy(), idx)
+    assert np.array_equal(host(out[0][0]), wk) and np.array_equal(host(out[0][1]), wv)
+    assert cache.importance_score[0].shape == (Hkv, L)
