@@ -807,6 +807,22 @@ def main():
                     q[i % L], None, Krd[i % L], Vd[i % L], new_len, cos, sin, new_len - 1, out=outs[i % L], workspace=ws, head_ids=hid), n=L), 2)
                 extras["c2_decode_2048_32_heads_us"] = round(_time(lambda i: ops.attn_decode(
                     q[i % L], None, Krd[i % L], Vd[i % L], new_len, cos, sin, new_len - 1, out=outs[i % L], workspace=ws), n=L), 2)
+                # batched decode (the C ABI takes a batch): B sequences on their own pruned 2048-row caches — the
+                # launch's fixed costs (boundary, ramp, split merge) amortise over B x the bytes
+                for Bb in (4, 8):
+                    NCb = max(2, 640 // (Bb * 34))                      # rotate over > 256 MB of K/V
+                    Kb = [rnd(Bb, HEADS, cap, d) for _ in range(NCb)]
+                    Vb = [rnd(Bb, HEADS, cap, d) for _ in range(NCb)]
+                    qb, ob = rnd(Bb, HEADS, d), torch.empty(Bb, HEADS * d, dtype=dt, device=dev)
+                    sb_ = torch.empty(Bb, HEADS, cap, dtype=dt, device=dev)
+                    wsb = ops.DecodeWorkspace(Bb, HEADS, d, dev)
+                    n_b = new_len + TURN // 2
+                    us_b = _time(lambda i: ops.attn_decode(qb, None, Kb[i % NCb], Vb[i % NCb], n_b, cos, sin, n_b - 1, out=ob,
+                                                           scores=sb_, workspace=wsb), n=max(8, 2 * NCb))
+                    by_b = 2 * Bb * HEADS * n_b * d * 2 + 2 * Bb * HEADS * d * 2 + Bb * HEADS * n_b * 2
+                    extras[f"decode_2080_batch{Bb}_us"] = round(us_b, 2)
+                    extras[f"decode_2080_batch{Bb}_frac_of_hbm_peak"] = round(by_b / us_b / 1e3 / HBM_PEAK_GBS, 4)
+                    del Kb, Vb
                 # the turn prefill of the multi-turn protocol: 64 new tokens on the 2048-row pruned cache of one layer
                 # (key-split flash kernel + merge; run_spatten_llama.py:71-86 feeds every new prompt this way)
                 qt = rnd(1, HEADS, 64, d)
