@@ -764,6 +764,15 @@ def main():
                 extras["prefill_8192_causal_ms_per_layer"] = round(tp * 1e3, 3)
                 extras["prefill_8192_causal_TFLOPs"] = round(fl / tp / 1e12, 1)
                 extras["prefill_frac_of_bf16_mfma_peak_2500TF"] = round(fl / tp / 2.5e15, 4)
+                # the run-time opt-in: fp32 logits instead of the reference's two roundings per logit (numerics="fast")
+                for _ in range(3):
+                    ops.attn_prefill(Qp, Krp2, Vp2, Np, cp, sp, 0, causal=True, out=op, numerics="fast")
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    ops.attn_prefill(Qp, Krp2, Vp2, Np, cp, sp, 0, causal=True, out=op, numerics="fast")
+                torch.cuda.synchronize()
+                extras["prefill_8192_causal_fast_numerics_TFLOPs"] = round(fl / ((time.perf_counter() - t0) / 20) / 1e12, 1)
                 # progressive-quant decode over the same 8192 keys: MSB-only vs always-refetch vs bf16 keys
                 planes = ops.PQPlanes(1, HEADS, Np, d, dev)
                 ops.pq_pack(Krp2, planes, 0, Np)

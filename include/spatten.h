@@ -223,7 +223,13 @@ int spatten_kv_append(int dtype, const void* k_new, const void* v_new, int64_t n
  *   v_cache      [B,Hkv,cap,d]      values; both must ALREADY hold the q_len new rows at [kv_len-q_len, kv_len)
  *   pos_q0       rotary position of query row 0 (row i uses pos_q0 + i) unless
  *   position_ids optional int64 [B, q_len] DEVICE pointer (stride pos_sb, rows contiguous)
- *   causal       1: HF causal mask (key j visible to row i iff j <= kv_len - q_len + i); 0: none
+ *   causal       flag word.  Bit 0 (1): HF causal mask (key j visible to row i iff j <= kv_len - q_len + i); 0: none.
+ *                Bit 1 (SPATTEN_PREFILL_FAST_NUMERICS): opt OUT of the reference's two 16-bit roundings of every logit
+ *                (matmul -> dtype, / sqrt(d) -> dtype, modify_llama.py:111-113): logits stay fp32 and the scale is folded
+ *                into the exponent — a faster softmax phase whose output stays within the stated tolerance of the
+ *                reference EXCEPT where logits are large (one 16-bit ulp of a logit of magnitude 20-30 is a 13-28 % change
+ *                of its probability).  Honoured by the MFMA leg without mask / scores / col_importance / lse (those are
+ *                defined on the rounded logits); ignored elsewhere.
  *   mask         optional additive [B, q_len, kv_len] in the model dtype (the [B,1,q,N] HF mask), strides
  *                mask_sb, mask_sq; applied in addition to `causal`
  *   out          [B, q_len, H*d]    (strides out_sb, out_sq)
@@ -237,6 +243,7 @@ int spatten_kv_append(int dtype, const void* k_new, const void* v_new, int64_t n
  *                query blocks on a long cache — few query blocks x heads — also the fp32 partials of the KEY SPLIT:
  *                up to 8 workgroups per (b, h, 256-query block), each over a range of key tiles, folded by a merge launch)
  * ---------------------------------------------------------------------------------------------- */
+#define SPATTEN_PREFILL_FAST_NUMERICS 2
 size_t spatten_prefill_workspace_bytes(int dtype, int batch, int heads, int kv_heads, int head_dim,
                                        int q_len, int kv_len);
 int spatten_attn_prefill(int dtype,

@@ -114,6 +114,7 @@ struct FlashParams {
   int32_t* need;      // [B,H,q_len]: pass 1 writes max prob < thr, pass 2 recomputes the flagged rows
   float pq_thr;
   int B, H, Hkv, q_len, N, Npad, causal, nqb;
+  int fast;    // SPATTEN_PREFILL_FAST_NUMERICS: fp32 logits, no reference roundings (plain causal / unmasked flash leg only)
   float sqrt_d;
   // key split (prefill_pp128_kernel, plain keys): a (b, h, query block) is served by ksplit workgroups, each over a
   // contiguous range of key tiles; they leave un-normalised partial outputs + (m, l) here and prefill_merge_kernel
@@ -134,9 +135,10 @@ struct FlashParams {
 #ifndef SPATTEN_PF_DMA_MODE     // who issues a stage's LDS-DMA: 0 half 0 in its matrix / half 1 in its vector phase (r01, 762);
 #define SPATTEN_PF_DMA_MODE ((SPATTEN_PF_EXPMODE & 4) ? 2 : 1)   // 1 both in their matrix phase (r02, 810); 2 both in their vector phase (743)
 #endif
-#ifndef SPATTEN_PF_FASTNUM      // logits kept in fp32 (no reference roundings), scale folded into the exponent: +6-8 %, NOT the
-#define SPATTEN_PF_FASTNUM (SPATTEN_PF_EXPMODE & 1)   // default — the flash kernel's logits stay the reference's
-#endif
+// FAST (template flag of prefill_pp128_kernel; run-time opt-in SPATTEN_PREFILL_FAST_NUMERICS of spatten_attn_prefill):
+// logits kept in fp32 — no reference roundings (matmul -> dtype, / sqrt(d) -> dtype) — with the scale folded into the
+// exponent: -384 of ~609 VALU per wave-tile.  NOT the default: the flash kernel's logits stay the reference's (DESIGN
+// §3.4).  The harness bit SPATTEN_PF_EXPMODE & 1 forces it for every launch (anatomy builds).
 #ifndef SPATTEN_PF_ROWSUM_MFMA  // row sums of P on the matrix pipe instead of 64 VALU adds per lane and tile: MEASURED SLOWER
 #define SPATTEN_PF_ROWSUM_MFMA 0   // (713 vs 768): the 8 extra MFMAs per tile cost more than the adds they replace.  Off.
 #endif
@@ -581,8 +583,9 @@ template <int ROWB> __device__ inline int swz_slot(int row, int p) {   // logica
   return ROWB == 256 ? (p ^ (row & 15)) : (p ^ ((row >> 1) & 7));
 }
 
-template <typename T, int D, bool MASK, int PQK = 0>
+template <typename T, int D, bool MASK, int PQK = 0, bool FASTN = false>
 __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams<T> p) {
+  constexpr bool FAST = FASTN || (SPATTEN_PF_EXPMODE & 1);
   constexpr int KT = 128, NKB = KT / 32;                      // keys per tile, 32-key blocks per tile
   constexpr int KK = D / 16, DB = D / 32, KROWB = D * 2;
   constexpr int KBYTES = KT * KROWB, VBYTES = D * 256, BUF = KBYTES + VBYTES;   // Vt row = 128 keys = 256 B
@@ -820,19 +823,19 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     } else {
     // both reference roundings of every logit (matmul -> dtype, "/ sqrt(d)" -> dtype, modify_llama.py:111-113), two
     // scores at a time: at large logits a 16-bit ulp is a visible change of P
-    if (!(SPATTEN_PF_FASTNUM && !MASK && !edge)) {
+    if (!(FAST && !MASK && !edge)) {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-#if SPATTEN_PF_FASTNUM
-        s[kb][r] *= rsqrt_d; s[kb][r + 1] *= rsqrt_d;
-#else
-        const f32x2 x = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
-        const f32x2 v = round2<T>(f32x2{logit_scale<T>(x[0], p.sqrt_d, rsqrt_d), logit_scale<T>(x[1], p.sqrt_d, rsqrt_d)});
-        s[kb][r] = v[0];
-        s[kb][r + 1] = v[1];
-#endif
+        if constexpr (FAST) {
+          s[kb][r] *= rsqrt_d; s[kb][r + 1] *= rsqrt_d;
+        } else {
+          const f32x2 x = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
+          const f32x2 v = round2<T>(f32x2{logit_scale<T>(x[0], p.sqrt_d, rsqrt_d), logit_scale<T>(x[1], p.sqrt_d, rsqrt_d)});
+          s[kb][r] = v[0];
+          s[kb][r + 1] = v[1];
+        }
       }
     }
     }
@@ -850,7 +853,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 #pragma unroll
         for (int r = 0; r < 16; r += 2) mt[kb] = max3_raw(mt[kb], s[kb][r], s[kb][r + 1]);
       }
-      const float m_tile = xor32_max(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3]))) * (SPATTEN_PF_FASTNUM && !PQK ? rsqrt_d : 1.0f);
+      const float m_tile = xor32_max(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3]))) * (FAST && !PQK ? rsqrt_d : 1.0f);
       const bool move = __builtin_amdgcn_ballot_w64(m_tile - m_run > kDeferMax) != 0;   // -inf start: inf > thr
       m_new = move ? fmaxf(m_run, m_tile) : m_run;
       if (PQK == 1) m_true = fmaxf(m_true, m_tile);
@@ -875,7 +878,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
       m_base = (m_new == -INFINITY) ? 0.f : m_new;  // a fully masked row: exp2(-inf) = 0 for every key
     }
     const float m2 = m_base * kLog2e;
-    const float sc2 = (SPATTEN_PF_FASTNUM && !PQK && !MASK && !edge) ? kLog2e * rsqrt_d : kLog2e;
+    const float sc2 = (FAST && !PQK && !MASK && !edge) ? kLog2e * rsqrt_d : kLog2e;
     float ls[4] = {0.f, 0.f, 0.f, 0.f};             // independent partial sums
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
@@ -1234,6 +1237,7 @@ static void launch_flash_m(const FlashParams<T>& p, hipStream_t st) {
     if (prefill_variant() == 0) {
       const dim3 gridk((unsigned)(p.nqb * p.H * p.B * (p.ksplit > 1 ? p.ksplit : 1)));
       if (p.mask) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, true>), gridk, dim3(512), 0, st, p);
+      else if (p.fast) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, 0, true>), gridk, dim3(512), 0, st, p);
       else hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false>), gridk, dim3(512), 0, st, p);
       if (p.ksplit > 1) {
         const long long rows = (long long)p.B * p.H * p.q_len;
@@ -1316,7 +1320,7 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
       c.lse = lse ? lse + (int64_t)i0 * 2 : nullptr; c.lse_q = q_len;
       c.workspace = ws; c.ws_units = units; c.ws_splits = S;
       c.batch = batch; c.heads = heads; c.kv_heads = kv_heads; c.head_dim = head_dim;
-      c.kv_len = kv_len; c.pos_q = pos_q0 + i0; c.n_q = nq; c.causal = causal; c.n_splits = S;
+      c.kv_len = kv_len; c.pos_q = pos_q0 + i0; c.n_q = nq; c.causal = causal & 1; c.n_splits = S;
       c.vis0 = kv_len - q_len + i0 + 1;          // HF causal rule for row i0 of the whole block
       const int rc = decode_rows(c, st);
       if (rc != SPATTEN_OK) return rc;
@@ -1349,7 +1353,8 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
     p.scores = (T*)scores; p.sc_sb = sc_sb; p.sc_sh = sc_sh; p.sc_sq = sc_sq;                          \
     p.col_imp = col_importance; p.lse = lse; p.kscale = nullptr; p.ks_sb = p.ks_sh = 0; p.need = nullptr; p.pq_thr = 0.f; \
     p.B = batch; p.H = heads; p.Hkv = kv_heads; p.q_len = q_len; p.N = kv_len; p.Npad = npad;          \
-    p.causal = causal; p.sqrt_d = sqrtf((float)head_dim); p.nqb = ceil_div(q_len, 256);                \
+    p.causal = causal & 1; p.fast = (causal & SPATTEN_PREFILL_FAST_NUMERICS) != 0 && !scores && !col_importance && !lse; \
+    p.sqrt_d = sqrtf((float)head_dim); p.nqb = ceil_div(q_len, 256);                                   \
     p.ksplit = (!scores && !col_importance && prefill_variant() == 0) ? flash_ksplit(batch, heads, q_len, kv_len) : 1; \
     p.part_o = (float*)(ws + align256((size_t)batch * kv_heads * head_dim * npad * 2));                \
     p.part_ml = p.part_o + (size_t)batch * heads * p.nqb * p.ksplit * 256 * head_dim;                   \
@@ -1393,7 +1398,7 @@ extern "C" int spatten_importance_accumulate_prefill(int dtype, const void* q, i
     ColProbParams<T> p;                                                                                     \
     p.qrot = (const T*)ws; p.q_sb = qr_sb; p.q_sh = qr_sh; p.kr = (const T*)kr_cache; p.kv_sb = kv_sb; p.kv_sh = kv_sh; \
     p.lse = lse; p.acc = acc; p.acc_sh = acc_sh; p.H = heads; p.Hkv = kv_heads; p.q_len = q_len; p.N = kv_len; \
-    p.causal = causal; p.sqrt_d = sqrtf((float)head_dim);                                                   \
+    p.causal = causal & 1; p.sqrt_d = sqrtf((float)head_dim);                                               \
     hipLaunchKernelGGL((prefill_colprob_kernel<T, DD>), grid, dim3(512), 0, (hipStream_t)stream, p);         \
   }
   if (dtype == SPATTEN_BF16) { if (head_dim == 128) SPATTEN_COLPROB(bf16_t, 128) else SPATTEN_COLPROB(bf16_t, 64) }
@@ -1461,7 +1466,7 @@ extern "C" int spatten_attn_prefill_pq(int dtype, const void* q, int64_t q_sb, i
     p.scores = nullptr; p.sc_sb = p.sc_sh = p.sc_sq = 0; p.col_imp = nullptr; p.lse = nullptr;         \
     p.kscale = kscale; p.ks_sb = (int64_t)kv_heads * kv_len; p.ks_sh = kv_len; p.need = need_lsb; p.pq_thr = (THR); \
     p.B = batch; p.H = heads; p.Hkv = kv_heads; p.q_len = q_len; p.N = kv_len; p.Npad = npad;          \
-    p.causal = causal; p.sqrt_d = sqrtf((float)head_dim); p.nqb = ceil_div(q_len, 256);                \
+    p.causal = causal & 1; p.fast = 0; p.sqrt_d = sqrtf((float)head_dim); p.nqb = ceil_div(q_len, 256);   \
     p.ksplit = 1; p.part_o = nullptr; p.part_ml = nullptr;                                             \
     rc = launch_flash<T, DD>(p, st);                                                                   \
   }

@@ -25,7 +25,7 @@ _FAMILIES: Dict[str, Callable] = {"llama": _patch_llama}
 
 def enable_spatten_llm(model, start_size, important_size, recent_size, importance_mode="reference",
                        prefill_stash=True, assume_causal=False, head_keep=None, pq_threshold=None, local_v_keep=None,
-                       layer_keep=None, fuse_qkv=False, native_gemv=False, head_parallel=None):
+                       layer_keep=None, fuse_qkv=False, native_gemv=False, head_parallel=None, numerics="reference"):
     """The reference's four positional arguments (enable_spatten_llm.py:5) plus opt-in extensions:
 
     ``prefill_stash=False``: forwards with ``q_len > 1`` do not materialise ``self.attn_scores`` ([B,H,q,N]: 4 GiB per
@@ -43,6 +43,9 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     of the decode step's bytes (same fp32 accumulation and single rounding as ``nn.Linear``; a different summation order,
     so the last bit can differ).  Multi-token forwards keep torch's GEMMs.
 
+    ``numerics="fast"``: multi-token forwards that materialise no stash (``prefill_stash=False``) keep their logits in
+    fp32 instead of reproducing the reference's two 16-bit roundings per logit (modify_llama.py:111-113) — a faster
+    prefill whose output leaves the stated tolerance only where logits are large.
     ``head_parallel=HeadParallel(H, Hkv)`` (spatten_amd/parallel.py; one process per GPU): this rank's modules project,
     cache, attend and prune only its H/G heads (column-sharded q/k/v projections; ``past_key_values`` and ``attn_scores``
     hold the local heads) and all-gather the attention outputs [B, q, H/G*d] in front of the full ``o_proj``
@@ -75,6 +78,9 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
         m.__dict__.pop("_spatten_geom", None)       # geometry cache of the patched forward: re-read on the next call
         m._spatten_qkv = None
         m.__dict__["_spatten_gemv"] = bool(native_gemv)
+        if numerics not in ("reference", "fast"):
+            raise ValueError("numerics must be 'reference' or 'fast'")
+        m.__dict__["_spatten_numerics"] = numerics
         m.__dict__.pop("_spatten_hp", None)
         if head_parallel is not None:
             from .pos_shift.modify_llama import shard_attention_projections

@@ -398,11 +398,16 @@ def attn_prefill(q: torch.Tensor, kr_cache: torch.Tensor, v_cache: torch.Tensor,
                  cos: torch.Tensor, sin: torch.Tensor, pos_q0: int, causal: bool = True,
                  position_ids: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
                  out: Optional[torch.Tensor] = None, scores: Optional[torch.Tensor] = None,
-                 col_importance: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 col_importance: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,
+                 numerics: str = "reference") -> torch.Tensor:
     """Flash-style prefill (modify_llama.py:86-147 at q_len>1).  q [B,H,q,d] un-rotated (any strides with d
     contiguous); kr_cache = ROTATED shadow of the keys, v_cache values, both already holding the q new rows
     at [kv_len-q, kv_len); mask additive [B,q,kv_len]; position_ids int64 [B,q]; lse optional fp32 [B,H,q,2] output
-    (row reference max, sum exp): the softmax statistics.  Returns out [B, q, H*d]."""
+    (row reference max, sum exp): the softmax statistics.  ``numerics="fast"``: fp32 logits without the reference's two
+    16-bit roundings (include/spatten.h, SPATTEN_PREFILL_FAST_NUMERICS) where no by-product needs them.
+    Returns out [B, q, H*d]."""
+    if numerics not in ("reference", "fast"):
+        raise ValueError("numerics must be 'reference' or 'fast'")
     _dev(q, kr_cache, v_cache, cos, sin, out, scores, col_importance, position_ids, mask, lse)
     if lse is not None and (lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != q.shape[0] * q.shape[1] * q.shape[2] * 2):
         raise ValueError("lse must be a contiguous fp32 [B,H,q,2] tensor")
@@ -429,7 +434,7 @@ def attn_prefill(q: torch.Tensor, kr_cache: torch.Tensor, v_cache: torch.Tensor,
         out.data_ptr(), out.stride(0), out.stride(1),
         _ptr(scores), *((0, 0, 0) if scores is None else (scores.stride(0), scores.stride(1), scores.stride(2))),
         _ptr(col_importance), _ptr(lse), ws.data_ptr(),
-        B, H, Hkv, d, ql, kv_len, pos_q0, int(causal), _stream())
+        B, H, Hkv, d, ql, kv_len, pos_q0, int(bool(causal)) | (2 if numerics == "fast" else 0), _stream())
     _lib.check(rc, "spatten_attn_prefill")
     return out
 
