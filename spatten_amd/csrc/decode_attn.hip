@@ -82,6 +82,9 @@ struct DecodeParams {
   float sqrt_d;
 };
 
+#ifndef SPATTEN_PQ_UP
+#define SPATTEN_PQ_UP 4          // row-groups per pipelined tile of the MSB-plane pass (A/B switch, see launch_decode)
+#endif
 constexpr int kDecodeThreads = 256;
 constexpr int kDecodeCoResident = 256;   // workgroups the chip starts without waiting for another to finish: one per CU
 
@@ -178,8 +181,11 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   // stream alone takes 6.5.)
   struct Tile {
     raw_t k_lo[UNR], k_hi[UNR], v_lo[UNR], v_hi[UNR];
-    uint32_t pm_lo[UNR], pm_hi[UNR], pl_lo[UNR], pl_hi[UNR];   // PQ: 8 nibbles each (elements [8c,8c+8) / [d/2+8c, ..))
-    float pscale[UNR];
+    // PQ: a plane row is D/2 bytes and is fetched as 16-byte pieces — LPP = D/32 lanes per row, so ONE wave instruction
+    // covers the wave's rows of TWO row-groups (u, u+1): lanes [0,32) hold group u, lanes [32,64) group u+1 (r03: the
+    // 4-byte pieces of r02 used a quarter of a line per lane and streamed at 4.2 TB/s where the 16-bit keys reach 5.2)
+    u32x4 pm[(UNR + 1) / 2], pl[(UNR + 1) / 2];
+    float pscale[(UNR + 1) / 2];
     T prev[UNR];                                               // CASC: the previous step's logit of the row
   };
   Tile tile_a;
@@ -189,19 +195,24 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   const float* pq_s = PQ ? p.pq_scale + b * p.ps_sb + hkv * p.ps_sh : nullptr;
   const T* prevp = CASC ? p.prev_scores + b * p.pv_sb + h * p.pv_sh : nullptr;
   auto row_of = [&](int t0, int u) { return max(min(t0 + u * RPI + r, rl - 1), 0); };   // (an empty split reads row 0)
+  // PQ lane mapping (see Tile): lane = (g * RW + r8) * LPP + cc — row-group u + g, row r8 of the wave's RW rows, 16-byte piece cc
+  constexpr int LPP = D / 32, RW = kWave / LPR;
+  const int pq_cc = lane % LPP, pq_rr = lane / LPP, pq_g = pq_rr / RW, pq_r8 = pq_rr % RW;
   auto issue_keys = [&](Tile& tl, int t0) {
+    if (PQ) {
+#pragma unroll
+      for (int u = 0; u < UNR; u += 2) {
+        const int j = max(min(t0 + (u + pq_g) * RPI + wave * RW + pq_r8, rl - 1), 0);
+        const int64_t po = (int64_t)j * HALF + 16 * pq_cc;   // a plane row is D/2 bytes
+        tl.pm[u / 2] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pq_m + po));
+        if (KSRC == 2) tl.pl[u / 2] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pq_l + po));
+        tl.pscale[u / 2] = pq_s[j];
+      }
+    }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int j = row_of(t0, u);
       if (PQ) {
-        const int64_t po = (int64_t)j * HALF + 4 * c;   // a plane row is D/2 bytes
-        tl.pm_lo[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pq_m + po));
-        tl.pm_hi[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pq_m + po + HALF / 2));
-        if (KSRC == 2) {
-          tl.pl_lo[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pq_l + po));
-          tl.pl_hi[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pq_l + po + HALF / 2));
-        }
-        tl.pscale[u] = pq_s[j];
       } else {
         const T* kp = krbase + (int64_t)j * D;
         tl.k_lo[u] = NT ? V8::ldg_stream(kp + 8 * c) : V8::ldg(kp + 8 * c);
@@ -265,7 +276,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
 
   // ---- rotate the query (its data was requested first, so it is here long before the keys) -----------------------
   typename D8::packed q_lo, q_hi;                // rotated query, packed in the model dtype (exact: it IS rounded)
-  typename NibbleDot<T>::packed qn_lo, qn_hi;    // PQ: the same rotated query, arranged for the nibble dot product
+  typename NibbleDot<T>::packed qn[4];           // PQ: the same rotated query, arranged for the nibble dot product
   {
     float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8];
     V8::unpack(q_raw[0], xlo);
@@ -275,7 +286,22 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
     rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
     q_lo = D8::pack(ylo);
     q_hi = D8::pack(yhi);
-    if (PQ) { qn_lo = NibbleDot<T>::prep(ylo); qn_hi = NibbleDot<T>::prep(yhi); }
+    if (PQ) {
+      // the rotated query re-dealt for the plane mapping: piece cc covers elements [32 cc, 32 cc + 32) = 4 dwords of 8
+      // nibbles; dword k's elements sit in lane c_src of this lane's LPR-group, in its lower or upper half-row
+      const int half = pq_cc / (LPP / 2), grp0 = lane & ~(LPR - 1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int src = grp0 + (pq_cc % (LPP / 2)) * 4 + k;
+        float e8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float lo_ = __shfl(ylo[i], src, kWave), hi_ = __shfl(yhi[i], src, kWave);
+          e8[i] = half ? hi_ : lo_;
+        }
+        qn[k] = NibbleDot<T>::prep(e8);
+      }
+    }
   }
   SPATTEN_TSTAMP(6);
   const float rsqrt_d = 1.0f / p.sqrt_d;
@@ -306,16 +332,35 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
 
     // ---- scores of the row groups, in the order their keys arrive (the values are still in flight) ------------
     float sc[UNR];
+    if (PQ) {
+      // sum_i q_i * q8_i with q8 = 16 * sext(msb nibble) + lsb nibble over this lane's 32 elements, reduced over the LPP
+      // lanes of the row, scaled per row; then dealt back to the value mapping: lane (row r, any c) of group u takes the
+      // logit from plane lane (g = u & 1, r8 = r, cc = 0)
+#pragma unroll
+      for (int u = 0; u < UNR; u += 2) {
+        float a = 0.f;
+        if (u < ng) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) a += NibbleDot<T>::dot(qn[k], tl.pm[u / 2][k] ^ 0x88888888u, 8.f);
+          a *= 16.f;
+          if (KSRC == 2) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a += NibbleDot<T>::dot(qn[k], tl.pl[u / 2][k], 0.f);
+          }
+          a += dpp_mov<kDppXor1>(a);
+          if (LPP == 4) a += dpp_mov<kDppXor2>(a);
+          a = a * tl.pscale[u / 2] / p.sqrt_d;                  // fp32 logits
+        }
+        const int r8v = (lane / LPR) * LPP;
+        sc[u] = __shfl(a, r8v, kWave);
+        if (u + 1 < UNR) sc[u + 1] = __shfl(a, RW * LPP + r8v, kWave);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      sc[u] = 0.f;
+      if (!PQ) sc[u] = 0.f;
       if (u < ng) {
         if (PQ) {
-          // sum_i q_i * q8_i with q8 = 16 * sext(msb nibble) + lsb nibble; the row scale is applied after the reduction
-          float a = NibbleDot<T>::dot(qn_lo, tl.pm_lo[u] ^ 0x88888888u, 8.f) + NibbleDot<T>::dot(qn_hi, tl.pm_hi[u] ^ 0x88888888u, 8.f);
-          a *= 16.f;
-          if (KSRC == 2) a += NibbleDot<T>::dot(qn_lo, tl.pl_lo[u], 0.f) + NibbleDot<T>::dot(qn_hi, tl.pl_hi[u], 0.f);
-          sc[u] = group_sum<LPR>(a) * tl.pscale[u] / p.sqrt_d;   // fp32 logits
         } else {
           const float a = group_sum<LPR>(D8::dot(q_hi, tl.k_hi[u], D8::dot(q_lo, tl.k_lo[u], 0.f)));
           // matmul result -> dtype, then the separate divide -> dtype (modify_llama.py:111-113)
@@ -711,7 +756,10 @@ static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_onl
     else {
       // the fused cascade accumulation rides on pass 1 only (pass 2 re-streams the flagged heads: no double count)
       if (pipe) {
-        if (casc) SPATTEN_LAUNCH(UP, 0, false, 1, true, true, true); else SPATTEN_LAUNCH(UP, 0, false, 1, true, false, true);
+        // (r03, measured and NOT adopted: 6 / 8 row-groups per pipelined tile for this pass — a plane row is a quarter of
+        //  a 16-bit key row, so the registers are there — 22.9 / 23.3 us against 20.7 with 4; SPATTEN_PQ_UP keeps the A/B)
+        constexpr int UPQ = (sizeof(T) == 2 && D <= 128) ? SPATTEN_PQ_UP : UP;
+        if (casc) SPATTEN_LAUNCH(UP, 0, false, 1, true, true, true); else SPATTEN_LAUNCH(UPQ, 0, false, 1, true, false, true);
         SPATTEN_LAUNCH(UP, 0, false, 2, true, false, true);
       } else {
         if (casc) SPATTEN_LAUNCH(U, 0, false, 1, true, true); else SPATTEN_LAUNCH(U, 0, false, 1, true);
