@@ -250,7 +250,7 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False, Fals
             import contextlib
             import io
             with contextlib.redirect_stdout(io.StringIO()):       # the constructor prints the reference's banner
-                enable_spatten_llm(model, START, IMPORTANT, RECENT, prefill_stash=False, assume_causal=flag, fuse_qkv=fuse,
+                cache = enable_spatten_llm(model, START, IMPORTANT, RECENT, prefill_stash=False, assume_causal=flag, fuse_qkv=fuse,
                                    native_gemv=gemv)
             hid = HEADS * HEAD_DIM
             x = torch.randn(1, P, hid, device=dev, dtype=torch.float32).to(dt)
@@ -316,6 +316,32 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False, Fals
             sfx = "_fused_qkv_native_gemv" if gemv else ("_fused_qkv" if fuse else "")
             out[f"plugin_path_graph{sfx}_tokens_per_s"] = round(n_rep / t_rep, 2)
             out[f"plugin_path_graph{sfx}_turn_incl_capture_tokens_per_s"] = round(TURN / t_turn, 2)
+            if gemv:
+                # the reference's whole caller protocol through the plugin (run_spatten_llama.py:60-87), two chat turns:
+                # prune event from the last decode step's stashes -> prefill of a 64-token prompt through the patched
+                # forward -> 63 greedy-decode steps under ONE captured graph (re-captured per turn: the prune moves the cache)
+                past = graph.past_key_values
+                xp = torch.randn(1, TURN, hid, device=dev, dtype=torch.float32).to(dt)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n_tok = 0
+                for turn in range(2):
+                    past = cache.apply_token_pruning(past, 2 * TURN, [m.attn_scores for m in model.layers])
+                    n0 = past[0][0].shape[2]
+                    pm = torch.zeros(1, 1, TURN, n0 + TURN, dtype=dt, device=dev)
+                    pm[..., n0:].masked_fill_(torch.ones(TURN, TURN, dtype=torch.bool, device=dev).triu(1), torch.finfo(dt).min)
+                    pp = torch.arange(n0, n0 + TURN, device=dev)[None]
+                    past = [m(xp, attention_mask=pm, position_ids=pp, past_key_value=past[i], use_cache=True)[2]
+                            for i, m in enumerate(model.layers)]
+                    graph = DecodeGraph(step_fn, past, horizon=TURN)
+                    for t in range(TURN - 1):
+                        graph.step(xt)
+                    past = graph.past_key_values
+                    n_tok += TURN - 1
+                torch.cuda.synchronize()
+                dt_s = time.perf_counter() - t0
+                out["plugin_protocol_two_turns_decode_tokens_per_s"] = round(n_tok / dt_s, 2)
+                out["plugin_protocol_ms_per_turn"] = round(dt_s / 2 * 1e3, 2)
             del graph
             del past
     # bytes one token of this path must move at least: the four projection matrices of every layer + the kept K/V rows

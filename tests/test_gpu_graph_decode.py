@@ -314,3 +314,40 @@ def test_native_gemv_forward_stays_within_rounding_of_the_torch_projections():
     yh, _ = b(x0.half(), None)
     yh1, _ = b(x.half(), _)
     assert yh.dtype == torch.float16 and torch.isfinite(yh1.float()).all()
+
+
+def test_decode_graph_holds_the_head_parallel_exchange():
+    """Head-parallel plugin + DecodeGraph: with the library-owned RCCL communicator initialised (world size 1 here — a
+    multi-GPU node is the driver's) the all-gather in front of o_proj is an ordinary stream operation INSIDE the captured
+    decode step; replays equal the eager loop bit for bit."""
+    import contextlib
+    import io
+
+    from spatten_amd import enable_spatten_llm
+    from spatten_amd.graph import DecodeGraph
+    from spatten_amd.parallel import HeadParallel
+    dt = torch.bfloat16
+    a, b, _ = _models(dt)
+    hp = HeadParallel(H)
+    try:
+        hp.init_native()
+    except RuntimeError as e:
+        assert "unsupported" in str(e)
+        pytest.skip("librccl not installed")
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            enable_spatten_llm(b, 4, 60, 64, head_parallel=hp)
+        g = torch.Generator(device="cuda").manual_seed(6)
+        x0 = torch.randn(1, 90, HID, device="cuda", generator=g).to(dt)
+        _, past_a = a(x0, None)
+        _, past_b = b(x0, None)
+        graph = DecodeGraph(lambda past, x: tuple(reversed(b(x, past))), past_b, horizon=10)
+        for t in range(8):
+            x = torch.randn(1, 1, HID, device="cuda", generator=g).to(dt)
+            ya, past_a = a(x, past_a)
+            yb = graph.step(x)
+            torch.cuda.synchronize()
+            assert torch.equal(ya, yb), t
+        assert graph.n_replays == 7
+    finally:
+        hp.close_native()
