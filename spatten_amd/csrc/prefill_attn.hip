@@ -1268,9 +1268,20 @@ extern "C" size_t spatten_prefill_workspace_bytes(int dtype, int batch, int head
                                                   int q_len, int kv_len) {
   if (batch <= 0 || heads <= 0 || kv_heads <= 0 || head_dim <= 0 || q_len <= 0 || kv_len <= 0) return 0;
   if (rows_leg(dtype, head_dim, q_len)) {
-    const size_t units = (size_t)batch * heads * (size_t)(q_len < kRowsPerLaunch ? q_len : kRowsPerLaunch);
-    const int S = rows_splits((int)(units > (1u << 30) ? (1u << 30) : units));
-    return 256 + kDecodeWsHeader + decode_cnt_bytes(units) + (S > 1 ? units * S * (head_dim + 2) * sizeof(unsigned long long) : 0);
+    // the maximum over the slices spatten_attn_prefill launches: full slices of rows_per query rows and a shorter tail,
+    // whose FEWER units mean MORE splits per unit (round-2 advisor finding: sizing from the first slice alone under-sized
+    // the tail's partial region, e.g. fp32 B = 1, H = 8, q_len = 4097)
+    const int rows_per = max(1, min(kRowsPerLaunch, 65535 / batch));
+    size_t need = 0;
+    const int slices[2] = {min(q_len, rows_per), q_len % rows_per};
+    for (int nq : slices) {
+      if (nq <= 0) continue;
+      const size_t units = (size_t)batch * heads * (size_t)nq;
+      const int S = rows_splits((int)(units > (1u << 30) ? (1u << 30) : units));
+      const size_t b = kDecodeWsHeader + decode_cnt_bytes(units) + (S > 1 ? units * S * (head_dim + 2) * sizeof(unsigned long long) : 0);
+      need = b > need ? b : need;
+    }
+    return 256 + need;
   }
   const size_t es = 2, npad = (size_t)ceil_div(kv_len, 128) * 128;
   return 256 + align256((size_t)batch * kv_heads * head_dim * npad * es)      // the key-contiguous copy of V

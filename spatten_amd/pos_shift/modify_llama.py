@@ -155,6 +155,15 @@ def llama_pos_shift_attention_forward(
     kv_seq_len = past_len + q_len
     ext = getattr(self, "_spatten_ext", None)         # (SpattenExtensions, layer index) — opt-in SpAtten semantics
     assume_causal = bool(getattr(self, "spatten_assume_causal", False)) or ext is not None
+    if ext is not None and ext[0].layer_keep is None and attention_mask is not None and q_len > 1 \
+            and not bool(getattr(self, "spatten_assume_causal", False)) and attention_mask.numel() \
+            and not _mask_is_causal(attention_mask, past_len):
+        # the extension modes run on the causal rule (their kernels take no mask): a padding / custom mask would be dropped
+        # silently — refuse it instead (round-2 advisor finding).  One device comparison per forward, cached on the tensor.
+        raise ValueError("the SpAtten extension modes (cascade importance, head / local-V / layer pruning, progressive "
+                         "quantisation) assume the HF causal mask; this forward was given another attention_mask "
+                         "(left-padded batch?) — run it without the extensions, or pass assume_causal=True to take the "
+                         "responsibility")
     if ext is not None and ext[0].layer_keep is not None:
         # layer-to-layer cascade: the layers' caches have different lengths, HF sizes its mask / positions for layer 0 —
         # every layer uses the causal rule and its own cache-relative positions instead

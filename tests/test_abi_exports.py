@@ -97,3 +97,20 @@ def test_integration_md_c_snippet_compiles_against_the_header(tmp_path):
                    "      void* stash, void* ws, const int32_t* kept, void* stream, int H, int Hkv, int d, int cap, int rows,\n"
                    "      int B, int n) {\n" + body + "  return rc;\n}\n")
     subprocess.check_call([gcc, "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)])
+
+
+def test_prefill_workspace_covers_the_tail_slice_of_the_rows_leg():
+    """Round-2 advisor finding: the rows leg (fp32 / short blocks) runs in slices of 4096 query rows; a shorter tail slice
+    has fewer units, hence MORE splits per unit, and needs more partial space than the first slice (fp32, B = 1, H = 8,
+    d = 128, q_len = 4097: 262.6 KB for the first slice, ~267 KB for the one-row tail)."""
+    from spatten_amd import _lib
+    lib = _lib.load()
+    B, H, d = 1, 8, 128
+    got = lib.spatten_prefill_workspace_bytes(0, B, H, H, d, 4097, 4097)
+    units_tail = B * H * 1
+    S_tail = min(64, 256 // units_tail)
+    cnt = (units_tail * 2 * 4 + 255) // 256 * 256
+    need_tail = 256 + cnt + units_tail * S_tail * (d + 2) * 8
+    assert got >= 256 + need_tail, (got, need_tail)
+    # and never below what one full slice needs
+    assert got >= lib.spatten_prefill_workspace_bytes(0, B, H, H, d, 4096, 4096)

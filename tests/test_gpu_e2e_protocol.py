@@ -381,3 +381,22 @@ def test_multi_turn_protocol_layer_cascade():
         assert tg == tr, f"turn {turn}: generated tokens differ {tg} vs {tr}"
         np.testing.assert_allclose(lg_.cpu().numpy(), lr_, atol=5e-4, rtol=5e-4)
     assert kv_cache.n_pruned_total > 0
+
+
+def test_extension_modes_refuse_a_non_causal_mask():
+    """Round-2 advisor finding: with an extension mode on, the forward used to drop HF's attention_mask silently — a
+    left-padded batch then attended to its padding.  It now refuses any multi-token mask that is not the causal one."""
+    from spatten_amd import enable_spatten_llm
+    torch.manual_seed(0)
+    model = TinyLlama().cuda().float()
+    enable_spatten_llm(model, start_size=START, important_size=IMPORTANT, recent_size=RECENT, importance_mode="cascade")
+    attn = model.layers[0].self_attn
+    B, q = 2, 12
+    x = torch.randn(B, q, HID, device="cuda")
+    pos = torch.arange(q, device="cuda")[None].expand(B, q)
+    causal = torch.from_numpy(orc.causal_mask(B, q, q, "f32")).cuda()
+    attn(x, attention_mask=causal, position_ids=pos, past_key_value=None, use_cache=True)       # the HF causal mask: fine
+    padded = causal.clone()
+    padded[1, :, :, :3] = torch.finfo(torch.float32).min                                         # left padding of sequence 1
+    with pytest.raises(ValueError, match="causal mask"):
+        attn(x, attention_mask=padded, position_ids=pos, past_key_value=None, use_cache=True)
