@@ -179,7 +179,11 @@ int spatten_attn_decode_args(const spatten_decode_args_t* args, void* stream);
  *     load address in the attention kernel depends on the length.
  *   - rows [length, bound) of kr_cache and v_cache are read and discarded (weight 0): they must hold FINITE values —
  *     zero-fill the planes once when they are allocated.  Stash entries [length, bound) are left untouched.
- *   - admitted for the plain single-token step (mask, position_ids, pq_*, importance_acc, SCORES_ONLY must be unset).
+ *   - admitted for the single-token step without mask, position_ids, pq_* and SCORES_ONLY; head_ids / head_abs_acc as usual.
+ *   - importance_acc (the fused cascade accumulation) IS admitted: `scores` / `lse` and `prev_scores` / `prev_lse` are
+ *     then the TWO buffers that swap roles every step (same strides, rows up to the bound): step k since the last
+ *     spatten_step_set writes buffer (k - 1) & 1 — `scores` first — and folds the other one over the rows the previous
+ *     step wrote (state word 3; 0 for the first step).  prev_len is ignored.
  * A token of a captured graph = spatten_step_advance(state, ..., 1) followed by the layers' spatten_attn_decode_args
  * launches sharing the state; before the first replay of a turn: spatten_step_set(state, ..., cache_len, cache_len - 1).
  * The state is spatten_step_state_bytes(dtype, head_dim) bytes of device memory owned by the caller.

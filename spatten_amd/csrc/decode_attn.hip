@@ -150,8 +150,17 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
 
   // DYN: the length is requested FIRST (vector loads return in order: it is back before the query) and read after the
   // tile loads have been issued
-  int n_dyn = 0;
+  int n_dyn = 0, cnt_dyn = 0, pl_dyn = 0;
   if (DYN) n_dyn = p.step[opaque_lane(0)];
+  if (DYN && CASC) { cnt_dyn = p.step[2 + opaque_lane(0)]; pl_dyn = p.step[3 + opaque_lane(0)]; }
+  // CASC: (max, sum) of the previous step's row, requested BEFORE the tile (r03: behind the tile these 8 bytes came back
+  // after it — returns are in order — and the first accumulation waited for the whole stream); DYN: of both buffers
+  float ml_a[2] = {0.f, 1.f}, ml_b[2] = {0.f, 1.f};
+  if (CASC) {
+    const float* ml = p.prev_lse + 2 * (b * p.H + h) + opaque_lane(0);
+    ml_a[0] = ml[0]; ml_a[1] = ml[1];
+    if (DYN) { const float* m2 = p.lse + 2 * (b * p.H + h) + opaque_lane(0); ml_b[0] = m2[0]; ml_b[1] = m2[1]; }
+  }
   // rows [lo, lo + chunk) of this split: chunks are balanced (ceil(N / S), any N) and need not be whole tiles — the last
   // tile of a chunk runs with fewer live row-groups.  The tile loads touch rows [lo, rl): a launch constant.
   const int lo = split * p.chunk;
@@ -187,6 +196,8 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
     u32x4 pm[(UNR + 1) / 2], pl[(UNR + 1) / 2];
     float pscale[(UNR + 1) / 2];
     T prev[UNR];                                               // CASC: the previous step's logit of the row
+    T prev2[UNR];                                              // CASC && DYN: the same from the OTHER stash buffer (the device
+                                                               // step count decides which of the two is "previous")
   };
   Tile tile_a;
   Tile tile_b;   // PIPE only: the second half of the double buffer (dead code otherwise)
@@ -194,6 +205,8 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   const uint8_t* pq_l = KSRC == 2 ? p.pq_lsb + b * p.pl_sb + hkv * p.pl_sh : nullptr;
   const float* pq_s = PQ ? p.pq_scale + b * p.ps_sb + hkv * p.ps_sh : nullptr;
   const T* prevp = CASC ? p.prev_scores + b * p.pv_sb + h * p.pv_sh : nullptr;
+  const T* prevp2 = (CASC && DYN) ? p.scores + b * p.sc_sb + h * p.sc_sh : nullptr;
+  const int prev_clamp = (CASC && DYN) ? p.N : p.prev_len;     // static bound of the previous-row addresses
   auto row_of = [&](int t0, int u) { return max(min(t0 + u * RPI + r, rl - 1), 0); };   // (an empty split reads row 0)
   // PQ lane mapping (see Tile): lane = (g * RW + r8) * LPP + cc — row-group u + g, row r8 of the wave's RW rows, 16-byte piece cc
   constexpr int LPP = D / 32, RW = kWave / LPR;
@@ -218,7 +231,8 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
         tl.k_lo[u] = NT ? V8::ldg_stream(kp + 8 * c) : V8::ldg(kp + 8 * c);
         tl.k_hi[u] = NT ? V8::ldg_stream(kp + HALF + 8 * c) : V8::ldg(kp + HALF + 8 * c);
       }
-      if (CASC) tl.prev[u] = prevp[max(min(j, p.prev_len - 1), 0)];
+      if (CASC) tl.prev[u] = prevp[max(min(j, prev_clamp - 1), 0)];
+      if (CASC && DYN) tl.prev2[u] = prevp2[max(min(j, prev_clamp - 1), 0)];
     }
   };
   auto issue_values = [&](Tile& tl, int t0) {
@@ -265,6 +279,10 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   SPATTEN_TSTAMP(5);
   // ---- the live rows of this split ------------------------------------------------------------------------------
   const int N = DYN ? __builtin_amdgcn_readfirstlane(n_dyn) : p.N;
+  // CASC && DYN: the two stash / (max, sum) buffers swap roles every step — step k (1-based count in the state) writes
+  // buffer (k - 1) & 1 and folds the other one, whose rows [0, prev_len) the previous step wrote (0 after a set)
+  const bool odd = (CASC && DYN) ? ((__builtin_amdgcn_readfirstlane(cnt_dyn) - 1) & 1) != 0 : false;
+  const int prev_len = (CASC && DYN) ? __builtin_amdgcn_readfirstlane(pl_dyn) : p.prev_len;
   // keys this query may attend to (HF causal: j <= P + i with P = N - n_q); the stash covers all N
   const int n_vis = (!LEAN && p.causal) ? min(N, p.vis0 + qi) : N;
   const int hi_all = min(lo + p.chunk, (p.scores != nullptr) ? N : n_vis);
@@ -307,13 +325,14 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   const float rsqrt_d = 1.0f / p.sqrt_d;
   const T* maskp = (!LEAN && p.mask) ? p.mask + b * p.mask_sb + qi * p.mask_sq : nullptr;
   T* stashp = p.scores ? p.scores + b * p.sc_sb + h * p.sc_sh + (LEAN ? 0 : qi * p.sc_sq) : nullptr;
-  // CASC: (max, sum) of the previous step's row — wave-uniform, but fetched per lane behind the tile loads like `gen`
+  if (CASC && DYN && odd) stashp = const_cast<T*>(p.prev_scores) + b * p.pv_sb + h * p.pv_sh;
+  float* lse_cur = (CASC && DYN && odd) ? const_cast<float*>(p.prev_lse) : p.lse;
   float casc_m = 0.f, casc_rl = 0.f;
   float* accp = nullptr;
   if (CASC) {
-    const float* ml = p.prev_lse + 2 * (b * p.H + h) + opaque_lane(0);
-    casc_m = (ml[0] == -INFINITY) ? 0.f : ml[0];
-    casc_rl = 1.0f / ml[1];
+    const float pm = odd ? ml_b[0] : ml_a[0], pl = odd ? ml_b[1] : ml_a[1];
+    casc_m = (pm == -INFINITY) ? 0.f : pm;
+    casc_rl = 1.0f / pl;
     accp = p.acc + h * p.acc_sh;
   }
 
@@ -408,8 +427,8 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
       const bool valid = u < ng && j < hi;
       float s = sc[u];
       if (stashp != nullptr && c == 0 && valid) stashp[j] = DT<T>::from_f32(s);       // pre-mask (:116-119)
-      if (CASC && c == 0 && valid && j < p.prev_len)                                  // last step's probability of key j
-        atomicAdd(accp + j, __expf(DT<T>::to_f32(tl.prev[u]) - casc_m) * casc_rl);
+      if (CASC && c == 0 && valid && j < prev_len)                                    // last step's probability of key j
+        atomicAdd(accp + j, __expf(DT<T>::to_f32((CASC && DYN && odd) ? tl.prev2[u] : tl.prev[u]) - casc_m) * casc_rl);
       if (maskp != nullptr) s = DT<T>::round(s + mk[u]);                               // :132
       s = (valid && j < n_vis) ? s : -INFINITY;
       sc[u] = s;
@@ -556,7 +575,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   };
   if (p.S == 1) {
     if (!SCORES_ONLY && tid < D) outp[tid] = DT<T>::from_f32(o_tot / l_tot);
-    if (p.lse != nullptr && tid == 0) { float* ls = p.lse + ((int64_t)(b * p.H + h) * p.lse_q + qi) * 2; ls[0] = m_run; ls[1] = l_tot; }
+    if (lse_cur != nullptr && tid == 0) { float* ls = lse_cur + ((int64_t)(b * p.H + h) * p.lse_q + qi) * 2; ls[0] = m_run; ls[1] = l_tot; }
     const bool need1 = KSRC == 1 && (1.0f / l_tot) < p.pq_thr;                          // max prob = exp(0) / sum
     if (KSRC == 1 && tid == 0) p.pq_need[unit] = need1 ? 1 : 0;
     if (!SCORES_ONLY && p.head_abs != nullptr) add_head_abs(o_tot / l_tot, tid < D, !need1);
@@ -683,7 +702,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
     add_head_abs(og / lg, g == 0, !(KSRC == 1 && s_ticket != 0u));
   }
   if (tid == 0) {
-    if (p.lse != nullptr) { float* ls = p.lse + ((int64_t)(b * p.H + h) * p.lse_q + qi) * 2; ls[0] = mg; ls[1] = lg; }
+    if (lse_cur != nullptr) { float* ls = lse_cur + ((int64_t)(b * p.H + h) * p.lse_q + qi) * 2; ls[0] = mg; ls[1] = lg; }
     if (KSRC == 1) p.pq_need[unit] = (1.0f / lg) < p.pq_thr ? 1 : 0;
     p.ws_cnt[2 * unit + 1] = gen + 1u;                                                         // next launch: new tag
     if (!p.poll_merge) __hip_atomic_store(p.ws_cnt + 2 * unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm the counter
@@ -775,12 +794,14 @@ static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_onl
 #define SPATTEN_LEAN(UU, CC, PP, DD)                                                                                    \
   hipLaunchKernelGGL((decode_lean_kernel<T, D, UU, CC, PP, DD>), grid, blk, 0, stream, p.krc, p.vc, p.q, p.cos, p.sin,   \
                      (int)p.kv_sb, (int)p.kv_sh, p.N, p.chunk, p.H, p.pos_q, p)
-      if (dyn) { if (pipe) SPATTEN_LEAN(UP, false, true, true); else SPATTEN_LEAN(U, false, false, true); }
+      if (dyn && casc) { if (pipe) SPATTEN_LEAN(UP, true, true, true); else SPATTEN_LEAN(U, true, false, true); }
+      else if (dyn) { if (pipe) SPATTEN_LEAN(UP, false, true, true); else SPATTEN_LEAN(U, false, false, true); }
       else if (pipe) { if (casc) SPATTEN_LEAN(UP, true, true, false); else SPATTEN_LEAN(UP, false, true, false); }
       else { if (casc) SPATTEN_LEAN(U, true, false, false); else SPATTEN_LEAN(U, false, false, false); }
 #undef SPATTEN_LEAN
     } else if (p.n_q == 1) {
-      if (dyn) { if (pipe) SPATTEN_LAUNCH(UP, 0, false, 0, true, false, true, true); else SPATTEN_LAUNCH(U, 0, false, 0, true, false, false, true); }
+      if (dyn && casc) { if (pipe) SPATTEN_LAUNCH(UP, 0, false, 0, true, true, true, true); else SPATTEN_LAUNCH(U, 0, false, 0, true, true, false, true); }
+      else if (dyn) { if (pipe) SPATTEN_LAUNCH(UP, 0, false, 0, true, false, true, true); else SPATTEN_LAUNCH(U, 0, false, 0, true, false, false, true); }
       else if (pipe) { if (casc) SPATTEN_LAUNCH(UP, 0, false, 0, true, true, true); else SPATTEN_LAUNCH(UP, 0, false, 0, true, false, true); }
       else { if (casc) SPATTEN_LAUNCH(U, 0, false, 0, true, true); else SPATTEN_LAUNCH(U, 0, false, 0, true); }
     } else {
@@ -815,11 +836,15 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   if (c.k_new && c.n_q != 1) return SPATTEN_ERR_INVALID;
   if (pq && (!pq->msb || !pq->lsb || !pq->scale || !pq->need || c.k_new || c.n_q != 1 || scores_only))
     return SPATTEN_ERR_INVALID;
-  if (c.acc && (!c.prev_scores || !c.prev_lse || c.mask || c.n_q != 1 || c.prev_len < 0 || c.prev_len > c.kv_len || scores_only))
+  if (c.acc && (!c.prev_scores || !c.prev_lse || c.mask || c.n_q != 1 || c.prev_len < 0 || (!c.step && c.prev_len > c.kv_len) || scores_only))
     return SPATTEN_ERR_INVALID;
   if (c.table_rows < c.kv_len || (!c.position_ids && c.pos_q + c.n_q > c.table_rows)) return SPATTEN_ERR_INVALID;
   // device-resident step state: the plain single-row step only (kv_len is then the BOUND the grid is laid out for)
-  if (c.step && (c.n_q != 1 || c.mask || c.position_ids || pq || scores_only || c.acc || c.causal)) return SPATTEN_ERR_INVALID;
+  if (c.step && (c.n_q != 1 || c.mask || c.position_ids || pq || scores_only || c.causal)) return SPATTEN_ERR_INVALID;
+  // ... with the fused cascade accumulation: `scores` / `lse` and `prev_scores` / `prev_lse` are the two buffers that swap
+  // roles every step (same strides, rows up to the bound)
+  if (c.step && c.acc && (!c.scores || !c.lse || !c.prev_scores || !c.prev_lse || c.pv_sb != c.sc_sb || c.pv_sh != c.sc_sh))
+    return SPATTEN_ERR_INVALID;
   if (c.head_dim != 64 && c.head_dim != 128 && c.head_dim != 256) return SPATTEN_ERR_UNSUPPORTED;
   if (c.dtype != SPATTEN_F32 && c.dtype != SPATTEN_F16 && c.dtype != SPATTEN_BF16) return SPATTEN_ERR_INVALID;
   const int units = c.batch * c.heads * c.n_q;          // workspace is indexed by the FULL head id
@@ -864,7 +889,7 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   p.pl_sb = pq ? pq->pl_sb : 0; p.pl_sh = pq ? pq->pl_sh : 0; p.ps_sb = pq ? pq->sc_sb : 0; p.ps_sh = pq ? pq->sc_sh : 0; \
   p.pq_thr = pq ? pq->threshold : 0.f; p.pq_need = pq ? pq->need : nullptr;                              \
   p.prev_scores = (const T*)c.prev_scores; p.pv_sb = c.pv_sb; p.pv_sh = c.pv_sh; p.prev_lse = c.prev_lse; \
-  p.acc = c.prev_len > 0 ? c.acc : nullptr; p.acc_sh = c.acc_sh; p.prev_len = c.prev_len;               \
+  p.acc = (c.prev_len > 0 || c.step) ? c.acc : nullptr; p.acc_sh = c.acc_sh; p.prev_len = c.prev_len;   \
   p.head_abs = c.head_abs;                                                                               \
   p.ws_err = (unsigned*)c.workspace;                                                                     \
   p.ws_cnt = c.workspace ? (unsigned*)((char*)c.workspace + kDecodeWsHeader) : (unsigned*)c.cos;         \

@@ -10,14 +10,19 @@
 
 namespace spatten {
 
-// state: int32 words {kv_len, pos_q, 0...} | cos rows [2][half] | sin rows [2][half]   (row 0: pos_q, row 1: kv_len - 1)
+// state: int32 words {kv_len, pos_q, steps since the last set, rows the previous step's stash holds, 0...}
+//        | cos rows [2][half] | sin rows [2][half]   (row 0: pos_q, row 1: kv_len - 1)
 template <typename T>
 __global__ void step_update_kernel(int32_t* st, const T* cos, const T* sin, int table_rows, int half, int set, int kv_len,
                                    int pos_q, int delta) {
   int n = set ? kv_len : st[0] + delta;
   int pq = set ? pos_q : st[1] + delta;
+  // words 2 / 3 (the fused cascade accumulation of a captured step, decode_attn.hip): how many steps ran since the set,
+  // and how many rows the PREVIOUS step's stash holds (0 for the first step after a set: nothing to fold)
+  const int cnt = set ? 0 : st[2] + 1;
+  const int prev = (set || st[2] == 0) ? 0 : st[0];
   __syncthreads();                         // every thread has read the old words before thread 0 replaces them
-  if (threadIdx.x == 0) { st[0] = n; st[1] = pq; }
+  if (threadIdx.x == 0) { st[0] = n; st[1] = pq; st[2] = cnt; st[3] = prev; }
   T* rows = reinterpret_cast<T*>(reinterpret_cast<char*>(st) + kStepHeader);
   const int rq = min(max(pq, 0), table_rows - 1);
   const int rn = min(max(n - 1, 0), table_rows - 1);

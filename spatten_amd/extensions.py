@@ -121,6 +121,48 @@ class SpattenExtensions:
     # ------------------------------------------------------------------------------------------------
     # attention forward, q_len == 1
     # ------------------------------------------------------------------------------------------------
+    def graph_capable(self) -> bool:
+        """Modes whose decode step runs in the device-length form (spatten_amd/graph.py): cascade importance and head
+        pruning — one fused launch with fixed buffers.  Progressive quantisation, local V pruning and the layer cascade
+        launch helper kernels with host lengths and stay eager."""
+        return self.pq_threshold is None and self.local_v_keep is None and self.layer_keep is None
+
+    def decode_step_graph(self, layer: int, q, k_new, v_new, slab, kv_len: int, cos, sin, gctx):
+        """The decode step under a DecodeGraph: every buffer at capacity and at a fixed address; with cascade importance
+        the two stash / (max, sum) buffers swap roles on the DEVICE (state word 2), so one captured graph serves every
+        token.  Returns (attn_output [B, H*d], stash view of the buffer this step writes)."""
+        if getattr(self, "_graph_bind", None) is not gctx.bind_id:     # first traced step of this binding (eager)
+            self.graph_begin()
+            self._graph_bind = gctx.bind_id
+        st = self.layers[layer]
+        B, H, d = q.shape
+        cap = slab.capacity
+        st.ensure(B, H, d, cap, q.dtype, q.device, self.cascade)
+        if st.stash[0].shape[2] < cap or (self.cascade and st.acc.shape[1] < cap):
+            raise RuntimeError("extension buffers smaller than the slab capacity")
+        casc = (st.acc, st.stash[1], st.lse[1], 0) if self.cascade else None
+        step = gctx.state_for(slab, cos, sin)
+        ops.attn_decode(q, slab.k, slab.kr, slab.v, cap, cos, sin, 0, k_new=k_new, v_new=v_new, out=st.out,
+                        scores=st.stash[0], lse=st.lse[0], head_ids=st.head_ids, cascade=casc,
+                        head_abs=st.head_abs if self.head_keep is not None else None, step=step)
+        cur = (gctx.steps_traced & 1) if self.cascade else 0
+        return st.out, st.stash[cur][:, :, None, :kv_len]
+
+    def graph_begin(self):
+        """A DecodeGraph binds: fold whatever decode step is still pending and start from buffer 0."""
+        for layer, st in enumerate(self.layers):
+            self.flush(layer)
+            st.parity = 0
+
+    def graph_sync(self, steps: int, length: int):
+        """Host view of the per-layer state after ``steps`` device-length steps (replays do not run Python)."""
+        for st in self.layers:
+            if st.stash[0] is None:
+                continue
+            if self.cascade:
+                st.parity = steps & 1
+                st.pending_len = length if steps > 0 else st.pending_len
+
     def decode_step(self, layer: int, q, k_new, v_new, slab, kv_len: int, past_len: int, cos, sin):
         """q [B,H,d], k_new / v_new [B,Hkv,d].  Returns (attn_output [B, H*d], stash view [B,H,1,kv_len])."""
         st = self.layers[layer]
@@ -151,8 +193,11 @@ class SpattenExtensions:
             if head_abs is not None:
                 ops.head_scores(st.out, H, st.head_abs_prefill)
         else:
+            # (splits laid out for the slab capacity, like the plain plugin step: eager and captured steps then agree
+            # bit for bit — kv_slab.KVSlab.decode_step)
             ops.attn_decode(q, slab.k, slab.kr, slab.v, kv_len, cos, sin, past_len, k_new=k_new, v_new=v_new,
-                            out=st.out, scores=stash, lse=lse, head_ids=st.head_ids, cascade=casc, head_abs=head_abs)
+                            out=st.out, scores=stash, lse=lse, head_ids=st.head_ids, cascade=casc, head_abs=head_abs,
+                            layout=slab.capacity)
         if self.cascade:
             st.pending_len = kv_len
         return st.out, stash[:, :, None, :kv_len]

@@ -17,8 +17,9 @@ rebuilt on demand.  So:
 
 ``step_fn`` is whatever runs one token through the patched model, e.g.
 ``lambda past, tok: (lambda o: (o.past_key_values, o.logits))(model(tok, past_key_values=past, use_cache=True))``.
-Requirements: batch and shapes fixed; the plain plugin path (the SpAtten extension modes run eagerly); the HF mask /
-position_ids of the step are the ones transformers 4.33 builds (zeros / the past length) — they are not read.
+Requirements: batch and shapes fixed; the plain plugin path or the cascade-importance / head-pruning modes (progressive
+quantisation, local V pruning and the layer cascade run eagerly); the HF mask / position_ids of the step are the ones
+transformers 4.33 builds (zeros / the past length) — they are not read.
 
 Numerics: every step — the warm-up, and a plain eager step through the patched forward on slabs of the same capacity —
 lays its split-N decomposition out for the slab capacity, so graph replays and eager steps agree bit for bit
@@ -53,6 +54,8 @@ class DecodeGraph:
         self.static_in: Optional[List[torch.Tensor]] = None
         self.static_out = None
         self.n_replays = 0
+        self.steps_traced = 0                   # device-length steps since the state was set (= state word 2 before a step)
+        self._ext = None                        # SpattenExtensions of the patched modules, once a traced step met them
         self._past = None
         self._bind(past_key_values)
 
@@ -65,6 +68,8 @@ class DecodeGraph:
         self.graph = None
         self.state = None
         self.touched = []
+        self.steps_traced = 0
+        self.bind_id = object()                 # identity of this binding: the extensions restart their buffers with it
 
     def state_for(self, slab, cos, sin) -> ops.StepState:
         """Called by the patched forward while a step is traced: the step state every layer shares."""
@@ -108,6 +113,7 @@ class DecodeGraph:
                 out = self._trace(inputs)
             cur.wait_stream(self.stream)
             self.length += 1
+            self.steps_traced += 1
             return out
         if self.graph is None:
             self.static_in = [x.clone() if isinstance(x, torch.Tensor) else x for x in inputs]
@@ -124,6 +130,7 @@ class DecodeGraph:
         self.graph.replay()
         self.n_replays += 1
         self.length += 1
+        self.steps_traced += 1
         return self.static_out
 
     @property
@@ -136,8 +143,18 @@ class DecodeGraph:
             slab.length = slab.rot_len = self.length
             k, v = slab.views()
             out.append([k, v])
-        for module, slab in self.touched:
-            if slab.stash is not None:
-                object.__setattr__(module, "attn_scores", slab.stash[:, :, None, :self.length])
+        synced = set()
+        for module, slab, ext in self.touched:
+            if ext is None:
+                if slab.stash is not None:
+                    object.__setattr__(module, "attn_scores", slab.stash[:, :, None, :self.length])
+                continue
+            exts, layer = ext
+            if id(exts) not in synced:          # replays do not run Python: bring the per-layer host state up to date
+                exts.graph_sync(self.steps_traced, self.length)
+                synced.add(id(exts))
+            st = exts.layers[layer]
+            cur = ((self.steps_traced - 1) & 1) if (exts.cascade and self.steps_traced > 0) else 0
+            object.__setattr__(module, "attn_scores", st.stash[cur][:, :, None, :self.length])
         self._past = out
         return out

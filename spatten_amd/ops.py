@@ -144,6 +144,7 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: Opti
     traffic (pass 1 of local V pruning).
     cascade = (acc [H,>=prev_len] fp32, prev_scores [B,H,>=prev_len], prev_lse [B,H,2], prev_len): the PREVIOUS decode
     step's softmax probabilities are added to acc while this step streams (cumulative importance, no extra launch).
+    With ``step``: scores / lse and prev_scores / prev_lse are the two buffers that swap roles every step (prev_len unused).
     pq = (PQPlanes, threshold, need_lsb int32 [B*H]): keys come from the progressive-quantisation planes (MSB pass,
     LSB refetch for heads whose max probability is below threshold) instead of kr_cache.
     head_abs fp32 [B*H]: += sum |out| per (b, h) (cumulative head importance for head pruning).
@@ -266,10 +267,10 @@ class StepState:
         _lib.check(self.lib.spatten_step_advance(self.buf.data_ptr(), self.dt, self.d, self.cos.data_ptr(), self.sin.data_ptr(),
                                                  self.cos.shape[0], int(delta), _stream()), "spatten_step_advance")
 
-    def read(self):
-        """(kv_len, pos_q) — synchronises; for tests and assertions."""
-        w = self.buf[:8].view(torch.int32).cpu()
-        return int(w[0]), int(w[1])
+    def read(self, all_words: bool = False):
+        """(kv_len, pos_q) [, steps since the last set, rows of the previous step's stash] — synchronises; for tests."""
+        w = self.buf[:16].view(torch.int32).cpu()
+        return tuple(int(x) for x in w) if all_words else (int(w[0]), int(w[1]))
 
 
 class SlabDecodeCall:

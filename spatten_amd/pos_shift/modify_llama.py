@@ -205,9 +205,13 @@ def llama_pos_shift_attention_forward(
         q3 = query_states.view(bsz, num_heads, head_dim)
         k3, v3 = key_states.view(bsz, num_kv_heads, head_dim), value_states.view(bsz, num_kv_heads, head_dim)
         gctx = kv_slab.graph_ctx
-        if ext is not None:
-            if gctx is not None:
-                raise RuntimeError("DecodeGraph captures the plain decode step; the SpAtten extension modes run eagerly")
+        if ext is not None and gctx is not None:
+            if not ext[0].graph_capable():
+                raise RuntimeError("DecodeGraph captures the plain decode step and the cascade-importance / head-pruning "
+                                   "modes; progressive quantisation, local V pruning and the layer cascade run eagerly")
+            attn_output, stash = ext[0].decode_step_graph(ext[1], q3, k3, v3, slab, kv_seq_len, cos, sin, gctx)
+            gctx.touched.append((self, slab, ext))
+        elif ext is not None:
             attn_output, stash = ext[0].decode_step(ext[1], q3, k3, v3, slab, kv_seq_len, past_len, cos, sin)
         elif gctx is not None:
             # a DecodeGraph is warming up / capturing this step (spatten_amd/graph.py): the cache length is read from the
@@ -217,7 +221,7 @@ def llama_pos_shift_attention_forward(
             row = slab.stash_row(num_heads)
             attn_output = slab.decode_step(q3, k3, v3, kv_seq_len, past_len, cos, sin, row, step=gctx.state_for(slab, cos, sin))
             stash = row[:, :, None, :kv_seq_len]
-            gctx.touched.append((self, slab))
+            gctx.touched.append((self, slab, None))
         else:
             # the slab's prefilled argument block (host-path fast lane: per token only pointers and two lengths are
             # written).  With assume_causal the HF mask of a single-token step (all zeros) and its position_ids are not

@@ -351,3 +351,56 @@ def test_decode_graph_holds_the_head_parallel_exchange():
         assert graph.n_replays == 7
     finally:
         hp.close_native()
+
+
+@pytest.mark.parametrize("kw", [dict(importance_mode="cascade"), dict(head_keep=[6, 5, 5]),
+                                dict(importance_mode="cascade", head_keep=6, fuse_qkv=True, native_gemv=True)])
+def test_decode_graph_covers_cascade_importance_and_head_pruning(kw):
+    """The SpAtten modes whose decode step is ONE fused launch — cumulative importance (the previous step's probabilities
+    folded while this step streams; under the graph the two stash buffers swap roles on the device) and head pruning
+    (head list + fused head importance) — replayed from one captured graph: hidden states of every token equal the eager
+    loop's bit for bit, and so do the accumulators, the head scores and the prune event that follows (kept positions,
+    kept heads, compacted caches); then a second turn on the pruned caches."""
+    from spatten_amd.graph import DecodeGraph
+    dt = torch.bfloat16
+    a, b, (cache_a, cache_b) = _models(dt, **kw)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    P, T = 180, 9
+    x0 = torch.randn(1, P, HID, device="cuda", generator=g).to(dt)
+    _, past_a = a(x0, None)
+    _, past_b = b(x0, None)
+    for turn in range(2):
+        graph = DecodeGraph(lambda past, x: tuple(reversed(b(x, past))), past_b, horizon=T)
+        for t in range(T):
+            x = torch.randn(1, 1, HID, device="cuda", generator=g).to(dt)
+            ya, past_a = a(x, past_a)
+            yb = graph.step(x)
+            torch.cuda.synchronize()
+            assert torch.equal(ya, yb), (turn, t, (ya.float() - yb.float()).abs().max().item())
+        assert graph.n_replays == T - 1
+        past_b = graph.past_key_values
+        n = past_a[0][0].shape[2]
+        for ma, mb, la in zip(a.layers, b.layers, cache_a.ext.layers):
+            if la.head_ids is None:
+                assert torch.equal(ma.attn_scores, mb.attn_scores)
+            else:           # pruned heads are not launched: their stash rows are whatever an earlier step left there
+                kept = la.head_ids.long()
+                assert torch.equal(ma.attn_scores[:, kept], mb.attn_scores[:, kept])
+        coming = 6 + T
+        launched = [slice(None) if la.head_ids is None else la.head_ids.long() for la in cache_a.ext.layers]   # heads of this turn
+        new_a = cache_a.apply_token_pruning(past_a, coming, [m.attn_scores for m in a.layers])
+        new_b = cache_b.apply_token_pruning(past_b, coming, [m.attn_scores for m in b.layers])
+        assert new_a is not past_a
+        for la, lb, hk in zip(cache_a.ext.layers, cache_b.ext.layers, launched):
+            if cache_a.ext.cascade:
+                assert torch.equal(la.acc[hk, :new_a[0][0].shape[2]], lb.acc[hk, :new_a[0][0].shape[2]])
+            assert torch.equal(la.head_abs, lb.head_abs)
+            assert (la.head_ids is None and lb.head_ids is None) or torch.equal(la.head_ids, lb.head_ids)
+        for (ka, va), (kb, vb), la in zip(new_a, new_b, cache_a.ext.layers):
+            kept = slice(None) if la.head_ids is None else la.head_ids.long()
+            assert torch.equal(ka[:, kept], kb[:, kept]) and torch.equal(va[:, kept], vb[:, kept])
+        if "head_keep" in kw:
+            assert any(st.head_ids is not None for st in cache_b.ext.layers)
+        xp = torch.randn(1, 6, HID, device="cuda", generator=g).to(dt)
+        _, past_a = a(xp, new_a)
+        _, past_b = b(xp, new_b)
