@@ -35,6 +35,8 @@
 // P in fp32.  Tolerance stated in tests/util.py.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 #ifdef SPATTEN_TRACE   // developer instrumentation: per-workgroup phase timestamps (tools/mb/decode_trace.cpp)
@@ -749,6 +751,11 @@ static int auto_splits(int units, int d, int kv_len) {
   if (env_s > 0) s = env_s;
   const int max_by_len = ceil_div(kv_len, 2 * decode_group_rows(d));   // at least two row-groups per split
   if (s > max_by_len) s = max_by_len;
+  // few units (a head-parallel rank holding 4-8 heads): the launch is pure latency, and every 16 further splits are one
+  // more round trip of the merge — r03, 4 heads x 2081 rows: 33 splits 9.7 us, 16 splits 8.45; 5 heads x 8192 rows: 51
+  // splits 12.4 us, 32 splits 10.9 (tools/probe_few_heads.py).  One round unless the rows are long enough to pay for more.
+  const int cap_by_merge = std::max(16, ceil_div(kv_len, 256));
+  if (env_s <= 0 && s > cap_by_merge) s = cap_by_merge;
   if (s < 1) s = 1;
   if (s > kDecodeMaxSplits) s = kDecodeMaxSplits;
   return s;
