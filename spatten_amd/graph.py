@@ -119,8 +119,17 @@ class DecodeGraph:
             self.static_in = [x.clone() if isinstance(x, torch.Tensor) else x for x in inputs]
             self.stream.wait_stream(cur)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self.stream):
-                self.static_out = self._trace(self.static_in)
+            # capture_begin / capture_end directly: the torch.cuda.graph context manager also runs gc.collect() and
+            # torch.cuda.empty_cache() on entry — after a prune the previous turn's slabs (1.6 GB at Llama-2-7B) sit in the
+            # caching allocator, and handing them back to the driver cost 20 ms per turn here, plus the hipMallocs of the
+            # next prune.
+            with torch.cuda.stream(self.stream):
+                self.stream.synchronize()
+                g.capture_begin()
+                try:
+                    self.static_out = self._trace(self.static_in)
+                finally:
+                    g.capture_end()
             cur.wait_stream(self.stream)
             self.graph = g
         else:
