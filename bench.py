@@ -702,6 +702,19 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             result["prune_event"]["cascade_prune_event_us"] = round(e0.elapsed_time(e1) * 1e3 / 5, 1)
+            # layer-to-layer cascade (the traces' key_fetch_num shrinks layer by layer): layer l keeps k_l window tokens
+            # among those layer l-1 kept, k from 1020 down to 510; one chain kernel (a workgroup per head walks the
+            # layers) + ragged gathers; includes the allocation of the new planes (ops.prune_layer_cascade returns them)
+            keeps_lc = [IMPORTANT - (IMPORTANT // 2) * l // (L - 1) for l in range(L)]
+            lc = lambda: ops.prune_layer_cascade(importance, [None] * L, 0, Kp, Vp, [CTX] * L, [hi] * L, keeps_lc, START,
+                                                 [cap] * L, (cos, sin), accs)
+            lc()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                lc()
+            torch.cuda.synchronize()
+            result["prune_event"]["layer_cascade_prune_event_us_incl_allocation"] = round((time.perf_counter() - t0) / 3 * 1e6, 1)
             del accs, acc_new, plan3
             prune()   # restore the shadow planes for whatever runs next
 

@@ -373,6 +373,25 @@ int spatten_importance_compact(const float* src, int64_t src_sh, float* dst, int
 int spatten_cascade_rank(int dtype, const void* score, int64_t score_sh, const int32_t* ids, int64_t ids_sh,
                          const int32_t* prev_ids, int64_t prev_sh, int n_prev, float* rank, int64_t rank_sh,
                          int heads, int len, void* stream);
+/* The whole prune event of the layer-to-layer cascade in three launches (one workgroup per head walks the layers — the
+ * dependency "layer l chooses among the tokens layer l-1 kept" runs per head —, one ragged K/V gather + shadow, one ragged
+ * accumulator gather).  Per-layer geometry travels as a table of 16 int64 words per layer, given twice: in DEVICE memory
+ * (read by the kernels) and in host memory (validated, sizes the grids):
+ *   { len, hi, k, new_len,  score_sh, n_known, known_sh, new_ids_sh,  src_sb, src_sh, dst_sb, dst_sh,  acc_src_sh, acc_dst_sh,
+ *     id_base, 0 }   with new_len = start + k + (len - hi), k non-increasing over the layers.
+ * score_ptrs[l] -> [H, >= len] importance in score_dtype; known_ptrs[l] -> int32 [H, n_known] token ids of the slots the
+ * last prune left (NULL when n_known = 0), slots j >= n_known hold token id_base + (j - n_known) (appended since);
+ * new_ids_ptrs[l] -> int32 [H, new_len] out; idx int32 [layers, H, kmax] out (kept window positions, ascending);
+ * key_scratch uint32 [H, key_scratch_sh >= max window]; K / V / shadow / accumulator pointer tables as in
+ * spatten_prune_layers_scored (accumulators optional).  Same selection as spatten_cascade_rank + spatten_topk_select. */
+int spatten_prune_layer_cascade(int score_dtype, int kv_dtype, int layers, const void* lay_dev, const void* lay_host,
+                                const void* const* score_ptrs, const int32_t* const* known_ptrs, int32_t* const* new_ids_ptrs,
+                                const void* const* k_src_ptrs, const void* const* v_src_ptrs,
+                                void* const* k_dst_ptrs, void* const* v_dst_ptrs, void* const* kr_dst_ptrs /* optional */,
+                                const void* cos, const void* sin, int table_rows,
+                                int32_t* idx, int kmax, uint32_t* key_scratch, int64_t key_scratch_sh,
+                                const float* const* acc_src_ptrs, float* const* acc_dst_ptrs /* both or neither */,
+                                int batch, int heads, int head_dim, int start, void* stream);
 /* Head importance (head pruning, README.md:21): scores[h] += sum over b, i, d of |out[b, i, h*d : (h+1)*d]|; out [B,q,H*d]. */
 int spatten_head_scores(int dtype, const void* out, int64_t out_sb, int64_t out_sq, float* scores,
                         int batch, int q_len, int heads, int head_dim, void* stream);

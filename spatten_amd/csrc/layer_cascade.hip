@@ -1,0 +1,284 @@
+// layer_cascade.hip — the prune event of the layer-to-layer cascade (README.md:11; the traces' `key_fetch_num` shrinks
+// layer by layer: spatten_hardware/hardware/workloads/*.csv) for ALL layers in three launches.
+// PARITY UNPINNED (no numeric implementation in the reference; oracle: layer_cascade_prune).
+//
+// Layer l keeps k_l tokens of its window, ranked by its own importance but among the tokens layer l-1 just kept.  That
+// dependency runs PER HEAD — head h of layer l only needs head h's kept ids of layer l-1 — so one workgroup per head
+// walks the layers in order and no launch boundary separates them (round 2: a Python loop of rank -> select -> id gather
+// -> K/V gather per layer, ~10 launches x 32 layers).  Then ONE ragged gather moves K / V / shadow rows of every layer
+// (the layers keep different numbers of rows, so lengths and strides come from a per-layer table), and one moves the
+// cascade accumulators.
+#include "common.h"
+
+namespace spatten {
+
+// per-layer geometry, DEVICE array (all lengths in rows / elements)
+struct LayerPrune {
+  int64_t len, hi, k, new_len;         // cache length, window end (= tail start), kept in the window, new length
+  int64_t score_sh, n_known, known_sh, new_ids_sh;   // importance row stride; token ids known for slots [0, n_known)
+  int64_t src_sb, src_sh, dst_sb, dst_sh;            // K / V planes (elements)
+  int64_t acc_src_sh, acc_dst_sh, id_base, pad_;     // fp32 accumulators; ids of slots >= n_known are id_base + (j - n_known)
+};
+static_assert(sizeof(LayerPrune) == 128, "table stride");
+
+struct ChainParams {
+  const LayerPrune* lay;
+  const void* const* score_ptrs;       // [layers] -> [H, >= len] scores (model dtype or fp32)
+  const int32_t* const* known_ptrs;    // [layers] -> int32 [H, n_known] token ids of the slots seen by the last prune (may be NULL rows)
+  int32_t* const* new_ids_ptrs;        // [layers] -> int32 [H, new_len] out: ids of the new cache's slots
+  int32_t* idx; int64_t idx_sl, idx_sh;   // [layers, H, kmax] out: kept window positions, ascending
+  uint32_t* keys; int64_t keys_sh;     // [H, >= max window] scratch
+  int layers, start;
+};
+
+__device__ inline int32_t slot_id(const LayerPrune& L, const int32_t* known, int j) {
+  return j < (int)L.n_known ? known[j] : (int32_t)(L.id_base + (j - L.n_known));
+}
+
+// one workgroup per head walks the layers: rank (membership in the previous layer's kept ids -> score or -inf), exact top-k
+// of the window (radix select, ties: lowest position), the new slot ids.  Same keys, tie rule and output order as
+// cascade_rank_kernel + topk_select_kernel<float> + the id gather of round 2.
+template <typename T>
+__global__ __launch_bounds__(256) void layer_cascade_select_kernel(const ChainParams p) {
+  __shared__ unsigned s_hist[256];
+  __shared__ unsigned s_sel[2];
+  __shared__ unsigned s_cnt[2][4][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.x;
+  uint32_t* keys = p.keys + h * p.keys_sh;
+  const int32_t* prev = nullptr;
+  int n_prev = 0;
+  for (int l = 0; l < p.layers; ++l) {
+    const LayerPrune L = p.lay[l];
+    const T* score = (const T*)p.score_ptrs[l] + h * L.score_sh;
+    const int32_t* known = p.known_ptrs[l] ? p.known_ptrs[l] + h * L.known_sh : nullptr;
+    const int W = (int)L.hi - p.start, k = (int)L.k;
+    int32_t* out = p.idx + l * p.idx_sl + h * p.idx_sh;
+    // ---- keys of the window
+    for (int i = tid; i < W; i += 256) {
+      const int j = p.start + i;
+      bool member = true;
+      if (prev) {
+        const int32_t want = slot_id(L, known, j);
+        int lo = 0, hi = n_prev;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (prev[mid] < want) lo = mid + 1; else hi = mid; }
+        member = lo < n_prev && prev[lo] == want;
+      }
+      keys[i] = ordered_key(member ? DT<T>::to_f32(score[j]) : -INFINITY);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- the key of the k-th largest (8-bit digits, most significant first)
+    unsigned prefix = 0, pmask = 0, k_rem = (unsigned)k;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      s_hist[tid] = 0;
+      __syncthreads();
+      for (int i = tid; i < W; i += 256) {
+        const unsigned key = keys[i];
+        if ((key & pmask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (wave == 0) {
+        unsigned c[4], tot = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c[j] = s_hist[255 - 4 * lane - j]; tot += c[j]; }
+        unsigned inc = tot;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+          const unsigned t = __shfl_up(inc, off, kWave);
+          if (lane >= off) inc += t;
+        }
+        unsigned ex = inc - tot;
+        if (ex < k_rem && k_rem <= inc) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (ex < k_rem && k_rem <= ex + c[j]) { s_sel[0] = 255 - 4 * lane - j; s_sel[1] = ex; }
+            ex += c[j];
+          }
+        }
+      }
+      __syncthreads();
+      prefix |= s_sel[0] << shift;
+      pmask |= 255u << shift;
+      k_rem -= s_sel[1];
+    }
+    const unsigned thr = prefix, need_eq = k_rem;
+    // ---- order-preserving compaction: everything above the threshold, the first need_eq at it
+    unsigned run_eq = 0, run_kept = 0;
+    int parity = 0;
+    for (int base = 0; base < W; base += 256, parity ^= 1) {
+      const int i = base + tid;
+      const bool in = i < W;
+      const unsigned key = in ? keys[i] : 0u;
+      const bool gt = in && key > thr, eq = in && key == thr;
+      const unsigned long long m_gt = __ballot(gt), m_eq = __ballot(eq);
+      if (lane == 0) { s_cnt[parity][wave][0] = __popcll(m_gt); s_cnt[parity][wave][1] = __popcll(m_eq); }
+      __syncthreads();
+      unsigned eq_base = run_eq, kept_base = run_kept, tot_eq = run_eq, tot_kept = run_kept;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const unsigned g = s_cnt[parity][w][0], e = s_cnt[parity][w][1];
+        const unsigned room = tot_eq < need_eq ? need_eq - tot_eq : 0u;
+        const unsigned kept_w = g + (e < room ? e : room);
+        if (w < wave) { eq_base += e; kept_base += kept_w; }
+        tot_eq += e;
+        tot_kept += kept_w;
+      }
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      const bool keep = gt || (eq && eq_base + __popcll(m_eq & lt) < need_eq);
+      const unsigned pos = kept_base + __popcll(__ballot(keep) & lt);
+      if (keep && pos < (unsigned)k) out[pos] = p.start + i;
+      run_eq = tot_eq;
+      run_kept = tot_kept;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- the ids of the new cache's slots (start | kept | tail): what the next layer tests membership against
+    int32_t* nid = p.new_ids_ptrs[l] + h * L.new_ids_sh;
+    const int lp = (int)L.new_len;
+    for (int r = tid; r < lp; r += 256) {
+      const int src = r < p.start ? r : (r < p.start + k ? out[r - p.start] : (int)L.hi + (r - p.start - k));
+      nid[r] = slot_id(L, known, src);
+    }
+    __threadfence_block();
+    __syncthreads();
+    prev = nid;
+    n_prev = lp;
+  }
+}
+
+struct RaggedParams {
+  const LayerPrune* lay;
+  const void* const* k_src_ptrs; const void* const* v_src_ptrs;
+  void* const* k_dst_ptrs; void* const* v_dst_ptrs; void* const* kr_dst_ptrs;
+  const void* cos; const void* sin; int table_rows;
+  const int32_t* idx; int64_t idx_sl, idx_sh;
+  int B, H, start, row_bytes, es, half_ppr, rows_per_block;
+};
+
+// the fused gather + concat (+ rotated shadow) of kv_compact_kernel with every layer's own lengths and strides
+template <typename T>
+__global__ __launch_bounds__(256) void kv_compact_ragged_kernel(const RaggedParams p) {
+  const int layer = blockIdx.z >> 1, t = blockIdx.z & 1;
+  const LayerPrune L = p.lay[layer];
+  const int rloc = threadIdx.x / p.half_ppr, piece = threadIdx.x - rloc * p.half_ppr;
+  const int r = blockIdx.x * p.rows_per_block + rloc;
+  if (rloc >= p.rows_per_block || r >= (int)L.new_len) return;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int k = (int)L.k, half_bytes = p.row_bytes >> 1;
+  int src_row;
+  if (r < p.start) src_row = r;
+  else if (r < p.start + k) src_row = p.idx[layer * p.idx_sl + h * p.idx_sh + (r - p.start)];
+  else src_row = (int)L.hi + (r - p.start - k);
+  const char* sbase = (const char*)(t == 0 ? p.k_src_ptrs[layer] : p.v_src_ptrs[layer]);
+  char* dbase = (char*)(t == 0 ? p.k_dst_ptrs[layer] : p.v_dst_ptrs[layer]);
+  const char* sp = sbase + (b * L.src_sb + h * L.src_sh) * p.es + (int64_t)src_row * p.row_bytes + piece * 16;
+  const int64_t doff = (b * L.dst_sb + h * L.dst_sh) * p.es + (int64_t)r * p.row_bytes + piece * 16;
+  const u32x4 lo_v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp));
+  const u32x4 hi_v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp + half_bytes));
+  __builtin_nontemporal_store(lo_v, reinterpret_cast<u32x4*>(dbase + doff));
+  __builtin_nontemporal_store(hi_v, reinterpret_cast<u32x4*>(dbase + doff + half_bytes));
+  if (t == 0 && p.kr_dst_ptrs) {       // the rotated shadow of the new cache: row r at position r (modify_llama.py:103-104)
+    const int pos = min(r, p.table_rows - 1);
+    const int64_t toff = (int64_t)pos * half_bytes + piece * 16;
+    const u32x4 cs = *reinterpret_cast<const u32x4*>((const char*)p.cos + toff);
+    const u32x4 sn = *reinterpret_cast<const u32x4*>((const char*)p.sin + toff);
+    constexpr int E = 16 / sizeof(T);
+    const T* xl = reinterpret_cast<const T*>(&lo_v);
+    const T* xh = reinterpret_cast<const T*>(&hi_v);
+    const T* cc = reinterpret_cast<const T*>(&cs);
+    const T* ss = reinterpret_cast<const T*>(&sn);
+    u32x4 olo, ohi;
+    T* yl = reinterpret_cast<T*>(&olo);
+    T* yh = reinterpret_cast<T*>(&ohi);
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float a = DT<T>::to_f32(xl[e]), bb = DT<T>::to_f32(xh[e]);
+        const float c = DT<T>::to_f32(cc[e]), s_ = DT<T>::to_f32(ss[e]);
+        yl[e] = DT<T>::from_f32(DT<T>::round(a * c) + DT<T>::round(-bb * s_));
+        yh[e] = DT<T>::from_f32(DT<T>::round(bb * c) + DT<T>::round(a * s_));
+      }
+    }
+    char* rbase = (char*)p.kr_dst_ptrs[layer];
+    __builtin_nontemporal_store(olo, reinterpret_cast<u32x4*>(rbase + doff));
+    __builtin_nontemporal_store(ohi, reinterpret_cast<u32x4*>(rbase + doff + half_bytes));
+  }
+}
+
+__global__ __launch_bounds__(256) void acc_compact_ragged_kernel(const LayerPrune* __restrict__ lay,
+                                                                 const float* const* __restrict__ src_ptrs,
+                                                                 float* const* __restrict__ dst_ptrs,
+                                                                 const int32_t* __restrict__ idx, int64_t idx_sl, int64_t idx_sh,
+                                                                 int start) {
+  const int r = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, l = blockIdx.z;
+  const LayerPrune L = lay[l];
+  if (r >= (int)L.new_len) return;
+  const int k = (int)L.k;
+  const int j = r < start ? r : (r < start + k ? idx[l * idx_sl + h * idx_sh + (r - start)] : (int)L.hi + (r - start - k));
+  dst_ptrs[l][h * L.acc_dst_sh + r] = src_ptrs[l][h * L.acc_src_sh + j];
+}
+
+}  // namespace spatten
+
+using namespace spatten;
+
+extern "C" int spatten_prune_layer_cascade(int score_dtype, int kv_dtype, int layers, const void* lay_dev, const void* lay_host,
+                                           const void* const* score_ptrs, const int32_t* const* known_ptrs,
+                                           int32_t* const* new_ids_ptrs, const void* const* k_src_ptrs,
+                                           const void* const* v_src_ptrs, void* const* k_dst_ptrs, void* const* v_dst_ptrs,
+                                           void* const* kr_dst_ptrs, const void* cos, const void* sin, int table_rows,
+                                           int32_t* idx, int kmax, uint32_t* key_scratch, int64_t key_scratch_sh,
+                                           const float* const* acc_src_ptrs, float* const* acc_dst_ptrs, int batch, int heads,
+                                           int head_dim, int start, void* stream) {
+  if (!ok_dtype(score_dtype) || !ok_dtype(kv_dtype) || layers <= 0 || !lay_dev || !lay_host || !score_ptrs || !known_ptrs ||
+      !new_ids_ptrs || !k_src_ptrs || !v_src_ptrs || !k_dst_ptrs || !v_dst_ptrs || !idx || !key_scratch || batch <= 0 ||
+      heads <= 0 || start < 0 || kmax <= 0)
+    return SPATTEN_ERR_INVALID;
+  if ((acc_src_ptrs == nullptr) != (acc_dst_ptrs == nullptr)) return SPATTEN_ERR_INVALID;
+  if (kr_dst_ptrs && (!cos || !sin)) return SPATTEN_ERR_INVALID;
+  const LayerPrune* H_ = (const LayerPrune*)lay_host;
+  int64_t max_new = 0, prev_k = -1;
+  for (int l = 0; l < layers; ++l) {
+    const LayerPrune& L = H_[l];
+    if (L.len <= 0 || L.hi > L.len || L.hi < start || L.k <= 0 || L.k > kmax || L.new_len != start + L.k + (L.len - L.hi) ||
+        L.n_known < 0 || L.n_known > L.len)
+      return SPATTEN_ERR_INVALID;
+    if (L.hi - start < L.k) return SPATTEN_ERR_WINDOW;
+    if (L.hi - start > key_scratch_sh) return SPATTEN_ERR_INVALID;
+    if (kr_dst_ptrs && table_rows < L.new_len) return SPATTEN_ERR_INVALID;
+    if (prev_k >= 0 && L.k > prev_k) return SPATTEN_ERR_INVALID;       // the surviving set does not grow through the layers
+    prev_k = L.k;
+    max_new = L.new_len > max_new ? L.new_len : max_new;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  ChainParams c{};
+  c.lay = (const LayerPrune*)lay_dev; c.score_ptrs = score_ptrs; c.known_ptrs = known_ptrs; c.new_ids_ptrs = new_ids_ptrs;
+  c.idx = idx; c.idx_sl = (int64_t)heads * kmax; c.idx_sh = kmax; c.keys = key_scratch; c.keys_sh = key_scratch_sh;
+  c.layers = layers; c.start = start;
+  SPATTEN_BY_DTYPE(score_dtype, hipLaunchKernelGGL((layer_cascade_select_kernel<T>), dim3((unsigned)heads), dim3(256), 0, st, c));
+  if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
+  const int es = kv_dtype == SPATTEN_F32 ? 4 : 2;
+  RaggedParams r{};
+  r.lay = (const LayerPrune*)lay_dev; r.k_src_ptrs = k_src_ptrs; r.v_src_ptrs = v_src_ptrs; r.k_dst_ptrs = k_dst_ptrs;
+  r.v_dst_ptrs = v_dst_ptrs; r.kr_dst_ptrs = kr_dst_ptrs; r.cos = cos; r.sin = sin; r.table_rows = table_rows;
+  r.idx = idx; r.idx_sl = (int64_t)heads * kmax; r.idx_sh = kmax;
+  r.B = batch; r.H = heads; r.start = start; r.row_bytes = head_dim * es; r.es = es;
+  if (r.row_bytes % 32 != 0) return SPATTEN_ERR_UNSUPPORTED;
+  r.half_ppr = r.row_bytes / 32;
+  if (r.half_ppr > 256) return SPATTEN_ERR_UNSUPPORTED;
+  r.rows_per_block = 256 / r.half_ppr;
+  if ((long long)batch * heads > 65535 || 2 * layers > 65535) return SPATTEN_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)ceil_div((int)max_new, r.rows_per_block), (unsigned)(batch * heads), (unsigned)(2 * layers));
+  SPATTEN_BY_DTYPE(kv_dtype, hipLaunchKernelGGL((kv_compact_ragged_kernel<T>), grid, dim3(256), 0, st, r));
+  if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
+  if (acc_src_ptrs) {
+    hipLaunchKernelGGL(acc_compact_ragged_kernel, dim3((unsigned)ceil_div((int)max_new, 256), (unsigned)heads, (unsigned)layers),
+                       dim3(256), 0, st, (const LayerPrune*)lay_dev, acc_src_ptrs, acc_dst_ptrs, idx, (int64_t)heads * kmax,
+                       (int64_t)kmax, start);
+    if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
+  }
+  return SPATTEN_OK;
+}

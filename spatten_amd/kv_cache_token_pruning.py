@@ -175,46 +175,51 @@ class SpAttenKVCache:
 
     def _prune_layer_cascade(self, past_key_values, num_coming, attn_score_all):
         """Layer-to-layer cascade (extension, parity unpinned; oracle: layer_cascade_prune): layer l keeps layer_keep[l]
-        window tokens, chosen among the tokens layer l-1 just kept; layers end up with different cache lengths."""
+        window tokens, chosen among the tokens layer l-1 just kept; layers end up with different cache lengths.  All layers
+        in three launches (ops.prune_layer_cascade): the chain "layer l chooses among what layer l-1 kept" runs per head
+        inside one kernel, then one ragged K/V gather and one ragged accumulator gather."""
         ext = self.ext
-        out, idxs = [], []
-        self.importance_score = []
-        prev_ids = None
-        new_ids = []
-        pruned = 0
+        n_layers = len(past_key_values)
+        start = self.start_size
+        Ks, Vs, lens, his, keeps, scores, caps = [], [], [], [], [], [], []
         for layer, (K, V) in enumerate(past_key_values):
             K, V = _rows(K), _rows(V)
             if V.stride() != K.stride():
                 K, V = K.contiguous(), V.contiguous()
-            B, H, L, d = K.shape
+            L = K.shape[2]
             k_l = ext.layer_keep[layer]
             hi = min(L - self.recent_size + num_coming, L)
-            if hi - self.start_size < k_l:
-                raise ValueError(f"layer {layer}: top-k window [{self.start_size},{hi}) holds fewer than {k_l} candidates")
-            new_len = self.start_size + k_l + (L - hi)
+            if hi - start < k_l:
+                raise ValueError(f"layer {layer}: top-k window [{start},{hi}) holds fewer than {k_l} candidates")
             if self.importance_mode == "cascade":
                 score = ext.layers[layer].acc[:, :L]
             else:
                 score = ops.importance(attn_score_all[layer])[:, :L]
             if score.stride(1) != 1:
                 score = score.contiguous()
-            self.importance_score.append(score)
-            ids = ext.token_ids(layer, H, L, K.device)
-            rank = score if prev_ids is None else ops.cascade_rank(score, ids, prev_ids)
-            idx = ops.topk_select(rank, self.start_size, hi, k_l)
-            base, scaling = _rope_of(past_key_values[layer:layer + 1])
-            cap = kv_slab.round_capacity(new_len + max(int(num_coming), 0))
-            rope = kv_slab.rope_tables(cap, d, K.dtype, K.device, base, scaling)
-            k, v, kr = ops.kv_compact(K, V, idx, self.start_size, hi, L=L, capacity=cap, rope=rope)
-            if self.importance_mode == "cascade":
-                ext.compact_importance(layer, idx, self.start_size, hi, L)
-            ext.layers[layer].pending_len = 0
-            prev_ids = ops.gather_rows_i32(ids, idx, self.start_size, hi, L)
-            new_ids.append(prev_ids)
-            kv_slab.attach(k, v, kr, new_len, base, scaling)
-            out.append([k, v])
-            idxs.append(idx)
-            pruned += L - new_len
+            Ks.append(K); Vs.append(V); lens.append(L); his.append(hi); keeps.append(k_l); scores.append(score)
+            caps.append(kv_slab.round_capacity(start + k_l + (L - hi) + max(int(num_coming), 0)))
+        self.importance_score = scores
+        B, H, _, d = Ks[0].shape
+        known = [ext.tok_ids[layer] for layer in range(n_layers)]
+        n_known0 = 0 if known[0] is None else known[0].shape[1]
+        id_base, appended = ext.next_token_id, lens[0] - n_known0      # the same tokens were appended to every layer
+        base, scaling = _rope_of(past_key_values[:1])
+        rope = kv_slab.rope_tables(max(caps), d, Ks[0].dtype, Ks[0].device, base, scaling)
+        accs = [ext.layers[layer].acc for layer in range(n_layers)] if self.importance_mode == "cascade" else None
+        Kn, Vn, Krn, idxs, new_ids, new_accs = ops.prune_layer_cascade(scores, known, id_base, Ks, Vs, lens, his, keeps, start,
+                                                                       caps, rope, accs)
+        out, pruned = [], 0
+        for layer in range(n_layers):
+            new_len = Kn[layer].shape[2]
+            st = ext.layers[layer]
+            if new_accs is not None:
+                st.acc = new_accs[layer]
+            st.pending_len = 0
+            kv_slab.attach(Kn[layer], Vn[layer], Krn[layer], new_len, base, scaling)
+            out.append([Kn[layer], Vn[layer]])
+            pruned += lens[layer] - new_len
+        ext._append_base, ext._append_count = id_base, appended
         ext.after_layer_cascade(new_ids)
         self.keep_indices = idxs                      # a list: the layers keep different numbers of tokens
         self.n_pruned_last = pruned // max(len(out), 1)

@@ -656,6 +656,63 @@ def prune_layers(scores: Sequence[torch.Tensor], Ks: Sequence[torch.Tensor], Vs:
             None if Krd is None else [x[:, :, :Lp] for x in Krd], idx)
 
 
+def prune_layer_cascade(scores: Sequence[torch.Tensor], known_ids: Sequence[Optional[torch.Tensor]], id_base: int,
+                        Ks: Sequence[torch.Tensor], Vs: Sequence[torch.Tensor], lens: Sequence[int], his: Sequence[int],
+                        keeps: Sequence[int], start: int, capacities: Sequence[int],
+                        rope: Tuple[torch.Tensor, torch.Tensor],
+                        accs: Optional[Sequence[torch.Tensor]] = None):
+    """The layer-to-layer cascade's prune event for all layers in three launches (include/spatten.h:
+    spatten_prune_layer_cascade).  scores[l] [H, >= len_l] (one dtype; rows contiguous); known_ids[l] int32 [H, n_known_l] or
+    None; Ks[l] / Vs[l] [B, H, >= len_l, d] (rows contiguous, K and V of a layer with equal strides); his[l] = window end;
+    keeps[l] = tokens kept in the window (non-increasing); accs[l] fp32 [H, >= len_l] cascade accumulators (optional).
+    Returns (K' list, V' list, Kr' list, idx list [H, k_l], new_ids list [H, new_len_l], new accs or None)."""
+    _dev(*scores, *Ks, *Vs)
+    lib = _lib.load()
+    nl = len(Ks)
+    B, H, _, d = Ks[0].shape
+    dev, dt = Ks[0].device, Ks[0].dtype
+    cos, sin = rope
+    new_lens = [start + keeps[l] + (lens[l] - his[l]) for l in range(nl)]
+    kmax = max(keeps)
+    Kd = [torch.empty(B, H, max(capacities[l], new_lens[l]), d, dtype=dt, device=dev) for l in range(nl)]
+    Vd = [torch.empty_like(x) for x in Kd]
+    Krd = [torch.empty_like(x) for x in Kd]
+    new_ids = [torch.empty(H, new_lens[l], dtype=torch.int32, device=dev) for l in range(nl)]
+    new_accs = None
+    if accs is not None:
+        new_accs = [torch.zeros(H, max(Kd[l].shape[2], accs[l].shape[1]), dtype=torch.float32, device=dev) for l in range(nl)]
+    idx = torch.empty(nl, H, kmax, dtype=torch.int32, device=dev)
+    wmax = max(his[l] - start for l in range(nl))
+    scratch = torch.empty(H, wmax, dtype=torch.int32, device=dev)
+    tab = torch.zeros(nl, 16, dtype=torch.int64)
+    for l in range(nl):
+        K, V, sc = Ks[l], Vs[l], scores[l]
+        if K.stride(3) != 1 or K.stride(2) != d or V.stride() != K.stride() or sc.stride(1) != 1 or sc.dtype != scores[0].dtype:
+            raise ValueError("layer cascade: K / V need contiguous rows and equal strides, scores contiguous rows of one dtype")
+        kn = known_ids[l]
+        if kn is not None and (kn.dtype != torch.int32 or kn.stride(1) != 1 or kn.shape[0] != H):
+            raise ValueError("known ids must be int32 [H, n] with contiguous rows")
+        tab[l] = torch.tensor([lens[l], his[l], keeps[l], new_lens[l],
+                               sc.stride(0), 0 if kn is None else kn.shape[1], 0 if kn is None else kn.stride(0), new_ids[l].stride(0),
+                               K.stride(0), K.stride(1), Kd[l].stride(0), Kd[l].stride(1),
+                               0 if accs is None else accs[l].stride(0), 0 if accs is None else new_accs[l].stride(0),
+                               int(id_base), 0], dtype=torch.int64)
+    groups = [scores, [None if k is None else k for k in known_ids], new_ids, Ks, Vs, Kd, Vd, Krd] + \
+             ([list(accs), new_accs] if accs is not None else [])
+    flat = torch.tensor([0 if t is None else t.data_ptr() for g in groups for t in g], dtype=torch.int64).to(dev)
+    ptr = lambda i: flat[i * nl:(i + 1) * nl].data_ptr()
+    tab_dev = tab.to(dev)
+    rc = lib.spatten_prune_layer_cascade(
+        _dt(scores[0]), _dt(Ks[0]), nl, tab_dev.data_ptr(), tab.data_ptr(), ptr(0), ptr(1), ptr(2), ptr(3), ptr(4), ptr(5), ptr(6),
+        ptr(7), cos.data_ptr(), sin.data_ptr(), cos.shape[0], idx.data_ptr(), kmax, scratch.data_ptr(), scratch.stride(0),
+        ptr(8) if accs is not None else None, ptr(9) if accs is not None else None, B, H, d, start, _stream())
+    _lib.check(rc, "spatten_prune_layer_cascade")
+    keep_alive = (flat, tab_dev, scratch)            # referenced until the launches were issued
+    del keep_alive
+    return ([Kd[l][:, :, :new_lens[l]] for l in range(nl)], [Vd[l][:, :, :new_lens[l]] for l in range(nl)],
+            [Krd[l][:, :, :new_lens[l]] for l in range(nl)], [idx[l, :, :keeps[l]] for l in range(nl)], new_ids, new_accs)
+
+
 # ------------------------------------------------------------------------------------------------
 # SpAtten semantics beyond the reference's Python (parity unpinned; oracle/spatten_oracle.py restates them)
 # ------------------------------------------------------------------------------------------------

@@ -274,3 +274,69 @@ def test_progressive_quant_planes_and_decode_vs_oracle(dt, d, Hkv):
     full = ops.attn_decode(qd, None, krd, vd, N, cos, sin, N - 1)
     out8 = ops.attn_decode_pq(qd, planes, vd, N, cos, sin, N - 1, 2.0)
     assert float((full.float() - out8.float()).abs().max()) < 0.05
+
+
+@pytest.mark.parametrize("with_acc", [False, True])
+def test_layer_cascade_event_in_three_launches_equals_the_per_layer_composition(with_acc):
+    """spatten_prune_layer_cascade (one workgroup per head walking the layers + ragged gathers) against the round-2
+    composition of per-layer launches — cascade_rank -> topk_select -> kv_compact (+ shadow) -> id gather -> accumulator
+    compaction — at Llama-like geometry with ragged layers (different lengths, shrinking keeps, ids known from an earlier
+    prune plus rows appended since): kept positions, new ids, K / V / shadow rows and accumulators bit for bit."""
+    from spatten_amd import ops
+    tdt, B, H, d, start, recent, coming = torch.bfloat16, 1, 32, 128, 4, 256, 40
+    g = torch.Generator(device="cuda").manual_seed(5)
+    lens = [1500, 1400, 1400, 1300, 1210]
+    keeps = [700, 650, 650, 500, 400]
+    nl = len(lens)
+    appended = 90                                             # rows appended to every layer since the last prune
+    cos, sin = ops.rope_table(2048, d, tdt, "cuda")
+    Ks = [torch.randn(B, H, L + 13, d, device="cuda", generator=g).to(tdt) for L in lens]
+    Vs = [torch.randn(B, H, L + 13, d, device="cuda", generator=g).to(tdt) for L in lens]
+    his = [min(L - recent + coming, L) for L in lens]
+    # ids: ascending per head; the slots of layer l hold a subset of layer l-1's tokens (what an earlier cascade leaves)
+    pool = torch.arange(5000, device="cuda")
+    known, prev = [], None
+    for l, L in enumerate(lens):
+        nk = L - appended
+        rows = []
+        for h in range(H):
+            src = pool[:4000] if prev is None else prev[h]
+            pick = torch.randperm(src.numel(), device="cuda", generator=g)[:nk].sort().values
+            rows.append(src[pick])
+        ids = torch.stack(rows).to(torch.int32).contiguous()
+        known.append(ids)
+        prev = [r for r in ids.long()]
+    id_base = 6000
+    if with_acc:
+        scores = [torch.rand(H, L + 50, device="cuda", generator=g) for L in lens]          # fp32 accumulators, wider than the cache
+        accs = scores
+    else:
+        scores = [torch.randn(H, L, device="cuda", generator=g).to(tdt) for L in lens]
+        accs = None
+    caps = [(start + k + (L - hi) + coming + 127) // 128 * 128 for L, hi, k in zip(lens, his, keeps)]
+    Kn, Vn, Krn, idxs, new_ids, new_accs = ops.prune_layer_cascade(
+        [s[:, :L] for s, L in zip(scores, lens)], known, id_base, [K[:, :, :L] for K, L in zip(Ks, lens)],
+        [V[:, :, :L] for V, L in zip(Vs, lens)], lens, his, keeps, start, caps, (cos, sin),
+        None if accs is None else accs)
+    torch.cuda.synchronize()
+    # ---- the same event, one layer at a time
+    prev_ids = None
+    for l, L in enumerate(lens):
+        fresh = (torch.arange(appended, dtype=torch.int32, device="cuda") + id_base)[None].expand(H, appended)
+        ids = torch.cat([known[l], fresh], 1).contiguous()
+        sc = scores[l][:, :L].contiguous()
+        rank = sc if prev_ids is None else ops.cascade_rank(sc, ids, prev_ids)
+        idx = ops.topk_select(rank, start, his[l], keeps[l])
+        k, v, kr = ops.kv_compact(Ks[l][:, :, :L], Vs[l][:, :, :L], idx, start, his[l], L=L, capacity=caps[l], rope=(cos, sin))
+        prev_ids = ops.gather_rows_i32(ids, idx, start, his[l], L)
+        assert torch.equal(idxs[l], idx), l
+        assert torch.equal(new_ids[l], prev_ids), l
+        assert torch.equal(Kn[l], k) and torch.equal(Vn[l], v) and torch.equal(Krn[l], kr), l
+        if with_acc:
+            want = ops.importance_compact(accs[l], idx, start, his[l], L, new_accs[l].shape[1])
+            n = k.shape[2]
+            assert torch.equal(new_accs[l][:, :n], want[:, :n]) and (new_accs[l][:, n:] == 0).all(), l
+    # a window that cannot supply layer_keep candidates is refused (reference: torch.topk RuntimeError)
+    with pytest.raises(ValueError):
+        ops.prune_layer_cascade([s[:, :L] for s, L in zip(scores, lens)], known, id_base, [K[:, :, :L] for K, L in zip(Ks, lens)],
+                                [V[:, :, :L] for V, L in zip(Vs, lens)], lens, [start + 10] * nl, keeps, start, caps, (cos, sin))
