@@ -8,6 +8,8 @@
 // -> K/V gather per layer, ~10 launches x 32 layers).  Then ONE ragged gather moves K / V / shadow rows of every layer
 // (the layers keep different numbers of rows, so lengths and strides come from a per-layer table), and one moves the
 // cascade accumulators.
+#include <algorithm>
+
 #include "common.h"
 
 namespace spatten {
@@ -27,9 +29,13 @@ struct ChainParams {
   const int32_t* const* known_ptrs;    // [layers] -> int32 [H, n_known] token ids of the slots seen by the last prune (may be NULL rows)
   int32_t* const* new_ids_ptrs;        // [layers] -> int32 [H, new_len] out: ids of the new cache's slots
   int32_t* idx; int64_t idx_sl, idx_sh;   // [layers, H, kmax] out: kept window positions, ascending
-  uint32_t* keys; int64_t keys_sh;     // [H, >= max window] scratch
-  int layers, start;
+  uint32_t* keys; int64_t keys_sh;     // [H, >= max window] scratch (windows that do not fit the LDS copy)
+  int layers, start, lds_keys;         // windows up to lds_keys entries keep their keys in LDS
+  int lds_ids;                         // ... and new-id rows up to lds_ids entries stay in LDS for the next layer's membership test
 };
+
+constexpr int kChainThreads = 1024;    // the chain is latency-bound on ONE workgroup per head: many threads, few iterations
+constexpr int kChainWaves = kChainThreads / 64;
 
 __device__ inline int32_t slot_id(const LayerPrune& L, const int32_t* known, int j) {
   return j < (int)L.n_known ? known[j] : (int32_t)(L.id_base + (j - L.n_known));
@@ -39,12 +45,22 @@ __device__ inline int32_t slot_id(const LayerPrune& L, const int32_t* known, int
 // of the window (radix select, ties: lowest position), the new slot ids.  Same keys, tie rule and output order as
 // cascade_rank_kernel + topk_select_kernel<float> + the id gather of round 2.
 template <typename T>
-__global__ __launch_bounds__(256) void layer_cascade_select_kernel(const ChainParams p) {
-  __shared__ unsigned s_hist[256];
+__global__ __launch_bounds__(kChainThreads) void layer_cascade_select_kernel(const ChainParams p) {
+  // kHistCopies private histograms (wave w counts into copy w % kHistCopies): real score windows fall into a handful of
+  // exponent bins, and same-address LDS atomics serialise (r03: one shared histogram was most of the chain's time)
+  constexpr int kHistCopies = 8;
+  __shared__ unsigned s_hist[kHistCopies][256];
   __shared__ unsigned s_sel[2];
-  __shared__ unsigned s_cnt[2][4][2];
+  __shared__ unsigned s_cnt[2][kChainWaves][2];
+  extern __shared__ uint32_t s_keys[];
+  // keys of model-dtype scores populate the top 16 (bf16) / 19 (f16) bits; the bits below only repeat the sign (all ones for
+  // negative values, -inf of a non-member included), so the digits below them cannot separate two keys: skipped
+  constexpr int kPasses = sizeof(T) == 4 ? 4 : (DT<T>::kId == SPATTEN_BF16 ? 2 : 3);
+  constexpr unsigned kKeyMask = kPasses == 4 ? 0xFFFFFFFFu : (kPasses == 3 ? 0xFFFFFF00u : 0xFFFF0000u);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.x;
-  uint32_t* keys = p.keys + h * p.keys_sh;
+  // the previous layer's new slot ids: the membership test is a binary search — 11 DEPENDENT loads per key — so the row is
+  // kept in LDS when it fits (539 -> 438 us for the 32-layer chain at 3068-entry windows)
+  int32_t* s_prev = reinterpret_cast<int32_t*>(s_keys + p.lds_keys);
   const int32_t* prev = nullptr;
   int n_prev = 0;
   for (int l = 0; l < p.layers; ++l) {
@@ -53,8 +69,9 @@ __global__ __launch_bounds__(256) void layer_cascade_select_kernel(const ChainPa
     const int32_t* known = p.known_ptrs[l] ? p.known_ptrs[l] + h * L.known_sh : nullptr;
     const int W = (int)L.hi - p.start, k = (int)L.k;
     int32_t* out = p.idx + l * p.idx_sl + h * p.idx_sh;
+    uint32_t* keys = W <= p.lds_keys ? s_keys : p.keys + h * p.keys_sh;
     // ---- keys of the window
-    for (int i = tid; i < W; i += 256) {
+    for (int i = tid; i < W; i += kChainThreads) {
       const int j = p.start + i;
       bool member = true;
       if (prev) {
@@ -63,26 +80,32 @@ __global__ __launch_bounds__(256) void layer_cascade_select_kernel(const ChainPa
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (prev[mid] < want) lo = mid + 1; else hi = mid; }
         member = lo < n_prev && prev[lo] == want;
       }
-      keys[i] = ordered_key(member ? DT<T>::to_f32(score[j]) : -INFINITY);
+      keys[i] = ordered_key(member ? DT<T>::to_f32(score[j]) : -INFINITY) & kKeyMask;
     }
     __threadfence_block();
     __syncthreads();
     // ---- the key of the k-th largest (8-bit digits, most significant first)
     unsigned prefix = 0, pmask = 0, k_rem = (unsigned)k;
 #pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = 0; pass < kPasses; ++pass) {
       const int shift = 24 - 8 * pass;
-      s_hist[tid] = 0;
+      for (int t = tid; t < kHistCopies * 256; t += kChainThreads) (&s_hist[0][0])[t] = 0;
       __syncthreads();
-      for (int i = tid; i < W; i += 256) {
+      unsigned* my_hist = s_hist[wave % kHistCopies];
+      for (int i = tid; i < W; i += kChainThreads) {
         const unsigned key = keys[i];
-        if ((key & pmask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
+        if ((key & pmask) == prefix) atomicAdd(&my_hist[(key >> shift) & 255u], 1u);
       }
       __syncthreads();
       if (wave == 0) {
         unsigned c[4], tot = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { c[j] = s_hist[255 - 4 * lane - j]; tot += c[j]; }
+        for (int j = 0; j < 4; ++j) {
+          c[j] = 0;
+#pragma unroll
+          for (int q = 0; q < kHistCopies; ++q) c[j] += s_hist[q][255 - 4 * lane - j];
+          tot += c[j];
+        }
         unsigned inc = tot;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
@@ -107,7 +130,7 @@ __global__ __launch_bounds__(256) void layer_cascade_select_kernel(const ChainPa
     // ---- order-preserving compaction: everything above the threshold, the first need_eq at it
     unsigned run_eq = 0, run_kept = 0;
     int parity = 0;
-    for (int base = 0; base < W; base += 256, parity ^= 1) {
+    for (int base = 0; base < W; base += kChainThreads, parity ^= 1) {
       const int i = base + tid;
       const bool in = i < W;
       const unsigned key = in ? keys[i] : 0u;
@@ -117,7 +140,7 @@ __global__ __launch_bounds__(256) void layer_cascade_select_kernel(const ChainPa
       __syncthreads();
       unsigned eq_base = run_eq, kept_base = run_kept, tot_eq = run_eq, tot_kept = run_kept;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
+      for (int w = 0; w < kChainWaves; ++w) {
         const unsigned g = s_cnt[parity][w][0], e = s_cnt[parity][w][1];
         const unsigned room = tot_eq < need_eq ? need_eq - tot_eq : 0u;
         const unsigned kept_w = g + (e < room ? e : room);
@@ -137,13 +160,16 @@ __global__ __launch_bounds__(256) void layer_cascade_select_kernel(const ChainPa
     // ---- the ids of the new cache's slots (start | kept | tail): what the next layer tests membership against
     int32_t* nid = p.new_ids_ptrs[l] + h * L.new_ids_sh;
     const int lp = (int)L.new_len;
-    for (int r = tid; r < lp; r += 256) {
+    const bool in_lds = lp <= p.lds_ids;
+    for (int r = tid; r < lp; r += kChainThreads) {
       const int src = r < p.start ? r : (r < p.start + k ? out[r - p.start] : (int)L.hi + (r - p.start - k));
-      nid[r] = slot_id(L, known, src);
+      const int32_t id = slot_id(L, known, src);
+      nid[r] = id;
+      if (in_lds) s_prev[r] = id;
     }
     __threadfence_block();
     __syncthreads();
-    prev = nid;
+    prev = in_lds ? s_prev : nid;
     n_prev = lp;
   }
 }
@@ -258,7 +284,14 @@ extern "C" int spatten_prune_layer_cascade(int score_dtype, int kv_dtype, int la
   c.lay = (const LayerPrune*)lay_dev; c.score_ptrs = score_ptrs; c.known_ptrs = known_ptrs; c.new_ids_ptrs = new_ids_ptrs;
   c.idx = idx; c.idx_sl = (int64_t)heads * kmax; c.idx_sh = kmax; c.keys = key_scratch; c.keys_sh = key_scratch_sh;
   c.layers = layers; c.start = start;
-  SPATTEN_BY_DTYPE(score_dtype, hipLaunchKernelGGL((layer_cascade_select_kernel<T>), dim3((unsigned)heads), dim3(256), 0, st, c));
+  int64_t max_w = 0;
+  for (int l = 0; l < layers; ++l) max_w = std::max(max_w, H_[l].hi - start);
+  // 60 KB of dynamic LDS (+ the histogram): the window's keys first, the previous layer's ids in what is left; longer
+  // windows / rows fall back to the global scratch / the global id rows
+  c.lds_keys = (int)std::min<int64_t>(max_w, 15360);
+  c.lds_ids = (int)std::min<int64_t>(max_new, 15360 - c.lds_keys);
+  SPATTEN_BY_DTYPE(score_dtype, hipLaunchKernelGGL((layer_cascade_select_kernel<T>), dim3((unsigned)heads), dim3(kChainThreads),
+                                                   (size_t)(c.lds_keys + c.lds_ids) * sizeof(uint32_t), st, c));
   if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
   const int es = kv_dtype == SPATTEN_F32 ? 4 : 2;
   RaggedParams r{};
