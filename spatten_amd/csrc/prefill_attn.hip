@@ -102,6 +102,8 @@ struct FlashParams {
   const T* kr;        // rotated shadow [B,Hkv,cap,D]
   int64_t kv_sb, kv_sh;
   const T* vt;        // [B,Hkv,D,Npad]
+  const T* v; int64_t v_sb, v_sh;   // the value cache itself [B,Hkv,>=N,D] (rows contiguous): read by the transposing
+                                    // LDS reads of the 128-key kernel at D = 128 (SPATTEN_PF_VTR), no Vt pre-pass
   const T* mask; int64_t mask_sb, mask_sq;
   T* out; int64_t out_sb, out_sq;
   T* scores; int64_t sc_sb, sc_sh, sc_sq;
@@ -114,6 +116,7 @@ struct FlashParams {
   int32_t* need;      // [B,H,q_len]: pass 1 writes max prob < thr, pass 2 recomputes the flagged rows
   float pq_thr;
   int B, H, Hkv, q_len, N, Npad, causal, nqb;
+  int vtr;     // this launch reads V through the transposing LDS reads (no Vt copy was made)
   int fast;    // SPATTEN_PREFILL_FAST_NUMERICS: fp32 logits, no reference roundings (plain causal / unmasked flash leg only)
   float sqrt_d;
   // key split (prefill_pp128_kernel, plain keys): a (b, h, query block) is served by ksplit workgroups, each over a
@@ -139,6 +142,14 @@ struct FlashParams {
 // logits kept in fp32 — no reference roundings (matmul -> dtype, / sqrt(d) -> dtype) — with the scale folded into the
 // exponent: -384 of ~609 VALU per wave-tile.  NOT the default: the flash kernel's logits stay the reference's (DESIGN
 // §3.4).  The harness bit SPATTEN_PF_EXPMODE & 1 forces it for every launch (anatomy builds).
+// VTRP (template flag of prefill_pp128_kernel, d = 128): the V operand of P.V straight from the value rows — the tile is
+// DMA-ed row-major ([128 keys][D]) and read with ds_read_b64_tr_b16 (gfx950's transposing LDS read), so the launch needs no
+// key-contiguous copy of V (the vt_kernel pre-pass: 9 of the 36 us of the 64-token turn prefill).  Two 8-byte transposing
+// reads per fragment instead of one 16-byte read make the flash kernel itself slower, so the form is chosen per shape
+// (use_vtr below); SPATTEN_PREFILL_VTR=0|1 forces it (A/B).
+#ifndef SPATTEN_PF_VTR_MAXQ
+#define SPATTEN_PF_VTR_MAXQ 512  // transposing reads for query blocks up to this length
+#endif
 #ifndef SPATTEN_PF_ROWSUM_MFMA  // row sums of P on the matrix pipe instead of 64 VALU adds per lane and tile: MEASURED SLOWER
 #define SPATTEN_PF_ROWSUM_MFMA 0   // (713 vs 768): the 8 extra MFMAs per tile cost more than the adds they replace.  Off.
 #endif
@@ -583,7 +594,7 @@ template <int ROWB> __device__ inline int swz_slot(int row, int p) {   // logica
   return ROWB == 256 ? (p ^ (row & 15)) : (p ^ ((row >> 1) & 7));
 }
 
-template <typename T, int D, bool MASK, int PQK = 0, bool FASTN = false>
+template <typename T, int D, bool MASK, int PQK = 0, bool FASTN = false, bool VTRP = false>
 __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams<T> p) {
   constexpr bool FAST = FASTN || (SPATTEN_PF_EXPMODE & 1);
   constexpr int KT = 128, NKB = KT / 32;                      // keys per tile, 32-key blocks per tile
@@ -696,7 +707,9 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   const int wave_tiles = wave_att_tiles;
 
   const T* krb = p.kr + b * p.kv_sb + hkv * p.kv_sh;
+  constexpr bool VTR = VTRP && D == 128;
   const T* vtb = p.vt + ((int64_t)(b * p.Hkv + hkv) * D) * p.Npad;
+  const T* vrb = p.v + b * p.v_sb + hkv * p.v_sh;
   const T* maskrow = MASK ? p.mask + b * p.mask_sb + (int64_t)min(myq, p.q_len - 1) * p.mask_sq : nullptr;
 
   auto k_area = [&](int stage) -> char* { return lds + (stage & 1) * BUF; };            // holds K(stage + 1)
@@ -734,6 +747,20 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   auto dma_v = [&](int tile, char* area) {
     const int ln = opaque_lane(lane);
     const int l4 = ln >> 4, ps = ln & 15;
+    if (VTR) {
+      // row-major value tile: 128 keys x 256 B; a 1-KiB piece = 4 consecutive rows (keys 4p .. 4p+3).  Physical 16-byte
+      // slot ps of row r holds logical slot ps ^ 4 (r & 3): the four rows a transposing read touches per 16-lane group then
+      // sit in four different 64-byte quarters of the bank space, and the two groups of a half-wave in disjoint halves of
+      // each quarter — a half-wave's 32 eight-byte reads cover the 64 banks exactly once.
+      const int base = l4 * 256 + ((ps ^ (4 * l4)) << 4);
+      const int64_t vr_bytes = (int64_t)p.N * D * 2;       // rows past N read as zeros (out of range)
+#pragma unroll
+      for (int i = 0; i < VINST; ++i) {
+        const int piece = wave_u * VINST + i;
+        dma16(vrb, vr_bytes, area + piece * 1024, base, tile * (KT * 256) + piece * 1024);
+      }
+      return;
+    }
     const int base = l4 * p.Npad * 2 + ((ps ^ l4) << 4);
 #pragma unroll
     for (int i = 0; i < VINST; ++i) {
@@ -781,9 +808,26 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   auto pv = [&](const char* vbuf) {
     frag a[RING];
     const unsigned vu = (unsigned)(vbuf - lds) + qi * 256 + ((qi & 15) << 4);
+    // VTR: lane (qi, hi) needs, for d = 32 db + qi, the 8 keys its P fragment holds — elements 0..3: keys k16 + 4 hi + 0..3,
+    // elements 4..7: keys k16 + 8 + 4 hi + 0..3 with k16 = 32 kb + 16 t (the 32x32 accumulator's row order, the order the Vt
+    // pre-pass bakes into its copy) — i.e. two 4-key COLUMN pieces of the row-major tile.  ds_read_b64_tr_b16 hands lane l
+    // of a 16-lane group element (row j, column l) of the 4 x 16 block whose row (i >> 2), columns 4 (i & 3) .. +3 lane i
+    // points at (measured: tools/mb/tr_read.hip): two reads, 8 rows (2 KiB) apart.
+    const int li = lane & 15, kr = li >> 2;
+    const unsigned vtu = (unsigned)(vbuf - lds) + (4 * hi + kr) * 256 + ((lane >> 4) & 1) * 32 + ((li & 3) >> 1) * 16 + (li & 1) * 8;
     auto vfrag = [&](int i) {   // step i: db = i % DB, (kb, t) = i / DB
       const int db = i % DB, kt = i / DB, kb = kt >> 1, t = kt & 1;
-      return *reinterpret_cast<const frag*>(lds + ((vu ^ ((kb * 4 + t * 2 + hi) << 4)) + db * 32 * 256));
+      if constexpr (VTR) {
+        typedef short v4s __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) v4s* lds_v4s;
+        const unsigned a0 = vtu + (kb * 32 + t * 16) * 256 + (((unsigned)db ^ (unsigned)kr) << 6);
+        union { v4s h[2]; frag f; } u;
+        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(lds + a0));
+        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(lds + a0 + 2048));
+        return u.f;
+      } else {
+        return *reinterpret_cast<const frag*>(lds + ((vu ^ ((kb * 4 + t * 2 + hi) << 4)) + db * 32 * 256));
+      }
     };
 #pragma unroll
     for (int i = 0; i < RING; ++i) a[i] = vfrag(i);
@@ -1200,6 +1244,19 @@ static int prefill_variant() {
   return v;
 }
 
+// Transposing-read form of the 128-key kernel (no Vt pre-pass): when the pre-pass — all kv_len keys, whatever q_len — is
+// a large part of the launch, i.e. a short query block on a long cache.
+static inline bool use_vtr_for(int head_dim, int q_len, int kv_len) {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("SPATTEN_PREFILL_VTR"); env = e ? atoi(e) : 2; }   // 0 off, 1 on, 2 by shape
+  if (head_dim != 128 || env == 0) return false;
+  if (env == 1) return true;
+  // measured (tools/probe_vtr.py, H = 32, us per layer, Vt form | transposing reads): q = 64 on 2112: 36.2 | 28.7; 256 on
+  // 2304: 44.3 | 37.5; 512 on 2560: 56.9 | 51.2; 1024 on 2048: 76.8 | 81.1; 1024 on 4096: 132.5 | 149.3; 2048 on 2048:
+  // 79.9 | 83.5; 4096 on 4096: 246 | 265 — the pre-pass costs ~9 us per 2k keys, the two-read fragments ~7 % of the flash time
+  return q_len <= SPATTEN_PF_VTR_MAXQ;
+}
+
 // Key split of the plain flash kernel: only when the launch would leave most of the chip idle (few query blocks x heads)
 // and every range still has >= 2 key tiles.  The same rule sizes the workspace.
 static inline int flash_ksplit(int batch, int heads, int q_len, int kv_len) {
@@ -1238,6 +1295,7 @@ static void launch_flash_m(const FlashParams<T>& p, hipStream_t st) {
       const dim3 gridk((unsigned)(p.nqb * p.H * p.B * (p.ksplit > 1 ? p.ksplit : 1)));
       if (p.mask) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, true>), gridk, dim3(512), 0, st, p);
       else if (p.fast) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, 0, true>), gridk, dim3(512), 0, st, p);
+      else if (p.vtr) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, 0, false, true>), gridk, dim3(512), 0, st, p);
       else hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false>), gridk, dim3(512), 0, st, p);
       if (p.ksplit > 1) {
         const long long rows = (long long)p.B * p.H * p.q_len;
@@ -1342,8 +1400,11 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
   const int npad = ceil_div(kv_len, 128) * 128;      // Vt rows padded to whole 128-key tiles (zeros beyond kv_len)
   void* vt = ws;
   // (1) the queries are rotated inside the flash kernel (its prologue)
-  // (2) key-contiguous V
-  {
+  // (2) key-contiguous V — only for the kernels that still read it: the 64-key kernel (stash / column-importance outputs,
+  // SPATTEN_PREFILL_VARIANT=1) and d = 64; the 128-key kernel at d = 128 reads the value rows themselves (SPATTEN_PF_VTR)
+  const bool use_vtr = use_vtr_for(head_dim, q_len, kv_len) && !scores && !col_importance && !mask && prefill_variant() == 0 &&
+                       !(causal & SPATTEN_PREFILL_FAST_NUMERICS);
+  if (!use_vtr) {
     const dim3 grid((unsigned)(npad / 64), (unsigned)kv_heads, (unsigned)batch);
     if (head_dim == 128)
       hipLaunchKernelGGL((vt_kernel<128>), grid, dim3(256), 0, st, (const uint16_t*)v_cache, kv_sb, kv_sh, (uint16_t*)vt, kv_len, npad, kv_heads);
@@ -1360,6 +1421,7 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
     p.pos_ids = position_ids; p.pos_sb = pos_sb; p.pos_q0 = pos_q0;                                    \
     p.kr = (const T*)kr_cache; p.kv_sb = kv_sb; p.kv_sh = kv_sh;                                       \
     p.vt = (const T*)vt; p.mask = (const T*)mask; p.mask_sb = mask_sb; p.mask_sq = mask_sq;            \
+    p.v = (const T*)v_cache; p.v_sb = kv_sb; p.v_sh = kv_sh; p.vtr = use_vtr ? 1 : 0;                  \
     p.out = (T*)out; p.out_sb = out_sb; p.out_sq = out_sq;                                             \
     p.scores = (T*)scores; p.sc_sb = sc_sb; p.sc_sh = sc_sh; p.sc_sq = sc_sq;                          \
     p.col_imp = col_importance; p.lse = lse; p.kscale = nullptr; p.ks_sb = p.ks_sh = 0; p.need = nullptr; p.pq_thr = 0.f; \
@@ -1473,6 +1535,7 @@ extern "C" int spatten_attn_prefill_pq(int dtype, const void* q, int64_t q_sb, i
     p.pos_ids = position_ids; p.pos_sb = pos_sb; p.pos_q0 = pos_q0;                                    \
     p.kr = (const T*)(KPTR); p.kv_sb = (int64_t)kv_heads * kv_len * head_dim; p.kv_sh = (int64_t)kv_len * head_dim; \
     p.vt = (const T*)vt; p.mask = (const T*)mask; p.mask_sb = mask_sb; p.mask_sq = mask_sq;            \
+    p.v = (const T*)v_cache; p.v_sb = kv_sb; p.v_sh = kv_sh; p.vtr = 0;                                \
     p.out = (T*)out; p.out_sb = out_sb; p.out_sq = out_sq;                                             \
     p.scores = nullptr; p.sc_sb = p.sc_sh = p.sc_sq = 0; p.col_imp = nullptr; p.lse = nullptr;         \
     p.kscale = kscale; p.ks_sb = (int64_t)kv_heads * kv_len; p.ks_sh = kv_len; p.need = need_lsb; p.pq_thr = (THR); \

@@ -495,3 +495,19 @@ def test_prefill_fast_numerics_stays_within_the_stated_tolerance(dt, d, P, ql):
     check_stash(stash, stash_ref, dt, "fast numerics with a stash")
     with pytest.raises(ValueError):
         run_prefill(q, k, v, past, dt, causal=True, stash=False, numerics="sloppy")
+
+
+@pytest.mark.parametrize("case", [("bf16", 1, 8, 8, 2000, 64), ("f16", 2, 4, 2, 700, 300), ("bf16", 1, 4, 4, 0, 512), ("bf16", 1, 4, 1, 3000, 17)])
+def test_prefill_transposing_read_form_vs_oracle(case):
+    """Query blocks of up to 512 rows at d = 128 run the flash kernel that reads V through gfx950's transposing LDS reads
+    (ds_read_b64_tr_b16) from the value rows themselves — no key-contiguous copy of V is made; longer blocks keep the Vt
+    pre-pass.  Both forms against the oracle (GQA, key split, ragged lengths, a past longer than the block)."""
+    dt, B, H, Hkv, P, ql = case
+    d = 128
+    q, k, v, past = attn_inputs(B, H, Hkv, d, P, ql, dt, seed=1200 + P + ql)
+    N = P + ql
+    pos = np.tile(np.arange(P, N)[None], (B, 1))
+    o_ref, _, _ = orc.attention_core(q, k, v, None if past is None else past[0], None if past is None else past[1],
+                                     pos, orc.causal_mask(B, ql, N, dt), dt)
+    out, _, _ = run_prefill(q, k, v, past, dt, causal=True, stash=False)
+    np.testing.assert_allclose(out, o_ref, **OUT_TOL[dt])
