@@ -164,6 +164,12 @@ typedef struct spatten_decode_args {
                                       launch and a step_state launch whose bound (its kv_len) is this value add their
                                       partials in the same order: bit-identical outputs.  Later splits may then be empty. */
   int32_t pad3_;
+  /* ABI 3: the output projection of the step (modify_llama.py:163) in the same CALL: proj_out[b, n] = sum_k out[b, k] *
+     proj_weight[n, k] (+ proj_bias[n]); weight [proj_n, heads*head_dim] row stride proj_w_sn (elements), output row stride
+     proj_out_sb.  `out` is still written; the projection is a second launch (spatten_gemv's kernel: bit-identical with
+     spatten_gemv(out)) issued by the same call — one host call per layer-step instead of two. */
+  const void* proj_weight; int64_t proj_w_sn; const void* proj_bias; void* proj_out; int64_t proj_out_sb; int32_t proj_n;
+  int32_t pad4_;
 } spatten_decode_args_t;
 int spatten_attn_decode_args(const spatten_decode_args_t* args, void* stream);
 

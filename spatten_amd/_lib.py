@@ -39,6 +39,8 @@ class DecodeArgs(ctypes.Structure):
         ("pq_threshold", c_float), ("pad2_", c_int32),
         ("pq_need_lsb", c_void_p),
         ("step_state", c_void_p), ("kv_len_layout", c_int32), ("pad3_", c_int32),
+        ("proj_weight", c_void_p), ("proj_w_sn", c_int64), ("proj_bias", c_void_p), ("proj_out", c_void_p),
+        ("proj_out_sb", c_int64), ("proj_n", c_int32), ("pad4_", c_int32),
     ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

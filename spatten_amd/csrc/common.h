@@ -428,8 +428,14 @@ struct DecodeCall {
   float* head_abs = nullptr;   // [B*H] head importance accumulators (n_q == 1 only)
   const void* step = nullptr;  // device-resident step state (step.hip): kv_len above is then a bound
   int layout_len = 0;          // > kv_len: lay the splits out for this length (spatten_decode_args_t::kv_len_layout)
+  // fused / trailing output projection (spatten_decode_args_t::proj_*)
+  const void* proj_w = nullptr; int64_t proj_w_sn = 0; const void* proj_bias = nullptr; void* proj_out = nullptr;
+  int64_t proj_out_sb = 0; int proj_n = 0;
 };
 int decode_rows(const DecodeCall& c, hipStream_t stream);
+// y[m, n] = sum_k x[m, k] W[n, k] (+ bias): the weight-streaming kernel of gemv.hip (C++ linkage for the other units)
+int gemv_rows(int dtype, const void* x, int64_t x_sm, const void* W, int64_t w_sn, const void* bias, void* y, int64_t y_sm,
+              int M, int N, int K, hipStream_t stream);
 
 // planes -> integer-valued keys in the model dtype (msb*16 and msb*16+lsb, both exact) + scale / sqrt(d) per key
 // (pq.hip; used by the progressive-quant prefill)

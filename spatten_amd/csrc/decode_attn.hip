@@ -874,6 +874,15 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   if (env_poll < 0) { const char* e = getenv("SPATTEN_DECODE_POLL"); env_poll = e ? atoi(e) : 1; }
   const int poll_merge = (env_poll != 0 && S > 1 && c.n_q == 1 && (long long)S * n_active * c.batch <= kDecodeCoResident) ? 1 : 0;
 
+  // ---- the output projection of the step (modify_llama.py:163) as a second launch of the same call: one C call per
+  // layer-step for the host.  (r03: fusing it INTO the launch — projection waves in the decode workgroups that stream the
+  // weight rows while the attention runs and wait only for the merged output — was built and measured: 21.2 us against
+  // 18.4 for the two launches; the weight stream does hide under the decode step (15.3 us with the wait removed), but the
+  // hand-off "all heads merged -> every CU" costs a poll round trip plus an activation read under load, more than the
+  // kernel boundary it replaces.  DESIGN 3.9.)
+  const bool want_proj = c.proj_w != nullptr;
+  if (want_proj && (!c.proj_out || c.proj_n <= 0 || c.n_q != 1 || scores_only || c.proj_w_sn < (int64_t)c.heads * c.head_dim))
+    return SPATTEN_ERR_INVALID;
 #define SPATTEN_FILL(T)                                                                                  \
   DecodeParams<T> p;                                                                                     \
   p.q = (const T*)c.q; p.q_sb = c.q_sb; p.q_sh = c.q_sh; p.q_sq = c.q_sq;                                \
@@ -906,7 +915,12 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   p.n_q = c.n_q; p.causal = c.causal; p.vis0 = c.vis0 > 0 ? c.vis0 : c.kv_len - c.n_q + 1;                \
   p.poll_merge = poll_merge;                                                                             \
   p.sqrt_d = sqrtf((float)c.head_dim);                                                                   \
-  return dispatch_decode<T>(p, c.head_dim, n_active, scores_only, stream);
+  {                                                                                                      \
+    const int rc_ = dispatch_decode<T>(p, c.head_dim, n_active, scores_only, stream);                    \
+    if (rc_ != SPATTEN_OK || !want_proj) return rc_;                                                     \
+    return gemv_rows(c.dtype, c.out, c.out_sb, c.proj_w, c.proj_w_sn, c.proj_bias, c.proj_out, c.proj_out_sb, c.batch, \
+                     c.proj_n, c.heads * c.head_dim, stream);                                            \
+  }
 
   switch (c.dtype) {
     case SPATTEN_F32: { SPATTEN_FILL(float) }
@@ -964,6 +978,8 @@ extern "C" int spatten_attn_decode_args(const spatten_decode_args_t* a, void* st
   c.acc = a->importance_acc; c.acc_sh = a->acc_sh; c.prev_len = a->prev_len;
   c.head_abs = a->head_abs_acc;
   c.step = a->step_state; c.layout_len = a->kv_len_layout;
+  c.proj_w = a->proj_weight; c.proj_w_sn = a->proj_w_sn; c.proj_bias = a->proj_bias; c.proj_out = a->proj_out;
+  c.proj_out_sb = a->proj_out_sb; c.proj_n = a->proj_n;
   PQKeys keys;
   if (a->pq_msb) {
     if (!a->pq_lsb || !a->pq_scale || !a->pq_need_lsb) return SPATTEN_ERR_INVALID;

@@ -79,6 +79,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ x, cons
 
 using namespace spatten;
 
+namespace spatten {
+int gemv_rows(int dtype, const void* x, int64_t x_sm, const void* W, int64_t w_sn, const void* bias, void* y, int64_t y_sm,
+              int M, int N, int K, hipStream_t stream) {
+  return spatten_gemv(dtype, x, x_sm, W, w_sn, bias, y, y_sm, M, N, K, (void*)stream);
+}
+}  // namespace spatten
+
 extern "C" int spatten_gemv(int dtype, const void* x, int64_t x_sm, const void* W, int64_t w_sn, const void* bias, void* y,
                             int64_t y_sm, int M, int N, int K, void* stream) {
   if (!ok_dtype(dtype) || !x || !W || !y || M <= 0 || N <= 0 || K <= 0 || w_sn < K) return SPATTEN_ERR_INVALID;

@@ -80,7 +80,7 @@ class KVSlab:
         return t
 
     def decode_step(self, q, k_new, v_new, kv_len: int, pos_q: int, cos, sin, scores, position_ids=None, mask=None,
-                    step=None):
+                    step=None, proj=None):
         """The plain fused decode step on this slab through its prefilled argument block (ops.SlabDecodeCall).
         The split-N decomposition is laid out for the slab's CAPACITY, whatever the current length: every step of a turn
         — launched with a host length, or (``step``: ops.StepState) with the device-resident length inside a captured
@@ -90,8 +90,8 @@ class KVSlab:
             dec = self.dec = ops.SlabDecodeCall(self.k, self.kr, self.v, cos, sin, q)
         cap = self.k.shape[2]
         if step is not None:
-            return dec.run(q, k_new, v_new, cap, 0, scores, step=step)
-        return dec.run(q, k_new, v_new, kv_len, pos_q, scores, position_ids, mask, layout=cap)
+            return dec.run(q, k_new, v_new, cap, 0, scores, step=step, proj=proj)
+        return dec.run(q, k_new, v_new, kv_len, pos_q, scores, position_ids, mask, layout=cap, proj=proj)
 
     def stash_row(self, heads: int) -> torch.Tensor:
         """[B, H, cap] in the model dtype, zero-filled once: where a captured decode step leaves its logits (the

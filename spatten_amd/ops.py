@@ -132,7 +132,7 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: Opti
                 head_ids: Optional[torch.Tensor] = None, scores_only: bool = False,
                 cascade: Optional[tuple] = None, pq: Optional[tuple] = None,
                 head_abs: Optional[torch.Tensor] = None, step: Optional["StepState"] = None,
-                layout: int = 0) -> torch.Tensor:
+                layout: int = 0, proj: Optional[tuple] = None) -> torch.Tensor:
     """Fused decode attention (modify_llama.py:86-147 at q_len=1).
 
     q [B,H,d]; k_cache (un-rotated, only appended to) / kr_cache (rotated shadow, see build_shadow) /
@@ -151,6 +151,8 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: Opti
     layout: lay the split-N decomposition out for this length (>= kv_len) instead of kv_len.
     step (StepState): the device-resident length — ``kv_len`` is then the BOUND of the launch, ``pos_q`` is not read, rows
     [length, bound) of kr_cache / v_cache must hold finite values.
+    proj = (weight [N, H*d], bias [N] or None, proj_out [B, N]): the step's output projection (modify_llama.py:163) issued by
+    the same C call (a second launch of spatten_gemv's kernel: one host call per layer-step); ``proj_out`` is filled.
     Returns out [B, H*d]."""
     _dev(q, k_cache, kr_cache, v_cache, cos, sin, k_new, v_new, mask, out, scores, lse, position_ids, head_abs)
     if position_ids is not None and position_ids.dtype != torch.int64:
@@ -204,6 +206,8 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: Opti
     if head_ids is not None:
         a.head_ids, a.n_active_heads = head_ids.data_ptr(), head_ids.numel()
     a.flags = 1 if scores_only else 0
+    if proj is not None:
+        _fill_proj(a, proj, q, B, H * d)
     a.kv_len_layout = int(layout)
     if layout > cap:
         raise ValueError("layout length exceeds the cache capacity")
@@ -233,6 +237,18 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: Opti
         a.pq_threshold, a.pq_need_lsb = float(threshold), need_lsb.data_ptr()
     _lib.check(lib.spatten_attn_decode_args(ctypes.byref(a), stream), "spatten_attn_decode")
     return out
+
+
+def _fill_proj(a, proj, q, B, K):
+    """proj = (weight [N, K], bias or None, out [B, N]) -> the proj_* fields of a decode argument block."""
+    w, bias, y = proj
+    _dev(w, bias, y)
+    if w.dtype != q.dtype or w.dim() != 2 or w.shape[1] != K or w.stride(1) != 1 or y.dtype != q.dtype \
+            or y.shape[0] != B or y.shape[-1] != w.shape[0] or y.stride(-1) != 1 \
+            or (bias is not None and (bias.dtype != q.dtype or bias.numel() != w.shape[0] or not bias.is_contiguous())):
+        raise ValueError("proj: weight [N, H*d] rows contiguous, bias [N], out [B, N], all in the model dtype")
+    a.proj_weight, a.proj_w_sn, a.proj_bias = w.data_ptr(), w.stride(0), _ptr(bias)
+    a.proj_out, a.proj_out_sb, a.proj_n = y.data_ptr(), y.stride(0), w.shape[0]
 
 
 class StepState:
@@ -303,7 +319,7 @@ class SlabDecodeCall:
 
     def run(self, q, k_new, v_new, kv_len: int, pos_q: int, scores: torch.Tensor,
             position_ids: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
-            step: Optional[StepState] = None, layout: int = 0) -> torch.Tensor:
+            step: Optional[StepState] = None, layout: int = 0, proj: Optional[tuple] = None) -> torch.Tensor:
         """q [B,H,d], k_new / v_new [B,Hkv,d] (rows contiguous), scores [B,H,>=kv_len]; optional position_ids int64 [B]
         (device) and additive mask [B,kv_len] as in attn_decode; returns out [B, H*d].
         ``layout``: lay the split-N decomposition out for this length (>= kv_len) instead of kv_len.  ``step``: the
@@ -330,6 +346,11 @@ class SlabDecodeCall:
         a.kv_len, a.pos_q = kv_len, pos_q
         a.kv_len_layout = layout
         a.step_state = None if step is None else step.data_ptr()
+        if proj is not None:
+            y = torch.empty(self.B, proj[0].shape[0], dtype=q.dtype, device=q.device)
+            _fill_proj(a, (proj[0], proj[1], y), q, self.B, self.H * self.d)
+        else:
+            a.proj_weight = None
         if position_ids is not None:
             a.position_ids, a.pos_sb = position_ids.data_ptr(), position_ids.stride(0)
         else:
@@ -339,7 +360,7 @@ class SlabDecodeCall:
         else:
             a.mask = None
         _lib.check(self.lib.spatten_attn_decode_args(ctypes.byref(a), stream), "spatten_attn_decode")
-        return out
+        return out if proj is None else (out, y)
 
 
 def gemv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,

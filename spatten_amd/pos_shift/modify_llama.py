@@ -205,6 +205,10 @@ def llama_pos_shift_attention_forward(
         q3 = query_states.view(bsz, num_heads, head_dim)
         k3, v3 = key_states.view(bsz, num_kv_heads, head_dim), value_states.view(bsz, num_kv_heads, head_dim)
         gctx = kv_slab.graph_ctx
+        # native projections (opt-in) on the plain path: o_proj rides in the attention call (include/spatten.h: proj_* — the
+        # library issues both launches: one host call per layer-step)
+        fused_proj = (self.o_proj.weight, self.o_proj.bias) if (native_rows and hp is None and ext is None) else None
+        projected = None
         if ext is not None and gctx is not None:
             if not ext[0].graph_capable():
                 raise RuntimeError("DecodeGraph captures the plain decode step and the cascade-importance / head-pruning "
@@ -219,7 +223,8 @@ def llama_pos_shift_attention_forward(
             # launch depends on a host value that changes from token to token.  The HF mask / position_ids of a
             # single-token step (zeros / past_len, transformers 4.33) are not read, as with assume_causal.
             row = slab.stash_row(num_heads)
-            attn_output = slab.decode_step(q3, k3, v3, kv_seq_len, past_len, cos, sin, row, step=gctx.state_for(slab, cos, sin))
+            attn_output = slab.decode_step(q3, k3, v3, kv_seq_len, past_len, cos, sin, row, step=gctx.state_for(slab, cos, sin),
+                                           proj=fused_proj)
             stash = row[:, :, None, :kv_seq_len]
             gctx.touched.append((self, slab, None))
         else:
@@ -230,10 +235,14 @@ def llama_pos_shift_attention_forward(
             attn_output = slab.decode_step(
                 q3, k3, v3, kv_seq_len, past_len, cos, sin, stash.view(bsz, num_heads, kv_seq_len),
                 None if position_ids is None else position_ids[:, 0],
-                None if (attention_mask is None or assume_causal) else attention_mask[:, 0, 0, :])
+                None if (attention_mask is None or assume_causal) else attention_mask[:, 0, 0, :], proj=fused_proj)
         slab.length = slab.rot_len = kv_seq_len
+        if isinstance(attn_output, tuple):
+            attn_output, projected = attn_output
+            projected = projected.view(bsz, 1, -1)
         attn_output = attn_output.view(bsz, 1, num_heads * head_dim)
     else:
+        projected = None
         stash = torch.empty(bsz, num_heads, q_len, kv_seq_len, dtype=dtype, device=device) if want_stash else None
         ops.kv_append(key_states.view(bsz, q_len, num_kv_heads, head_dim).transpose(1, 2),
                       value_states.view(bsz, q_len, num_kv_heads, head_dim).transpose(1, 2),
@@ -279,6 +288,8 @@ def llama_pos_shift_attention_forward(
         attn_output = attn_output.split(hidden_size // tp, dim=2)
         o_slices = self.o_proj.weight.split(hidden_size // tp, dim=1)
         attn_output = sum(F.linear(attn_output[i], o_slices[i]) for i in range(tp))
+    elif projected is not None:
+        attn_output = projected                                                   # :163, computed inside the attention call
     elif native_rows:
         attn_output = ops.gemv(attn_output, self.o_proj.weight, self.o_proj.bias)
     else:

@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 cp spatten_amd/lib/libspatten_hip.so /tmp/lib_orig.so
 mkdir -p /tmp/dex; rm -f /tmp/dex/*.o
-for f in prune cascade pq comm step gemv; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -c spatten_amd/csrc/$f.hip -o /tmp/dex/$f.o & done
+for f in prune cascade pq comm step gemv layer_cascade; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -c spatten_amd/csrc/$f.hip -o /tmp/dex/$f.o & done
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -fno-slp-vectorize -c spatten_amd/csrc/prefill_attn.hip -o /tmp/dex/prefill_attn.o &
 wait
 for var in "$@"; do

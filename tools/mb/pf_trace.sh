@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 cp spatten_amd/lib/libspatten_hip.so /tmp/lib_orig.so
 mkdir -p /tmp/pft; rm -f /tmp/pft/*.o
-for f in decode_attn prune cascade pq comm step gemv; do
+for f in decode_attn prune cascade pq comm step gemv layer_cascade; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -c spatten_amd/csrc/$f.hip -o /tmp/pft/$f.o &
 done
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -fno-slp-vectorize -DSPATTEN_PF_TRACE $EXTRA -c spatten_amd/csrc/prefill_attn.hip -o /tmp/pft/prefill_attn.o &
