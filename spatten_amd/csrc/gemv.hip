@@ -16,7 +16,10 @@
 
 namespace spatten {
 
-constexpr int kGemvRows = 4;      // weight rows per wave
+#ifndef SPATTEN_GEMV_ROWS
+#define SPATTEN_GEMV_ROWS 4
+#endif
+constexpr int kGemvRows = SPATTEN_GEMV_ROWS;      // weight rows per wave
 constexpr int kGemvChunks = 8;    // 512-column chunks per pass
 
 template <typename T>
