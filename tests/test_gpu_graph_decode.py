@@ -404,3 +404,96 @@ def test_decode_graph_covers_cascade_importance_and_head_pruning(kw):
         xp = torch.randn(1, 6, HID, device="cuda", generator=g).to(dt)
         _, past_a = a(xp, new_a)
         _, past_b = b(xp, new_b)
+
+
+class _RMSNorm(nn.Module):
+    def __init__(self, n, dt):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(n, dtype=dt, device="cuda"))
+
+    def forward(self, x):
+        v = x.float()
+        return (v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + 1e-5)).to(x.dtype) * self.weight
+
+
+class _DecoderLayer(nn.Module):
+    def __init__(self, dt):
+        super().__init__()
+        self.self_attn = LlamaAttention(dt)
+        self.ln1, self.ln2 = _RMSNorm(HID, dt), _RMSNorm(HID, dt)
+        self.up = nn.Linear(HID, 2 * HID, bias=False, dtype=dt, device="cuda")
+        self.down = nn.Linear(2 * HID, HID, bias=False, dtype=dt, device="cuda")
+
+
+class _TinyLM(nn.Module):
+    """A whole (small) Llama-like decoder — embedding, pre-norm blocks with the patched attention and an MLP, final norm,
+    lm_head — under the transformers 4.33 calling convention (device-built mask / position_ids)."""
+    VOCAB = 211
+
+    def __init__(self, dt):
+        super().__init__()
+        self.config = SimpleNamespace(model_type="llama")
+        self.embed = nn.Embedding(self.VOCAB, HID, dtype=dt, device="cuda")
+        self.layers = nn.ModuleList([_DecoderLayer(dt) for _ in range(LAYERS)])
+        self.norm = _RMSNorm(HID, dt)
+        self.lm_head = nn.Linear(HID, self.VOCAB, bias=False, dtype=dt, device="cuda")
+
+    @torch.no_grad()
+    def forward(self, ids, past):
+        B, q = ids.shape
+        P = 0 if past is None else past[0][0].shape[2]
+        pos = torch.arange(P, P + q, device=ids.device)[None]
+        mask = torch.zeros(B, 1, q, P + q, dtype=self.embed.weight.dtype, device=ids.device)
+        if q > 1:
+            mask.masked_fill_(torch.ones(q, P + q, dtype=torch.bool, device=ids.device).triu(P + 1), torch.finfo(mask.dtype).min)
+        x = self.embed(ids)
+        new_past = []
+        for i, layer in enumerate(self.layers):
+            a, _, kv = layer.self_attn(layer.ln1(x), attention_mask=mask, position_ids=pos,
+                                       past_key_value=None if past is None else past[i], use_cache=True)
+            x = x + a
+            x = x + layer.down(torch.nn.functional.silu(layer.up(layer.ln2(x))))
+            new_past.append(kv)
+        return self.lm_head(self.norm(x)), new_past
+
+
+def test_greedy_decoding_of_a_whole_model_under_one_graph():
+    """The reference's greedy_generate (run_spatten_llama.py:18-57) with the per-token `model(...)` call replaced by
+    DecodeGraph.step: embedding, norms, MLPs, the patched attention of every layer and the lm_head are ONE captured graph;
+    the argmax token is fed back on the device.  Same tokens, same logits (bit for bit) as the eager loop; then the prune of
+    the turn boundary from the graph's stashes."""
+    import contextlib
+    import io
+
+    from spatten_amd import enable_spatten_llm
+    from spatten_amd.graph import DecodeGraph
+    dt = torch.bfloat16
+    torch.manual_seed(3)
+    a = _TinyLM(dt)
+    b = _TinyLM(dt)
+    b.load_state_dict(a.state_dict())
+    caches = []
+    for m in (a, b):
+        with contextlib.redirect_stdout(io.StringIO()):
+            caches.append(enable_spatten_llm(m, 4, 40, 40, native_gemv=True))
+    prompt = torch.randint(0, _TinyLM.VOCAB, (1, 120), device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
+    la, past_a = a(prompt, None)
+    lb, past_b = b(prompt, None)
+    assert torch.equal(la, lb)
+    tok_a = la[:, -1:].argmax(-1)
+    tok_b = lb[:, -1:].argmax(-1)
+    graph = DecodeGraph(lambda past, ids: tuple(reversed(b(ids, past))), past_b, horizon=24)
+    toks_a, toks_b = [], []
+    for t in range(20):
+        la, past_a = a(tok_a, past_a)
+        lb = graph.step(tok_b)
+        assert torch.equal(la, lb), t
+        tok_a, tok_b = la[:, -1:].argmax(-1), lb[:, -1:].argmax(-1)       # stays on the device: no host sync per token
+        toks_a.append(tok_a)
+        toks_b.append(tok_b.clone())
+    assert torch.equal(torch.cat(toks_a, 1), torch.cat(toks_b, 1)) and graph.n_replays == 19
+    past_b = graph.past_key_values
+    new_a = caches[0].apply_token_pruning(past_a, 30, [l.self_attn.attn_scores for l in a.layers])
+    new_b = caches[1].apply_token_pruning(past_b, 30, [l.self_attn.attn_scores for l in b.layers])
+    for (ka, va), (kb, vb) in zip(new_a, new_b):
+        assert torch.equal(ka, kb) and torch.equal(va, vb)
