@@ -12,7 +12,7 @@ all: lib oracle
 
 lib: $(LIB)
 
-build/%.o: spatten_amd/csrc/%.hip spatten_amd/csrc/common.h include/spatten.h
+build/%.o: spatten_amd/csrc/%.hip spatten_amd/csrc/common.h include/spatten.h $(wildcard spatten_amd/csrc/*.h)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) $(FLAGS_$*) -c $< -o $@
 

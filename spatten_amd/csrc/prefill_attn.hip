@@ -1055,6 +1055,8 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 }
 
 
+#include "prefill_w4.h"
+
 // Fold the key-split partials of prefill_pp128_kernel: one wave per query row (D/64 output elements per lane).
 // out = sum_s O_s e^(m_s - m) / sum_s l_s e^(m_s - m),  m = max_s m_s   (a split without keys has m = -inf, l = 0)
 template <typename T, int D>
@@ -1257,6 +1259,15 @@ static inline bool use_vtr_for(int head_dim, int q_len, int kv_len) {
   return q_len <= SPATTEN_PF_VTR_MAXQ;
 }
 
+// The one-wave-per-SIMD kernel (prefill_w4.h) is an EXPERIMENT, off unless SPATTEN_PREFILL_W4=1: correct (tests/
+// test_gpu_prefill_w4.py) but 616-642 TFLOP/s against 740-766 for prefill_pp128_kernel at q = N = 8192.
+static int g_last_flash_kernel = 0;     // developer diagnostic: 1 = pp128, 2 = w4, 3 = the 64-key kernel
+static inline bool use_w4_for(int q_len) {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("SPATTEN_PREFILL_W4"); env = e ? atoi(e) : 0; }
+  return env == 1;
+}
+
 // Key split of the plain flash kernel: only when the launch would leave most of the chip idle (few query blocks x heads)
 // and every range still has >= 2 key tiles.  The same rule sizes the workspace.
 static inline int flash_ksplit(int batch, int heads, int q_len, int kv_len) {
@@ -1292,6 +1303,15 @@ static void launch_flash_m(const FlashParams<T>& p, hipStream_t st) {
       return;
     }
     if (prefill_variant() == 0) {
+      if constexpr (D == 128) {
+        if (use_w4_for(p.q_len) && !p.mask && !p.vtr && p.ksplit <= 1) {
+          if (p.fast) hipLaunchKernelGGL((prefill_w4_kernel<T, true>), grid, dim3(256), 0, st, p);
+          else hipLaunchKernelGGL((prefill_w4_kernel<T, false>), grid, dim3(256), 0, st, p);
+          g_last_flash_kernel = 2;
+          return;
+        }
+      }
+      g_last_flash_kernel = 1;
       const dim3 gridk((unsigned)(p.nqb * p.H * p.B * (p.ksplit > 1 ? p.ksplit : 1)));
       if (p.mask) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, true>), gridk, dim3(512), 0, st, p);
       else if (p.fast) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, 0, true>), gridk, dim3(512), 0, st, p);
@@ -1304,6 +1324,7 @@ static void launch_flash_m(const FlashParams<T>& p, hipStream_t st) {
       return;
     }
   }
+  g_last_flash_kernel = 3;
   if (p.mask) hipLaunchKernelGGL((prefill_pp_kernel<T, D, ST, CI, true>), grid, dim3(512), 0, st, p);
   else hipLaunchKernelGGL((prefill_pp_kernel<T, D, ST, CI, false>), grid, dim3(512), 0, st, p);
 }
@@ -1554,6 +1575,9 @@ extern "C" int spatten_attn_prefill_pq(int dtype, const void* q, int64_t q_sb, i
 #undef SPATTEN_FLASH_PQ
   return rc;
 }
+
+// developer diagnostic (not part of the boundary, not in include/spatten.h): which flash kernel the last prefill call launched
+extern "C" int spatten_debug_last_prefill_kernel(void) { return g_last_flash_kernel; }
 
 #ifdef SPATTEN_PF_TRACE
 extern "C" int spatten_debug_set_pf_trace(unsigned long long* buf) {
