@@ -279,7 +279,7 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False, Fals
             torch.cuda.synchronize()
             key = "plugin_path_assume_causal_fused_qkv_native_gemv_tokens_per_s" if gemv else (
                 "plugin_path_assume_causal_fused_qkv_tokens_per_s" if fuse else (
-                    "plugin_path_assume_causal_tokens_per_s" if flag else "plugin_path_tokens_per_s"))
+                    "plugin_path_assume_causal_tokens_per_s" if flag else "plugin_path_eager_tokens_per_s"))
             out[key] = round(n_tokens / (time.perf_counter() - t0), 2)
             # ---- the same decode step as ONE captured HIP graph of the whole layer stack (spatten_amd/graph.py): the
             # device-resident step state (ABI 3) lets a single graph replay for every token of the turn
@@ -348,6 +348,14 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False, Fals
             del past
     # bytes one token of this path must move at least: the four projection matrices of every layer + the kept K/V rows
     hid = HEADS * HEAD_DIM
+    # the drop-in surface as it is meant to be driven: enable_spatten_llm(fuse_qkv, native_gemv) with the
+    # per-token model call replaced by DecodeGraph.step — one captured HIP graph of the whole patched layer stack per turn.
+    # `plugin_path_eager_tokens_per_s` is the same patched forward launched op by op from Python, as the reference's loop does.
+    if "plugin_path_graph_fused_qkv_native_gemv_tokens_per_s" in out:
+        out["plugin_path_tokens_per_s"] = out["plugin_path_graph_fused_qkv_native_gemv_tokens_per_s"]
+        out["plugin_path_config"] = ("enable_spatten_llm(fuse_qkv=True, native_gemv=True) + spatten_amd.graph.DecodeGraph (replays of one "
+                                     "captured graph per turn; *_turn_incl_capture_* includes the warm-up step and the capture; "
+                                     "plugin_protocol_* the whole prune -> prefill -> decode turn)")
     out["plugin_path_min_bytes_per_token"] = int(LAYERS * (4 * hid * hid * 2 + 2 * HEADS * (P + TURN) * HEAD_DIM * 2))
     out["plugin_path_tokens_per_s_at_hbm_peak"] = round(HBM_PEAK_GBS * 1e9 / out["plugin_path_min_bytes_per_token"], 1)
     return out
@@ -779,7 +787,7 @@ def main():
                 extras["plugin_path_error"] = f"{type(e).__name__}: {e}"
             try:
                 extras.update(dense_with_projections_tokens_per_s(dev, dt))
-                for k_ in ("plugin_path_tokens_per_s", "plugin_path_graph_tokens_per_s", "plugin_path_graph_fused_qkv_tokens_per_s",
+                for k_ in ("plugin_path_eager_tokens_per_s", "plugin_path_graph_tokens_per_s", "plugin_path_graph_fused_qkv_tokens_per_s",
                            "plugin_path_graph_fused_qkv_native_gemv_tokens_per_s"):
                     if k_ in extras:
                         extras[k_.replace("_tokens_per_s", "") + "_speedup_vs_dense_eager_with_projections"] = round(
