@@ -185,7 +185,9 @@ int spatten_attn_decode_args(const spatten_decode_args_t* args, void* stream);
  *     load address in the attention kernel depends on the length.
  *   - rows [length, bound) of kr_cache and v_cache are read and discarded (weight 0): they must hold FINITE values —
  *     zero-fill the planes once when they are allocated.  Stash entries [length, bound) are left untouched.
- *   - admitted for the single-token step without mask, position_ids, pq_* and SCORES_ONLY; head_ids / head_abs_acc as usual.
+ *   - admitted for the single-token step without mask, position_ids and SCORES_ONLY; head_ids / head_abs_acc as usual.
+ *   - pq_* (progressive-quant keys) are admitted without importance_acc: the step's row is appended beforehand by
+ *     spatten_kv_append_step (which also packs its planes); plane rows [length, bound) must be finite too.
  *   - importance_acc (the fused cascade accumulation) IS admitted: `scores` / `lse` and `prev_scores` / `prev_lse` are
  *     then the TWO buffers that swap roles every step (same strides, rows up to the bound): step k since the last
  *     spatten_step_set writes buffer (k - 1) & 1 — `scores` first — and folds the other one over the rows the previous
@@ -203,6 +205,16 @@ int spatten_step_set(void* state, int dtype, int head_dim, const void* cos, cons
  * values of the length, hence capturable. */
 int spatten_step_advance(void* state, int dtype, int head_dim, const void* cos, const void* sin, int table_rows,
                          int delta, void* stream);
+
+/* The append of ONE decode step in device-length form, for the modes whose attention launch appends nothing (pq_*):
+ * row (state word 0) - 1 of k_cache (optional) / v_cache <- k_new / v_new [B,Hkv,d] (strides new_sb, new_sh), of kr_cache
+ * <- k_new rotated with the state's staged row of that slot (modify_llama.py:95-104), and — msb / lsb / scale given, or
+ * all three NULL — that row of the progressive-quant planes (what spatten_kv_append + spatten_pq_pack leave there, bit for
+ * bit).  Call it after the token's spatten_step_advance; a row >= capacity is not written.  head_dim 64 / 128. */
+int spatten_kv_append_step(int dtype, const void* k_new, const void* v_new, int64_t new_sb, int64_t new_sh, void* k_cache,
+                           void* kr_cache, void* v_cache, int64_t kv_sb, int64_t kv_sh, void* msb, void* lsb, float* scale,
+                           int64_t pl_sb, int64_t pl_sh, int64_t sc_sb, int64_t sc_sh, int batch, int kv_heads,
+                           int head_dim, int capacity, const void* step_state, void* stream);
 
 /* The projections of a single-token step (modify_llama.py:72-74 q/k/v_proj, :163 o_proj; nn.Linear semantics):
  *   y[m, n] = sum_k x[m, k] * W[n, k] (+ bias[n]),  W [N, K] row-major with row stride w_sn (elements), x [M, K] row stride

@@ -85,6 +85,8 @@ def _declare(lib):
     lib.spatten_gemv.argtypes = [i, p, i64, p, i64, p, p, i64, i, i, i, p]
     lib.spatten_kv_append.restype = c_int
     lib.spatten_kv_append.argtypes = [i, p, p, i64, i64, i64, p, p, p, i64, i64, p, p, i, i, i, i, i, i, p]
+    lib.spatten_kv_append_step.restype = c_int
+    lib.spatten_kv_append_step.argtypes = [i, p, p, i64, i64, p, p, p, i64, i64, p, p, p, i64, i64, i64, i64, i, i, i, i, p, p]
     lib.spatten_importance_accumulate.restype = c_int
     lib.spatten_importance_accumulate.argtypes = [i, p, i64, i64, i64, p, p, i64, i64, p, i64, i, i, i, i, i, p]
     lib.spatten_row_lse.restype = c_int

@@ -781,7 +781,11 @@ static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_onl
     if constexpr (D == 256) return SPATTEN_ERR_UNSUPPORTED;
     else {
       // the fused cascade accumulation rides on pass 1 only (pass 2 re-streams the flagged heads: no double count)
-      if (pipe) {
+      if (dyn) {      // device-length form (the step appended by spatten_kv_append_step): no fused cascade accumulation
+        if (casc) return SPATTEN_ERR_INVALID;
+        if (pipe) { SPATTEN_LAUNCH(UP, 0, false, 1, true, false, true, true); SPATTEN_LAUNCH(UP, 0, false, 2, true, false, true, true); }
+        else { SPATTEN_LAUNCH(U, 0, false, 1, true, false, false, true); SPATTEN_LAUNCH(U, 0, false, 2, true, false, false, true); }
+      } else if (pipe) {
         // (r03, measured and NOT adopted: 6 / 8 row-groups per pipelined tile for this pass — a plane row is a quarter of
         //  a 16-bit key row, so the registers are there — 22.9 / 23.3 us against 20.7 with 4; SPATTEN_PQ_UP keeps the A/B)
         constexpr int UPQ = (sizeof(T) == 2 && D <= 128) ? SPATTEN_PQ_UP : UP;
@@ -847,7 +851,7 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
     return SPATTEN_ERR_INVALID;
   if (c.table_rows < c.kv_len || (!c.position_ids && c.pos_q + c.n_q > c.table_rows)) return SPATTEN_ERR_INVALID;
   // device-resident step state: the plain single-row step only (kv_len is then the BOUND the grid is laid out for)
-  if (c.step && (c.n_q != 1 || c.mask || c.position_ids || pq || scores_only || c.causal)) return SPATTEN_ERR_INVALID;
+  if (c.step && (c.n_q != 1 || c.mask || c.position_ids || (pq && c.acc) || scores_only || c.causal)) return SPATTEN_ERR_INVALID;
   // ... with the fused cascade accumulation: `scores` / `lse` and `prev_scores` / `prev_lse` are the two buffers that swap
   // roles every step (same strides, rows up to the bound)
   if (c.step && c.acc && (!c.scores || !c.lse || !c.prev_scores || !c.prev_lse || c.pv_sb != c.sc_sb || c.pv_sh != c.sc_sh))

@@ -49,6 +49,71 @@ __global__ __launch_bounds__(256) void pq_pack_kernel(const T* __restrict__ kr, 
   if (c == 0) scale[b * sc_sb + hkv * sc_sh + row] = sc;
 }
 
+// ---- one decode step's append in device-length form (step.hip): row n - 1 (n = state word 0, already advanced) of k / v,
+// its rotation into the shadow with the state's staged rotary row 1 (modify_llama.py:95-104) and — when planes are given —
+// that row's MSB / LSB nibbles and scale, bit for bit what kv_append_kernel + pq_pack_kernel leave there.  Nothing in the
+// launch depends on a host length, so the progressive-quantisation decode step (whose attention launch appends nothing) can
+// be captured into the per-token graph.  D/16 lanes per (b, h): 8 lower-half + 8 upper-half elements each.
+template <typename T, int D>
+__global__ __launch_bounds__(64) void kv_append_pq_step_kernel(const T* __restrict__ k_new, const T* __restrict__ v_new,
+                                                               int64_t new_sb, int64_t new_sh, T* __restrict__ kc,
+                                                               T* __restrict__ krc, T* __restrict__ vc, int64_t kv_sb,
+                                                               int64_t kv_sh, uint8_t* __restrict__ msb,
+                                                               uint8_t* __restrict__ lsb, float* __restrict__ scale,
+                                                               int64_t pl_sb, int64_t pl_sh, int64_t sc_sb, int64_t sc_sh,
+                                                               int B, int H, int cap, const int32_t* __restrict__ step) {
+  constexpr int HALF = D / 2, LPR = D / 16, RPB = 64 / LPR;
+  const int lane = threadIdx.x, c = lane % LPR;
+  const int unit = blockIdx.x * RPB + lane / LPR;
+  const int row = step[0] - 1;
+  if (unit >= B * H || row < 0 || row >= cap) return;      // (whole LPR-groups leave together)
+  const int b = unit / H, h = unit % H;
+  using V8 = Vec8<T>;
+  const T* rows = reinterpret_cast<const T*>(reinterpret_cast<const char*>(step) + kStepHeader);   // cos[2][HALF] | sin[2][HALF]
+  const T* kp = k_new + b * new_sb + h * new_sh;
+  const T* vp = v_new + b * new_sb + h * new_sh;
+  const typename V8::raw k0 = V8::ldg(kp + 8 * c), k1 = V8::ldg(kp + HALF + 8 * c);
+  const typename V8::raw v0 = V8::ldg(vp + 8 * c), v1 = V8::ldg(vp + HALF + 8 * c);
+  float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8];
+  V8::unpack(k0, xlo);
+  V8::unpack(k1, xhi);
+  V8::unpack(V8::ldg(rows + HALF + 8 * c), cc);
+  V8::unpack(V8::ldg(rows + 3 * HALF + 8 * c), ss);
+  rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
+  const int64_t dst = b * kv_sb + h * kv_sh + (int64_t)row * D;
+  if (kc) { V8::stg(kc + dst + 8 * c, k0); V8::stg(kc + dst + HALF + 8 * c, k1); }
+  V8::stg(krc + dst + 8 * c, V8::pack(ylo));
+  V8::stg(krc + dst + HALF + 8 * c, V8::pack(yhi));
+  V8::stg(vc + dst + 8 * c, v0);
+  V8::stg(vc + dst + HALF + 8 * c, v1);
+  if (msb == nullptr) return;
+  // the planes of the row (pq_pack_kernel's arithmetic; ylo / yhi ARE the values the shadow now holds: rope_pair rounds)
+  float amax = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fmaxf(fabsf(ylo[e]), fabsf(yhi[e])));
+  amax = fmaxf(amax, dpp_mov<kDppXor1>(amax));
+  amax = fmaxf(amax, dpp_mov<kDppXor2>(amax));
+  if (LPR == 8) amax = fmaxf(amax, dpp_mov<kDppHalfMirror>(amax));
+  const float sc = amax > 0.f ? amax / 127.0f : 1.0f;
+  uint32_t m_lo = 0, l_lo = 0, m_hi = 0, l_hi = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    int qa = (int)rintf(ylo[e] / sc), qb = (int)rintf(yhi[e] / sc);
+    qa = max(-128, min(127, qa));
+    qb = max(-128, min(127, qb));
+    m_lo |= (uint32_t)((qa >> 4) & 15) << (4 * e);
+    l_lo |= (uint32_t)(qa & 15) << (4 * e);
+    m_hi |= (uint32_t)((qb >> 4) & 15) << (4 * e);
+    l_hi |= (uint32_t)(qb & 15) << (4 * e);
+  }
+  const int64_t po = b * pl_sb + h * pl_sh + (int64_t)row * (D / 2);
+  *reinterpret_cast<uint32_t*>(msb + po + 4 * c) = m_lo;
+  *reinterpret_cast<uint32_t*>(lsb + po + 4 * c) = l_lo;
+  *reinterpret_cast<uint32_t*>(msb + po + 4 * (LPR + c)) = m_hi;
+  *reinterpret_cast<uint32_t*>(lsb + po + 4 * (LPR + c)) = l_hi;
+  if (c == 0) scale[b * sc_sb + h * sc_sh + row] = sc;
+}
+
 // ---- expand: planes -> integer-valued keys for the matrix cores (progressive-quant prefill) ----------------------------
 // k_msb[row][e] = 16 * sext(msb nibble), k_full[row][e] = that + lsb nibble — exact in bf16 / f16 (|value| <= 128) —
 // contiguous [B,Hkv,rows,D]; kscale[row] = scale / sqrt(D).  One lane per 8 elements.
@@ -116,6 +181,29 @@ extern "C" int spatten_pq_pack(int dtype, const void* kr_cache, int64_t kv_sb, i
                                              row_lo, row_hi))
   if (head_dim == 128) { SPATTEN_PACK(128); } else { SPATTEN_PACK(64); }
 #undef SPATTEN_PACK
+  return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+}
+
+extern "C" int spatten_kv_append_step(int dtype, const void* k_new, const void* v_new, int64_t new_sb, int64_t new_sh,
+                                      void* k_cache, void* kr_cache, void* v_cache, int64_t kv_sb, int64_t kv_sh, void* msb,
+                                      void* lsb, float* scale, int64_t pl_sb, int64_t pl_sh, int64_t sc_sb, int64_t sc_sh,
+                                      int batch, int kv_heads, int head_dim, int capacity, const void* step_state,
+                                      void* stream) {
+  if (!k_new || !v_new || !kr_cache || !v_cache || !step_state || batch <= 0 || kv_heads <= 0 || capacity <= 0)
+    return SPATTEN_ERR_INVALID;
+  if ((msb == nullptr) != (lsb == nullptr) || (msb == nullptr) != (scale == nullptr)) return SPATTEN_ERR_INVALID;
+  if (dtype != SPATTEN_F32 && dtype != SPATTEN_F16 && dtype != SPATTEN_BF16) return SPATTEN_ERR_INVALID;
+  if (head_dim != 64 && head_dim != 128) return SPATTEN_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int rpb = 64 / (head_dim / 16);
+  const dim3 grid((unsigned)ceil_div(batch * kv_heads, rpb));
+#define SPATTEN_APPEND_STEP(DD)                                                                                          \
+  SPATTEN_BY_DTYPE(dtype, hipLaunchKernelGGL((kv_append_pq_step_kernel<T, DD>), grid, dim3(64), 0, st, (const T*)k_new,     \
+                                             (const T*)v_new, new_sb, new_sh, (T*)k_cache, (T*)kr_cache, (T*)v_cache, kv_sb, \
+                                             kv_sh, (uint8_t*)msb, (uint8_t*)lsb, scale, pl_sb, pl_sh, sc_sb, sc_sh, batch,  \
+                                             kv_heads, capacity, (const int32_t*)step_state))
+  if (head_dim == 128) { SPATTEN_APPEND_STEP(128); } else { SPATTEN_APPEND_STEP(64); }
+#undef SPATTEN_APPEND_STEP
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }
 

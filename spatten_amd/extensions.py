@@ -123,9 +123,12 @@ class SpattenExtensions:
     # ------------------------------------------------------------------------------------------------
     def graph_capable(self) -> bool:
         """Modes whose decode step runs in the device-length form (spatten_amd/graph.py): cascade importance and head
-        pruning — one fused launch with fixed buffers.  Progressive quantisation, local V pruning and the layer cascade
-        launch helper kernels with host lengths and stay eager."""
-        return self.pq_threshold is None and self.local_v_keep is None and self.layer_keep is None
+        pruning — one fused launch with fixed buffers — and progressive quantisation without cascade importance (the step's
+        append + plane packing as one device-length launch, then the two passes over the planes).  Local V pruning and the
+        layer cascade launch helper kernels with host lengths and stay eager."""
+        if self.pq_threshold is not None and self.cascade:
+            return False
+        return self.local_v_keep is None and self.layer_keep is None
 
     def decode_step_graph(self, layer: int, q, k_new, v_new, slab, kv_len: int, cos, sin, gctx):
         """The decode step under a DecodeGraph: every buffer at capacity and at a fixed address; with cascade importance
@@ -142,6 +145,18 @@ class SpattenExtensions:
             raise RuntimeError("extension buffers smaller than the slab capacity")
         casc = (st.acc, st.stash[1], st.lse[1], 0) if self.cascade else None
         step = gctx.state_for(slab, cos, sin)
+        if self.pq_threshold is not None:
+            # rows [0, kv_len - 1) packed with host lengths BEFORE the capture (the eager first step of the binding does it:
+            # nothing is left for the captured trace), this step's row by the device-length append
+            slab.ensure_pq(kv_len - 1)
+            if slab.pq.msb.shape[2] < cap:
+                raise RuntimeError("progressive-quant planes smaller than the slab capacity")
+            ops.kv_append_step(k_new, v_new, slab.k, slab.kr, slab.v, step, slab.pq)
+            slab.pq_len = kv_len
+            ops.attn_decode(q, None, None, slab.v, cap, cos, sin, 0, out=st.out, scores=st.stash[0], lse=st.lse[0],
+                            head_ids=st.head_ids, pq=(slab.pq, self.pq_threshold, st.need_lsb),
+                            head_abs=st.head_abs if self.head_keep is not None else None, step=step)
+            return st.out, st.stash[0][:, :, None, :kv_len]
         ops.attn_decode(q, slab.k, slab.kr, slab.v, cap, cos, sin, 0, k_new=k_new, v_new=v_new, out=st.out,
                         scores=st.stash[0], lse=st.lse[0], head_ids=st.head_ids, cascade=casc,
                         head_abs=st.head_abs if self.head_keep is not None else None, step=step)

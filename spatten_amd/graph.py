@@ -150,6 +150,8 @@ class DecodeGraph:
         out = []
         for slab in slabs:
             slab.length = slab.rot_len = self.length
+            if slab.pq is not None and slab.pq_len >= self.length - self.steps_traced:
+                slab.pq_len = self.length          # progressive quantisation: every replayed step packed its own row
             k, v = slab.views()
             out.append([k, v])
         synced = set()

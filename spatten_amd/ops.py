@@ -405,6 +405,34 @@ def kv_append(k_new: torch.Tensor, v_new: torch.Tensor, k_cache: Optional[torch.
     _lib.check(rc, "spatten_kv_append")
 
 
+def kv_append_step(k_new: torch.Tensor, v_new: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: torch.Tensor,
+                   v_cache: torch.Tensor, step: "StepState", planes: Optional["PQPlanes"] = None):
+    """The append of one decode step in device-length form: row (state length) - 1 of the slab planes from k_new / v_new
+    [B,Hkv,d], rotated with the state's staged row — and, with ``planes``, that row's progressive-quant nibbles and scale.
+    No host length: capturable (the modes whose attention launch does not append: spatten_amd/extensions.py)."""
+    _dev(k_new, v_new, k_cache, kr_cache, v_cache)
+    B, Hkv, d = k_new.shape
+    if k_new.stride(2) != 1 or v_new.stride() != k_new.stride():
+        raise ValueError("k_new / v_new need contiguous d and identical strides")
+    if kr_cache.stride(3) != 1 or kr_cache.stride(2) != d or v_cache.stride() != kr_cache.stride() \
+            or (k_cache is not None and k_cache.stride() != kr_cache.stride()):
+        raise ValueError("cache planes need contiguous rows (pitch d) and identical strides")
+    cap = kr_cache.shape[2]
+    m = l = sc = None
+    psb = psh = ssb = ssh = 0
+    if planes is not None:
+        if planes.msb.shape[2] < cap or planes.msb.stride(3) != 1 or planes.msb.stride(2) != d // 2 \
+                or planes.lsb.stride() != planes.msb.stride() or planes.scale.stride(2) != 1:
+            raise ValueError("planes smaller than the cache or not row-contiguous")
+        m, l, sc = planes.msb, planes.lsb, planes.scale
+        psb, psh, ssb, ssh = m.stride(0), m.stride(1), sc.stride(0), sc.stride(1)
+    rc = _lib.load().spatten_kv_append_step(_dt(k_new), k_new.data_ptr(), v_new.data_ptr(), k_new.stride(0), k_new.stride(1),
+                                            _ptr(k_cache), kr_cache.data_ptr(), v_cache.data_ptr(), kr_cache.stride(0),
+                                            kr_cache.stride(1), _ptr(m), _ptr(l), _ptr(sc), psb, psh, ssb, ssh, B, Hkv, d, cap,
+                                            step.data_ptr(), _stream())
+    _lib.check(rc, "spatten_kv_append_step")
+
+
 _pf_ws = _LRU(4)
 
 

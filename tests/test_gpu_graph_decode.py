@@ -354,7 +354,8 @@ def test_decode_graph_holds_the_head_parallel_exchange():
 
 
 @pytest.mark.parametrize("kw", [dict(importance_mode="cascade"), dict(head_keep=[6, 5, 5]),
-                                dict(importance_mode="cascade", head_keep=6, fuse_qkv=True, native_gemv=True)])
+                                dict(importance_mode="cascade", head_keep=6, fuse_qkv=True, native_gemv=True),
+                                dict(pq_threshold=0.05), dict(pq_threshold=0.02, head_keep=6, fuse_qkv=True)])
 def test_decode_graph_covers_cascade_importance_and_head_pruning(kw):
     """The SpAtten modes whose decode step is ONE fused launch — cumulative importance (the previous step's probabilities
     folded while this step streams; under the graph the two stash buffers swap roles on the device) and head pruning
@@ -386,6 +387,18 @@ def test_decode_graph_covers_cascade_importance_and_head_pruning(kw):
             else:           # pruned heads are not launched: their stash rows are whatever an earlier step left there
                 kept = la.head_ids.long()
                 assert torch.equal(ma.attn_scores[:, kept], mb.attn_scores[:, kept])
+        if "pq_threshold" in kw:    # progressive quantisation: the planes every replayed step packed, and the refetch flags
+            from spatten_amd import kv_slab
+            flagged = 0
+            for (ka, _), (kb, _), la, lb in zip(past_a, past_b, cache_a.ext.layers, cache_b.ext.layers):
+                sa, sb = kv_slab.slab_of(ka), kv_slab.slab_of(kb)
+                assert sa.pq_len == n and sb.pq_len == n
+                assert torch.equal(sa.pq.msb[:, :, :n], sb.pq.msb[:, :, :n]) and torch.equal(sa.pq.lsb[:, :, :n], sb.pq.lsb[:, :, :n])
+                assert torch.equal(sa.pq.scale[:, :, :n], sb.pq.scale[:, :, :n])
+                heads = slice(None) if la.head_ids is None else la.head_ids.long()
+                assert torch.equal(la.need_lsb[heads], lb.need_lsb[heads])
+                flagged += int(la.need_lsb[heads].sum())
+            assert flagged > 0          # the threshold is chosen so that both the confident and the refetch branch run
         coming = 6 + T
         launched = [slice(None) if la.head_ids is None else la.head_ids.long() for la in cache_a.ext.layers]   # heads of this turn
         new_a = cache_a.apply_token_pruning(past_a, coming, [m.attn_scores for m in a.layers])
