@@ -210,7 +210,8 @@ int spatten_step_advance(void* state, int dtype, int head_dim, const void* cos, 
  * row (state word 0) - 1 of k_cache (optional) / v_cache <- k_new / v_new [B,Hkv,d] (strides new_sb, new_sh), of kr_cache
  * <- k_new rotated with the state's staged row of that slot (modify_llama.py:95-104), and — msb / lsb / scale given, or
  * all three NULL — that row of the progressive-quant planes (what spatten_kv_append + spatten_pq_pack leave there, bit for
- * bit).  Call it after the token's spatten_step_advance; a row >= capacity is not written.  head_dim 64 / 128. */
+ * bit).  Call it after the token's spatten_step_advance; `capacity` = rows of the cache planes AND of the quantised planes:
+ * a row >= capacity is not written.  head_dim 64 / 128. */
 int spatten_kv_append_step(int dtype, const void* k_new, const void* v_new, int64_t new_sb, int64_t new_sh, void* k_cache,
                            void* kr_cache, void* v_cache, int64_t kv_sb, int64_t kv_sh, void* msb, void* lsb, float* scale,
                            int64_t pl_sb, int64_t pl_sh, int64_t sc_sb, int64_t sc_sh, int batch, int kv_heads,
