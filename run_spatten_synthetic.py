@@ -7,6 +7,7 @@ step's stashed scores, prefill the prompt, greedy-decode ``max_gen_len`` tokens}
 "N pruned token this round" counters.
 
     python run_spatten_synthetic.py --layers 8 --turns 5
+    python run_spatten_synthetic.py --layers 32 --turns 4 --auto-graph                            # the same loop, one graph replay per token
     python run_spatten_synthetic.py --layers 8 --cascade --head-keep 24 --pq-threshold 0.05     # SpAtten modes, through the plugin
     python run_spatten_synthetic.py --layers 12 --schedule tests/golden/trace_synthetic.csv      # per-layer keeps from a trace
     python run_spatten_synthetic.py --prompts tests/golden/mt_bench_sample.jsonl                 # MT-Bench turn structure
@@ -55,7 +56,7 @@ class SyntheticLlama(nn.Module):
         self.dtype = dtype
 
     @torch.no_grad()
-    def forward(self, input_ids, past_key_values=None, use_cache=True):
+    def forward(self, input_ids=None, past_key_values=None, use_cache=True):
         B, q = input_ids.shape
         P = 0 if past_key_values is None else past_key_values[0][0].shape[2]
         pos = torch.arange(P, P + q, device=input_ids.device)[None]
@@ -76,16 +77,18 @@ class SyntheticLlama(nn.Module):
 
 @torch.no_grad()
 def greedy_generate(model, input_ids, past_key_values, max_gen_len):          # run_spatten_llama.py:18-57
-    out = model(input_ids, past_key_values)
+    out = model(input_ids=input_ids, past_key_values=past_key_values, use_cache=True)
     past_key_values = out.past_key_values
     tok = out.logits[:, -1, :].argmax(dim=-1).unsqueeze(1)
-    n = 1
+    generated = [tok.item()]                                                  # the reference reads every token on the host
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for _ in range(max_gen_len - 1):
-        out = model(tok, past_key_values)
+        out = model(input_ids=tok, past_key_values=past_key_values, use_cache=True)
         past_key_values = out.past_key_values
         tok = out.logits[:, -1, :].argmax(dim=-1).unsqueeze(1)
-        n += 1
-    return past_key_values, n
+        generated.append(tok.item())
+    return past_key_values, len(generated), (max_gen_len - 1) / max(time.perf_counter() - t0, 1e-9)
 
 
 def chat(args):
@@ -120,6 +123,8 @@ def chat(args):
         if thr and args.pq_threshold is None and args.local_v_keep is None:
             ext["pq_threshold"] = float(thr[0])
         print("schedule:", {k: v for k, v in ext.items()})
+    if args.auto_graph:       # the loop below stays the reference's: its single-token calls replay one captured graph per token
+        ext.update(auto_graph=True, fuse_qkv=True, native_gemv=True)
     kv_cache = enable_spatten_llm(model, args.start_size, args.important_size, args.recent_size, **ext)     # :110-115
     attn = [m for m in model.modules() if type(m).__name__ == "LlamaAttention"]
     gen = torch.Generator(device="cuda").manual_seed(1)
@@ -146,11 +151,11 @@ def chat(args):
             print(f"N pruned token this round: {pruned}, cumulative: {cumulative}")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        past, n = greedy_generate(model, input_ids, past, args.max_gen_len)
+        past, n, dec_rate = greedy_generate(model, input_ids, past, args.max_gen_len)
         torch.cuda.synchronize()
         dtm = time.perf_counter() - t0
         lens = sorted({kv[0].size(2) for kv in past})
-        print(f"<{n} tokens> kv_len={lens[0] if len(lens) == 1 else lens}  ({(plen + n) / dtm:.0f} tok/s incl. prefill, {args.layers} layers)")
+        print(f"<{n} tokens> kv_len={lens[0] if len(lens) == 1 else lens}  ({(plen + n) / dtm:.0f} tok/s incl. prefill, decode {dec_rate:.0f} tok/s, {args.layers} layers)")
     if kv_cache.ext is not None:
         print("extensions:", kv_cache.ext.stats())
 
@@ -223,6 +228,8 @@ def main():
     ap.add_argument("--head-keep", type=int, default=0, help="cascade head pruning: heads kept per layer")
     ap.add_argument("--pq-threshold", type=float, default=None, help="progressive quantisation: LSB refetch below this max prob")
     ap.add_argument("--local-v-keep", type=float, default=None, help="local V pruning: fraction of V rows fetched at decode")
+    ap.add_argument("--auto-graph", action="store_true", help="enable_spatten_llm(auto_graph=True, fuse_qkv=True, native_gemv=True): "
+                    "the unchanged per-token loop replays one captured HIP graph per token")
     ap.add_argument("--schedule", default=None, help="per-layer keeps (layer cascade / heads / requant) from a trace CSV")
     ap.add_argument("--prompts", default=None, help="MT-Bench style question.jsonl: its turns drive the chat loop")
     ap.add_argument("--trace", default=None, help="cascade schedule CSV (format of the reference's workloads/*.csv)")

@@ -25,7 +25,8 @@ _FAMILIES: Dict[str, Callable] = {"llama": _patch_llama}
 
 def enable_spatten_llm(model, start_size, important_size, recent_size, importance_mode="reference",
                        prefill_stash=True, assume_causal=False, head_keep=None, pq_threshold=None, local_v_keep=None,
-                       layer_keep=None, fuse_qkv=False, native_gemv=False, head_parallel=None, numerics="reference"):
+                       layer_keep=None, fuse_qkv=False, native_gemv=False, head_parallel=None, numerics="reference",
+                       auto_graph=False):
     """The reference's four positional arguments (enable_spatten_llm.py:5) plus opt-in extensions:
 
     ``prefill_stash=False``: forwards with ``q_len > 1`` do not materialise ``self.attn_scores`` ([B,H,q,N]: 4 GiB per
@@ -42,6 +43,10 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     (``spatten_gemv``) instead of torch's GEMM library — at q_len = 1 they are HBM-bound streams that make up four fifths
     of the decode step's bytes (same fp32 accumulation and single rounding as ``nn.Linear``; a different summation order,
     so the last bit can differ).  Multi-token forwards keep torch's GEMMs.
+
+    ``auto_graph=True`` (or a token horizon): ``model.forward`` is wrapped so that the reference's per-token loop
+    (run_spatten_llama.py:27-35), unchanged, replays one captured HIP graph of the whole patched stack per token
+    (spatten_amd/graph.py:auto_graph) — the zero-change form of ``DecodeGraph``.
 
     ``numerics="fast"``: multi-token forwards that materialise no stash (``prefill_stash=False``) keep their logits in
     fp32 instead of reproducing the reference's two 16-bit roundings per logit (modify_llama.py:111-113) — a faster
@@ -98,4 +103,8 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
                                       head_parallel=head_parallel)
         for layer, m in enumerate(mods):
             m._spatten_ext = (cache.ext, layer)
+    if auto_graph:
+        from .graph import auto_graph as _auto
+
+        _auto(model, horizon=256 if auto_graph is True else int(auto_graph))
     return cache

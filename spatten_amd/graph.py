@@ -33,7 +33,7 @@ import torch
 
 from . import kv_slab, ops
 
-__all__ = ["DecodeGraph"]
+__all__ = ["DecodeGraph", "auto_graph"]
 
 
 class DecodeGraph:
@@ -142,6 +142,23 @@ class DecodeGraph:
         self.steps_traced += 1
         return self.static_out
 
+    def sync_scores(self):
+        """Point every patched module's ``attn_scores`` at its stash row of the last step (modify_llama.py:116-119) without
+        rebuilding the cache views — what a caller that reads only ``m.attn_scores`` between steps needs."""
+        synced = set()
+        for module, slab, ext in self.touched:
+            if ext is None:
+                if slab.stash is not None:
+                    object.__setattr__(module, "attn_scores", slab.stash[:, :, None, :self.length])
+                continue
+            exts, layer = ext
+            if id(exts) not in synced:
+                exts.graph_sync(self.steps_traced, self.length)
+                synced.add(id(exts))
+            st = exts.layers[layer]
+            cur = ((self.steps_traced - 1) & 1) if (exts.cascade and self.steps_traced > 0) else 0
+            object.__setattr__(module, "attn_scores", st.stash[cur][:, :, None, :self.length])
+
     @property
     def past_key_values(self):
         """``[K, V]`` views of every layer at the CURRENT length (the tuples a replayed step cannot update), in layer
@@ -169,3 +186,78 @@ class DecodeGraph:
             object.__setattr__(module, "attn_scores", st.stash[cur][:, :, None, :self.length])
         self._past = out
         return out
+
+
+class _LazyPast(list):
+    """``past_key_values`` of a replayed step: the per-layer ``[K, V]`` views are built when somebody looks (the next
+    captured step does not need them; ``apply_token_pruning`` and a multi-token forward do)."""
+
+    def __init__(self, graph: DecodeGraph):
+        super().__init__()
+        self._graph, self._length, self._done = graph, graph.length, False
+
+    def _fill(self):
+        if not self._done:
+            if self._graph.length != self._length:
+                raise RuntimeError("stale past_key_values: the model has decoded further since this object was returned")
+            super().extend(self._graph.past_key_values)
+            self._done = True
+
+    def __getitem__(self, i):
+        self._fill()
+        return super().__getitem__(i)
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def __len__(self):
+        self._fill()
+        return super().__len__()
+
+
+def auto_graph(model, horizon: int = 256):
+    """Zero-change mode of the drop-in: wrap ``model.forward`` so that the reference's own per-token loop
+    (run_spatten_llama.py:27-35: ``model(input_ids=tok, past_key_values=past, use_cache=True)``) runs every single-token call
+    as a replay of ONE captured graph of the whole patched stack.  A call is taken over when it has exactly ``input_ids``
+    [B, 1], ``past_key_values`` and ``use_cache=True`` (keywords) under ``torch.no_grad()``; the first such call on a cache
+    (after a prefill or a prune) runs eagerly, the second is captured, later ones replay.  Everything else — prefill, calls
+    with masks / positions / embeddings — goes to the original forward.  The returned ``logits`` are a static buffer the
+    next call overwrites; ``past_key_values`` is materialised when it is indexed; ``m.attn_scores`` is current after every
+    call.  Returns the wrapped model (the same object)."""
+    orig = model.forward
+    state = {"graph": None, "lazy": None, "proto": None}
+
+    def step_fn(past, ids):
+        out = orig(input_ids=ids, past_key_values=past, use_cache=True)
+        state["proto"] = out
+        if isinstance(out, tuple):
+            return out[1], out[0]
+        return out.past_key_values, out.logits
+
+    def forward(*args, **kw):
+        ids, past = kw.get("input_ids"), kw.get("past_key_values")
+        others = [k for k, v in kw.items() if k not in ("input_ids", "past_key_values", "use_cache") and v is not None]
+        take = (not args and not others and isinstance(ids, torch.Tensor) and ids.dim() == 2 and ids.shape[1] == 1 and ids.is_cuda
+                and past is not None and bool(kw.get("use_cache")) and not torch.is_grad_enabled())
+        if not take:
+            state["graph"] = state["lazy"] = None
+            return orig(*args, **kw)
+        if state["graph"] is None or past is not state["lazy"]:
+            state["graph"] = DecodeGraph(step_fn, list(past), horizon=horizon)
+        graph = state["graph"]
+        logits = graph.step(ids)
+        graph.sync_scores()
+        lazy = state["lazy"] = _LazyPast(graph)
+        proto = state["proto"]
+        if isinstance(proto, tuple):
+            return (logits, lazy) + tuple(proto[2:])
+        try:
+            return type(proto)(logits=logits, past_key_values=lazy)
+        except TypeError:
+            proto.logits, proto.past_key_values = logits, lazy
+            return proto
+
+    model.forward = forward
+    model._spatten_auto_graph = state
+    return model

@@ -510,3 +510,82 @@ def test_greedy_decoding_of_a_whole_model_under_one_graph():
     new_b = caches[1].apply_token_pruning(past_b, 30, [l.self_attn.attn_scores for l in b.layers])
     for (ka, va), (kb, vb) in zip(new_a, new_b):
         assert torch.equal(ka, kb) and torch.equal(va, vb)
+
+
+class _LMOutput:
+    def __init__(self, logits=None, past_key_values=None):
+        self.logits, self.past_key_values = logits, past_key_values
+
+
+class _HFStyleLM(_TinyLM):
+    """_TinyLM under the keyword calling convention of a transformers causal LM (what run_spatten_llama.py calls)."""
+
+    def forward(self, input_ids=None, past_key_values=None, use_cache=None, attention_mask=None, position_ids=None):
+        logits, new_past = _TinyLM.forward(self, input_ids, past_key_values)
+        return _LMOutput(logits=logits, past_key_values=new_past)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(importance_mode="cascade", head_keep=6)])
+def test_the_reference_loop_unchanged_replays_one_graph_per_token(kw):
+    """enable_spatten_llm(..., auto_graph=True): the reference's caller (run_spatten_llama.py:18-57 greedy_generate, :60-87
+    the turn protocol — collect m.attn_scores, apply_token_pruning, prefill the next prompt, decode token by token with
+    keyword calls and a host read of every token) runs UNCHANGED and every single-token call after the first two of a turn
+    is a graph replay.  Tokens, logits, stashes and pruned caches equal the same loop without auto_graph, bit for bit."""
+    import contextlib
+    import io
+
+    from spatten_amd import enable_spatten_llm
+    dt = torch.bfloat16
+    torch.manual_seed(5)
+    a, b = _HFStyleLM(dt), _HFStyleLM(dt)
+    b.load_state_dict(a.state_dict())
+    caches = []
+    for m, auto in ((a, False), (b, True)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            caches.append(enable_spatten_llm(m, 4, 40, 40, auto_graph=auto, **kw))
+    assert hasattr(b, "_spatten_auto_graph") and not hasattr(a, "_spatten_auto_graph")
+
+    def greedy_generate(model, input_ids, past_key_values, max_gen_len):          # run_spatten_llama.py:18-57
+        outputs = model(input_ids=input_ids, past_key_values=past_key_values, use_cache=True)
+        past_key_values = outputs.past_key_values
+        pred = outputs.logits[:, -1, :].argmax(dim=-1).unsqueeze(1)
+        generated, logits = [pred.item()], [outputs.logits[:, -1].clone()]
+        for _ in range(max_gen_len - 1):
+            outputs = model(input_ids=pred, past_key_values=past_key_values, use_cache=True)
+            past_key_values = outputs.past_key_values
+            pred = outputs.logits[:, -1, :].argmax(dim=-1).unsqueeze(1)
+            generated.append(pred.item())
+            logits.append(outputs.logits[:, -1].clone())
+        return past_key_values, generated, logits
+
+    def inference(model, kv_cache, prompts, max_gen_len):                         # run_spatten_llama.py:60-87
+        past, trace = None, []
+        for idx, ids in enumerate(prompts):
+            if idx > 0:
+                scores = [m.self_attn.attn_scores for m in model.layers]
+                n_prev = past[0][0].size(2)
+                past = kv_cache.apply_token_pruning(past, ids.shape[1] + max_gen_len, scores)
+                trace.append((n_prev, past[0][0].size(2)))
+            past, gen, logits = greedy_generate(model, ids, past, max_gen_len)
+            trace.append((gen, logits))
+        return past, trace
+
+    g = torch.Generator(device="cuda").manual_seed(21)
+    prompts = [torch.randint(0, _TinyLM.VOCAB, (1, n), device="cuda", generator=g) for n in (90, 17, 23)]
+    with torch.no_grad():
+        past_a, tr_a = inference(a, caches[0], prompts, 12)
+        past_b, tr_b = inference(b, caches[1], prompts, 12)
+    for ea, eb in zip(tr_a, tr_b):
+        if isinstance(ea[0], int):
+            assert ea == eb                                  # cache lengths before / after each prune
+        else:
+            assert ea[0] == eb[0]                            # the generated tokens
+            assert all(torch.equal(x, y) for x, y in zip(ea[1], eb[1]))
+    ext = getattr(caches[0], "ext", None)      # (pruned heads are not launched: their rows are whatever an earlier step left)
+    kept = [slice(None) if ext is None or st.head_ids is None else st.head_ids.long() for st in (ext.layers if ext else a.layers)]
+    for (ka, va), (kb, vb), hk in zip(past_a, past_b, kept):
+        assert torch.equal(ka[:, hk], kb[:, hk]) and torch.equal(va[:, hk], vb[:, hk])
+    for la, lb, hk in zip(a.layers, b.layers, kept):
+        assert torch.equal(la.self_attn.attn_scores[:, hk], lb.self_attn.attn_scores[:, hk])
+    graph = b._spatten_auto_graph["graph"]
+    assert graph is not None and graph.n_replays == 12 - 1 - 1       # 11 single-token calls per turn: 1 eager, then capture + replays

@@ -141,3 +141,27 @@ def test_fuse_qkv_projections_stacks_weights_as_views():
     mixed = M()
     mixed.k_proj = nn.Linear(16, 8, bias=False)
     assert not fuse_qkv_projections(mixed)
+
+
+def test_auto_graph_leaves_every_other_call_to_the_original_forward():
+    """spatten_amd.graph.auto_graph takes over only single-token keyword calls on device tensors under no_grad; on this
+    (GPU-less) box every call must reach the original forward untouched — prefill, positional calls, calls with a mask."""
+    import torch
+    from spatten_amd.graph import auto_graph
+
+    calls = []
+
+    class M:
+        def forward(self, *a, **kw):
+            calls.append((a, sorted(kw)))
+            return "orig"
+
+    m = auto_graph(M())
+    ids1, ids5 = torch.zeros(1, 1, dtype=torch.long), torch.zeros(1, 5, dtype=torch.long)
+    past = [[torch.zeros(1, 2, 3, 4), torch.zeros(1, 2, 3, 4)]]
+    with torch.no_grad():
+        assert m.forward(input_ids=ids5, past_key_values=None, use_cache=True) == "orig"          # prefill
+        assert m.forward(input_ids=ids1, past_key_values=past, use_cache=True) == "orig"          # CPU tensors: not taken
+        assert m.forward(ids1, past) == "orig"                                                    # positional
+        assert m.forward(input_ids=ids1, past_key_values=past, use_cache=True, attention_mask=torch.ones(1, 4)) == "orig"
+    assert len(calls) == 4 and m._spatten_auto_graph["graph"] is None
