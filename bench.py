@@ -344,6 +344,46 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False, Fals
                 dt_s = time.perf_counter() - t0
                 out["plugin_protocol_two_turns_decode_tokens_per_s"] = round(n_tok / dt_s, 2)
                 out["plugin_protocol_ms_per_turn"] = round(dt_s / 2 * 1e3, 2)
+                # the same protocol with NOTHING changed in the caller's loop (run_spatten_llama.py:18-57): keyword calls of
+                # model(...), outputs.past_key_values handed back, one host read per token — spatten_amd.graph.auto_graph
+                # wraps model.forward (enable_spatten_llm(auto_graph=True)) and replays the captured graph underneath
+                from types import SimpleNamespace as _NS
+                from spatten_amd.graph import auto_graph
+
+                class _Stack:
+                    def forward(self, input_ids=None, past_key_values=None, use_cache=None):
+                        n0, ql = past_key_values[0][0].shape[2], input_ids.shape[1]
+                        pm = torch.zeros(1, 1, ql, n0 + ql, dtype=dt, device=dev)
+                        if ql > 1:
+                            pm[..., n0:].masked_fill_(torch.ones(ql, ql, dtype=torch.bool, device=dev).triu(1), torch.finfo(dt).min)
+                        pp = torch.arange(n0, n0 + ql, device=dev)[None]
+                        new, o = [], None
+                        for i, m in enumerate(model.layers):
+                            o, _, kv = m(input_ids, attention_mask=pm, position_ids=pp, past_key_value=past_key_values[i], use_cache=True)
+                            new.append(kv)
+                        return _NS(logits=o, past_key_values=new)
+
+                    __call__ = lambda self, **kw: self.forward(**kw)
+                stack = auto_graph(_Stack(), horizon=TURN)
+                past = graph.past_key_values
+                for turn in range(3):
+                    if turn == 1:
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        n_tok = 0
+                    past = cache.apply_token_pruning(past, 2 * TURN, [m.attn_scores for m in model.layers])
+                    outp = stack(input_ids=xp, past_key_values=past, use_cache=True)
+                    past = outp.past_key_values
+                    for t in range(TURN - 1):
+                        outp = stack(input_ids=xt, past_key_values=past, use_cache=True)
+                        past = outp.past_key_values
+                        outp.logits[0, 0, 0].item()                     # the reference reads every token on the host
+                    n_tok += TURN - 1
+                torch.cuda.synchronize()
+                dt_s = time.perf_counter() - t0
+                out["plugin_protocol_unchanged_loop_auto_graph_decode_tokens_per_s"] = round(n_tok / dt_s, 2)
+                out["plugin_protocol_unchanged_loop_auto_graph_ms_per_turn"] = round(dt_s / 2 * 1e3, 2)
+                del stack
             del graph
             del past
     # bytes one token of this path must move at least: the four projection matrices of every layer + the kept K/V rows

@@ -220,7 +220,7 @@ def auto_graph(model, horizon: int = 256):
     """Zero-change mode of the drop-in: wrap ``model.forward`` so that the reference's own per-token loop
     (run_spatten_llama.py:27-35: ``model(input_ids=tok, past_key_values=past, use_cache=True)``) runs every single-token call
     as a replay of ONE captured graph of the whole patched stack.  A call is taken over when it has exactly ``input_ids``
-    [B, 1], ``past_key_values`` and ``use_cache=True`` (keywords) under ``torch.no_grad()``; the first such call on a cache
+    [B, 1] (or [B, 1, hidden] for a stack fed with embeddings), ``past_key_values`` and ``use_cache=True`` (keywords) under ``torch.no_grad()``; the first such call on a cache
     (after a prefill or a prune) runs eagerly, the second is captured, later ones replay.  Everything else — prefill, calls
     with masks / positions / embeddings — goes to the original forward.  The returned ``logits`` are a static buffer the
     next call overwrites; ``past_key_values`` is materialised when it is indexed; ``m.attn_scores`` is current after every
@@ -238,7 +238,7 @@ def auto_graph(model, horizon: int = 256):
     def forward(*args, **kw):
         ids, past = kw.get("input_ids"), kw.get("past_key_values")
         others = [k for k, v in kw.items() if k not in ("input_ids", "past_key_values", "use_cache") and v is not None]
-        take = (not args and not others and isinstance(ids, torch.Tensor) and ids.dim() == 2 and ids.shape[1] == 1 and ids.is_cuda
+        take = (not args and not others and isinstance(ids, torch.Tensor) and ids.dim() >= 2 and ids.shape[1] == 1 and ids.is_cuda
                 and past is not None and bool(kw.get("use_cache")) and not torch.is_grad_enabled())
         if not take:
             state["graph"] = state["lazy"] = None
