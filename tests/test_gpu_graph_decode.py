@@ -589,3 +589,35 @@ def test_the_reference_loop_unchanged_replays_one_graph_per_token(kw):
         assert torch.equal(la.self_attn.attn_scores[:, hk], lb.self_attn.attn_scores[:, hk])
     graph = b._spatten_auto_graph["graph"]
     assert graph is not None and graph.n_replays == 12 - 1 - 1       # 11 single-token calls per turn: 1 eager, then capture + replays
+
+
+@pytest.mark.parametrize("dt,d", [(torch.bfloat16, 128), (torch.float16, 64), (torch.float32, 128)])
+def test_kv_append_step_equals_append_plus_pack_bitwise(dt, d):
+    """spatten_kv_append_step (row from the device state, rotary row staged in the state) leaves in k / kr / v and in the
+    progressive-quant planes exactly what spatten_kv_append + spatten_pq_pack leave with host lengths; a row at or past the
+    capacity is not written."""
+    from spatten_amd import ops
+    B, Hkv, cap = 2, 3, 64
+    g = torch.Generator(device="cuda").manual_seed(4)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g).to(dt)
+    cos, sin = ops.rope_table(cap + 8, d, dt, "cuda")
+    ka, kra, va = rnd(B, Hkv, cap, d), rnd(B, Hkv, cap, d), rnd(B, Hkv, cap, d)
+    kb, krb, vb = ka.clone(), kra.clone(), va.clone()
+    pa, pb = ops.PQPlanes(B, Hkv, cap, d, "cuda"), ops.PQPlanes(B, Hkv, cap, d, "cuda")
+    st = ops.StepState(cos, sin)
+    st.set(10, 9)
+    for n in range(11, 15):
+        kn, vn = rnd(B, Hkv, d), rnd(B, Hkv, d)
+        ops.kv_append(kn[:, :, None], vn[:, :, None], ka, kra, va, n - 1, cos, sin)
+        ops.pq_pack(kra, pa, n - 1, n)
+        st.advance(1)
+        ops.kv_append_step(kn, vn, kb, krb, vb, st, pb)
+    torch.cuda.synchronize()
+    assert torch.equal(ka, kb) and torch.equal(kra, krb) and torch.equal(va, vb)
+    assert torch.equal(pa.msb, pb.msb) and torch.equal(pa.lsb, pb.lsb) and torch.equal(pa.scale, pb.scale)
+    st.set(cap + 1, cap)                    # row = capacity: nothing may be written
+    before = (kb.clone(), krb.clone(), vb.clone(), pb.msb.clone())
+    ops.kv_append_step(rnd(B, Hkv, d), rnd(B, Hkv, d), kb, krb, vb, st, pb)
+    ops.kv_append_step(rnd(B, Hkv, d), rnd(B, Hkv, d), None, krb, vb, st, None)     # without planes / un-rotated plane
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(before, (kb, krb, vb, pb.msb)))
