@@ -186,7 +186,7 @@ int spatten_attn_decode_args(const spatten_decode_args_t* args, void* stream);
  *   - rows [length, bound) of kr_cache and v_cache are read and discarded (weight 0): they must hold FINITE values —
  *     zero-fill the planes once when they are allocated.  Stash entries [length, bound) are left untouched.
  *   - admitted for the single-token step without mask, position_ids and SCORES_ONLY; head_ids / head_abs_acc as usual.
- *   - pq_* (progressive-quant keys) are admitted without importance_acc: the step's row is appended beforehand by
+ *   - pq_* (progressive-quant keys) are admitted (with or without importance_acc): the step's row is appended beforehand by
  *     spatten_kv_append_step (which also packs its planes); plane rows [length, bound) must be finite too.
  *   - importance_acc (the fused cascade accumulation) IS admitted: `scores` / `lse` and `prev_scores` / `prev_lse` are
  *     then the TWO buffers that swap roles every step (same strides, rows up to the bound): step k since the last

@@ -154,7 +154,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   // tile loads have been issued
   int n_dyn = 0, cnt_dyn = 0, pl_dyn = 0;
   if (DYN) n_dyn = p.step[opaque_lane(0)];
-  if (DYN && CASC) { cnt_dyn = p.step[2 + opaque_lane(0)]; pl_dyn = p.step[3 + opaque_lane(0)]; }
+  if (DYN && (CASC || KSRC == 2)) { cnt_dyn = p.step[2 + opaque_lane(0)]; pl_dyn = p.step[3 + opaque_lane(0)]; }
   // CASC: (max, sum) of the previous step's row, requested BEFORE the tile (r03: behind the tile these 8 bytes came back
   // after it — returns are in order — and the first accumulation waited for the whole stream); DYN: of both buffers
   float ml_a[2] = {0.f, 1.f}, ml_b[2] = {0.f, 1.f};
@@ -283,7 +283,8 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   const int N = DYN ? __builtin_amdgcn_readfirstlane(n_dyn) : p.N;
   // CASC && DYN: the two stash / (max, sum) buffers swap roles every step — step k (1-based count in the state) writes
   // buffer (k - 1) & 1 and folds the other one, whose rows [0, prev_len) the previous step wrote (0 after a set)
-  const bool odd = (CASC && DYN) ? ((__builtin_amdgcn_readfirstlane(cnt_dyn) - 1) & 1) != 0 : false;
+  // (the refetch pass of progressive quantisation follows a CASC pass 1 of the same step: it writes the same buffer)
+  const bool odd = (DYN && (CASC || (KSRC == 2 && p.prev_scores != nullptr))) ? ((__builtin_amdgcn_readfirstlane(cnt_dyn) - 1) & 1) != 0 : false;
   const int prev_len = (CASC && DYN) ? __builtin_amdgcn_readfirstlane(pl_dyn) : p.prev_len;
   // keys this query may attend to (HF causal: j <= P + i with P = N - n_q); the stash covers all N
   const int n_vis = (!LEAN && p.causal) ? min(N, p.vis0 + qi) : N;
@@ -327,8 +328,8 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   const float rsqrt_d = 1.0f / p.sqrt_d;
   const T* maskp = (!LEAN && p.mask) ? p.mask + b * p.mask_sb + qi * p.mask_sq : nullptr;
   T* stashp = p.scores ? p.scores + b * p.sc_sb + h * p.sc_sh + (LEAN ? 0 : qi * p.sc_sq) : nullptr;
-  if (CASC && DYN && odd) stashp = const_cast<T*>(p.prev_scores) + b * p.pv_sb + h * p.pv_sh;
-  float* lse_cur = (CASC && DYN && odd) ? const_cast<float*>(p.prev_lse) : p.lse;
+  if (DYN && odd) stashp = const_cast<T*>(p.prev_scores) + b * p.pv_sb + h * p.pv_sh;
+  float* lse_cur = (DYN && odd) ? const_cast<float*>(p.prev_lse) : p.lse;
   float casc_m = 0.f, casc_rl = 0.f;
   float* accp = nullptr;
   if (CASC) {
@@ -781,10 +782,14 @@ static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_onl
     if constexpr (D == 256) return SPATTEN_ERR_UNSUPPORTED;
     else {
       // the fused cascade accumulation rides on pass 1 only (pass 2 re-streams the flagged heads: no double count)
-      if (dyn) {      // device-length form (the step appended by spatten_kv_append_step): no fused cascade accumulation
-        if (casc) return SPATTEN_ERR_INVALID;
-        if (pipe) { SPATTEN_LAUNCH(UP, 0, false, 1, true, false, true, true); SPATTEN_LAUNCH(UP, 0, false, 2, true, false, true, true); }
-        else { SPATTEN_LAUNCH(U, 0, false, 1, true, false, false, true); SPATTEN_LAUNCH(U, 0, false, 2, true, false, false, true); }
+      if (dyn) {      // device-length form (the step's row appended by spatten_kv_append_step)
+        if (pipe) {
+          if (casc) SPATTEN_LAUNCH(UP, 0, false, 1, true, true, true, true); else SPATTEN_LAUNCH(UP, 0, false, 1, true, false, true, true);
+          SPATTEN_LAUNCH(UP, 0, false, 2, true, false, true, true);
+        } else {
+          if (casc) SPATTEN_LAUNCH(U, 0, false, 1, true, true, false, true); else SPATTEN_LAUNCH(U, 0, false, 1, true, false, false, true);
+          SPATTEN_LAUNCH(U, 0, false, 2, true, false, false, true);
+        }
       } else if (pipe) {
         // (r03, measured and NOT adopted: 6 / 8 row-groups per pipelined tile for this pass — a plane row is a quarter of
         //  a 16-bit key row, so the registers are there — 22.9 / 23.3 us against 20.7 with 4; SPATTEN_PQ_UP keeps the A/B)
@@ -851,7 +856,7 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
     return SPATTEN_ERR_INVALID;
   if (c.table_rows < c.kv_len || (!c.position_ids && c.pos_q + c.n_q > c.table_rows)) return SPATTEN_ERR_INVALID;
   // device-resident step state: the plain single-row step only (kv_len is then the BOUND the grid is laid out for)
-  if (c.step && (c.n_q != 1 || c.mask || c.position_ids || (pq && c.acc) || scores_only || c.causal)) return SPATTEN_ERR_INVALID;
+  if (c.step && (c.n_q != 1 || c.mask || c.position_ids || scores_only || c.causal)) return SPATTEN_ERR_INVALID;
   // ... with the fused cascade accumulation: `scores` / `lse` and `prev_scores` / `prev_lse` are the two buffers that swap
   // roles every step (same strides, rows up to the bound)
   if (c.step && c.acc && (!c.scores || !c.lse || !c.prev_scores || !c.prev_lse || c.pv_sb != c.sc_sb || c.pv_sh != c.sc_sh))

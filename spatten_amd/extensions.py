@@ -123,11 +123,9 @@ class SpattenExtensions:
     # ------------------------------------------------------------------------------------------------
     def graph_capable(self) -> bool:
         """Modes whose decode step runs in the device-length form (spatten_amd/graph.py): cascade importance and head
-        pruning — one fused launch with fixed buffers — and progressive quantisation without cascade importance (the step's
-        append + plane packing as one device-length launch, then the two passes over the planes).  Local V pruning and the
-        layer cascade launch helper kernels with host lengths and stay eager."""
-        if self.pq_threshold is not None and self.cascade:
-            return False
+        pruning — one fused launch with fixed buffers — and progressive quantisation (the step's append + plane packing as
+        one device-length launch, then the two passes over the planes).  Local V pruning and the layer cascade launch helper
+        kernels with host lengths and stay eager."""
         return self.local_v_keep is None and self.layer_keep is None
 
     def decode_step_graph(self, layer: int, q, k_new, v_new, slab, kv_len: int, cos, sin, gctx):
@@ -154,9 +152,10 @@ class SpattenExtensions:
             ops.kv_append_step(k_new, v_new, slab.k, slab.kr, slab.v, step, slab.pq)
             slab.pq_len = kv_len
             ops.attn_decode(q, None, None, slab.v, cap, cos, sin, 0, out=st.out, scores=st.stash[0], lse=st.lse[0],
-                            head_ids=st.head_ids, pq=(slab.pq, self.pq_threshold, st.need_lsb),
+                            head_ids=st.head_ids, cascade=casc, pq=(slab.pq, self.pq_threshold, st.need_lsb),
                             head_abs=st.head_abs if self.head_keep is not None else None, step=step)
-            return st.out, st.stash[0][:, :, None, :kv_len]
+            cur = (gctx.steps_traced & 1) if self.cascade else 0
+            return st.out, st.stash[cur][:, :, None, :kv_len]
         ops.attn_decode(q, slab.k, slab.kr, slab.v, cap, cos, sin, 0, k_new=k_new, v_new=v_new, out=st.out,
                         scores=st.stash[0], lse=st.lse[0], head_ids=st.head_ids, cascade=casc,
                         head_abs=st.head_abs if self.head_keep is not None else None, step=step)

@@ -355,7 +355,8 @@ def test_decode_graph_holds_the_head_parallel_exchange():
 
 @pytest.mark.parametrize("kw", [dict(importance_mode="cascade"), dict(head_keep=[6, 5, 5]),
                                 dict(importance_mode="cascade", head_keep=6, fuse_qkv=True, native_gemv=True),
-                                dict(pq_threshold=0.05), dict(pq_threshold=0.02, head_keep=6, fuse_qkv=True)])
+                                dict(pq_threshold=0.05), dict(pq_threshold=0.02, head_keep=6, fuse_qkv=True),
+                                dict(pq_threshold=0.05, importance_mode="cascade")])
 def test_decode_graph_covers_cascade_importance_and_head_pruning(kw):
     """The SpAtten modes whose decode step is ONE fused launch — cumulative importance (the previous step's probabilities
     folded while this step streams; under the graph the two stash buffers swap roles on the device) and head pruning
