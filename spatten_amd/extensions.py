@@ -124,9 +124,10 @@ class SpattenExtensions:
     def graph_capable(self) -> bool:
         """Modes whose decode step runs in the device-length form (spatten_amd/graph.py): cascade importance and head
         pruning — one fused launch with fixed buffers — and progressive quantisation (the step's append + plane packing as
-        one device-length launch, then the two passes over the planes).  Local V pruning and the layer cascade launch helper
-        kernels with host lengths and stay eager."""
-        return self.local_v_keep is None and self.layer_keep is None
+        one device-length launch, then the two passes over the planes); the layer cascade changes only the prune events (its
+        layers decode on caches of different lengths: one step state per length).  Local V pruning launches helper kernels
+        with host lengths and stays eager."""
+        return self.local_v_keep is None
 
     def decode_step_graph(self, layer: int, q, k_new, v_new, slab, kv_len: int, cos, sin, gctx):
         """The decode step under a DecodeGraph: every buffer at capacity and at a fixed address; with cascade importance
@@ -168,14 +169,16 @@ class SpattenExtensions:
             self.flush(layer)
             st.parity = 0
 
-    def graph_sync(self, steps: int, length: int):
-        """Host view of the per-layer state after ``steps`` device-length steps (replays do not run Python)."""
-        for st in self.layers:
+    def graph_sync(self, steps: int, length):
+        """Host view of the per-layer state after ``steps`` device-length steps (replays do not run Python); ``length``:
+        the cache length, or one per layer."""
+        lengths = list(length) if isinstance(length, (list, tuple)) else [int(length)] * len(self.layers)
+        for st, n in zip(self.layers, lengths):
             if st.stash[0] is None:
                 continue
             if self.cascade:
                 st.parity = steps & 1
-                st.pending_len = length if steps > 0 else st.pending_len
+                st.pending_len = n if steps > 0 else st.pending_len
 
     def decode_step(self, layer: int, q, k_new, v_new, slab, kv_len: int, past_len: int, cos, sin):
         """q [B,H,d], k_new / v_new [B,Hkv,d].  Returns (attn_output [B, H*d], stash view [B,H,1,kv_len])."""

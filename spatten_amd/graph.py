@@ -44,12 +44,13 @@ class DecodeGraph:
             raise ValueError("DecodeGraph needs the past_key_values of a prefilled / pruned cache")
         self.step_fn = step_fn
         self.horizon = int(horizon)
+        # the layers' caches may differ in length (layer-to-layer cascade pruning: the surviving set shrinks through the
+        # layers); every step appends one row to each, so layer i stays at length + offsets[i] — one step state per offset
         self.length = int(past_key_values[0][0].shape[2])
-        if any(int(kv[0].shape[2]) != self.length for kv in past_key_values):
-            raise ValueError("DecodeGraph needs one cache length for all layers (layer_keep caches differ per layer)")
+        self.offsets = [int(kv[0].shape[2]) - self.length for kv in past_key_values]
         self.stream = torch.cuda.Stream(device=past_key_values[0][0].device)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
-        self.state: Optional[ops.StepState] = None
+        self.states: dict = {}                  # cache-length offset (vs layer 0) -> ops.StepState
         self.touched: List[tuple] = []          # (module, slab) pairs of the last traced step, in call order
         self.static_in: Optional[List[torch.Tensor]] = None
         self.static_out = None
@@ -61,27 +62,36 @@ class DecodeGraph:
 
     # ------------------------------------------------------------------------------------------------
     def _bind(self, past_key_values):
-        """Size the slabs for the next ``horizon`` tokens, zero their tails, (re)create the step state."""
-        past = kv_slab.reserve(past_key_values, self.length + self.horizon)
+        """Size the slabs for the next ``horizon`` tokens, zero their tails, (re)create the step states."""
+        past = kv_slab.reserve(past_key_values, [self.length + o + self.horizon for o in self.offsets])
         self._past = past
-        self.bound = min(kv_slab.slab_of(kv[0]).capacity for kv in past)
+        slabs = [kv_slab.slab_of(kv[0]) for kv in past]
+        self._offset_of = {id(sl): o for sl, o in zip(slabs, self.offsets)}
+        self.bound = min(sl.capacity - o for sl, o in zip(slabs, self.offsets))     # in units of layer 0's length
         self.graph = None
-        self.state = None
+        self.states = {}
         self.touched = []
         self.steps_traced = 0
         self.bind_id = object()                 # identity of this binding: the extensions restart their buffers with it
 
+    def length_of(self, slab) -> int:
+        return self.length + self._offset_of.get(id(slab), 0)
+
     def state_for(self, slab, cos, sin) -> ops.StepState:
-        """Called by the patched forward while a step is traced: the step state every layer shares."""
-        if self.state is None:
-            self.state = ops.StepState(cos, sin)
-            self.state.set(self.length, self.length - 1)
-            self.state.advance(1)             # the traced step is already under way: its advance, issued late
-        elif self.state.cos.data_ptr() != cos.data_ptr():
-            raise RuntimeError("DecodeGraph: the layers rotate with different rotary tables")
-        if slab.capacity < self.bound:
+        """Called by the patched forward while a step is traced: the step state of the layers with this cache length."""
+        off = self._offset_of.get(id(slab))
+        if off is None:
+            raise RuntimeError("DecodeGraph: a layer ran on a cache this graph was not bound to")
+        st = self.states.get(off)
+        if st is None:
+            st = self.states[off] = ops.StepState(cos, sin)
+            st.set(self.length + off, self.length + off - 1)
+            st.advance(1)                     # the traced step is already under way: its advance, issued late
+        elif st.cos.data_ptr() != cos.data_ptr():
+            raise RuntimeError("DecodeGraph: layers of one cache length rotate with different rotary tables")
+        if slab.capacity < self.bound + off:
             raise RuntimeError("DecodeGraph: a layer's slab is smaller than the graph's bound")
-        return self.state
+        return st
 
     def _trace(self, inputs):
         """Run step_fn once in device-length mode on the current stream (eagerly, or under capture)."""
@@ -89,8 +99,8 @@ class DecodeGraph:
         prev = kv_slab.graph_ctx
         kv_slab.graph_ctx = self
         try:
-            if self.state is not None:
-                self.state.advance(1)
+            for st in self.states.values():
+                st.advance(1)
             new_past, out = self.step_fn(self._past, *inputs)
         finally:
             kv_slab.graph_ctx = prev
@@ -105,7 +115,7 @@ class DecodeGraph:
         if self.length + 1 > self.bound:                   # out of room: larger slabs, new graph
             self._bind(self.past_key_values)
         cur = torch.cuda.current_stream()
-        if self.graph is None and self.state is None:
+        if self.graph is None and not self.states:
             # call 1 on these slabs: eager, on the capture stream (creates the per-stream workspaces, warms the allocator
             # and the GEMM heuristics) — the same device-length kernels the graph will replay
             self.stream.wait_stream(cur)
@@ -149,15 +159,15 @@ class DecodeGraph:
         for module, slab, ext in self.touched:
             if ext is None:
                 if slab.stash is not None:
-                    object.__setattr__(module, "attn_scores", slab.stash[:, :, None, :self.length])
+                    object.__setattr__(module, "attn_scores", slab.stash[:, :, None, :self.length_of(slab)])
                 continue
             exts, layer = ext
             if id(exts) not in synced:
-                exts.graph_sync(self.steps_traced, self.length)
+                exts.graph_sync(self.steps_traced, [self.length + o for o in self.offsets])
                 synced.add(id(exts))
             st = exts.layers[layer]
             cur = ((self.steps_traced - 1) & 1) if (exts.cascade and self.steps_traced > 0) else 0
-            object.__setattr__(module, "attn_scores", st.stash[cur][:, :, None, :self.length])
+            object.__setattr__(module, "attn_scores", st.stash[cur][:, :, None, :self.length_of(slab)])
 
     @property
     def past_key_values(self):
@@ -165,25 +175,13 @@ class DecodeGraph:
         order; also points every patched module's ``attn_scores`` at its stash row of the last step (:116-119)."""
         slabs = [kv_slab.slab_of(kv[0]) for kv in self._past]
         out = []
-        for slab in slabs:
-            slab.length = slab.rot_len = self.length
-            if slab.pq is not None and slab.pq_len >= self.length - self.steps_traced:
-                slab.pq_len = self.length          # progressive quantisation: every replayed step packed its own row
+        for slab, off in zip(slabs, self.offsets):
+            slab.length = slab.rot_len = self.length + off
+            if slab.pq is not None and slab.pq_len >= slab.length - self.steps_traced:
+                slab.pq_len = slab.length          # progressive quantisation: every replayed step packed its own row
             k, v = slab.views()
             out.append([k, v])
-        synced = set()
-        for module, slab, ext in self.touched:
-            if ext is None:
-                if slab.stash is not None:
-                    object.__setattr__(module, "attn_scores", slab.stash[:, :, None, :self.length])
-                continue
-            exts, layer = ext
-            if id(exts) not in synced:          # replays do not run Python: bring the per-layer host state up to date
-                exts.graph_sync(self.steps_traced, self.length)
-                synced.add(id(exts))
-            st = exts.layers[layer]
-            cur = ((self.steps_traced - 1) & 1) if (exts.cascade and self.steps_traced > 0) else 0
-            object.__setattr__(module, "attn_scores", st.stash[cur][:, :, None, :self.length])
+        self.sync_scores()
         self._past = out
         return out
 

@@ -174,12 +174,13 @@ def slab_for(k_view: Optional[torch.Tensor], v_view: Optional[torch.Tensor], nee
     return KVSlab(k, kr, v, P, rot, base, scaling)
 
 
-def reserve(past_key_values, need: int):
-    """Make every layer's slab hold ``need`` rows and give the rows past the current length finite contents (zeros) —
-    what a captured decode step requires (include/spatten.h, "Device-resident step state").  Returns the list of
-    ``[K, V]`` views to continue with (the same tensors when nothing had to grow)."""
+def reserve(past_key_values, need):
+    """Make every layer's slab hold ``need`` rows (one int, or one per layer) and give the rows past the current length
+    finite contents (zeros) — what a captured decode step requires (include/spatten.h, "Device-resident step state").
+    Returns the list of ``[K, V]`` views to continue with (the same tensors when nothing had to grow)."""
     out = []
-    for K, V in past_key_values:
+    needs = [int(need)] * len(past_key_values) if not isinstance(need, (list, tuple)) else [int(x) for x in need]
+    for (K, V), need in zip(past_key_values, needs):
         slab = slab_of(K)
         B, Hkv, P, d = K.shape
         if slab is None:
