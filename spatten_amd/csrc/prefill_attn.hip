@@ -133,7 +133,7 @@ struct FlashParams {
 #define SPATTEN_PF_PRIO 0
 #endif
 #ifndef SPATTEN_PF_EXPMODE      // harness bits: 1 = FASTNUM; 2 = no DMA in the tile loop and 8 = no softmax (both give WRONG
-#define SPATTEN_PF_EXPMODE 0    // results: anatomy only); 4 = DMA_MODE 2
+#define SPATTEN_PF_EXPMODE 0    // results: anatomy only); 4 = DMA_MODE 2; 16 = no exp2 in the softmax (wrong results)
 #endif
 #ifndef SPATTEN_PF_DMA_MODE     // who issues a stage's LDS-DMA: 0 half 0 in its matrix / half 1 in its vector phase (r01, 762);
 #define SPATTEN_PF_DMA_MODE ((SPATTEN_PF_EXPMODE & 4) ? 2 : 1)   // 1 both in their matrix phase (r02, 810); 2 both in their vector phase (743)
@@ -930,7 +930,11 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
+#if SPATTEN_PF_EXPMODE & 16      // anatomy: what do the 64 transcendentals per wave-tile cost?  (WRONG results)
+          const float pvv = fmaf(s[kb][t * 8 + e], sc2, -m2);
+#else
           const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], sc2, -m2));
+#endif
 #if !SPATTEN_PF_ROWSUM_MFMA
           ls[e & 3] += pvv;
 #endif
