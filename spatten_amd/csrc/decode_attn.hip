@@ -740,7 +740,11 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_lean_kernel(T* krc, T* 
 // row-groups per tile.  Single-shot instantiation: 16-bit dtypes 10 (d = 128: 320 rows — a whole Llama-2-7B split — in
 // flight per workgroup).  Pipelined instantiation (chunks longer than that): two tiles of 4 (fp32: 2) row-groups.
 template <typename T, int D> constexpr int decode_unr() { return sizeof(T) == 4 ? (D == 256 ? 2 : 4) : (D == 256 ? 4 : 10); }
-template <typename T, int D> constexpr int decode_unr_pipe() { return sizeof(T) == 4 ? 2 : 4; }
+#ifndef SPATTEN_DECODE_UP      // row-groups per pipelined tile, 16-bit dtypes.  r03 A/B at 16384 rows x 40 heads (tools/mb/dec_exp.sh
+                               // "-DSPATTEN_DECODE_UP=n"): 3: 55.7-56.5 us, 4: 55.3, 5: 56.2-56.7, 6: 58.1-58.7
+#define SPATTEN_DECODE_UP 4
+#endif
+template <typename T, int D> constexpr int decode_unr_pipe() { return sizeof(T) == 4 ? 2 : SPATTEN_DECODE_UP; }
 static inline int decode_group_rows(int d) { return kDecodeThreads / (d / 16); }
 
 static int auto_splits(int units, int d, int kv_len) {
