@@ -1,24 +1,28 @@
 // spatten_amd — the one-wave-per-SIMD flash kernel (round 3).  Included by prefill_attn.hip (inside
 // namespace spatten, after the helpers it uses: FlashParams, Mfma, dma16, rope_pair, round2, logit_scale ...).
 //
+// STATUS: an EXPERIMENT, selected by SPATTEN_PREFILL_W4=1.  Parity-green (tests/test_gpu_prefill_w4.py and the whole prefill /
+// full-size / protocol suites with the switch on) and SLOWER than prefill_pp128_kernel: 616-642 against 740-766 TFLOP/s at
+// q = N = 8192 (profiles/r03_prefill_w4_anatomy.txt) — with one wave per SIMD nothing hides that wave's own
+// issue slots, and the reference's two roundings per logit are ~8 vector instructions per MFMA.
+//
 // Same arithmetic as prefill_pp128_kernel (modify_llama.py:92 rotary on the queries, :111-113 both roundings of a logit,
 // :137 fp32 softmax, P rounded to the model dtype before P.V, deferred rescale) on a different machine shape:
 //
 //   workgroup = 4 waves = one 256-row query block, ONE wave per SIMD, each wave 64 query rows (two 32-row q-blocks) and the
 //   whole 512-entry register file: O^T (2 x 4 x 16 = 128) and the rotated Q fragments (2 x 8 x 4 = 64) live in the
-//   ACCUMULATOR file for the whole launch (inline-asm MFMAs with "a" operands — the compiler alone put them in arch VGPRs
-//   behind 1,064 v_accvgpr copies per tile, r02), the scores S (2 x 2 x 16), P (2 x 2 x 2 x 4) and the LDS operand ring in
-//   the arch VGPRs.  64-key tiles; per tile a wave issues 64 MFMAs in two halves:
-//       half A:  S0(t+1) = K(t+1) Q0^T ;  O0 += Vt(t) P0(t)      beside   softmax(S1(t)) -> P1(t)
-//       half B:  S1(t+1) = K(t+1) Q1^T ;  O1 += Vt(t) P1(t)      beside   softmax(S0(t+1)) -> P0(t+1)
-//   i.e. the two-wave ping-pong of prefill_pp128_kernel folded into ONE instruction stream: the softmax of one q-block is
-//   cut into 32 slices and slice i sits in the gap behind MFMA i of the other q-block (source order pinned with
-//   sched_barrier), so the matrix pipe and the vector ALU of a SIMD are fed by one wave instead of two waves competing for
-//   the issue port (the loss r02's anatomy priced at 2x on both phases).
-//   K/Vt tiles by LDS-DMA into a 3-deep ring (stage j = { K(j+1), Vt(j) }, issued two tiles ahead, ONE barrier per tile,
-//   counted vmcnt — the wave never drains its DMA queue).
-// Tiles that straddle the causal diagonal (or the end of the keys), the first tile and the last one run the same pieces
-// one after the other (qk / softmax / pv, not interleaved).
+//   ACCUMULATOR file for the whole launch, named inside the inline-asm MFMAs (below); the scores S (2 x 2 x 16), P
+//   (2 x 2 x 2 x 4 packed words) and the LDS operand ring in the arch VGPRs.  64-key tiles; per tile a wave issues 64 MFMAs in
+//   two halves:
+//       half A:  S0(t+1) = K(t+1) Q0^T ;  O0 += Vt(t) P0(t)      beside   softmax(S1(t)) -> P1(t)      + the 8 LDS-DMA instructions
+//       half B:  S1(t+1) = K(t+1) Q1^T ;  O1 += Vt(t) P1(t)      beside   softmax(S0(t+1)) -> P0(t+1)    of stage t + 2
+//   i.e. the two-wave ping-pong of prefill_pp128_kernel folded into ONE instruction stream: the softmax of one q-block runs as
+//   a software pipeline over its 16 logit pairs, one stage per MFMA gap of the other q-block (source order pinned with
+//   sched_barrier + input-only empty asm statements).
+//   K/Vt tiles by LDS-DMA into a 3-deep ring (stage j = { K(j+1), Vt(j) }, issued two tiles ahead — always 8 instructions per
+//   wave and stage, also past the last tile — ONE barrier per tile and a counted vmcnt(8): the wave never drains its DMA queue).
+// The first Q.K^T + softmax (loop iteration t = -1), the tiles that straddle the causal diagonal (or the end of the keys) and the
+// last tile run the same pieces one after the other (qk_seq / sm_seq / pv_seq, not interleaved).
 //
 // Serves: 16-bit dtypes, d = 128, no mask / stash / column importance / progressive quantisation / key split.
 
