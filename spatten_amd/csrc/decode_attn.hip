@@ -508,7 +508,12 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   }
 
 #ifdef SPATTEN_EXP_NOREDUCE   // A/B harness only: what does everything after the streaming loop cost?
-  if (tid < D) p.out[b * p.out_sb + h * D + tid] = DT<T>::from_f32(olo[0] + l_run + m_run);
+  {   // (every accumulator stays live: with only olo[0] written the compiler drops the upper-half value loads)
+    float keep = l_run + m_run;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) keep += olo[i] + ohi[i];
+    if (tid < D) p.out[b * p.out_sb + h * D + tid] = DT<T>::from_f32(keep);
+  }
   return;
 #endif
   SPATTEN_TSTAMP(1);
