@@ -36,6 +36,21 @@ from . import kv_slab, ops
 __all__ = ["DecodeGraph", "auto_graph"]
 
 
+_capture_streams: dict = {}
+
+
+def _capture_stream(device) -> torch.cuda.Stream:
+    """ONE side stream per device for every DecodeGraph of the process: the decode workspaces and the caching allocator's
+    pools are per stream, so a stream per graph (a graph per turn) grew device memory turn after turn (a 60-turn run:
+    +38 MiB per turn until torch's 32 pooled streams repeated) and left the workspace cache evicting buffers of live graphs."""
+    key = torch.device(device)
+    key = (key.type, torch.cuda.current_device() if key.index is None else key.index)
+    st = _capture_streams.get(key)
+    if st is None:
+        st = _capture_streams[key] = torch.cuda.Stream(device=torch.device(*key))
+    return st
+
+
 class DecodeGraph:
     def __init__(self, step_fn: Callable, past_key_values: Sequence, horizon: int = 128):
         """``past_key_values``: the per-layer ``(K, V)`` pairs the patched forward (or ``apply_token_pruning``) returned;
@@ -48,7 +63,7 @@ class DecodeGraph:
         # layers); every step appends one row to each, so layer i stays at length + offsets[i] — one step state per offset
         self.length = int(past_key_values[0][0].shape[2])
         self.offsets = [int(kv[0].shape[2]) - self.length for kv in past_key_values]
-        self.stream = torch.cuda.Stream(device=past_key_values[0][0].device)
+        self.stream = _capture_stream(past_key_values[0][0].device)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.states: dict = {}                  # cache-length offset (vs layer 0) -> ops.StepState
         self.touched: List[tuple] = []          # (module, slab) pairs of the last traced step, in call order
