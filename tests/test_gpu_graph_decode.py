@@ -623,3 +623,57 @@ def test_kv_append_step_equals_append_plus_pack_bitwise(dt, d):
     ops.kv_append_step(rnd(B, Hkv, d), rnd(B, Hkv, d), None, krb, vb, st, None)     # without planes / un-rotated plane
     torch.cuda.synchronize()
     assert all(torch.equal(x, y) for x, y in zip(before, (kb, krb, vb, pb.msb)))
+
+
+def test_decode_graph_at_llama2_7b_geometry_equals_the_eager_loop_bitwise(monkeypatch):
+    """The graph path at BASELINE.json configs[1] scale — 32 heads x 128, a 4096-token cache pruned to 2048 (start 4 /
+    important 1020 / recent 1024), 64-token turn — on a 2-layer stack: prune event from the stashes of the turn, prompt
+    prefill, then every decode step of the next turn through DecodeGraph (stacked q/k/v + native projections) against the
+    eager loop: hidden states, stashes and caches bit for bit."""
+    import contextlib
+    import io
+    import sys
+
+    from spatten_amd import enable_spatten_llm
+    from spatten_amd.graph import DecodeGraph
+    mod = sys.modules[__name__]
+    monkeypatch.setattr(mod, "LAYERS", 2)
+    monkeypatch.setattr(mod, "H", 32)
+    monkeypatch.setattr(mod, "HID", 32 * 128)
+    dt = torch.bfloat16
+    torch.manual_seed(1)
+    a = Stack(dt)
+    for p in a.parameters():
+        p.data.mul_(0.25)
+    b = Stack(dt)
+    b.load_state_dict(a.state_dict())
+    caches = []
+    for m in (a, b):
+        with contextlib.redirect_stdout(io.StringIO()):
+            caches.append(enable_spatten_llm(m, 4, 1020, 1024, fuse_qkv=True, native_gemv=True, assume_causal=True))
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x0 = (torch.randn(1, 4096 - 64, 32 * 128, device="cuda", generator=g) * 0.5).to(dt)
+    _, past_a = a(x0, None)
+    _, past_b = b(x0, None)
+    for turn in range(2):
+        graph = DecodeGraph(lambda past, x: tuple(reversed(b(x, past))), past_b, horizon=64)
+        for t in range(64 if turn == 0 else 8):
+            x = (torch.randn(1, 1, 32 * 128, device="cuda", generator=g) * 0.5).to(dt)
+            ya, past_a = a(x, past_a)
+            yb = graph.step(x)
+            assert torch.equal(ya, yb), (turn, t)
+        past_b = graph.past_key_values
+        for la, lb in zip(a.layers, b.layers):
+            assert torch.equal(la.attn_scores, lb.attn_scores)
+        for (ka, va), (kb, vb) in zip(past_a, past_b):
+            assert torch.equal(ka, kb) and torch.equal(va, vb)
+        if turn == 0:
+            assert past_a[0][0].shape[2] == 4096
+            new_a = caches[0].apply_token_pruning(past_a, 128, [m.attn_scores for m in a.layers])
+            new_b = caches[1].apply_token_pruning(past_b, 128, [m.attn_scores for m in b.layers])
+            assert new_a[0][0].shape[2] == new_b[0][0].shape[2] <= 2048          # 4 + 1020 + what is left of the recent window
+            for (ka, va), (kb, vb) in zip(new_a, new_b):
+                assert torch.equal(ka, kb) and torch.equal(va, vb)
+            xp = (torch.randn(1, 64, 32 * 128, device="cuda", generator=g) * 0.5).to(dt)
+            _, past_a = a(xp, new_a)
+            _, past_b = b(xp, new_b)
