@@ -149,8 +149,13 @@ class SpAttenKVCache:
         Ks, Vs = _common_strides(Ks, Vs)
         B, H, _, d = Ks[0].shape
         accs = [self.ext.layers[layer].acc for layer in range(n_layers)]
-        if any(a.shape[0] != H or a.shape[1] < seq_len for a in accs):
+        if any(a.shape[1] < seq_len for a in accs):
             raise RuntimeError("cascade importance accumulators do not cover the cache")
+        if any(a.shape[0] != H for a in accs):
+            # grouped-query cache: the accumulators have one row per QUERY head, the cache one plane per KV head — a key's
+            # importance is the sum over its group (as in reference mode, apply_token_pruning), every query head's
+            # accumulator row then follows its KV head's row map
+            return self._prune_cascade_gqa(past_key_values, Ks, Vs, accs, seq_len, num_coming, lo, hi, new_len, base, scaling)
         if any(a.stride(0) != accs[0].stride(0) for a in accs):
             width = max(a.shape[1] for a in accs)
             accs = [torch.nn.functional.pad(a, (0, width - a.shape[1])) for a in accs]
@@ -172,6 +177,28 @@ class SpAttenKVCache:
         self.n_pruned_total += self.n_pruned_last
         return out
 
+
+    def _prune_cascade_gqa(self, past_key_values, Ks, Vs, accs, seq_len, num_coming, lo, hi, new_len, base, scaling):
+        n_layers = len(past_key_values)
+        B, Hkv, _, d = Ks[0].shape
+        group = accs[0].shape[0] // Hkv
+        scores = _common_rows([_group_rows(a[:, :seq_len], Hkv) for a in accs])
+        self.importance_score = scores
+        cap = kv_slab.round_capacity(new_len + max(int(num_coming), 0))
+        rope = kv_slab.rope_tables(cap, d, Ks[0].dtype, Ks[0].device, base, scaling)
+        Kn, Vn, Krn, idx = ops.prune_layers(scores, Ks, Vs, seq_len, lo, hi, self.important_size, capacity=cap, rope=rope)
+        out = []
+        for layer, (k, v, kr) in enumerate(zip(Kn, Vn, Krn)):
+            st = self.ext.layers[layer]
+            rows = idx[layer].repeat_interleave(group, dim=0).contiguous()          # query head h -> KV head h // group
+            st.acc = ops.importance_compact(accs[layer], rows, self.start_size, hi, seq_len, max(cap, accs[layer].shape[1]))
+            st.pending_len = 0
+            kv_slab.attach(k, v, kr, new_len, base, scaling)
+            out.append([k, v])
+        self.keep_indices = idx
+        self.n_pruned_last = seq_len - new_len
+        self.n_pruned_total += self.n_pruned_last
+        return out
 
     def _prune_layer_cascade(self, past_key_values, num_coming, attn_score_all):
         """Layer-to-layer cascade (extension, parity unpinned; oracle: layer_cascade_prune): layer l keeps layer_keep[l]

@@ -340,3 +340,34 @@ def test_layer_cascade_event_in_three_launches_equals_the_per_layer_composition(
     with pytest.raises(ValueError):
         ops.prune_layer_cascade([s[:, :L] for s, L in zip(scores, lens)], known, id_base, [K[:, :, :L] for K, L in zip(Ks, lens)],
                                 [V[:, :, :L] for V, L in zip(Vs, lens)], lens, [start + 10] * nl, keeps, start, caps, (cos, sin))
+
+
+def test_cascade_prune_of_a_grouped_query_cache_vs_oracle(capsys):
+    """importance_mode="cascade" on a grouped-query cache (Hkv < H): a key's importance is the sum of its group's
+    accumulator rows (the reference-mode rule for GQA), the kept rows are the oracle's top-k of that sum per KV head, and
+    every QUERY head's accumulator row follows its KV head's row map."""
+    from spatten_amd.extensions import SpattenExtensions
+    from spatten_amd.kv_cache_token_pruning import SpAttenKVCache
+    B, H, Hkv, d, L, layers, coming = 1, 8, 2, 64, 300, 3, 10
+    G = H // Hkv
+    cache = SpAttenKVCache(start_size=4, recent_size=40, important_size=50, importance_mode="cascade")
+    cache.ext = SpattenExtensions(cache, layers, cascade=True)
+    rng = np.random.default_rng(5)
+    past, accs = [], []
+    for i in range(layers):
+        K = orc.round_dt(rng.standard_normal((B, Hkv, L, d)).astype(np.float32), "bf16")
+        V = orc.round_dt(rng.standard_normal((B, Hkv, L, d)).astype(np.float32), "bf16")
+        acc = rng.random((H, L + 16)).astype(np.float32)
+        past.append([dev(K, "bf16"), dev(V, "bf16")])
+        accs.append(acc)
+        cache.ext.layers[i].acc = torch.from_numpy(acc).cuda()
+    new = cache.apply_token_pruning(past, coming, [None] * layers)
+    lo, hi = 4, L - 40 + coming
+    for i in range(layers):
+        score = accs[i][:, :L].reshape(Hkv, G, L).sum(1)
+        idx = orc.topk_window(score, lo, hi, 50)
+        Kw, Vw = orc.kv_compact(host(past[i][0]), host(past[i][1]), idx, 4, hi)
+        assert np.array_equal(host(new[i][0]), Kw) and np.array_equal(host(new[i][1]), Vw)
+        want = np.stack([np.concatenate([accs[i][h, :4], accs[i][h, idx[h // G]], accs[i][h, hi:L]]) for h in range(H)])
+        got = cache.ext.layers[i].acc[:, :want.shape[1]].cpu().numpy()
+        assert np.array_equal(got, want)

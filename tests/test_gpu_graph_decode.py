@@ -677,3 +677,54 @@ def test_decode_graph_at_llama2_7b_geometry_equals_the_eager_loop_bitwise(monkey
             xp = (torch.randn(1, 64, 32 * 128, device="cuda", generator=g) * 0.5).to(dt)
             _, past_a = a(xp, new_a)
             _, past_b = b(xp, new_b)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(fuse_qkv=True, native_gemv=True), dict(importance_mode="cascade")])
+def test_decode_graph_on_a_grouped_query_stack(kw):
+    """Grouped-query attention (num_key_value_heads < num_heads: k_proj / v_proj are narrower, the cache holds Hkv heads,
+    modify_llama.py:106-108 repeat_kv) through DecodeGraph against the eager loop, with a prune event on the GQA cache."""
+    import contextlib
+    import io
+
+    from spatten_amd import enable_spatten_llm
+    from spatten_amd.graph import DecodeGraph
+    dt, Hkv = torch.bfloat16, 2
+    torch.manual_seed(7)
+
+    def gqa_stack():
+        st = Stack(dt)
+        for m in st.layers:
+            m.num_key_value_heads, m.num_key_value_groups = Hkv, H // Hkv
+            m.k_proj = nn.Linear(HID, Hkv * D, bias=False, dtype=dt, device="cuda")
+            m.v_proj = nn.Linear(HID, Hkv * D, bias=False, dtype=dt, device="cuda")
+        return st
+    a = gqa_stack()
+    for p in a.parameters():
+        p.data.mul_(0.5)
+    b = gqa_stack()
+    b.load_state_dict(a.state_dict())
+    caches = []
+    for m in (a, b):
+        with contextlib.redirect_stdout(io.StringIO()):
+            caches.append(enable_spatten_llm(m, 4, 60, 64, **kw))
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x0 = torch.randn(1, 170, HID, device="cuda", generator=g).to(dt)
+    _, past_a = a(x0, None)
+    _, past_b = b(x0, None)
+    assert past_a[0][0].shape[1] == Hkv
+    for turn in range(2):
+        graph = DecodeGraph(lambda past, x: tuple(reversed(b(x, past))), past_b, horizon=8)
+        for t in range(8):
+            x = torch.randn(1, 1, HID, device="cuda", generator=g).to(dt)
+            ya, past_a = a(x, past_a)
+            yb = graph.step(x)
+            assert torch.equal(ya, yb), (turn, t)
+        past_b = graph.past_key_values
+        new_a = caches[0].apply_token_pruning(past_a, 14, [m.attn_scores for m in a.layers])
+        new_b = caches[1].apply_token_pruning(past_b, 14, [m.attn_scores for m in b.layers])
+        assert new_a is not past_a
+        for (ka, va), (kb, vb) in zip(new_a, new_b):
+            assert ka.shape[1] == Hkv and torch.equal(ka, kb) and torch.equal(va, vb)
+        xp = torch.randn(1, 6, HID, device="cuda", generator=g).to(dt)
+        _, past_a = a(xp, new_a)
+        _, past_b = b(xp, new_b)
