@@ -222,6 +222,11 @@ class SpAttenKVCache:
                 score = ext.layers[layer].acc[:, :L]
             else:
                 score = ops.importance(attn_score_all[layer])[:, :L]
+            if score.shape[0] != K.shape[1]:
+                if self.importance_mode == "cascade":
+                    raise NotImplementedError("layer_keep with cascade importance on a grouped-query cache: the accumulators "
+                                              "have one row per query head")
+                score = _group_rows(score, K.shape[1])        # grouped-query cache: a key's importance = its group's sum
             if score.stride(1) != 1:
                 score = score.contiguous()
             Ks.append(K); Vs.append(V); lens.append(L); his.append(hi); keeps.append(k_l); scores.append(score)

@@ -679,7 +679,9 @@ def test_decode_graph_at_llama2_7b_geometry_equals_the_eager_loop_bitwise(monkey
             _, past_b = b(xp, new_b)
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(fuse_qkv=True, native_gemv=True), dict(importance_mode="cascade")])
+@pytest.mark.parametrize("kw", [dict(), dict(fuse_qkv=True, native_gemv=True), dict(importance_mode="cascade"),
+                                dict(head_keep=6), dict(pq_threshold=0.05), dict(layer_keep=[50, 40, 30]),
+                                dict(importance_mode="cascade", head_keep=6, pq_threshold=0.05)])
 def test_decode_graph_on_a_grouped_query_stack(kw):
     """Grouped-query attention (num_key_value_heads < num_heads: k_proj / v_proj are narrower, the cache holds Hkv heads,
     modify_llama.py:106-108 repeat_kv) through DecodeGraph against the eager loop, with a prune event on the GQA cache."""
@@ -726,5 +728,6 @@ def test_decode_graph_on_a_grouped_query_stack(kw):
         for (ka, va), (kb, vb) in zip(new_a, new_b):
             assert ka.shape[1] == Hkv and torch.equal(ka, kb) and torch.equal(va, vb)
         xp = torch.randn(1, 6, HID, device="cuda", generator=g).to(dt)
-        _, past_a = a(xp, new_a)
-        _, past_b = b(xp, new_b)
+        ya, past_a = a(xp, new_a)
+        yb, past_b = b(xp, new_b)
+        assert torch.equal(ya, yb)
