@@ -195,9 +195,10 @@ class SpattenExtensions:
         if self.pq_threshold is not None:
             ops.kv_append(k_new[:, :, None], v_new[:, :, None], slab.k, slab.kr, slab.v, past_len, cos, sin)
             slab.ensure_pq(kv_len)
+            # (splits laid out for the slab capacity, as below: the eager and the captured step then agree bit for bit)
             ops.attn_decode(q, None, None, slab.v, kv_len, cos, sin, past_len, out=st.out, scores=stash, lse=lse,
                             head_ids=st.head_ids, cascade=casc, pq=(slab.pq, self.pq_threshold, st.need_lsb),
-                            head_abs=head_abs)
+                            head_abs=head_abs, layout=slab.capacity)
         elif self.local_v_keep is not None:
             from .cascade import local_v_decode
             ops.kv_append(k_new[:, :, None], v_new[:, :, None], slab.k, slab.kr, slab.v, past_len, cos, sin)

@@ -731,3 +731,33 @@ def test_decode_graph_on_a_grouped_query_stack(kw):
         ya, past_a = a(xp, new_a)
         yb, past_b = b(xp, new_b)
         assert torch.equal(ya, yb)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(importance_mode="cascade"), dict(pq_threshold=0.05, head_keep=6), dict(fuse_qkv=True, native_gemv=True)])
+def test_decode_graph_with_a_batch_of_two_sequences(kw):
+    """B = 2 through the patched forward (the reference chats with one sequence; the boundary carries a batch): the captured
+    loop equals the eager loop bit for bit, and so does the prune that follows."""
+    from spatten_amd.graph import DecodeGraph
+    dt = torch.bfloat16
+    a, b, (cache_a, cache_b) = _models(dt, **kw)
+    g = torch.Generator(device="cuda").manual_seed(17)
+    x0 = torch.randn(2, 150, HID, device="cuda", generator=g).to(dt)
+    _, past_a = a(x0, None)
+    _, past_b = b(x0, None)
+    for turn in range(2):
+        graph = DecodeGraph(lambda past, x: tuple(reversed(b(x, past))), past_b, horizon=7)
+        for t in range(7):
+            x = torch.randn(2, 1, HID, device="cuda", generator=g).to(dt)
+            ya, past_a = a(x, past_a)
+            yb = graph.step(x)
+            assert torch.equal(ya, yb), (turn, t)
+        past_b = graph.past_key_values
+        new_a = cache_a.apply_token_pruning(past_a, 12, [m.attn_scores for m in a.layers])
+        new_b = cache_b.apply_token_pruning(past_b, 12, [m.attn_scores for m in b.layers])
+        ext = getattr(cache_a, "ext", None)
+        kept = [slice(None) if ext is None or st.head_ids is None else st.head_ids.long() for st in (ext.layers if ext else a.layers)]
+        for (ka, va), (kb, vb), hk in zip(new_a, new_b, kept):
+            assert ka.shape[0] == 2 and torch.equal(ka[:, hk], kb[:, hk]) and torch.equal(va[:, hk], vb[:, hk])
+        xp = torch.randn(2, 5, HID, device="cuda", generator=g).to(dt)
+        _, past_a = a(xp, new_a)
+        _, past_b = b(xp, new_b)
