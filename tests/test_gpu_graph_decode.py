@@ -761,3 +761,40 @@ def test_decode_graph_with_a_batch_of_two_sequences(kw):
         xp = torch.randn(2, 5, HID, device="cuda", generator=g).to(dt)
         _, past_a = a(xp, new_a)
         _, past_b = b(xp, new_b)
+
+
+@pytest.mark.parametrize("dt,d,kw", [(torch.float16, 64, dict(fuse_qkv=True, native_gemv=True)), (torch.bfloat16, 64, dict(pq_threshold=0.05)),
+                                     (torch.bfloat16, 64, dict(importance_mode="cascade", head_keep=6)),
+                                     (torch.float32, 128, dict(importance_mode="cascade")), (torch.float32, 64, dict(head_keep=6)),
+                                     (torch.float16, 128, dict(pq_threshold=0.05, importance_mode="cascade")),
+                                     (torch.float16, 128, dict(layer_keep=[50, 44, 44]))])
+def test_decode_graph_other_head_dims_and_dtypes(monkeypatch, dt, d, kw):
+    """head_dim 64 and the fp32 / f16 instantiations of the modes the graph covers, against the eager loop, bit for bit."""
+    import sys
+
+    from spatten_amd.graph import DecodeGraph
+    mod = sys.modules[__name__]
+    monkeypatch.setattr(mod, "D", d)
+    monkeypatch.setattr(mod, "HID", H * d)
+    a, b, (cache_a, cache_b) = _models(dt, **kw)
+    g = torch.Generator(device="cuda").manual_seed(23)
+    x0 = torch.randn(1, 160, H * d, device="cuda", generator=g).to(dt)
+    _, past_a = a(x0, None)
+    _, past_b = b(x0, None)
+    for turn in range(2):
+        graph = DecodeGraph(lambda past, x: tuple(reversed(b(x, past))), past_b, horizon=6)
+        for t in range(6):
+            x = torch.randn(1, 1, H * d, device="cuda", generator=g).to(dt)
+            ya, past_a = a(x, past_a)
+            yb = graph.step(x)
+            assert torch.equal(ya, yb), (turn, t)
+        past_b = graph.past_key_values
+        new_a = cache_a.apply_token_pruning(past_a, 11, [m.attn_scores for m in a.layers])
+        new_b = cache_b.apply_token_pruning(past_b, 11, [m.attn_scores for m in b.layers])
+        ext = getattr(cache_a, "ext", None)
+        kept = [slice(None) if ext is None or st.head_ids is None else st.head_ids.long() for st in (ext.layers if ext else a.layers)]
+        for (ka, va), (kb, vb), hk in zip(new_a, new_b, kept):
+            assert torch.equal(ka[:, hk], kb[:, hk]) and torch.equal(va[:, hk], vb[:, hk])
+        xp = torch.randn(1, 5, H * d, device="cuda", generator=g).to(dt)
+        _, past_a = a(xp, new_a)
+        _, past_b = b(xp, new_b)
