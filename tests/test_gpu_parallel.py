@@ -130,7 +130,9 @@ def _hf_args(x, P):
 
 @pytest.mark.parametrize("dt,world,Hkv,kw", [
     (torch.float32, 2, 8, {}), (torch.float32, 4, 4, dict(fuse_qkv=True)), (torch.float32, 2, 8, dict(native_gemv=True, fuse_qkv=True)),
-    (torch.float32, 2, 8, dict(head_keep=[6, 5])), (torch.bfloat16, 2, 8, dict(native_gemv=True))])
+    (torch.float32, 2, 8, dict(head_keep=[6, 5])), (torch.bfloat16, 2, 8, dict(native_gemv=True)),
+    (torch.float32, 2, 8, dict(importance_mode="cascade")), (torch.float32, 2, 8, dict(pq_threshold=0.05)),
+    (torch.float32, 4, 4, dict(importance_mode="cascade", head_keep=[6, 5]))])
 def test_plugin_head_parallel_shards_run_in_sequence_equal_the_unsharded_plugin(dt, world, Hkv, kw):
     """Every rank's copy of the patched stack (its column-sharded q/k/v projections, its H/G heads of KV cache) is driven
     layer by layer in ONE process; the all-gather is a loopback that lays the slices out rank-major.  Prefill, decode
