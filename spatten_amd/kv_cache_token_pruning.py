@@ -111,7 +111,8 @@ class SpAttenKVCache:
             # grouped-query attention: one cached K/V head serves a GROUP of query heads.  The reference cannot prune such
             # a cache at all (its [H, L] mask meets a [Hkv, L, d] tensor: SURVEY A5); here a key's importance is the sum
             # of its group's rows — the rows of ``importance_score`` are then KV heads
-            self.importance_score = [_group_rows(s, kv_heads) for s in self.importance_score]
+            # (a pruned query head is not launched any more: its stash row is stale — it does not vote)
+            self.importance_score = [_group_rows(self._live_rows(layer, s), kv_heads) for layer, s in enumerate(self.importance_score)]
         scores = _common_rows(self.importance_score)
         Ks = [_rows(kv[0]) for kv in past_key_values]
         Vs = [_rows(kv[1]) for kv in past_key_values]
@@ -133,6 +134,14 @@ class SpAttenKVCache:
                 self.ext.layers[layer].pending_len = 0
             out.append([k, v])
         return out                                                            # list of lists (:72-96)
+
+    def _live_rows(self, layer: int, score: torch.Tensor) -> torch.Tensor:
+        """Grouped-query caches under head pruning: the rows of pruned query heads zeroed before the group sum."""
+        st = self.ext.layers[layer] if self.ext is not None and layer < len(self.ext.layers) else None
+        pruned = None if st is None else st.pruned_ids
+        if pruned is None or pruned.numel() == 0:
+            return score
+        return score.index_fill(0, pruned.to(score.device), 0)
 
     def _prune_cascade(self, past_key_values, seq_len, num_coming, lo, hi, new_len):
         """Same window / row map as the reference prune, but ranked by the accumulated probabilities; the
@@ -182,7 +191,7 @@ class SpAttenKVCache:
         n_layers = len(past_key_values)
         B, Hkv, _, d = Ks[0].shape
         group = accs[0].shape[0] // Hkv
-        scores = _common_rows([_group_rows(a[:, :seq_len], Hkv) for a in accs])
+        scores = _common_rows([_group_rows(self._live_rows(layer, a[:, :seq_len]), Hkv) for layer, a in enumerate(accs)])
         self.importance_score = scores
         cap = kv_slab.round_capacity(new_len + max(int(num_coming), 0))
         rope = kv_slab.rope_tables(cap, d, Ks[0].dtype, Ks[0].device, base, scaling)
@@ -223,6 +232,7 @@ class SpAttenKVCache:
             else:
                 score = ops.importance(attn_score_all[layer])[:, :L]
             if score.shape[0] != K.shape[1]:
+                score = self._live_rows(layer, score)
                 if self.importance_mode == "cascade":
                     raise NotImplementedError("layer_keep with cascade importance on a grouped-query cache: the accumulators "
                                               "have one row per query head")
