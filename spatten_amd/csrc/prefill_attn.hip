@@ -1042,6 +1042,37 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     const float pmax = __expf(m_true - m_run) * inv;
     if (qvalid && hi == 0) p.need[(int64_t)(b * p.H + h) * p.q_len + myq] = pmax < p.pq_thr ? 1 : 0;
   }
+#ifndef SPATTEN_PF_ROWSTORE    // 1: O staged through LDS and stored as whole rows (A/B: tools/mb/pf_exp.sh SPATTEN_PF_ROWSTORE 0 1)
+#define SPATTEN_PF_ROWSTORE 1
+#endif
+  if (SPATTEN_PF_ROWSTORE && PQK != 2 && D == 128) {
+    // Whole rows: the accumulator layout gives a lane 4 consecutive dv of ONE query row per store — 16 eight-byte stores per
+    // lane at a row stride, 32-64 lines touched by every wave instruction; the epilogue of a 256-row block then costs ~9k
+    // cycles of store issue (a tile is ~8k: 13 % of a q = N = 2048 block).  All tile traffic is over (the barrier above), so
+    // each wave transposes its 32 rows through its own 8.5 KB of the tile buffers (pitch 272 B: the 32 row starts spread over
+    // the banks) and stores 4 rows of 256 contiguous bytes per instruction.
+    constexpr int PITCH = D * 2 + 16;
+    char* stg = lds + wave * (32 * PITCH);
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dv = db * 32 + 8 * g + 4 * hi;
+        T v4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = DT<T>::from_f32(o[db][4 * g + e] * inv);
+        *reinterpret_cast<u32x2*>(stg + qi * PITCH + dv * 2) = *reinterpret_cast<u32x2*>(v4);
+      }
+    const int chunk = lane & 15, r4 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 4 * i + r4;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * PITCH + chunk * 16);
+      if (q0 + row < p.q_len)
+        *reinterpret_cast<u32x4*>(p.out + b * p.out_sb + (int64_t)(q0 + row) * p.out_sq + h * D + chunk * 8) = v;
+    }
+    return;
+  }
   if (qvalid && my_flag) {
     T* orow = p.out + b * p.out_sb + (int64_t)myq * p.out_sq + h * D;
 #pragma unroll
