@@ -256,10 +256,23 @@ def auto_graph(model, horizon: int = 256):
         if not take:
             state["graph"] = state["lazy"] = None
             return orig(*args, **kw)
-        if state["graph"] is None or past is not state["lazy"]:
-            state["graph"] = DecodeGraph(step_fn, list(past), horizon=horizon)
-        graph = state["graph"]
-        logits = graph.step(ids)
+        if state.get("disabled"):
+            return orig(*args, **kw)
+        try:
+            if state["graph"] is None or past is not state["lazy"]:
+                state["graph"] = DecodeGraph(step_fn, list(past), horizon=horizon)
+            graph = state["graph"]
+            logits = graph.step(ids)
+        except Exception as e:      # noqa: BLE001 - e.g. a forward that synchronises (.item(), .cpu()) cannot be captured
+            # nothing of the failed step ran on the device (a capture records, it does not execute): the caller's cache object
+            # is still current, so the original forward takes this call — and every later one
+            import warnings
+
+            warnings.warn(f"spatten auto_graph: the single-token step could not be captured ({type(e).__name__}: {e}); "
+                          "falling back to the per-call forward", RuntimeWarning)
+            state["disabled"] = True
+            state["graph"] = state["lazy"] = None
+            return orig(*args, **kw)
         graph.sync_scores()
         lazy = state["lazy"] = _LazyPast(graph)
         proto = state["proto"]

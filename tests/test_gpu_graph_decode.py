@@ -798,3 +798,43 @@ def test_decode_graph_other_head_dims_and_dtypes(monkeypatch, dt, d, kw):
         xp = torch.randn(1, 5, H * d, device="cuda", generator=g).to(dt)
         _, past_a = a(xp, new_a)
         _, past_b = b(xp, new_b)
+
+
+def test_auto_graph_falls_back_when_the_step_cannot_be_captured():
+    """A model whose single-token forward synchronises with the host (here: `.item()` on the logits) cannot be captured:
+    auto_graph warns once, hands the call — and every later one — to the original forward, and the loop's results are the
+    eager loop's."""
+    import contextlib
+    import io
+    import warnings
+
+    from spatten_amd import enable_spatten_llm
+    dt = torch.bfloat16
+
+    class _Syncing(_HFStyleLM):
+        def forward(self, input_ids=None, past_key_values=None, use_cache=None, attention_mask=None, position_ids=None):
+            out = _HFStyleLM.forward(self, input_ids, past_key_values, use_cache)
+            self.last = out.logits[0, -1, 0].item()            # a host read inside the model call
+            return out
+    torch.manual_seed(5)
+    a, b = _Syncing(dt), _Syncing(dt)
+    b.load_state_dict(a.state_dict())
+    for m, auto in ((a, False), (b, True)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            enable_spatten_llm(m, 4, 40, 40, auto_graph=auto)
+    ids = torch.randint(0, _TinyLM.VOCAB, (1, 60), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    with torch.no_grad(), warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        outs = []
+        for m in (a, b):
+            o = m(input_ids=ids, past_key_values=None, use_cache=True)
+            past, tok, logits = o.past_key_values, o.logits[:, -1:].argmax(-1), []
+            for _ in range(6):
+                o = m(input_ids=tok, past_key_values=past, use_cache=True)
+                past, tok = o.past_key_values, o.logits[:, -1:].argmax(-1)
+                logits.append(o.logits.clone())
+            outs.append((logits, past))
+    assert any("auto_graph" in str(w.message) for w in caught) and b._spatten_auto_graph.get("disabled")
+    assert all(torch.equal(x, y) for x, y in zip(outs[0][0], outs[1][0]))
+    for (ka, va), (kb, vb) in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(ka, kb) and torch.equal(va, vb)
