@@ -13,7 +13,7 @@ for d in ("pmc_pf", "pmc_pf2", "pmc_pf3"):
         print(d, "no output"); continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        if "prefill_pp128_kernel" in r["Kernel_Name"] and ("Lb0ELi0EEEv" in r["Kernel_Name"] or ", false, 0>" in r["Kernel_Name"]) and r["Grid_Size"] == str(64*32*256):
+        if "prefill_pp128_kernel" in r["Kernel_Name"] and ("Lb0ELi0ELb0ELb0EEEv" in r["Kernel_Name"] or ", false, 0>" in r["Kernel_Name"]) and r["Grid_Size"] == str(64*32*256):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in sorted(acc.items()):
         print(f"{k:34s} {len(v):3d} {sum(v) / len(v):16.0f}  per wave-tile {sum(v) / len(v) / 266240:9.1f}")
