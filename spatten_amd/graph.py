@@ -237,7 +237,9 @@ def auto_graph(model, horizon: int = 256):
     (after a prefill or a prune) runs eagerly, the second is captured, later ones replay.  Everything else — prefill, calls
     with masks / positions / embeddings — goes to the original forward.  The returned ``logits`` are a static buffer the
     next call overwrites; ``past_key_values`` is materialised when it is indexed; ``m.attn_scores`` is current after every
-    call.  Returns the wrapped model (the same object)."""
+    call.  Results equal the per-call forward's bit for bit when its slabs have the capacity the graph reserves (``horizon``
+    rows beyond the cache, rounded to 128) — the split layout of a decode step follows the slab capacity — and to rounding
+    otherwise.  Returns the wrapped model (the same object)."""
     orig = model.forward
     state = {"graph": None, "lazy": None, "proto": None}
 
