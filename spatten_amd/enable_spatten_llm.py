@@ -44,7 +44,7 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     of the decode step's bytes (same fp32 accumulation and single rounding as ``nn.Linear``; a different summation order,
     so the last bit can differ).  Multi-token forwards keep torch's GEMMs.
 
-    ``auto_graph=True`` (or a token horizon): ``model.forward`` is wrapped so that the reference's per-token loop
+    ``auto_graph=True`` (or a token horizon; True = 64, the reference's max_gen_len — run_spatten_llama.py:61): ``model.forward`` is wrapped so that the reference's per-token loop
     (run_spatten_llama.py:27-35), unchanged, replays one captured HIP graph of the whole patched stack per token
     (spatten_amd/graph.py:auto_graph) — the zero-change form of ``DecodeGraph``.
 
@@ -108,5 +108,5 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
             raise ValueError("auto_graph: local V pruning runs its decode step eagerly (SpattenExtensions.graph_capable)")
         from .graph import auto_graph as _auto
 
-        _auto(model, horizon=256 if auto_graph is True else int(auto_graph))
+        _auto(model, horizon=64 if auto_graph is True else int(auto_graph))
     return cache

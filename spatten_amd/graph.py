@@ -229,7 +229,7 @@ class _LazyPast(list):
         return super().__len__()
 
 
-def auto_graph(model, horizon: int = 256):
+def auto_graph(model, horizon: int = 64):
     """Zero-change mode of the drop-in: wrap ``model.forward`` so that the reference's own per-token loop
     (run_spatten_llama.py:27-35: ``model(input_ids=tok, past_key_values=past, use_cache=True)``) runs every single-token call
     as a replay of ONE captured graph of the whole patched stack.  A call is taken over when it has exactly ``input_ids``
@@ -239,7 +239,9 @@ def auto_graph(model, horizon: int = 256):
     next call overwrites; ``past_key_values`` is materialised when it is indexed; ``m.attn_scores`` is current after every
     call.  Results equal the per-call forward's bit for bit when its slabs have the capacity the graph reserves (``horizon``
     rows beyond the cache, rounded to 128) — the split layout of a decode step follows the slab capacity — and to rounding
-    otherwise.  Returns the wrapped model (the same object)."""
+    otherwise.  ``horizon``: rows reserved beyond the cache when a graph is bound (the captured step reads its slabs up to their
+    capacity: a larger horizon streams more discarded rows per token; a generation that outgrows it re-binds and re-captures,
+    a few ms).  Returns the wrapped model (the same object)."""
     orig = model.forward
     state = {"graph": None, "lazy": None, "proto": None}
 
