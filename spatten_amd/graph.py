@@ -17,9 +17,9 @@ rebuilt on demand.  So:
 
 ``step_fn`` is whatever runs one token through the patched model, e.g.
 ``lambda past, tok: (lambda o: (o.past_key_values, o.logits))(model(tok, past_key_values=past, use_cache=True))``.
-Requirements: batch and shapes fixed; the plain plugin path or the cascade-importance / head-pruning modes (progressive
-quantisation, local V pruning and the layer cascade run eagerly); the HF mask / position_ids of the step are the ones
-transformers 4.33 builds (zeros / the past length) — they are not read.
+Requirements: batch and shapes fixed; every mode of the plugin is captured (plain, cascade importance, head pruning,
+progressive quantisation, the layer cascade, local V pruning); the HF mask / position_ids of the step are the ones
+transformers 4.33 builds (zeros / the past length) — they are not read (a non-zero mask is refused while tracing).
 
 Numerics: every step — the warm-up, and a plain eager step through the patched forward on slabs of the same capacity —
 lays its split-N decomposition out for the slab capacity, so graph replays and eager steps agree bit for bit
@@ -33,7 +33,15 @@ import torch
 
 from . import kv_slab, ops
 
-__all__ = ["DecodeGraph", "auto_graph"]
+__all__ = ["DecodeGraph", "GraphCaptureError", "auto_graph"]
+
+
+class GraphCaptureError(RuntimeError):
+    """The step could not be CAPTURED (``step_fn`` synchronises with the host, runs a non-capturable collective, …).
+    Raised by ``DecodeGraph.step`` only for errors inside capture_begin / capture_end: a capture records, it does not
+    execute, so nothing of that step ran on the device, and the host-side slab state has been put back — the caller may
+    run the step eagerly instead.  Errors of the constructor, of a re-bind and of the eager warm-up step (which DOES run
+    on the device) are raised as they are."""
 
 
 _capture_streams: dict = {}
@@ -67,6 +75,8 @@ class DecodeGraph:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.states: dict = {}                  # cache-length offset (vs layer 0) -> ops.StepState
         self.touched: List[tuple] = []          # (module, slab) pairs of the last traced step, in call order
+        self.workspaces: List = []              # every scratch buffer a traced launch used: the captured graph holds raw
+                                                # pointers into them (ops._ws_pins), so it keeps them alive
         self.static_in: Optional[List[torch.Tensor]] = None
         self.static_out = None
         self.n_replays = 0
@@ -111,14 +121,15 @@ class DecodeGraph:
     def _trace(self, inputs):
         """Run step_fn once in device-length mode on the current stream (eagerly, or under capture)."""
         self.touched = []
-        prev = kv_slab.graph_ctx
-        kv_slab.graph_ctx = self
+        prev, prev_pins = kv_slab.set_graph_ctx(self), ops._ws_pins
+        ops._ws_pins = self.workspaces
         try:
             for st in self.states.values():
                 st.advance(1)
             new_past, out = self.step_fn(self._past, *inputs)
         finally:
-            kv_slab.graph_ctx = prev
+            kv_slab.set_graph_ctx(prev)
+            ops._ws_pins = prev_pins
         if not self.touched:
             raise RuntimeError("DecodeGraph: step_fn did not run a single-token step through the patched forward")
         self._past = new_past
@@ -148,14 +159,26 @@ class DecodeGraph:
             # torch.cuda.empty_cache() on entry — after a prune the previous turn's slabs (1.6 GB at Llama-2-7B) sit in the
             # caching allocator, and handing them back to the driver cost 20 ms per turn here, plus the hipMallocs of the
             # next prune.
-            with torch.cuda.stream(self.stream):
-                self.stream.synchronize()
-                g.capture_begin()
-                try:
-                    self.static_out = self._trace(self.static_in)
-                finally:
-                    g.capture_end()
-            cur.wait_stream(self.stream)
+            # host-side state a traced step moves (the patched forward sets slab.length / rot_len layer by layer): put back
+            # if the capture fails, so that the caller's views and an eager re-run of this step see the pre-step cache
+            slabs = [kv_slab.slab_of(kv[0]) for kv in self._past]
+            saved = [(sl.length, sl.rot_len, sl.pq_len) for sl in slabs]
+            past0, touched0 = self._past, self.touched
+            try:
+                with torch.cuda.stream(self.stream):
+                    self.stream.synchronize()
+                    g.capture_begin()
+                    try:
+                        self.static_out = self._trace(self.static_in)
+                    finally:
+                        g.capture_end()
+            except Exception as e:      # noqa: BLE001 - whatever broke the capture: nothing of this step ran
+                for sl, (n, r, pq_n) in zip(slabs, saved):
+                    sl.length, sl.rot_len, sl.pq_len = n, r, pq_n
+                self._past, self.touched, self.static_in, self.static_out = past0, touched0, None, None
+                raise GraphCaptureError(f"{type(e).__name__}: {e}") from e
+            finally:
+                cur.wait_stream(self.stream)
             self.graph = g
         else:
             for dst, src in zip(self.static_in, inputs):
@@ -262,19 +285,23 @@ def auto_graph(model, horizon: int = 64):
             return orig(*args, **kw)
         if state.get("disabled"):
             return orig(*args, **kw)
+        # errors of the constructor / a re-bind / the eager warm-up step (shape errors, OOM, genuine bugs — the warm-up DOES
+        # run on the device) propagate; only a failed CAPTURE falls back
+        if state["graph"] is None or past is not state["lazy"]:
+            state["graph"] = DecodeGraph(step_fn, list(past), horizon=horizon)
+        graph = state["graph"]
         try:
-            if state["graph"] is None or past is not state["lazy"]:
-                state["graph"] = DecodeGraph(step_fn, list(past), horizon=horizon)
-            graph = state["graph"]
             logits = graph.step(ids)
-        except Exception as e:      # noqa: BLE001 - e.g. a forward that synchronises (.item(), .cpu()) cannot be captured
-            # nothing of the failed step ran on the device (a capture records, it does not execute): the caller's cache object
-            # is still current, so the original forward takes this call — and every later one
+        except GraphCaptureError as e:    # e.g. a forward that synchronises (.item(), .cpu()) cannot be captured
+            # nothing of the failed step ran on the device (a capture records, it does not execute) and DecodeGraph.step has
+            # put the slabs' host-side lengths back: the cache at the pre-step length goes to the original forward, which
+            # takes this call — and every later one
             import warnings
 
-            warnings.warn(f"spatten auto_graph: the single-token step could not be captured ({type(e).__name__}: {e}); "
+            warnings.warn(f"spatten auto_graph: the single-token step could not be captured ({e}); "
                           "falling back to the per-call forward", RuntimeWarning)
             state["disabled"] = True
+            kw = dict(kw, past_key_values=graph.past_key_values)
             state["graph"] = state["lazy"] = None
             return orig(*args, **kw)
         graph.sync_scores()

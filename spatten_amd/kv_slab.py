@@ -48,9 +48,28 @@ def rope_tables(n: int, d: int, dtype: torch.dtype, device, base: float = 10000.
     return t
 
 
-# the DecodeGraph (spatten_amd/graph.py) that is warming up / capturing a decode step right now, or None: the patched
-# forward then runs its single-token step in the device-length form (ops.StepState) on persistent buffers
-graph_ctx = None
+# The DecodeGraph (spatten_amd/graph.py) that is warming up / capturing a decode step right now ON THIS THREAD, or None:
+# the patched forward then runs its single-token step in the device-length form (ops.StepState) on persistent buffers —
+# but only for the slabs that graph is bound to (``graph_ctx_for``): a single-token forward of another model while a
+# graph traces takes the ordinary eager path.
+import threading
+
+_tls = threading.local()
+
+
+def set_graph_ctx(ctx):
+    """Install ``ctx`` as this thread's tracing DecodeGraph; returns the previous one."""
+    prev = getattr(_tls, "graph_ctx", None)
+    _tls.graph_ctx = ctx
+    return prev
+
+
+def graph_ctx_for(slab):
+    """This thread's tracing DecodeGraph if ``slab`` is one of the slabs it is bound to, else None."""
+    ctx = getattr(_tls, "graph_ctx", None)
+    if ctx is not None and id(slab) in ctx._offset_of:
+        return ctx
+    return None
 
 
 class KVSlab:

@@ -107,13 +107,24 @@ class DecodeWorkspace:
 
 _ws_cache = _LRU(16)
 
+# While a DecodeGraph traces a step (spatten_amd/graph.py) every workspace a launch uses is also appended here: a captured
+# graph bakes the workspace's raw pointers in, so the graph — not only this LRU — has to keep the buffers alive (an entry
+# evicted by other streams / shapes would otherwise be replayed into freed memory).
+_ws_pins: Optional[list] = None
+
+
+def _pin(ws):
+    if _ws_pins is not None and not any(w is ws for w in _ws_pins):
+        _ws_pins.append(ws)
+    return ws
+
 
 def _workspace(batch, heads, head_dim, device, stream: Optional[int] = None) -> DecodeWorkspace:
     key = (batch, heads, head_dim, device, _stream() if stream is None else stream)
     ws = _ws_cache.get(key)
     if ws is None:
         ws = _ws_cache.put(key, DecodeWorkspace(batch, heads, head_dim, device))
-    return ws
+    return _pin(ws)
 
 
 def check_workspaces():
@@ -179,7 +190,7 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: Opti
     if mask is not None and mask.stride(-1) != 1:
         raise ValueError("mask rows must be contiguous")
     stream = _stream()
-    ws = workspace or _workspace(B, H, d, q.device, stream)
+    ws = _pin(workspace) if workspace is not None else _workspace(B, H, d, q.device, stream)
     if n_splits > ws.max_splits:
         raise ValueError("n_splits exceeds workspace")
     if head_ids is not None and (head_ids.dtype != torch.int32 or not head_ids.is_cuda or head_ids.dim() != 1):
@@ -337,6 +348,7 @@ class SlabDecodeCall:
         if stream != self.stream:                       # the workspace belongs to a stream
             self.stream, self.ws = stream, _workspace(self.B, self.H, self.d, q.device, stream)
             self.a.workspace = self.ws.buf.data_ptr()
+        _pin(self.ws)
         out = torch.empty(self.B, self.H * self.d, dtype=q.dtype, device=q.device)
         a = self.a
         a.q, a.q_sb, a.q_sh = q.data_ptr(), (self.H * self.d if self.B == 1 else q.stride(0)), q.stride(1)

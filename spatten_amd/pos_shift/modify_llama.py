@@ -106,9 +106,10 @@ def llama_pos_shift_attention_forward(
             raise NotImplementedError("head_parallel with config.pretraining_tp > 1")
         num_heads, num_kv_heads = hp[0].local_heads, hp[0].local_kv_heads
     # single-token rows through the library's weight-streaming kernel (opt-in), everything else through torch's GEMMs
+    # (only for PLAIN nn.Linear projections of the activation dtype — all four: the kernel reads ``.weight`` directly, which
+    #  would skip the forward of a wrapped projection (LoRA, a quantised linear exposing .weight) on single-token steps only)
     native_rows = (tp == 1 and bsz * q_len <= 4 and bool(self.__dict__.get("_spatten_gemv", False))
-                   and hidden_states.is_cuda and hidden_states.dtype == self.o_proj.weight.dtype
-                   and type(self.o_proj) is torch.nn.Linear)
+                   and hidden_states.is_cuda and _plain_linears(self, hidden_states.dtype))
     if tp > 1:                                                                    # :43-69
         kv_slicing = (num_kv_heads * head_dim) // tp
         q_slices = self.q_proj.weight.split((num_heads * head_dim) // tp, dim=0)
@@ -204,7 +205,12 @@ def llama_pos_shift_attention_forward(
     if q_len == 1:
         q3 = query_states.view(bsz, num_heads, head_dim)
         k3, v3 = key_states.view(bsz, num_kv_heads, head_dim), value_states.view(bsz, num_kv_heads, head_dim)
-        gctx = kv_slab.graph_ctx
+        gctx = kv_slab.graph_ctx_for(slab)     # this thread's tracing DecodeGraph, if THIS cache is one it is bound to
+        if gctx is not None and attention_mask is not None and attention_mask.numel() \
+                and not torch.cuda.is_current_stream_capturing() and bool((attention_mask != 0).any().item()):
+            # the captured step does not read the mask (device-length causal rule); checked on the eager warm-up step
+            raise ValueError("DecodeGraph: the single-token step was given a non-zero attention_mask (a padded batch?) — "
+                             "the captured step attends to the whole cache")
         # native projections (opt-in) on the plain path: o_proj rides in the attention call (include/spatten.h: proj_* — the
         # library issues both launches: one host call per layer-step)
         fused_proj = (self.o_proj.weight, self.o_proj.bias) if (native_rows and hp is None and ext is None) else None
@@ -302,6 +308,19 @@ def llama_pos_shift_attention_forward(
 
     new_past = slab.views() if use_cache else None                                # :100
     return attn_output, attn_weights, new_past
+
+
+def _plain_linears(module, dtype) -> bool:
+    """All four projections are exactly ``torch.nn.Linear`` with weights of ``dtype`` (answer cached per module and dtype)."""
+    mods = module._modules
+    ident = (dtype, id(mods.get("q_proj")), id(mods.get("k_proj")), id(mods.get("v_proj")), id(mods.get("o_proj")))
+    key = module.__dict__.get("_spatten_plain")
+    if key is not None and key[0] == ident:
+        return key[1]
+    ok = all(type(mods.get(n)) is torch.nn.Linear and mods[n].weight.dtype == dtype
+             for n in ("q_proj", "k_proj", "v_proj", "o_proj"))
+    module.__dict__["_spatten_plain"] = (ident, ok)
+    return ok
 
 
 def fuse_qkv_projections(module) -> bool:

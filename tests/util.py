@@ -11,8 +11,9 @@ TORCH_DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
 # Stated tolerances, HIP vs reference/oracle (see DESIGN.md "Parity bar"):
 #  * indices, masks, gathered KV rows, appended cache rows: bit exact
 #  * fp32 attention output / stash: accumulation ORDER differs -> atol 2e-5, rtol 1e-5
-#  * 16-bit attention output: the reference also rounds P to the model dtype before P.V, the kernel
-#    keeps P in fp32 -> a few output ulps: bf16 atol 1e-2 rtol 2e-2; f16 atol 2e-3 rtol 4e-3
+#  * 16-bit attention output: the reference rounds the NORMALISED P to the model dtype before P.V, the kernel rounds the
+#    un-normalised exp(s - running max) (decode_attn.hip header: the denominator is not known before the first V row)
+#    -> a few output ulps: bf16 atol 1e-2 rtol 2e-2; f16 atol 2e-3 rtol 4e-3
 #  * 16-bit stash: every reference rounding step is reproduced; a value may still land one ulp away
 #    where fp32 accumulation order crosses the matmul->dtype rounding boundary; the following
 #    /sqrt(d) -> dtype step stretches that to <= 2 ulp of the (smaller) quotient -> <2% of entries, <= 2 ulp.

@@ -1,4 +1,4 @@
-"""The one-wave-per-SIMD flash kernel (spatten_amd/csrc/prefill_w4.h — an experiment, selected by SPATTEN_PREFILL_W4=1)
+"""The one-wave-per-SIMD flash kernel (tools/experiments/prefill_w4.h — an experiment, selected by SPATTEN_PREFILL_W4=1)
 against the oracle.  The kernel choice is read once per process, so the cases run in a subprocess."""
 import os
 import subprocess
@@ -45,7 +45,7 @@ print("W4_CASES_OK", n + 1)
 
 
 def test_w4_kernel_matches_the_oracle():
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     env = dict(os.environ, SPATTEN_PREFILL_W4="1", SPATTEN_PREFILL_VTR="0", SPATTEN_PREFILL_KSPLIT="1", PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", CASES], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "W4_CASES_OK 17" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

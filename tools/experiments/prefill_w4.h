@@ -1,7 +1,7 @@
 // spatten_amd — the one-wave-per-SIMD flash kernel (round 3).  Included by prefill_attn.hip (inside
 // namespace spatten, after the helpers it uses: FlashParams, Mfma, dma16, rope_pair, round2, logit_scale ...).
 //
-// STATUS: an EXPERIMENT, selected by SPATTEN_PREFILL_W4=1.  Parity-green (tests/test_gpu_prefill_w4.py and the whole prefill /
+// STATUS: an EXPERIMENT, compiled only by tools/experiments/build_w4.sh (-DSPATTEN_WITH_W4_EXPERIMENT), selected by SPATTEN_PREFILL_W4=1.  Parity-green (tools/experiments/check_prefill_w4.py and the whole prefill /
 // full-size / protocol suites with the switch on) and SLOWER than prefill_pp128_kernel: 616-642 against 740-766 TFLOP/s at
 // q = N = 8192 (profiles/r03_prefill_w4_anatomy.txt) — with one wave per SIMD nothing hides that wave's own
 // issue slots, and the reference's two roundings per logit are ~8 vector instructions per MFMA.
