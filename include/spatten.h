@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SPATTEN_ABI_VERSION 3
+#define SPATTEN_ABI_VERSION 4
 
 typedef enum {
   SPATTEN_F32 = 0,
@@ -439,6 +439,71 @@ int spatten_pq_pack(int dtype, const void* kr_cache, int64_t kv_sb, int64_t kv_s
                     int64_t pl_sb, int64_t pl_sh, int64_t sc_sb, int64_t sc_sh, int batch, int kv_heads, int head_dim,
                     int row_lo, int row_hi, void* stream);
 /* The decode step over the planes is spatten_attn_decode_args with the pq_* fields set. */
+
+/* ------------------------------------------------------------------------------------------------
+ * Bit profiles and the quantised VALUE plane (ABI 4).  The accelerator fetches K at `profile_key.bit_count` MSBs — 4, 6
+ * (two lines fused per transaction) or 8 (MatrixFetcher.scala:48-51; TestSpAtten.scala:173-176) — left-aligned in its
+ * 12-bit lane, refetches 4 LSBs on low confidence (requantBitCount, SpAttenController.scala:35-39; write mask 0x00F,
+ * :230-232), and fetches V ONCE at `profile_val.bit_count` bits — 8 by default, 6 in the per8 trace
+ * (TestSpAtten.scala:64,83-97; SpAttenController.scala:716-723: `high_bits := True` = one fetch, not full precision).
+ * Here: K is quantised symmetric per row to T = key_msb_bits + 4 bits, q = clip(rint(x / scale)), scale = amax / (2^(T-1) - 1);
+ * the MSB plane holds q >> 4 (key_msb_bits signed bits), the LSB plane q & 15; pass 1 scores with 16 * msb, the refetch
+ * pass adds the LSB term to the MSB logit pass 1 left in `msb_logit` (fp32: the row is recomputed ONCE, :402, without
+ * re-reading the MSB plane).  V is quantised symmetric per row to value_bits: v ~ val_scale * qv.  Parity unpinned.
+ *
+ * Plane layouts (d = head_dim, LPR = d/16; "piece c" of a row = the 16 elements lane c of a row's LPR lanes owns in the
+ * decode kernels: t < 8 -> element 8c + t, t >= 8 -> element d/2 + 8c + (t - 8), c in [0, LPR)):
+ *   key_msb   [B,Hkv,cap,d*key_msb_bits/8] bytes, piece c at byte 2*key_msb_bits*c, field t (key_msb_bits wide) at bit
+ *             key_msb_bits*t of the piece (little endian) = msb + 2^(key_msb_bits-1)   (NOT the spatten_pq_pack layout)
+ *   key_lsb   [B,Hkv,cap,d/2] bytes, piece c at byte 8c, nibble t at bit 4t
+ *   val_q     [B,Hkv,cap,d*value_bits/8] bytes, the same piece layout, field = qv + 2^(value_bits-1)
+ *   key_scale, val_scale [B,Hkv,cap] fp32;  msb_logit [B,H,cap] fp32 scratch (written by pass 1, read by the refetch pass)
+ * Supported profiles (key_msb_bits, value_bits): (4, 8), (8, 8) — the RTL harness default —, (6, 6) — the per8 trace.
+ * (4 with V in the model dtype is the pq_* mode of spatten_attn_decode_args.)  All dtypes, head_dim 64 / 128.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct spatten_pq_planes {
+  uint32_t struct_size;            /* sizeof(spatten_pq_planes_t) of the caller */
+  int32_t key_msb_bits;            /* 4, 6 or 8 */
+  int32_t value_bits;              /* 8 or 6 */
+  int32_t pad0_;
+  void* key_msb; void* key_lsb; float* key_scale;
+  void* val_q; float* val_scale;
+  float* msb_logit;
+  int64_t km_sb, km_sh;            /* key_msb strides, BYTES */
+  int64_t kl_sb, kl_sh;            /* key_lsb strides, BYTES */
+  int64_t vq_sb, vq_sh;            /* val_q strides, BYTES */
+  int64_t sc_sb, sc_sh;            /* key_scale and val_scale strides, elements */
+  int64_t lg_sb, lg_sh;            /* msb_logit strides, elements */
+} spatten_pq_planes_t;
+/* bytes of one plane row: head_dim * bits / 8 */
+size_t spatten_pq_plane_row_bytes(int head_dim, int bits);
+/* Quantise rows [row_lo, row_hi) of the rotated shadow kr_cache into the key planes and of v_cache into the value plane.
+ * With `step_state` (device-resident length, see above) the ONE row (state word 0) - 1 is packed instead — the step's
+ * row, after spatten_kv_append_step wrote it — and row_hi is the planes' capacity (a row >= row_hi is not written). */
+int spatten_pq_pack_planes(int dtype, const void* kr_cache, const void* v_cache, int64_t kv_sb, int64_t kv_sh,
+                           const spatten_pq_planes_t* planes, int batch, int kv_heads, int head_dim, int row_lo, int row_hi,
+                           const void* step_state, void* stream);
+/* The decode step over the planes: pass 1 (MSB logits -> stash + msb_logit, softmax, P.V over the quantised V,
+ * need_lsb[b*H+h] = max_j prob_j < threshold; RequantDecision.scala:44-72) and the refetch pass for the flagged heads (LSB plane +
+ * msb_logit; V again, because the probabilities change).  Arguments as in spatten_decode_args_t; the launch appends nothing.
+ * flags bit 0: pass 1 only (measurements). */
+#define SPATTEN_PQ_MSB_PASS_ONLY 1
+typedef struct spatten_pq_decode_args {
+  uint32_t struct_size; int32_t dtype;
+  const void* q; int64_t q_sb, q_sh;
+  const spatten_pq_planes_t* planes;       /* host pointer */
+  const void* cos; const void* sin; int32_t table_rows; int32_t pos_q;
+  void* out; int64_t out_sb;
+  void* scores; int64_t sc_sb, sc_sh;      /* optional stash [B,H,>=kv_len] */
+  float* lse;                              /* optional [B,H,2] */
+  int32_t* need_lsb; float threshold; int32_t flags;
+  void* workspace; int32_t workspace_splits;
+  int32_t batch, heads, kv_heads, head_dim, kv_len, n_splits, kv_len_layout;
+  const int32_t* head_ids; int32_t n_active_heads; int32_t pad0_;
+  float* head_abs_acc;
+  const void* step_state;
+} spatten_pq_decode_args_t;
+int spatten_attn_decode_pq(const spatten_pq_decode_args_t* args, void* stream);
 
 /* Prefill over the planes (BASELINE.json configs[3]: prefill + progressive quantisation).  Same query / value / output /
  * mask / position arguments as spatten_attn_prefill; the keys come from the MSB / LSB planes: pass 1 scores every query

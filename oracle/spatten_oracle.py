@@ -426,6 +426,39 @@ def pq_decode_attention(qr: np.ndarray, msb, lsb, scale, V: np.ndarray, threshol
     return np.einsum("bhl,bhld->bhd", p, V.astype(np.float32)).astype(np.float32), need
 
 
+def pq_quantize_values(V: np.ndarray, bits: int = 8):
+    """The quantised VALUE plane: V is fetched ONCE at ``profile_val.bit_count`` bits — 8 by default, 6 in the per8 trace
+    (TestSpAtten.scala:64,83-97,175-176; SpAttenController.scala:716-723 `high_bits := True`: one fetch, not full
+    precision).  Symmetric per-row linear quantiser like the keys'.  V [..., d] -> (qv int32, vscale fp32 [..., 1])."""
+    V = V.astype(np.float32)
+    qmax = float(2 ** (bits - 1) - 1)
+    amax = np.abs(V).max(axis=-1, keepdims=True)
+    vscale = np.where(amax > 0, amax / qmax, np.float32(1.0)).astype(np.float32)
+    qv = np.clip(np.rint(V / vscale), -qmax - 1, qmax).astype(np.int32)
+    return qv, vscale
+
+
+def pq_decode_attention_profile(qr: np.ndarray, msb, lsb, scale, qv, vscale, threshold: float, lsb_bits: int = 4):
+    """Progressive-quant decode over a bit PROFILE (MatrixFetcher.scala:48-51: MSB plane of 4 / 6 / 8 bits; 4 LSBs on
+    refetch, SpAttenController.scala:35-39) with the quantised value plane: pass 1 = logits from the MSB plane
+    (left-aligned, MatrixFetcher.scala:345), need = max prob < threshold (RequantDecision.scala:44-72); flagged heads are
+    recomputed ONCE (SpAttenController.scala:402) as logit_msb + (q . lsb) scale / sqrt(d) — the LSB plane is added to the
+    pass-1 logit, the MSB plane is not fetched again (write mask 0x00F, :230-232) —; P.V over V ~ qv * vscale, P in fp32.
+    qr [B,H,d] rotated queries; planes [B,H,L,d].  Returns (out [B,H,d] fp32, need [B,H] bool, logits [B,H,L] fp32)."""
+    d = qr.shape[-1]
+    q32 = qr.astype(np.float32)
+    rs = np.float32(math.sqrt(d))
+    s1 = np.einsum("bhd,bhld->bhl", q32, pq_dequant(msb, None, scale, lsb_bits)) / rs
+    p1 = softmax_probs(s1)
+    need = p1.max(axis=-1) < np.float32(threshold)
+    s2 = s1 + np.einsum("bhd,bhld->bhl", q32, lsb.astype(np.float32) * scale) / rs
+    p2 = softmax_probs(s2)
+    p = np.where(need[..., None], p2, p1)
+    logits = np.where(need[..., None], s2, s1).astype(np.float32)
+    V = qv.astype(np.float32) * vscale
+    return np.einsum("bhl,bhld->bhd", p, V).astype(np.float32), need, logits
+
+
 # --------------------------------------------------------------------------- #
 # synthetic inputs: counter-based generator shared by tests / bench / goldens
 # --------------------------------------------------------------------------- #

@@ -9,7 +9,7 @@ import ctypes
 import os
 from ctypes import c_char_p, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p, POINTER, c_float
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 DECODE_MAX_SPLITS = 64
 
 
@@ -42,6 +42,38 @@ class DecodeArgs(ctypes.Structure):
         ("proj_weight", c_void_p), ("proj_w_sn", c_int64), ("proj_bias", c_void_p), ("proj_out", c_void_p),
         ("proj_out_sb", c_int64), ("proj_n", c_int32), ("pad4_", c_int32),
     ]
+
+class PQPlanesDesc(ctypes.Structure):
+    """``spatten_pq_planes_t`` (include/spatten.h, ABI 4): profiled key planes + the quantised value plane."""
+    _fields_ = [
+        ("struct_size", c_uint32), ("key_msb_bits", c_int32), ("value_bits", c_int32), ("pad0_", c_int32),
+        ("key_msb", c_void_p), ("key_lsb", c_void_p), ("key_scale", c_void_p),
+        ("val_q", c_void_p), ("val_scale", c_void_p), ("msb_logit", c_void_p),
+        ("km_sb", c_int64), ("km_sh", c_int64), ("kl_sb", c_int64), ("kl_sh", c_int64),
+        ("vq_sb", c_int64), ("vq_sh", c_int64), ("sc_sb", c_int64), ("sc_sh", c_int64),
+        ("lg_sb", c_int64), ("lg_sh", c_int64),
+    ]
+
+
+class PQDecodeArgs(ctypes.Structure):
+    """``spatten_pq_decode_args_t`` (include/spatten.h, ABI 4)."""
+    _fields_ = [
+        ("struct_size", c_uint32), ("dtype", c_int32),
+        ("q", c_void_p), ("q_sb", c_int64), ("q_sh", c_int64),
+        ("planes", POINTER(PQPlanesDesc)),
+        ("cos", c_void_p), ("sin", c_void_p), ("table_rows", c_int32), ("pos_q", c_int32),
+        ("out", c_void_p), ("out_sb", c_int64),
+        ("scores", c_void_p), ("sc_sb", c_int64), ("sc_sh", c_int64),
+        ("lse", c_void_p),
+        ("need_lsb", c_void_p), ("threshold", c_float), ("flags", c_int32),
+        ("workspace", c_void_p), ("workspace_splits", c_int32),
+        ("batch", c_int32), ("heads", c_int32), ("kv_heads", c_int32), ("head_dim", c_int32), ("kv_len", c_int32),
+        ("n_splits", c_int32), ("kv_len_layout", c_int32),
+        ("head_ids", c_void_p), ("n_active_heads", c_int32), ("pad0_", c_int32),
+        ("head_abs_acc", c_void_p),
+        ("step_state", c_void_p),
+    ]
+
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libspatten_hip.so")
@@ -103,6 +135,12 @@ def _declare(lib):
     lib.spatten_pv_gather_workspace_bytes.argtypes = [i, i, i]
     lib.spatten_pq_pack.restype = c_int
     lib.spatten_pq_pack.argtypes = [i, p, i64, i64, p, p, p, i64, i64, i64, i64, i, i, i, i, i, p]
+    lib.spatten_pq_plane_row_bytes.restype = c_size_t
+    lib.spatten_pq_plane_row_bytes.argtypes = [i, i]
+    lib.spatten_pq_pack_planes.restype = c_int
+    lib.spatten_pq_pack_planes.argtypes = [i, p, p, i64, i64, POINTER(PQPlanesDesc), i, i, i, i, i, p, p]
+    lib.spatten_attn_decode_pq.restype = c_int
+    lib.spatten_attn_decode_pq.argtypes = [POINTER(PQDecodeArgs), p]
     lib.spatten_prefill_workspace_bytes.restype = c_size_t
     lib.spatten_prefill_workspace_bytes.argtypes = [i, i, i, i, i, i, i]
     lib.spatten_attn_prefill.restype = c_int

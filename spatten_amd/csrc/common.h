@@ -443,6 +443,14 @@ int pq_expand(int dtype, const void* msb, const void* lsb, const float* scale, i
               int64_t sc_sh, void* k_msb, void* k_full, float* kscale, int batch, int kv_heads, int head_dim, int rows,
               hipStream_t stream);
 
+// profiled planes (pq.hip / pq_decode.hip): the device-side copy of spatten_pq_planes_t
+struct PlanesDev {
+  uint8_t* km; uint8_t* kl; float* ks; uint8_t* vq; float* vs; float* lg;
+  int64_t km_sb, km_sh, kl_sb, kl_sh, vq_sb, vq_sh, sc_sb, sc_sh, lg_sb, lg_sh;
+};
+bool planes_to_dev(const spatten_pq_planes_t* p, PlanesDev& d);
+bool pq_profile_supported(int key_msb_bits, int value_bits);
+
 constexpr int kDecodeMaxSplits = 64;
 constexpr size_t kStepHeader = 64;      // spatten_step_state_t: 16 int32 words, then the staged rotary rows
 constexpr size_t kDecodeWsHeader = 256;

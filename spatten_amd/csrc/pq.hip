@@ -161,6 +161,111 @@ int pq_expand(int dtype, const void* msb, const void* lsb, const float* scale, i
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }
 
+
+// ---- profiled planes (ABI 4): key MSB plane of 4 / 6 / 8 bits + 4-bit LSB plane, value plane of 8 / 6 bits ----------------
+// (layouts: include/spatten.h "Bit profiles and the quantised VALUE plane")
+
+// 16 unsigned fields of BITS bits (piece order t = 0..15) -> the piece's dwords: BITS 8 -> 4, 6 -> 3, 4 -> 2
+template <int BITS>
+__device__ inline void pack_fields(const uint32_t (&f)[16], uint32_t (&w)[BITS / 2]) {
+#pragma unroll
+  for (int i = 0; i < BITS / 2; ++i) w[i] = 0u;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int bit = BITS * t, wi = bit / 32, off = bit % 32;
+    w[wi] |= f[t] << off;
+    if (off + BITS > 32) w[wi + 1] |= f[t] >> (32 - off);
+  }
+}
+template <int W> __device__ inline void store_words(uint8_t* p, const uint32_t (&w)[W]) {
+  uint32_t* q = reinterpret_cast<uint32_t*>(p);
+#pragma unroll
+  for (int i = 0; i < W; ++i) q[i] = w[i];
+}
+
+// LPR = D/16 lanes per row (the decode kernels' value mapping): lane c owns elements [8c, 8c+8) and [D/2+8c, D/2+8c+8)
+template <typename T, int D, int KB, int VB>
+__global__ __launch_bounds__(256) void pq_pack_planes_kernel(const T* __restrict__ kr, const T* __restrict__ v,
+                                                             int64_t kv_sb, int64_t kv_sh, const PlanesDev pl, int lo, int hi,
+                                                             const int32_t* __restrict__ step) {
+  constexpr int LPR = D / 16, RPB = 256 / LPR, HALF = D / 2;
+  const int tid = threadIdx.x, c = tid % LPR, r = tid / LPR;
+  int row = lo + blockIdx.x * RPB + r;
+  if (step != nullptr) {                  // device-length form: the step's row only
+    if (r != 0) return;
+    row = step[0] - 1;
+  }
+  if (row < 0 || row >= hi) return;       // (whole LPR-groups leave together)
+  const int hkv = blockIdx.y, b = blockIdx.z;
+  using V8 = Vec8<T>;
+  auto quantise = [&](const T* src, int bits, float& sc_out, int (&q)[16]) {
+    float x[16];
+    {
+      float a[8], bq[8];
+      V8::unpack(V8::ldg(src + 8 * c), a);
+      V8::unpack(V8::ldg(src + HALF + 8 * c), bq);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x[e] = a[e]; x[8 + e] = bq[e]; }
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(x[e]));
+    amax = fmaxf(amax, dpp_mov<kDppXor1>(amax));
+    amax = fmaxf(amax, dpp_mov<kDppXor2>(amax));
+    if (LPR == 8) amax = fmaxf(amax, dpp_mov<kDppHalfMirror>(amax));
+    const float qmax = (float)((1 << (bits - 1)) - 1);
+    const float sc = amax > 0.f ? amax / qmax : 1.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int qv = (int)rintf(x[e] / sc);
+      q[e] = max(-(int)qmax - 1, min((int)qmax, qv));
+    }
+    sc_out = sc;
+  };
+  const int64_t src = b * kv_sb + hkv * kv_sh + (int64_t)row * D;
+  const int64_t so = b * pl.sc_sb + hkv * pl.sc_sh + row;
+  {   // keys: T = KB + 4 bits, MSB plane = q >> 4, LSB plane = q & 15
+    int q[16];
+    float sc;
+    quantise(kr + src, KB + 4, sc, q);
+    {
+      uint32_t fm[16], fl[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { fm[e] = (uint32_t)((q[e] >> 4) + (1 << (KB - 1))); fl[e] = (uint32_t)(q[e] & 15); }
+      uint32_t wm[KB / 2], wl[2];
+      pack_fields<KB>(fm, wm);
+      pack_fields<4>(fl, wl);
+      store_words<KB / 2>(pl.km + b * pl.km_sb + hkv * pl.km_sh + (int64_t)row * (D * KB / 8) + 2 * KB * c, wm);
+      store_words<2>(pl.kl + b * pl.kl_sb + hkv * pl.kl_sh + (int64_t)row * (D / 2) + 8 * c, wl);
+    }
+    if (c == 0) pl.ks[so] = sc;
+  }
+  {   // values: one plane of VB bits
+    int q[16];
+    float sc;
+    quantise(v + src, VB, sc, q);
+    uint32_t f[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) f[e] = (uint32_t)(q[e] + (1 << (VB - 1)));
+    uint32_t w[VB / 2];
+    pack_fields<VB>(f, w);
+    store_words<VB / 2>(pl.vq + b * pl.vq_sb + hkv * pl.vq_sh + (int64_t)row * (D * VB / 8) + 2 * VB * c, w);
+    if (c == 0) pl.vs[so] = sc;
+  }
+}
+
+bool planes_to_dev(const spatten_pq_planes_t* p, PlanesDev& d) {
+  if (!p || p->struct_size != sizeof(spatten_pq_planes_t) || !p->key_msb || !p->key_lsb || !p->key_scale || !p->val_q ||
+      !p->val_scale || !p->msb_logit)
+    return false;
+  d.km = (uint8_t*)p->key_msb; d.kl = (uint8_t*)p->key_lsb; d.ks = p->key_scale; d.vq = (uint8_t*)p->val_q;
+  d.vs = p->val_scale; d.lg = p->msb_logit;
+  d.km_sb = p->km_sb; d.km_sh = p->km_sh; d.kl_sb = p->kl_sb; d.kl_sh = p->kl_sh; d.vq_sb = p->vq_sb; d.vq_sh = p->vq_sh;
+  d.sc_sb = p->sc_sb; d.sc_sh = p->sc_sh; d.lg_sb = p->lg_sb; d.lg_sh = p->lg_sh;
+  return true;
+}
+bool pq_profile_supported(int kb, int vb) { return (kb == 4 && vb == 8) || (kb == 8 && vb == 8) || (kb == 6 && vb == 6); }
+
 }  // namespace spatten
 
 using namespace spatten;
@@ -208,3 +313,35 @@ extern "C" int spatten_kv_append_step(int dtype, const void* k_new, const void* 
 }
 
 // The decode step over the planes: spatten_attn_decode_args with the pq_* fields set (decode_attn.hip, KSRC = 1 / 2).
+
+extern "C" size_t spatten_pq_plane_row_bytes(int head_dim, int bits) {
+  if (head_dim <= 0 || bits <= 0 || (head_dim * bits) % 8 != 0) return 0;
+  return (size_t)head_dim * bits / 8;
+}
+
+extern "C" int spatten_pq_pack_planes(int dtype, const void* kr_cache, const void* v_cache, int64_t kv_sb, int64_t kv_sh,
+                                      const spatten_pq_planes_t* planes, int batch, int kv_heads, int head_dim, int row_lo,
+                                      int row_hi, const void* step_state, void* stream) {
+  PlanesDev pd;
+  if (!kr_cache || !v_cache || !planes_to_dev(planes, pd) || batch <= 0 || kv_heads <= 0 || row_lo < 0) return SPATTEN_ERR_INVALID;
+  if (!ok_dtype(dtype)) return SPATTEN_ERR_INVALID;
+  if (head_dim != 64 && head_dim != 128) return SPATTEN_ERR_UNSUPPORTED;
+  const int kb = planes->key_msb_bits, vb = planes->value_bits;
+  if (!pq_profile_supported(kb, vb)) return SPATTEN_ERR_UNSUPPORTED;
+  if (!step_state && row_hi <= row_lo) return SPATTEN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int rpb = 256 / (head_dim / 16);
+  const dim3 grid((unsigned)(step_state ? 1 : ceil_div(row_hi - row_lo, rpb)), (unsigned)kv_heads, (unsigned)batch);
+#define SPATTEN_PACKP(T, DD, KB, VB)                                                                                        \
+  hipLaunchKernelGGL((pq_pack_planes_kernel<T, DD, KB, VB>), grid, dim3(256), 0, st, (const T*)kr_cache, (const T*)v_cache,  \
+                     kv_sb, kv_sh, pd, row_lo, row_hi, (const int32_t*)step_state)
+#define SPATTEN_PACKP_D(T, KB, VB) do { if (head_dim == 128) SPATTEN_PACKP(T, 128, KB, VB); else SPATTEN_PACKP(T, 64, KB, VB); } while (0)
+#define SPATTEN_PACKP_T(KB, VB) do { if (dtype == SPATTEN_BF16) SPATTEN_PACKP_D(bf16_t, KB, VB); else if (dtype == SPATTEN_F16) SPATTEN_PACKP_D(f16_t, KB, VB); else SPATTEN_PACKP_D(float, KB, VB); } while (0)
+  if (kb == 4) SPATTEN_PACKP_T(4, 8);
+  else if (kb == 8) SPATTEN_PACKP_T(8, 8);
+  else SPATTEN_PACKP_T(6, 6);
+#undef SPATTEN_PACKP_T
+#undef SPATTEN_PACKP_D
+#undef SPATTEN_PACKP
+  return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+}

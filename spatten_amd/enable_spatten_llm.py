@@ -26,7 +26,7 @@ _FAMILIES: Dict[str, Callable] = {"llama": _patch_llama}
 def enable_spatten_llm(model, start_size, important_size, recent_size, importance_mode="reference",
                        prefill_stash=True, assume_causal=False, head_keep=None, pq_threshold=None, local_v_keep=None,
                        layer_keep=None, fuse_qkv=False, native_gemv=False, head_parallel=None, numerics="reference",
-                       auto_graph=False):
+                       auto_graph=False, pq_profile=None):
     """The reference's four positional arguments (enable_spatten_llm.py:5) plus opt-in extensions:
 
     ``prefill_stash=False``: forwards with ``q_len > 1`` do not materialise ``self.attn_scores`` ([B,H,q,N]: 4 GiB per
@@ -60,7 +60,9 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     SpAtten semantics the reference's Python does not implement (PARITY UNPINNED; spatten_amd/extensions.py):
     ``importance_mode="cascade"`` (cumulative importance = running sum of softmax probabilities, accumulated inside the
     decode launch), ``head_keep`` (cascade head pruning: int or one int per layer), ``pq_threshold`` (progressive
-    quantisation of the keys at decode: MSB plane first, LSB refetch below this max-probability), ``local_v_keep``
+    quantisation of the keys at decode: MSB plane first, LSB refetch below this max-probability), ``pq_profile`` ((key MSB
+    bits, value bits) of the planes: (4, 8), (8, 8) or (6, 6) — the quantised VALUE plane and the LSB-only refetch;
+    MatrixFetcher.scala:48-51, TestSpAtten.scala:64,83-97,173-176; None = 4-bit MSB plane, V in the model dtype), ``local_v_keep``
     (local V pruning at decode: fraction of the keys whose V row is fetched), ``layer_keep`` (layer-to-layer cascade token
     pruning: one important-token count per layer, non-increasing — the surviving set shrinks through the layers)."""
     model_type = model.config.model_type
@@ -73,6 +75,8 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     from .pos_shift.modify_llama import attention_modules
 
     mods = attention_modules(model)                                # model.modules() order = layer order (:74-77)
+    if pq_profile is not None and pq_threshold is None:
+        raise ValueError("pq_profile needs pq_threshold")
     extended = (importance_mode == "cascade" or head_keep is not None or pq_threshold is not None or local_v_keep is not None
                 or layer_keep is not None)
     for m in mods:
@@ -100,7 +104,7 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
 
         cache.ext = SpattenExtensions(cache, len(mods), cascade=importance_mode == "cascade", head_keep=head_keep,
                                       pq_threshold=pq_threshold, local_v_keep=local_v_keep, layer_keep=layer_keep,
-                                      head_parallel=head_parallel)
+                                      head_parallel=head_parallel, pq_profile=pq_profile)
         for layer, m in enumerate(mods):
             m._spatten_ext = (cache.ext, layer)
     if auto_graph:

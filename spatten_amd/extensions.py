@@ -17,6 +17,10 @@ against those restatements.
     pq_threshold=t              progressive quantisation of the keys at decode (RequantDecision.scala:44-72;
                                 MatrixFetcher.scala:341-348): MSB plane first, LSB refetch for heads whose max probability
                                 is below t.
+    pq_profile=(kb, vb)         the bit profile of the planes (MatrixFetcher.scala:48-51; TestSpAtten.scala:64,83-97,173-176):
+                                key MSB plane of kb bits (+ 4 LSBs on refetch), VALUE plane of vb bits — (4, 8), (8, 8) (the RTL
+                                harness default) or (6, 6) (the per8 trace).  None: 4-bit MSB, V in the model dtype (r02).
+                                With a profile the refetch pass reads ONLY the LSB plane (+ the stashed MSB logits).
     local_v_keep=f              local V pruning at decode (SpAttenController.scala:546-558,591-612): only the
                                 ceil(f * kv_len) most probable keys of a head fetch their V row.
     layer_keep=[k_0..k_L-1]     layer-to-layer cascade token pruning (README.md:11; the traces' key_fetch_num shrinks layer
@@ -93,7 +97,18 @@ def _per_layer(x, n_layers: int, name: str):
 class SpattenExtensions:
     def __init__(self, cache, n_layers: int, cascade: bool = False,
                  head_keep: Union[None, int, Sequence[int]] = None, pq_threshold: Optional[float] = None,
-                 local_v_keep: Optional[float] = None, layer_keep: Optional[Sequence[int]] = None, head_parallel=None):
+                 local_v_keep: Optional[float] = None, layer_keep: Optional[Sequence[int]] = None, head_parallel=None,
+                 pq_profile: Optional[Sequence[int]] = None):
+        if pq_profile is not None:
+            pq_profile = (int(pq_profile[0]), int(pq_profile[1]))
+            if pq_threshold is None:
+                raise ValueError("pq_profile needs pq_threshold")
+            if pq_profile not in ops.PQ_PROFILES:
+                raise ValueError(f"pq_profile {pq_profile}: one of {ops.PQ_PROFILES} (key MSB bits, value bits)")
+            if cascade:
+                raise ValueError("pq_profile with importance_mode='cascade': the profiled decode launch does not carry the fused "
+                                 "accumulation — use the default planes (pq_profile=None)")
+        self.pq_profile = pq_profile
         if pq_threshold is not None and local_v_keep is not None:
             raise ValueError("pq_threshold and local_v_keep cannot be combined (the local-V pass scores from the bf16 shadow)")
         if local_v_keep is not None and not (0.0 < float(local_v_keep) <= 1.0):
@@ -144,6 +159,19 @@ class SpattenExtensions:
             raise RuntimeError("extension buffers smaller than the slab capacity")
         casc = (st.acc, st.stash[1], st.lse[1], 0) if self.cascade else None
         step = gctx.state_for(slab, cos, sin)
+        if self.pq_threshold is not None and self.pq_profile is not None:
+            # profiled planes: rows [0, kv_len - 1) packed with host lengths before the capture, the step's row by the
+            # device-length append (k / kr / v) + the device-length pack of that row, then the two passes over the planes
+            slab.ensure_pq(kv_len - 1, self.pq_profile, H)
+            if slab.pq.capacity < cap:
+                raise RuntimeError("progressive-quant planes smaller than the slab capacity")
+            ops.kv_append_step(k_new, v_new, slab.k, slab.kr, slab.v, step, None)
+            ops.pq_pack_planes(slab.kr, slab.v, slab.pq, 0, cap, step=step)
+            slab.pq_len = kv_len
+            ops.attn_decode_pqv(q, slab.pq, cap, cos, sin, 0, self.pq_threshold, out=st.out, need_lsb=st.need_lsb,
+                                scores=st.stash[0], lse=st.lse[0], head_ids=st.head_ids,
+                                head_abs=st.head_abs if self.head_keep is not None else None, step=step)
+            return st.out, st.stash[0][:, :, None, :kv_len]
         if self.pq_threshold is not None:
             # rows [0, kv_len - 1) packed with host lengths BEFORE the capture (the eager first step of the binding does it:
             # nothing is left for the captured trace), this step's row by the device-length append
@@ -192,7 +220,12 @@ class SpattenExtensions:
         if self.cascade and st.pending_len > 0:
             casc = (st.acc, st.stash[cur ^ 1], st.lse[cur ^ 1], min(st.pending_len, kv_len))
         head_abs = st.head_abs if self.head_keep is not None else None
-        if self.pq_threshold is not None:
+        if self.pq_threshold is not None and self.pq_profile is not None:
+            ops.kv_append(k_new[:, :, None], v_new[:, :, None], slab.k, slab.kr, slab.v, past_len, cos, sin)
+            slab.ensure_pq(kv_len, self.pq_profile, H)
+            ops.attn_decode_pqv(q, slab.pq, kv_len, cos, sin, past_len, self.pq_threshold, out=st.out, need_lsb=st.need_lsb,
+                                scores=stash, lse=lse, head_ids=st.head_ids, head_abs=head_abs, layout=slab.capacity)
+        elif self.pq_threshold is not None:
             ops.kv_append(k_new[:, :, None], v_new[:, :, None], slab.k, slab.kr, slab.v, past_len, cos, sin)
             slab.ensure_pq(kv_len)
             # (splits laid out for the slab capacity, as below: the eager and the captured step then agree bit for bit)
@@ -223,8 +256,8 @@ class SpattenExtensions:
     def prefill_uses_pq(self, dtype, head_dim: int, q_len: int) -> bool:
         """The PQ-keyed flash kernel covers 16-bit dtypes at head_dim 64 / 128 and blocks of more than 8 rows (shorter
         blocks / fp32 run the exact rows leg on the un-quantised shadow)."""
-        return (self.pq_threshold is not None and not self.cascade and dtype in (torch.float16, torch.bfloat16)
-                and head_dim in (64, 128) and q_len > 8)
+        return (self.pq_threshold is not None and self.pq_profile is None and not self.cascade
+                and dtype in (torch.float16, torch.bfloat16) and head_dim in (64, 128) and q_len > 8)
 
     # ------------------------------------------------------------------------------------------------
     # attention forward, q_len > 1: by-products of the flash path

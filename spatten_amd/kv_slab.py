@@ -134,11 +134,24 @@ class KVSlab:
             ops.build_shadow(self.k, self.kr, self.rot_len, upto, cos, sin)
             self.rot_len = upto
 
-    def ensure_pq(self, upto: int):
-        """Quantise rows [pq_len, upto) of the rotated shadow into the MSB / LSB planes."""
-        if self.pq is None:
-            B, H, cap, d = self.k.shape
-            self.pq = ops.PQPlanes(B, H, cap, d, self.k.device)
+    def ensure_pq(self, upto: int, profile=None, heads: int = 0):
+        """Quantise rows [pq_len, upto) of the rotated shadow into the MSB / LSB planes.  ``profile`` = None: the r02 planes
+        (4-bit MSB + 4-bit LSB, V stays in the model dtype); (key MSB bits, value bits): the profiled planes with the
+        quantised value plane (ops.PQProfilePlanes; ``heads`` = query heads, for the MSB-logit scratch)."""
+        B, Hkv, cap, d = self.k.shape
+        if profile is not None:
+            kb, vb = profile
+            ok = isinstance(self.pq, ops.PQProfilePlanes) and (self.pq.key_bits, self.pq.value_bits) == (kb, vb) \
+                and self.pq.msb_logit.shape[1] == (heads or Hkv)
+            if not ok:
+                self.pq = ops.PQProfilePlanes(B, Hkv, heads or Hkv, cap, d, self.k.device, key_bits=kb, value_bits=vb)
+                self.pq_len = 0
+            if self.pq_len < upto:
+                ops.pq_pack_planes(self.kr, self.v, self.pq, self.pq_len, upto)
+                self.pq_len = upto
+            return
+        if self.pq is None or not isinstance(self.pq, ops.PQPlanes):
+            self.pq = ops.PQPlanes(B, Hkv, cap, d, self.k.device)
             self.pq_len = 0
         if self.pq_len < upto:
             ops.pq_pack(self.kr, self.pq, self.pq_len, upto)

@@ -949,6 +949,132 @@ class PQPlanes:
         return mm, ll, self.scale[:, :, :n, None].cpu().numpy()
 
 
+PQ_PROFILES = ((4, 8), (8, 8), (6, 6))      # (key MSB bits, value bits) of the profiled planes (include/spatten.h, ABI 4)
+
+
+class PQProfilePlanes:
+    """Profiled progressive-quantisation planes (include/spatten.h "Bit profiles and the quantised VALUE plane"): key MSB
+    plane of ``key_bits`` (4 / 6 / 8) bits + 4-bit LSB plane + per-row scale, value plane of ``value_bits`` (8 / 6) bits +
+    per-row scale, and the fp32 MSB-logit scratch [B, H, cap] the refetch pass reads.  Layouts are the library's (piece
+    order); ``unpack`` undoes them for tests."""
+
+    def __init__(self, batch, kv_heads, heads, cap, d, device, key_bits: int = 4, value_bits: int = 8):
+        if (key_bits, value_bits) not in PQ_PROFILES:
+            raise ValueError(f"unsupported bit profile {(key_bits, value_bits)}: one of {PQ_PROFILES}")
+        self.key_bits, self.value_bits, self.d = int(key_bits), int(value_bits), d
+        u8 = dict(dtype=torch.uint8, device=device)
+        self.msb = torch.zeros(batch, kv_heads, cap, d * key_bits // 8, **u8)
+        self.lsb = torch.zeros(batch, kv_heads, cap, d // 2, **u8)
+        self.scale = torch.ones(batch, kv_heads, cap, dtype=torch.float32, device=device)
+        self.vq = torch.zeros(batch, kv_heads, cap, d * value_bits // 8, **u8)
+        self.vscale = torch.ones(batch, kv_heads, cap, dtype=torch.float32, device=device)
+        self.msb_logit = torch.zeros(batch, heads, cap, dtype=torch.float32, device=device)
+        a = self.desc = _lib.PQPlanesDesc()
+        a.struct_size = ctypes.sizeof(_lib.PQPlanesDesc)
+        a.key_msb_bits, a.value_bits = self.key_bits, self.value_bits
+        a.key_msb, a.key_lsb, a.key_scale = self.msb.data_ptr(), self.lsb.data_ptr(), self.scale.data_ptr()
+        a.val_q, a.val_scale, a.msb_logit = self.vq.data_ptr(), self.vscale.data_ptr(), self.msb_logit.data_ptr()
+        a.km_sb, a.km_sh = self.msb.stride(0), self.msb.stride(1)
+        a.kl_sb, a.kl_sh = self.lsb.stride(0), self.lsb.stride(1)
+        a.vq_sb, a.vq_sh = self.vq.stride(0), self.vq.stride(1)
+        a.sc_sb, a.sc_sh = self.scale.stride(0), self.scale.stride(1)
+        a.lg_sb, a.lg_sh = self.msb_logit.stride(0), self.msb_logit.stride(1)
+
+    @property
+    def capacity(self) -> int:
+        return self.msb.shape[2]
+
+    @staticmethod
+    def _fields(plane, bits: int, d: int):
+        """[..., d*bits/8] bytes in piece order -> unsigned fields [..., d] in ELEMENT order (numpy)."""
+        import numpy as np
+        x = plane.cpu().numpy()
+        lpr = d // 16
+        pb = 2 * bits                                   # bytes per piece
+        bitsarr = np.unpackbits(x.reshape(*x.shape[:-1], lpr, pb), axis=-1, bitorder="little")       # [..., lpr, 8 pb]
+        f = (bitsarr.reshape(*bitsarr.shape[:-1], 16, bits).astype(np.int64) << np.arange(bits)).sum(-1)   # [..., lpr, 16]
+        out = np.zeros((*f.shape[:-2], d), dtype=np.int64)
+        for c in range(lpr):
+            out[..., 8 * c:8 * c + 8] = f[..., c, :8]
+            out[..., d // 2 + 8 * c:d // 2 + 8 * c + 8] = f[..., c, 8:]
+        return out
+
+    def unpack(self, n: int):
+        """(msb int [B,Hkv,n,d] signed, lsb [B,Hkv,n,d] in [0,15], scale [B,Hkv,n,1], qv int [B,Hkv,n,d] signed,
+        vscale [B,Hkv,n,1]) on the host — for tests."""
+        import numpy as np
+        d, kb, vb = self.d, self.key_bits, self.value_bits
+        mm = self._fields(self.msb[:, :, :n], kb, d) - (1 << (kb - 1))
+        ll = self._fields(self.lsb[:, :, :n], 4, d)
+        qv = self._fields(self.vq[:, :, :n], vb, d) - (1 << (vb - 1))
+        return (mm, ll, self.scale[:, :, :n, None].cpu().numpy(), qv, self.vscale[:, :, :n, None].cpu().numpy())
+
+
+def pq_pack_planes(kr_cache: torch.Tensor, v_cache: torch.Tensor, planes: PQProfilePlanes, lo: int, hi: int,
+                   step: Optional["StepState"] = None):
+    """Quantise rows [lo, hi) of the rotated shadow into the key planes and of the values into the value plane; with
+    ``step`` the one row (state length) - 1 (device-length form: capturable), ``hi`` = the planes' capacity."""
+    _dev(kr_cache, v_cache, planes.msb)
+    B, Hkv, cap, d = kr_cache.shape
+    if v_cache.stride() != kr_cache.stride() or kr_cache.stride(3) != 1 or kr_cache.stride(2) != d:
+        raise ValueError("kr_cache / v_cache need contiguous rows (pitch d) and identical strides")
+    if hi > planes.capacity or hi > cap:
+        raise ValueError("rows beyond the planes' capacity")
+    rc = _lib.load().spatten_pq_pack_planes(_dt(kr_cache), kr_cache.data_ptr(), v_cache.data_ptr(), kr_cache.stride(0),
+                                            kr_cache.stride(1), ctypes.byref(planes.desc), B, Hkv, d, int(lo), int(hi),
+                                            None if step is None else step.data_ptr(), _stream())
+    _lib.check(rc, "spatten_pq_pack_planes")
+
+
+def attn_decode_pqv(q: torch.Tensor, planes: PQProfilePlanes, kv_len: int, cos: torch.Tensor, sin: torch.Tensor, pos_q: int,
+                    threshold: float, out: Optional[torch.Tensor] = None, need_lsb: Optional[torch.Tensor] = None,
+                    scores: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,
+                    head_ids: Optional[torch.Tensor] = None, head_abs: Optional[torch.Tensor] = None,
+                    step: Optional["StepState"] = None, layout: int = 0, n_splits: int = 0, msb_only: bool = False,
+                    workspace: Optional[DecodeWorkspace] = None) -> torch.Tensor:
+    """Decode over the profiled planes (spatten_attn_decode_pq): MSB pass + LSB-only refetch for the flagged heads, P.V over
+    the quantised values.  q [B,H,d]; returns out [B, H*d]; ``need_lsb`` int32 [B*H] is written."""
+    _dev(q, planes.msb, cos, sin, out, need_lsb, scores, lse, head_ids, head_abs)
+    B, H, d = q.shape
+    Hkv = planes.msb.shape[1]
+    if d != planes.d or q.stride(2) != 1 or cos.shape[1] * 2 != d:
+        raise ValueError("q [B,H,d] with contiguous rows; planes and rotary tables of the same head_dim")
+    if kv_len > planes.capacity or (step is None and max(kv_len, pos_q + 1) > cos.shape[0]) or layout > planes.capacity:
+        raise ValueError("kv_len exceeds the planes' capacity or the rotary table")
+    if planes.msb_logit.shape[1] != H:
+        raise ValueError("planes were allocated for another number of query heads")
+    if out is None:
+        out = torch.empty(B, H * d, dtype=q.dtype, device=q.device)
+    if need_lsb is None:
+        need_lsb = torch.empty(B * H, dtype=torch.int32, device=q.device)
+    stream = _stream()
+    ws = _pin(workspace) if workspace is not None else _workspace(B, H, d, q.device, stream)
+    a = _lib.PQDecodeArgs()
+    a.struct_size = ctypes.sizeof(_lib.PQDecodeArgs)
+    a.dtype = _dt(q)
+    a.q, a.q_sb, a.q_sh = q.data_ptr(), (H * d if B == 1 else q.stride(0)), q.stride(1)
+    a.planes = ctypes.pointer(planes.desc)
+    a.cos, a.sin, a.table_rows, a.pos_q = cos.data_ptr(), sin.data_ptr(), cos.shape[0], int(pos_q)
+    a.out, a.out_sb = out.data_ptr(), out.stride(0)
+    if scores is not None:
+        if scores.stride(2) != 1 or scores.shape[2] < kv_len:
+            raise ValueError("scores [B,H,>=kv_len] with contiguous rows")
+        a.scores, a.sc_sb, a.sc_sh = scores.data_ptr(), scores.stride(0), scores.stride(1)
+    a.lse = _ptr(lse)
+    a.need_lsb, a.threshold, a.flags = need_lsb.data_ptr(), float(threshold), 1 if msb_only else 0
+    a.workspace, a.workspace_splits = ws.buf.data_ptr(), ws.max_splits
+    a.batch, a.heads, a.kv_heads, a.head_dim, a.kv_len = B, H, Hkv, d, int(kv_len)
+    a.n_splits, a.kv_len_layout = int(n_splits), int(layout)
+    if head_ids is not None:
+        if head_ids.dtype != torch.int32 or head_ids.dim() != 1:
+            raise TypeError("head_ids must be a 1-D int32 device tensor")
+        a.head_ids, a.n_active_heads = head_ids.data_ptr(), head_ids.numel()
+    a.head_abs_acc = _ptr(head_abs)
+    a.step_state = None if step is None else step.data_ptr()
+    _lib.check(_lib.load().spatten_attn_decode_pq(ctypes.byref(a), stream), "spatten_attn_decode_pq")
+    return out
+
+
 def pq_pack(kr_cache: torch.Tensor, planes: PQPlanes, lo: int, hi: int):
     """Quantise rows [lo, hi) of the rotated shadow into the MSB / LSB planes."""
     _dev(kr_cache, planes.msb)

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, f"declared in include/spatten.h but not exported: {missing}"
     lib.spatten_abi_version.restype = ctypes.c_int
-    assert lib.spatten_abi_version() == 3
+    assert lib.spatten_abi_version() == 4
     lib.spatten_status_string.restype = ctypes.c_char_p
     assert lib.spatten_status_string(-3).decode().startswith("top-k window")
     lib.spatten_decode_workspace_bytes.restype = ctypes.c_size_t

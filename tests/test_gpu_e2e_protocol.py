@@ -200,9 +200,10 @@ class ExtReplica(NumpyReplica):
     """NumpyReplica + the oracle's restatements of head pruning / progressive quantisation / local V pruning at
     single-token steps (the modes enable_spatten_llm wires into the patched forward)."""
 
-    def __init__(self, model, cascade=False, head_keep=None, pq_threshold=None, local_v_keep=None):
+    def __init__(self, model, cascade=False, head_keep=None, pq_threshold=None, local_v_keep=None, pq_profile=None):
         super().__init__(model, cascade)
         self.head_keep, self.pq_threshold, self.local_v_keep = head_keep, pq_threshold, local_v_keep
+        self.pq_profile = pq_profile
         self.head_abs = [np.zeros(H, np.float32) for _ in range(L)]
         self.kept = [None] * L
         self.need = [None] * L
@@ -228,7 +229,13 @@ class ExtReplica(NumpyReplica):
                 cos, sin = orc.rope_table(N, D, "f32")
                 qr = orc.apply_rotary_pos_emb_single(qh, cos, sin, pos, "f32")[:, :, 0]
                 kr = orc.apply_rotary_pos_emb_single(kc, cos, sin, np.arange(N)[None], "f32")
-                if self.pq_threshold is not None:
+                if self.pq_threshold is not None and self.pq_profile is not None:
+                    # bit profile: key MSB plane of kb bits (+ 4 LSBs on refetch), value plane of vb bits, LSB-only refetch
+                    kb, vb = self.pq_profile
+                    msb, lsb, scale = orc.pq_quantize(kr, bits=kb + 4)
+                    qv, vscale = orc.pq_quantize_values(vc, bits=vb)
+                    o, self.need[i], logits = orc.pq_decode_attention_profile(qr, msb, lsb, scale, qv, vscale, self.pq_threshold)
+                elif self.pq_threshold is not None:
                     msb, lsb, scale = orc.pq_quantize(kr)
                     logits, self.need[i] = orc.pq_logits(qr, msb, lsb, scale, self.pq_threshold)
                     o = np.einsum("bhl,bhld->bhd", orc.softmax_probs(logits), vc)
@@ -252,7 +259,7 @@ class ExtReplica(NumpyReplica):
         return x @ self.lm.T, new_past
 
 
-@pytest.mark.parametrize("mode", ["head", "pq", "local_v", "head+pq+cascade"])
+@pytest.mark.parametrize("mode", ["head", "pq", "local_v", "head+pq+cascade", "pq48", "pq88", "head+pq66"])
 def test_multi_turn_protocol_extension_modes(mode):
     """configs[2] / configs[4] through the plugin surface: head pruning, progressive quantisation and local V pruning are
     reached by enable_spatten_llm kwargs and run inside llama_pos_shift_attention_forward + apply_token_pruning; GPU vs
@@ -267,6 +274,9 @@ def test_multi_turn_protocol_extension_modes(mode):
         kw["head_keep"] = 3
     if "pq" in mode:
         kw["pq_threshold"] = 0.06
+    for tag, prof in (("pq48", (4, 8)), ("pq88", (8, 8)), ("pq66", (6, 6))):
+        if tag in mode:
+            kw["pq_profile"] = prof
     if "local_v" in mode:
         kw["local_v_keep"] = 0.4
     cascade = "cascade" in mode

@@ -357,6 +357,8 @@ def test_decode_graph_holds_the_head_parallel_exchange():
                                 dict(importance_mode="cascade", head_keep=6, fuse_qkv=True, native_gemv=True),
                                 dict(pq_threshold=0.05), dict(pq_threshold=0.02, head_keep=6, fuse_qkv=True),
                                 dict(pq_threshold=0.05, importance_mode="cascade"),
+                                dict(pq_threshold=0.05, pq_profile=(4, 8)), dict(pq_threshold=0.02, pq_profile=(8, 8), head_keep=6),
+                                dict(pq_threshold=0.05, pq_profile=(6, 6), fuse_qkv=True),
                                 dict(layer_keep=[36, 30, 24]), dict(layer_keep=[36, 30, 30], importance_mode="cascade", head_keep=7)])
 def test_decode_graph_covers_cascade_importance_and_head_pruning(kw):
     """The SpAtten modes whose decode step is ONE fused launch — cumulative importance (the previous step's probabilities
@@ -397,6 +399,9 @@ def test_decode_graph_covers_cascade_importance_and_head_pruning(kw):
                 assert sa.pq_len == n and sb.pq_len == n
                 assert torch.equal(sa.pq.msb[:, :, :n], sb.pq.msb[:, :, :n]) and torch.equal(sa.pq.lsb[:, :, :n], sb.pq.lsb[:, :, :n])
                 assert torch.equal(sa.pq.scale[:, :, :n], sb.pq.scale[:, :, :n])
+                if "pq_profile" in kw:      # the quantised value plane of the profile
+                    assert (sa.pq.key_bits, sa.pq.value_bits) == tuple(kw["pq_profile"])
+                    assert torch.equal(sa.pq.vq[:, :, :n], sb.pq.vq[:, :, :n]) and torch.equal(sa.pq.vscale[:, :, :n], sb.pq.vscale[:, :, :n])
                 heads = slice(None) if la.head_ids is None else la.head_ids.long()
                 assert torch.equal(la.need_lsb[heads], lb.need_lsb[heads])
                 flagged += int(la.need_lsb[heads].sum())
