@@ -122,6 +122,9 @@ def chat(args):
         thr = [f["requant_threshold"] for f in fr if f["requant_threshold"] is not None]
         if thr and args.pq_threshold is None and args.local_v_keep is None:
             ext["pq_threshold"] = float(thr[0])
+            prof = read_trace(args.schedule).pq_profile(0)         # the trace's bit columns: key MSB bits / value bits
+            if prof in ((4, 8), (8, 8), (6, 6)) and not args.cascade:
+                ext["pq_profile"] = prof
         print("schedule:", {k: v for k, v in ext.items()})
     if args.auto_graph:       # the loop below stays the reference's: its single-token calls replay one captured graph per token
         ext.update(auto_graph=True, fuse_qkv=True, native_gemv=True)
@@ -166,7 +169,9 @@ def cascade(args):
     from spatten_amd import kv_slab, ops
     from spatten_amd.cascade import CascadeImportance, HeadPruner, local_v_decode
     from spatten_amd.traces import read_trace
-    fr = read_trace(args.trace).fractions(0)
+    sched = read_trace(args.trace)
+    fr = sched.fractions(0)
+    prof = sched.pq_profile(0)            # (key MSB bits, value bits) of the trace, TestSpAtten.scala:64-97
     dt, H, d, N = torch.bfloat16, args.heads, args.head_dim, args.kv_len
     gen = torch.Generator(device="cuda").manual_seed(0)
     rnd = lambda *s: torch.randn(*s, device="cuda", generator=gen).to(dt)
@@ -192,7 +197,13 @@ def cascade(args):
         vkeep = max(int(round(f["value_keep"] * n)), 1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if f["requant_threshold"] is not None and args.pq:
+        if f["requant_threshold"] is not None and args.pq and prof in ops.PQ_PROFILES:
+            # the trace's bit profile: quantised value plane, LSB-only refetch (ops.PQProfilePlanes)
+            planes = ops.PQProfilePlanes(1, H, H, n, d, "cuda", key_bits=prof[0], value_bits=prof[1])
+            ops.pq_pack_planes(Kr, V, planes, 0, n)
+            out = ops.attn_decode_pqv(q, planes, n, cos, sin, n - 1, f["requant_threshold"])
+            ops.attn_decode(q, None, Kr, V, n, cos, sin, n - 1, scores=stash, lse=lse, scores_only=True)
+        elif f["requant_threshold"] is not None and args.pq:
             planes = ops.PQPlanes(1, H, n, d, "cuda")
             ops.pq_pack(Kr, planes, 0, n)
             out = ops.attn_decode_pq(q, planes, V, n, cos, sin, n - 1, f["requant_threshold"])

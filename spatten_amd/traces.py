@@ -8,7 +8,14 @@ if_accumulate_importance, if_rescale_previous_importance, if_topk, topk``.
 The traces carry no tensors; what they give is a realistic cascade SCHEDULE: how many keys each layer
 still fetches (global token pruning), how many values (local V pruning), which heads survive (head pruning shows as
 missing head rows), and the progressive-quantisation threshold.  ``CascadeSchedule.fractions()`` turns a trace into
-per-layer keep ratios that ``run_spatten_synthetic.py --trace`` applies to a model of any size.
+per-layer keep ratios that ``run_spatten_synthetic.py --trace`` applies to a model of any size, and
+``CascadeSchedule.pq_profile()`` the bit profile (key MSB bits, value bits) the accelerator model runs the trace at —
+the mapping of the reference's harness (TestSpAtten.scala:64-97): ``quant_key_bit`` -1 / 10 / 12 -> 8 with the requant
+forced on, ``quant_value_bit`` -1 / 10 / 12 -> 8; 6 is the fused (6, 2) fetch profile (TestSpAtten.scala:173-176);
+``auto_requant_incre`` = the LSB bits added by a refetch (4 in every trace, the RTL's requantBitCount,
+SpAttenController.scala:35).  ``if_rescale_previous_importance`` is carried as a field; NO code of the reference reads it
+(it is not among the columns TestSpAtten.scala maps, and the Python plugin has no accumulated importance at all), so there
+is no rule to restate — ``LayerStep.rescale_previous_importance`` only reports what the trace says.
 """
 from __future__ import annotations
 
@@ -34,8 +41,10 @@ class LayerStep:
     length: int = 0            # sentence_length_L
     keys: int = 0              # key_fetch_num   (tokens still fetched by this layer)
     values: int = 0            # value_fetch_num (local V pruning)
-    key_bits: int = -1
-    value_bits: int = -1
+    key_bits: int = -1         # quant_key_bit as written in the trace (-1: unquantised in the software model)
+    value_bits: int = -1       # quant_value_bit
+    lsb_bits: int = -1         # auto_requant_incre: bits a refetch adds
+    rescale_previous_importance: bool = False
     requant: bool = False
     requant_threshold: float = -1.0
     accumulate_importance: bool = False
@@ -48,6 +57,20 @@ class CascadeSchedule:
 
     def layers(self, iteration: int = 0) -> List[LayerStep]:
         return self.iterations[iteration]
+
+    def pq_profile(self, iteration: int = 0):
+        """(key MSB bits, value bits) the accelerator model fetches this trace at — TestSpAtten.scala:64-97: a key width of
+        -1 / 10 / 12 runs as 8 bits with the requant on, a value width of -1 / 10 / 12 as 8 — or None when no layer of the
+        iteration carries quantisation columns at all.  The widest profile over the layers (they agree in the reference's
+        traces)."""
+        best = None
+        for s in self.layers(iteration):
+            if s.key_bits == -1 and s.value_bits == -1:
+                continue
+            kb = 8 if s.key_bits in (-1, 10, 12) else s.key_bits
+            vb = 8 if s.value_bits in (-1, 10, 12) else s.value_bits
+            best = (kb, vb) if best is None else (max(best[0], kb), max(best[1], vb))
+        return best
 
     def fractions(self, iteration: int = 0):
         """Per layer: (token keep ratio, local-V keep ratio, head keep ratio, requant threshold or None)."""
@@ -81,6 +104,8 @@ def read_trace(path: str) -> CascadeSchedule:
             st.keys = int(r["key_fetch_num"])
             st.values = int(r["value_fetch_num"])
             st.key_bits, st.value_bits = int(r["quant_key_bit"]), int(r["quant_value_bit"])
+            st.lsb_bits = int(r["auto_requant_incre"])
+            st.rescale_previous_importance = st.rescale_previous_importance or _b(r["if_rescale_previous_importance"])
             st.requant = st.requant or _b(r["if_requant"])
             st.requant_threshold = float(r["auto_requant_thres"])
             st.accumulate_importance = _b(r["if_accumulate_importance"])

@@ -19,6 +19,22 @@ def test_read_synthetic_trace():
     assert all(abs(f["value_keep"] - 0.3) < 1e-9 for f in fr)
     assert [f["head_keep"] for f in fr] == [1.0, 1.0, 0.75]
     assert fr[0]["requant_threshold"] == 0.05 and steps[0].accumulate_importance
+    # the bit columns: 6-bit keys + 4 LSBs on refetch, 6-bit values — the (6, 2) fused profile of the per8 trace
+    assert (steps[0].key_bits, steps[0].lsb_bits, steps[0].value_bits) == (6, 4, 6) and s.pq_profile(0) == (6, 6)
+    assert not steps[0].rescale_previous_importance
+
+
+def test_pq_profile_follows_the_harness_mapping(tmp_path):
+    """TestSpAtten.scala:64-97: key width -1 / 10 / 12 runs as 8 bits (requant on), value width -1 / 10 / 12 as 8."""
+    from spatten_amd.traces import COLUMNS
+    rows = [",".join(COLUMNS),
+            "0,0,0,64.0,100,100,12,16,-1,False,-1,100,8,True,True,False,-1",
+            "0,1,0,64.0,100,80,-1,-1,-1,False,-1,80,-1,True,False,False,-1"]
+    p = tmp_path / "t.csv"
+    p.write_text("\n".join(rows) + "\n")
+    s = read_trace(str(p))
+    assert s.pq_profile(0) == (8, 8)
+    assert s.layers(0)[0].rescale_previous_importance and not s.layers(0)[1].rescale_previous_importance
 
 
 def test_rejects_other_csv(tmp_path):
