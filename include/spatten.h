@@ -428,6 +428,29 @@ int spatten_pv_gather(int dtype, const void* stash, int64_t sc_sb, int64_t sc_sh
                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Local value pruning as ONE launch (ABI 4; SpAttenController.scala:546-558,591-612; parity unpinned): per head the `keep`
+ * most probable keys of the step (k-th largest logit, ties lowest index first — TopK.scala:193-212) fetch their V row, P.V runs
+ * over them with the full softmax denominator (no renormalisation).  The launch streams the rotated keys once, writes the
+ * stash (`scores`, required: [B,H,>=kv_len], the logits with the reference's roundings, modify_llama.py:111-119) and (max, sum)
+ * (`lse`, optional [B,H,2]), selects exactly (radix select over the head's splits, hand-overs inside the launch) and gathers only
+ * the kept V rows.  It appends nothing.  Equivalent to spatten_attn_decode_args(SCORES_ONLY) + spatten_topk_select +
+ * spatten_pv_gather (same stash, same kept set).
+ *   keep            kept keys per head (host value), clamped to [1, kv_len]
+ *   step_state      device-resident length (see "Device-resident step state"): kv_len is then the BOUND and the kept count is
+ *                   ceil(keep_fraction * length) evaluated on the device in fp64 — what Python's math.ceil(f * n) gives
+ *   kv_len_layout   as in spatten_decode_args_t
+ *   workspace       spatten_local_v_workspace_bytes(batch, heads) bytes, zero-filled once, one per stream
+ * SPATTEN_ERR_UNSUPPORTED: a split longer than 16384 rows (B*H > 256 at very long contexts): use the three calls.
+ * ---------------------------------------------------------------------------------------------- */
+size_t spatten_local_v_workspace_bytes(int batch, int heads);
+int spatten_attn_decode_local_v(int dtype, const void* q, int64_t q_sb, int64_t q_sh, const void* kr_cache,
+                                const void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* cos, const void* sin,
+                                int table_rows, int pos_q, void* out, int64_t out_sb, void* scores, int64_t sc_sb,
+                                int64_t sc_sh, float* lse, void* workspace, int batch, int heads, int kv_heads,
+                                int head_dim, int kv_len, int keep, double keep_fraction, int kv_len_layout,
+                                const void* step_state, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Progressive quantisation of the (rotated) key cache — MSB-first fetch with LSB refetch on low confidence
  * (MatrixFetcher.scala:48-51,341-348; RequantDecision.scala:44-72; SpAttenController.scala:35-39,402).  Parity unpinned.
  *   msb, lsb  [B,Hkv,cap,d/2] bytes: two 4-bit fields per byte (element 2i low nibble), msb signed, lsb unsigned,

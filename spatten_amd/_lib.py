@@ -135,6 +135,11 @@ def _declare(lib):
     lib.spatten_pv_gather_workspace_bytes.argtypes = [i, i, i]
     lib.spatten_pq_pack.restype = c_int
     lib.spatten_pq_pack.argtypes = [i, p, i64, i64, p, p, p, i64, i64, i64, i64, i, i, i, i, i, p]
+    lib.spatten_local_v_workspace_bytes.restype = c_size_t
+    lib.spatten_local_v_workspace_bytes.argtypes = [i, i]
+    lib.spatten_attn_decode_local_v.restype = c_int
+    lib.spatten_attn_decode_local_v.argtypes = [i, p, i64, i64, p, p, i64, i64, p, p, i, i, p, i64, p, i64, i64, p, p,
+                                                i, i, i, i, i, i, ctypes.c_double, i, p, p]
     lib.spatten_pq_plane_row_bytes.restype = c_size_t
     lib.spatten_pq_plane_row_bytes.argtypes = [i, i]
     lib.spatten_pq_pack_planes.restype = c_int

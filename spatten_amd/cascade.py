@@ -41,15 +41,23 @@ class CascadeImportance:
 
 
 def local_v_decode(q, kr_cache, v_cache, kv_len, cos, sin, pos_q, keep, mask=None, workspace=None, out=None, stash=None,
-                   lse=None):
-    """Decode step with local V pruning: (1) scores + (max, sum) without touching V, (2) per-(b,h) top-``keep`` of the
-    masked logits (same order as the probabilities), (3) P·V over the kept rows only.  Returns (out [B,H*d], stash);
-    ``stash`` [B,H,>=kv_len] / ``lse`` [B,H,2] may be caller buffers."""
+                   lse=None, three_launches: bool = False, layout: int = 0):
+    """Decode step with local V pruning: scores + (max, sum) without touching V, per-(b,h) top-``keep`` of the logits
+    (same order as the probabilities), P·V over the kept rows only — ONE launch (ops.attn_decode_local_v, round 4); with an
+    additive ``mask``, splits beyond 16384 rows or ``three_launches=True`` the r02 form: three dependent launches.
+    Returns (out [B,H*d], stash); ``stash`` [B,H,>=kv_len] / ``lse`` [B,H,2] may be caller buffers."""
     B, H, d = q.shape
     if stash is None:
         stash = torch.empty(B, H, kv_len, dtype=q.dtype, device=q.device)
     if lse is None:
         lse = torch.empty(B, H, 2, dtype=torch.float32, device=q.device)
+    if mask is None and not three_launches and d in (64, 128):
+        try:
+            out = ops.attn_decode_local_v(q, kr_cache, v_cache, kv_len, cos, sin, pos_q, min(keep, kv_len), stash, out=out,
+                                          lse=lse, layout=layout)
+            return out, stash
+        except NotImplementedError:
+            pass
     ops.attn_decode(q, None, kr_cache, v_cache, kv_len, cos, sin, pos_q, mask=mask, scores=stash, lse=lse,
                     scores_only=True, workspace=workspace)
     keep = min(keep, kv_len)

@@ -1,0 +1,535 @@
+// local_v.hip — the decode step with LOCAL VALUE PRUNING as ONE launch (PARITY UNPINNED: restated from
+// the RTL control flow and checked against oracle/spatten_oracle.py:local_value_prune).
+//
+//   SpAttenController.scala:546-558   after the softmax of a head, the top `val_fetch_num` probabilities of its `key_fetch_num`
+//                                     keys are selected (the TopK engine: k-th largest, ties lowest index first, H1) ...
+//   SpAttenController.scala:591-612   ... and only those V rows are fetched; P.V runs over them with the probabilities as they
+//                                     are (no renormalisation); the stage is skipped when val_fetch_num >= key_fetch_num
+//
+// r02 / r03 ran this as three dependent chip-wide launches (scores-only decode -> per-head top-k -> gather P.V): 67 us at
+// 16384 rows x 40 heads, 30 % kept, against 56 us for the plain fused decode — a slowdown.  Here the
+// splits of a head are co-resident BY CONSTRUCTION (grid <= CUs: every workgroup is running or will start without another
+// having to finish), so the three phases run inside one launch and hand over through {value, tag} granules (the decode
+// kernel's publication protocol, one memory hop per hand-over, placement independent):
+//
+//   phase 1  every split streams its chunk of the rotated keys ONCE, leaves the logits in the stash (model dtype, the
+//            reference's roundings, modify_llama.py:111-119) and keeps them in LDS as order-preserving integer keys; (max, sum)
+//            of the chunk go out with the first histogram
+//   phase 2  exact k-th largest logit of the HEAD by radix select, 8 bits per pass (2 passes for 16-bit logits, 4 for fp32):
+//            every split publishes the 256-bin histogram of its chunk, every split reads all of them — no atomics, nothing to
+//            clear, the same sum everywhere — and narrows the prefix; ties at the threshold go to the lowest indices: split s
+//            keeps the first (t - ties of the splits before it) of its own
+//   phase 3  every split compacts ITS kept rows (order preserved), gathers only those V rows — probabilities with the head's
+//            full denominator — and publishes its partial sum; the head's last split adds the partials in split order
+//
+// Nothing in the launch appends (spatten_kv_append[_step] first).  DYN: the cache length and hence the kept count
+// ceil(fraction * length) are read from the device-resident step state, so the step is capturable.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace spatten {
+
+constexpr int kLvThreads = 256;
+constexpr int kLvMaxSplits = 32;
+constexpr int kLvMaxPasses = 4;
+// granules of one split's slot: a 256-bin histogram per pass, 4 auxiliary words, the partial output (D <= 256)
+constexpr int kLvSlot = kLvMaxPasses * 256 + 4 + 256;
+constexpr size_t kLvHeader = 256;
+
+template <typename T>
+struct LvParams {
+  const T* q; int64_t q_sb, q_sh;
+  const T* krc; const T* vc; int64_t kv_sb, kv_sh;
+  const T* cos; const T* sin; int table_rows; int pos_q;
+  T* out; int64_t out_sb;
+  T* scores; int64_t sc_sb, sc_sh;
+  float* lse;
+  unsigned long long* ws; unsigned* ws_gen; unsigned* ws_err;
+  const int32_t* step;
+  double keep_frac; int keep;
+  int B, H, Hkv, N, S, chunk;
+  float sqrt_d;
+};
+
+// order-preserving integer key of a logit that IS a model-dtype value (NaN largest, -0 == +0: the order torch.topk ranks by)
+template <typename T> struct OKey {       // 16-bit dtypes: the 16-bit pattern
+  using type = uint16_t;
+  static constexpr int kPasses = 2;
+  __device__ static inline uint32_t from(float s) {
+    const T v = DT<T>::from_f32(s);
+    uint32_t u = *reinterpret_cast<const uint16_t*>(&v);
+    if (s != s) return 0xFFFFu;
+    if ((u & 0x7FFFu) == 0u) u = 0u;
+    return (u & 0x8000u) ? (~u & 0xFFFFu) : (u | 0x8000u);
+  }
+  __device__ static inline float to(uint32_t k) {
+    const uint16_t u = (uint16_t)((k & 0x8000u) ? (k ^ 0x8000u) : (~k & 0xFFFFu));
+    return DT<T>::to_f32(*reinterpret_cast<const T*>(&u));
+  }
+};
+template <> struct OKey<float> {
+  using type = uint32_t;
+  static constexpr int kPasses = 4;
+  __device__ static inline uint32_t from(float s) { return ordered_key(s); }
+  __device__ static inline float to(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
+};
+
+__device__ inline void lv_store(unsigned long long* g, unsigned v, unsigned tag) {
+  __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline unsigned long long lv_load(const unsigned long long* g) {
+  return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#ifndef SPATTEN_LV_UK
+#define SPATTEN_LV_UK 6          // key row-groups per pipelined tile of phase 1
+#endif
+#ifndef SPATTEN_LV_UV
+#define SPATTEN_LV_UV 6          // value row-groups per pipelined tile of phase 3
+#endif
+
+template <typename T, int D, bool DYN>
+__global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p) {
+  constexpr int LPR = D / 16, RPI = kLvThreads / LPR, HALF = D / 2;
+  constexpr int UK = SPATTEN_LV_UK, UV = SPATTEN_LV_UV;
+  constexpr int NP = OKey<T>::kPasses;
+  using V8 = Vec8<T>;
+  using raw_t = typename V8::raw;
+  using D8 = Dot8<T>;
+  using key_t = typename OKey<T>::type;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ unsigned s_hist[256];
+  __shared__ unsigned s_scan[260];
+  __shared__ float s_red[4][D + 2];
+  __shared__ unsigned s_misc[8];
+  __shared__ float s_aux[2][kLvMaxSplits];
+
+  const int tid = threadIdx.x, c = tid % LPR, r = tid / LPR, wave = tid / kWave, lane = tid % kWave;
+  const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int hkv = (p.Hkv == p.H) ? h : h / (p.H / p.Hkv);
+  const int unit = b * p.H + h;
+
+  int n_dyn = 0;
+  if (DYN) n_dyn = p.step[opaque_lane(0)];
+  const int lo = split * p.chunk;
+  const int rl = min(lo + p.chunk, p.N);                 // static limit of the load addresses (DYN: p.N is the bound)
+  key_t* skey = reinterpret_cast<key_t*>(smem);          // [chunk] ordered keys of this split's logits
+  uint16_t* klist = reinterpret_cast<uint16_t*>(smem + (size_t)((p.chunk * sizeof(key_t) + 15) / 16) * 16);   // [chunk] kept rows
+
+  const T* krbase = p.krc + b * p.kv_sb + hkv * p.kv_sh;
+  const T* vbase = p.vc + b * p.kv_sb + hkv * p.kv_sh;
+
+  // ================================ phase 1: logits of the chunk ====================================================
+  struct KTile { raw_t k_lo[UK], k_hi[UK]; };
+  KTile ka, kb;
+  auto issue_k = [&](KTile& tl, int t0) {
+#pragma unroll
+    for (int u = 0; u < UK; ++u) {
+      const int j = max(min(t0 + u * RPI + r, rl - 1), 0);
+      const T* kp = krbase + (int64_t)j * D;
+      tl.k_lo[u] = V8::ldg_stream(kp + 8 * c);
+      tl.k_hi[u] = V8::ldg_stream(kp + HALF + 8 * c);
+    }
+  };
+  raw_t q_raw[4];
+  {
+    const T* qp = p.q + b * p.q_sb + h * p.q_sh;
+    const int pq = min(max(p.pos_q, 0), p.table_rows - 1);
+    q_raw[0] = V8::ldg(qp + 8 * c);
+    q_raw[1] = V8::ldg(qp + HALF + 8 * c);
+    q_raw[2] = V8::ldg(p.cos + (int64_t)pq * HALF + 8 * c);
+    q_raw[3] = V8::ldg(p.sin + (int64_t)pq * HALF + 8 * c);
+  }
+  issue_k(ka, lo);
+  const unsigned gen = p.ws_gen[unit + opaque_lane(0)];
+  __builtin_amdgcn_sched_barrier(0);
+  const int N = DYN ? __builtin_amdgcn_readfirstlane(n_dyn) : p.N;
+  const int hi = min(lo + p.chunk, N);
+  const int n_loc = max(hi - lo, 0);
+  int keep = p.keep;
+  if (DYN) keep = (int)ceil(p.keep_frac * (double)N);
+  keep = max(1, min(keep, N));
+
+  typename D8::packed q_lo, q_hi;
+  {
+    float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8];
+    V8::unpack(q_raw[0], xlo);
+    V8::unpack(q_raw[1], xhi);
+    V8::unpack(q_raw[2], cc);
+    V8::unpack(q_raw[3], ss);
+    rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
+    q_lo = D8::pack(ylo);
+    q_hi = D8::pack(yhi);
+  }
+  const float rsqrt_d = 1.0f / p.sqrt_d;
+  T* stashp = p.scores + b * p.sc_sb + h * p.sc_sh;
+  float m_run = -INFINITY, l_run = 0.f;
+  auto score_tile = [&](KTile& tl, int t0) {
+    float sc[UK];
+#pragma unroll
+    for (int u = 0; u < UK; ++u) {
+      const float a = group_sum<LPR>(D8::dot(q_hi, tl.k_hi[u], D8::dot(q_lo, tl.k_lo[u], 0.f)));
+      sc[u] = DT<T>::round(div_by_const(DT<T>::round(a), p.sqrt_d, rsqrt_d));        // modify_llama.py:111-113
+    }
+    float m_new = m_run;
+#pragma unroll
+    for (int u = 0; u < UK; ++u) {
+      const int j = t0 + u * RPI + r;
+      const bool valid = j < hi;
+      if (c == 0 && valid) {
+        stashp[j] = DT<T>::from_f32(sc[u]);                                          // :116-119
+        skey[j - lo] = (key_t)OKey<T>::from(sc[u]);
+      }
+      sc[u] = valid ? sc[u] : -INFINITY;
+      m_new = fmaxf(m_new, sc[u]);
+    }
+    if (m_new > m_run) { l_run *= __expf(m_run - m_new); m_run = m_new; }
+#pragma unroll
+    for (int u = 0; u < UK; ++u) l_run += (sc[u] == -INFINITY) ? 0.f : __expf(sc[u] - m_run);
+  };
+  constexpr int KT = RPI * UK;
+  for (int t0 = lo; t0 < hi; t0 += 2 * KT) {
+    issue_k(kb, t0 + KT);
+    __builtin_amdgcn_sched_barrier(0);
+    score_tile(ka, t0);
+    issue_k(ka, t0 + 2 * KT);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t0 + KT < hi) score_tile(kb, t0 + KT);
+  }
+  // (max, sum) of the chunk: every row's LPR lanes agree, so only the row's first lane contributes its sum
+  float m_s, l_s;
+  {
+    const float mw = wave_max(m_run);
+    const float lw = wave_sum((c == 0 && m_run != -INFINITY) ? l_run * __expf(m_run - mw) : 0.f);
+    if (lane == 0) { s_red[wave][0] = mw; s_red[wave][1] = lw; }
+    __syncthreads();                                     // also: every key of the chunk is in LDS
+    const float m0 = s_red[0][0], m1 = s_red[1][0], m2 = s_red[2][0], m3 = s_red[3][0];
+    m_s = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    const float mu = (m_s == -INFINITY) ? 0.f : m_s;
+    l_s = (s_red[0][1] * __expf(m0 - mu) + s_red[1][1] * __expf(m1 - mu)) + (s_red[2][1] * __expf(m2 - mu) + s_red[3][1] * __expf(m3 - mu));
+  }
+
+  // ================================ phase 2: the head's k-th largest logit ===========================================
+  unsigned long long* wsu = p.ws + (int64_t)unit * (kLvMaxSplits * kLvSlot);
+  unsigned long long* slot = wsu + (int64_t)split * kLvSlot;
+  const unsigned tag = (gen & 0x7FFFFFFFu) + 1u;
+  bool expired = false;
+  uint32_t prefix = 0;            // the digits of the threshold found so far (most significant first)
+  int need = keep;                // rank of the threshold among the keys that match the prefix (1 = the largest)
+  unsigned ties_before = 0, ties_mine = 0;
+  float m_g = m_s, l_g = l_s;
+#pragma unroll
+  for (int pass = 0; pass < NP; ++pass) {
+    const int shift = 8 * (NP - 1 - pass);
+    s_hist[tid] = 0u;
+    __syncthreads();
+    for (int i = tid; i < n_loc; i += kLvThreads) {
+      const uint32_t k = skey[i];
+      if (pass == 0 || (k >> (shift + 8)) == prefix) atomicAdd(&s_hist[(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    unsigned tot = s_hist[tid], before = 0, mine = s_hist[tid];
+    if (p.S > 1) {
+      lv_store(slot + pass * 256 + tid, s_hist[tid], tag);
+      if (pass == 0 && tid < 2) lv_store(slot + kLvMaxPasses * 256 + tid, __float_as_uint(tid == 0 ? m_s : l_s), tag);
+      tot = 0;
+      for (int s0 = 0; s0 < p.S; s0 += 8) {             // bin `tid` of every split's histogram: 8 loads per round trip
+        unsigned long long g[8];
+        int spins = 0;
+        bool landed;
+        do {
+          unsigned diff = 0u;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int s = min(s0 + k, p.S - 1);
+            g[k] = lv_load(wsu + (int64_t)s * kLvSlot + pass * 256 + tid);
+            diff |= (unsigned)(g[k] >> 32) ^ tag;
+          }
+          landed = diff == 0u;
+        } while (!landed && ++spins < (1 << 16));
+        expired |= !landed;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (s0 + k < p.S) { tot += (unsigned)g[k]; if (s0 + k < split) before += (unsigned)g[k]; }
+      }
+    }
+    // suffix sums over the bins (keys are ranked largest first): above[t] = keys in bins > t
+    s_scan[tid] = tot;
+    __syncthreads();
+    if (wave == 0) {
+      unsigned v4[4], run = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v4[i] = s_scan[255 - (4 * lane + i)];       // descending bins
+      unsigned mysum = v4[0] + v4[1] + v4[2] + v4[3], incl = mysum;
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const unsigned o = __shfl_up(incl, off, kWave);
+        if (lane >= off) incl += o;
+      }
+      run = incl - mysum;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s_scan[255 - (4 * lane + i)] = run; run += v4[i]; }   // now: keys in bins above
+    }
+    __syncthreads();
+    const unsigned above = s_scan[tid];
+    if (above < (unsigned)need && (unsigned)need <= above + tot) {           // exactly one bin
+      s_misc[0] = (unsigned)tid; s_misc[1] = above; s_misc[2] = before; s_misc[3] = mine;
+    }
+    __syncthreads();
+    prefix = (prefix << 8) | s_misc[0];
+    need -= (int)s_misc[1];
+    ties_before = s_misc[2];
+    ties_mine = s_misc[3];
+    if (pass == 0 && p.S > 1) {   // the head's (max, sum): every split's pair, folded in split order by every thread
+      if (tid < p.S) {
+        const unsigned long long* ax = wsu + (int64_t)tid * kLvSlot + kLvMaxPasses * 256;
+        unsigned long long g0, g1;
+        int spins = 0;
+        do { g0 = lv_load(ax); g1 = lv_load(ax + 1); }
+        while (((unsigned)(g0 >> 32) != tag || (unsigned)(g1 >> 32) != tag) && ++spins < (1 << 16));
+        expired |= ((unsigned)(g0 >> 32) != tag || (unsigned)(g1 >> 32) != tag);
+        s_aux[0][tid] = __uint_as_float((unsigned)g0);
+        s_aux[1][tid] = __uint_as_float((unsigned)g1);
+      }
+      __syncthreads();
+      float mm = -INFINITY;
+      for (int s = 0; s < p.S; ++s) mm = fmaxf(mm, s_aux[0][s]);
+      const float mu = (mm == -INFINITY) ? 0.f : mm;
+      float ll = 0.f;
+      for (int s = 0; s < p.S; ++s) ll += s_aux[1][s] * __expf(s_aux[0][s] - mu);
+      m_g = mm; l_g = ll;
+    }
+  }
+  // threshold key = prefix; `need` of the keys EQUAL to it are kept, lowest index first: this split takes what the
+  // splits before it leave
+  const uint32_t thr = prefix;
+  const int t_mine = max(0, min((int)ties_mine, need - (int)ties_before));
+
+  // ================================ phase 3: compact the kept rows, gather their V rows ============================
+  // order-preserving compaction: per 64-row segment (one wave instruction) the (greater, equal) counts, a scan over the
+  // segments, then positions from ballots
+  const int n_seg = (n_loc + kWave - 1) / kWave;
+  unsigned* seg = s_scan;                                // [<= 256] packed (gt << 16 | eq) — chunks up to 16384 rows
+  for (int sg = wave; sg < n_seg; sg += 4) {
+    const int i = sg * kWave + lane;
+    const uint32_t k = i < n_loc ? (uint32_t)skey[i] : 0u;
+    const unsigned long long mg = __ballot(i < n_loc && k > thr), me = __ballot(i < n_loc && k == thr);
+    if (lane == 0) seg[sg] = ((unsigned)__popcll(mg) << 16) | (unsigned)__popcll(me);
+  }
+  __syncthreads();
+  if (wave == 0) {       // exclusive scan of the segments' (gt, eq) counts; 4 segments per lane (n_seg <= 256)
+    unsigned v4[4], s4 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v4[i] = (4 * lane + i) < n_seg ? seg[4 * lane + i] : 0u; s4 += v4[i]; }
+    unsigned incl = s4;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const unsigned o = __shfl_up(incl, off, kWave);
+      if (lane >= off) incl += o;
+    }
+    unsigned run = incl - s4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { if ((4 * lane + i) < n_seg) seg[4 * lane + i] = run; run += v4[i]; }
+  }
+  __syncthreads();
+  for (int sg = wave; sg < n_seg; sg += 4) {
+    const int i = sg * kWave + lane;
+    const uint32_t k = i < n_loc ? (uint32_t)skey[i] : 0u;
+    const bool gt = i < n_loc && k > thr, eq = i < n_loc && k == thr;
+    const unsigned long long mg = __ballot(gt), me = __ballot(eq);
+    const unsigned lt_mask_lo = __builtin_amdgcn_mbcnt_lo((unsigned)me, 0u);
+    const unsigned eq_rank = (seg[sg] & 0xFFFFu) + __builtin_amdgcn_mbcnt_hi((unsigned)(me >> 32), lt_mask_lo);   // equal keys before this one
+    const bool kept = gt || (eq && (int)eq_rank < t_mine);
+    // kept rows before this one = greater rows before + min(equal rows before, t_mine)
+    const unsigned gt_rank = (seg[sg] >> 16) + __builtin_amdgcn_mbcnt_hi((unsigned)(mg >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mg, 0u));
+    if (kept) klist[gt_rank + min(eq_rank, (unsigned)t_mine)] = (uint16_t)i;
+  }
+  __syncthreads();
+  int n_kept;
+  {
+    // total kept of this split: greater rows + its share of the ties
+    unsigned total_gt = 0;
+    if (n_seg > 0) {
+      const int last = n_seg - 1;
+      const int i0 = last * kWave;
+      // greater rows of the last segment, recounted by wave 0's lanes (cheap; avoids another LDS word)
+      const int i = i0 + lane;
+      const uint32_t k = (i < n_loc) ? (uint32_t)skey[i] : 0u;
+      const unsigned long long mg = __ballot(i < n_loc && k > thr);
+      total_gt = (seg[last] >> 16) + (unsigned)__popcll(mg);
+    }
+    n_kept = (int)total_gt + t_mine;
+  }
+  const float mu_g = (m_g == -INFINITY) ? 0.f : m_g;
+  const float rl_g = 1.0f / l_g;
+  struct VTile { raw_t v_lo[UV], v_hi[UV]; float pj[UV]; };
+  VTile va, vb;
+  auto issue_v = [&](VTile& tl, int g0) {
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      const int i = (g0 + u) * RPI + r;
+      const int li = (int)klist[min(i, max(n_kept - 1, 0))];
+      const T* vp = vbase + (int64_t)(lo + li) * D;
+      tl.v_lo[u] = V8::ldg_stream(vp + 8 * c);
+      tl.v_hi[u] = V8::ldg_stream(vp + HALF + 8 * c);
+      tl.pj[u] = (i < n_kept) ? __expf(OKey<T>::to((uint32_t)skey[li]) - mu_g) * rl_g : 0.f;
+    }
+  };
+  float olo[8], ohi[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { olo[i] = 0.f; ohi[i] = 0.f; }
+  auto pv_tile = [&](VTile& tl) {
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      float a[8], bq[8];
+      V8::unpack(tl.v_lo[u], a);
+      V8::unpack(tl.v_hi[u], bq);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { olo[e] = fmaf(tl.pj[u], a[e], olo[e]); ohi[e] = fmaf(tl.pj[u], bq[e], ohi[e]); }
+    }
+  };
+  const int n_grp = (n_kept + RPI - 1) / RPI;
+  if (n_kept > 0) {
+    issue_v(va, 0);
+    for (int g0 = 0; g0 < n_grp; g0 += 2 * UV) {
+      issue_v(vb, g0 + UV);
+      __builtin_amdgcn_sched_barrier(0);
+      pv_tile(va);
+      issue_v(va, g0 + 2 * UV);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g0 + UV < n_grp) pv_tile(vb);
+    }
+  }
+  // lanes with equal c across the wave's row groups, then the 4 waves (decode_attn.hip's reduction)
+  if (LPR == 4) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      olo[i] += dpp_mov<kDppRor8>(olo[i]); olo[i] += dpp_mov<kDppRor4>(olo[i]);
+      ohi[i] += dpp_mov<kDppRor8>(ohi[i]); ohi[i] += dpp_mov<kDppRor4>(ohi[i]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { olo[i] += dpp_mov<kDppRor8>(olo[i]); ohi[i] += dpp_mov<kDppRor8>(ohi[i]); }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { olo[i] = xor32_sum(xor16_sum(olo[i])); ohi[i] = xor32_sum(xor16_sum(ohi[i])); }
+  __syncthreads();
+  if (lane < LPR) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s_red[wave][8 * lane + i] = olo[i]; s_red[wave][HALF + 8 * lane + i] = ohi[i]; }
+  }
+  __syncthreads();
+  float o_tot = 0.f;
+  if (tid < D) o_tot = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+  T* outp = p.out + b * p.out_sb + (int64_t)h * D;
+  if (p.S == 1) {
+    if (tid < D) outp[tid] = DT<T>::from_f32(o_tot);
+    if (p.lse != nullptr && tid == 0) { p.lse[unit * 2] = m_g; p.lse[unit * 2 + 1] = l_g; }
+    if (tid == 0) p.ws_gen[unit] = gen + 1u;
+    return;
+  }
+  if (tid < D) lv_store(slot + kLvMaxPasses * 256 + 4 + tid, __float_as_uint(o_tot), tag);
+  if (split != p.S - 1) return;
+  float og = 0.f;
+  if (tid < D) {
+    for (int s0 = 0; s0 < p.S; s0 += 8) {
+      unsigned long long g[8];
+      int spins = 0;
+      bool landed;
+      do {
+        unsigned diff = 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int s = min(s0 + k, p.S - 1);
+          g[k] = lv_load(wsu + (int64_t)s * kLvSlot + kLvMaxPasses * 256 + 4 + tid);
+          diff |= (unsigned)(g[k] >> 32) ^ tag;
+        }
+        landed = diff == 0u;
+      } while (!landed && ++spins < (1 << 16));
+      expired |= !landed;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (s0 + k < p.S) og += __uint_as_float((unsigned)g[k]);        // split order: deterministic
+    }
+  }
+  if (expired) { atomicOr(p.ws_err, 1u); og = __builtin_nanf(""); }
+  if (tid < D) outp[tid] = DT<T>::from_f32(og);
+  if (tid == 0) {
+    if (p.lse != nullptr) { p.lse[unit * 2] = m_g; p.lse[unit * 2 + 1] = l_g; }
+    p.ws_gen[unit] = gen + 1u;
+  }
+}
+
+static inline size_t lv_gen_bytes(size_t units) { return (units * sizeof(unsigned) + 255) / 256 * 256; }
+
+}  // namespace spatten
+
+using namespace spatten;
+
+extern "C" size_t spatten_local_v_workspace_bytes(int batch, int heads) {
+  if (batch <= 0 || heads <= 0) return 0;
+  const size_t units = (size_t)batch * heads;
+  return kLvHeader + lv_gen_bytes(units) + units * kLvMaxSplits * kLvSlot * sizeof(unsigned long long);
+}
+
+extern "C" int spatten_attn_decode_local_v(int dtype, const void* q, int64_t q_sb, int64_t q_sh, const void* kr_cache,
+                                           const void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* cos, const void* sin,
+                                           int table_rows, int pos_q, void* out, int64_t out_sb, void* scores, int64_t sc_sb,
+                                           int64_t sc_sh, float* lse, void* workspace, int batch, int heads, int kv_heads,
+                                           int head_dim, int kv_len, int keep, double keep_fraction, int kv_len_layout,
+                                           const void* step_state, void* stream) {
+  if (!q || !kr_cache || !v_cache || !cos || !sin || !out || !scores || !workspace) return SPATTEN_ERR_INVALID;
+  if (!ok_dtype(dtype) || batch <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads != 0 || kv_len <= 0) return SPATTEN_ERR_INVALID;
+  if (head_dim != 64 && head_dim != 128) return SPATTEN_ERR_UNSUPPORTED;
+  if (step_state ? !(keep_fraction > 0.0 && keep_fraction <= 1.0) : keep <= 0) return SPATTEN_ERR_INVALID;
+  if (!step_state && (pos_q < 0 || pos_q >= table_rows)) return SPATTEN_ERR_INVALID;
+  const int lay = (!step_state && kv_len_layout > kv_len) ? kv_len_layout : kv_len;
+  const long long units = (long long)batch * heads;
+  int S = (int)std::max(1LL, 256 / units);
+  if (S > kLvMaxSplits) S = kLvMaxSplits;
+  const int min_rows = 256;                          // a split shorter than this is all latency
+  if (S > std::max(1, lay / min_rows)) S = std::max(1, lay / min_rows);
+  const int chunk = ceil_div(ceil_div(lay, S), 8) * 8;
+  S = ceil_div(lay, chunk);
+  const size_t key_b = dtype == SPATTEN_F32 ? 4 : 2;
+  const size_t lds = ((size_t)chunk * key_b + 15) / 16 * 16 + (size_t)chunk * 2;
+  if (chunk > 16384 || lds > 120 * 1024) return SPATTEN_ERR_UNSUPPORTED;   // (the three-launch path covers longer chunks)
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)S, (unsigned)heads, (unsigned)batch);
+#define SPATTEN_LV(T, DD, DYN_)                                                                                        \
+  {                                                                                                                    \
+    LvParams<T> p;                                                                                                     \
+    p.q = (const T*)q; p.q_sb = q_sb; p.q_sh = q_sh;                                                                   \
+    p.krc = (const T*)kr_cache; p.vc = (const T*)v_cache; p.kv_sb = kv_sb; p.kv_sh = kv_sh;                             \
+    p.cos = (const T*)cos; p.sin = (const T*)sin; p.table_rows = table_rows; p.pos_q = pos_q;                           \
+    p.step = (const int32_t*)step_state;                                                                               \
+    if (step_state) {                                                                                                  \
+      p.cos = (const T*)((const char*)step_state + kStepHeader); p.sin = p.cos + 2 * (head_dim / 2);                    \
+      p.table_rows = 2; p.pos_q = 0;                                                                                   \
+    }                                                                                                                  \
+    p.out = (T*)out; p.out_sb = out_sb; p.scores = (T*)scores; p.sc_sb = sc_sb; p.sc_sh = sc_sh; p.lse = lse;           \
+    p.ws_err = (unsigned*)workspace; p.ws_gen = (unsigned*)((char*)workspace + kLvHeader);                              \
+    p.ws = (unsigned long long*)((char*)workspace + kLvHeader + lv_gen_bytes((size_t)units));                           \
+    p.keep_frac = keep_fraction; p.keep = keep;                                                                        \
+    p.B = batch; p.H = heads; p.Hkv = kv_heads; p.N = kv_len; p.S = S; p.chunk = chunk;                                 \
+    p.sqrt_d = sqrtf((float)head_dim);                                                                                 \
+    static bool attr_set = false;                                                                                      \
+    if (!attr_set) {                                                                                                   \
+      (void)hipFuncSetAttribute((const void*)local_v_kernel<T, DD, DYN_>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((local_v_kernel<T, DD, DYN_>), grid, dim3(kLvThreads), lds, st, p);                              \
+  }
+#define SPATTEN_LV_D(T, DYN_) { if (head_dim == 128) SPATTEN_LV(T, 128, DYN_) else SPATTEN_LV(T, 64, DYN_) }
+#define SPATTEN_LV_T(DYN_)                                                                                             \
+  { if (dtype == SPATTEN_BF16) SPATTEN_LV_D(bf16_t, DYN_) else if (dtype == SPATTEN_F16) SPATTEN_LV_D(f16_t, DYN_) else SPATTEN_LV_D(float, DYN_) }
+  if (step_state) SPATTEN_LV_T(true) else SPATTEN_LV_T(false)
+#undef SPATTEN_LV_T
+#undef SPATTEN_LV_D
+#undef SPATTEN_LV
+  return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+}

@@ -109,7 +109,8 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
             m._spatten_ext = (cache.ext, layer)
     if auto_graph:
         if cache.ext is not None and not cache.ext.graph_capable():
-            raise ValueError("auto_graph: local V pruning runs its decode step eagerly (SpattenExtensions.graph_capable)")
+            raise ValueError("auto_graph: local V pruning together with cascade importance runs its decode step eagerly "
+                             "(SpattenExtensions.graph_capable)")
         from .graph import auto_graph as _auto
 
         _auto(model, horizon=64 if auto_graph is True else int(auto_graph))

@@ -140,9 +140,10 @@ class SpattenExtensions:
         """Modes whose decode step runs in the device-length form (spatten_amd/graph.py): cascade importance and head
         pruning — one fused launch with fixed buffers — and progressive quantisation (the step's append + plane packing as
         one device-length launch, then the two passes over the planes); the layer cascade changes only the prune events (its
-        layers decode on caches of different lengths: one step state per length).  Local V pruning launches helper kernels
-        with host lengths and stays eager."""
-        return self.local_v_keep is None
+        layers decode on caches of different lengths: one step state per length).  Local V pruning is ONE launch whose kept
+        count ceil(f * length) is evaluated on the device (round 4) — captured too, except together with cascade importance
+        (its accumulation there runs on host lengths)."""
+        return self.local_v_keep is None or not self.cascade
 
     def decode_step_graph(self, layer: int, q, k_new, v_new, slab, kv_len: int, cos, sin, gctx):
         """The decode step under a DecodeGraph: every buffer at capacity and at a fixed address; with cascade importance
@@ -159,6 +160,17 @@ class SpattenExtensions:
             raise RuntimeError("extension buffers smaller than the slab capacity")
         casc = (st.acc, st.stash[1], st.lse[1], 0) if self.cascade else None
         step = gctx.state_for(slab, cos, sin)
+        if self.local_v_keep is not None:
+            # local V pruning: the step's append in device-length form, then the one-launch step (the kept count follows the
+            # device length); head pruning's zero-fill and head scores are stream operations on fixed buffers
+            ops.kv_append_step(k_new, v_new, slab.k, slab.kr, slab.v, step, None)
+            ops.attn_decode_local_v(q, slab.kr, slab.v, cap, cos, sin, 0, 1, st.stash[0], out=st.out, lse=st.lse[0],
+                                    keep_fraction=self.local_v_keep, step=step)
+            if st.pruned_ids is not None:
+                st.out.view(B, H, d).index_fill_(1, st.pruned_ids, 0)
+            if self.head_keep is not None:
+                ops.head_scores(st.out, H, st.head_abs_prefill)
+            return st.out, st.stash[0][:, :, None, :kv_len]
         if self.pq_threshold is not None and self.pq_profile is not None:
             # profiled planes: rows [0, kv_len - 1) packed with host lengths before the capture, the step's row by the
             # device-length append (k / kr / v) + the device-length pack of that row, then the two passes over the planes
@@ -236,7 +248,8 @@ class SpattenExtensions:
             from .cascade import local_v_decode
             ops.kv_append(k_new[:, :, None], v_new[:, :, None], slab.k, slab.kr, slab.v, past_len, cos, sin)
             keep = max(1, min(kv_len, math.ceil(self.local_v_keep * kv_len)))
-            local_v_decode(q, slab.kr, slab.v, kv_len, cos, sin, past_len, keep, out=st.out, stash=stash, lse=lse)
+            local_v_decode(q, slab.kr, slab.v, kv_len, cos, sin, past_len, keep, out=st.out, stash=stash, lse=lse,
+                           layout=slab.capacity)
             if casc is not None:        # the scores-only launch does not carry the fused accumulation
                 ops.importance_accumulate(st.acc, casc[1][:, :, None, :casc[3]], casc[2][:, :, None, :])
             if st.pruned_ids is not None:

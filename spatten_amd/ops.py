@@ -930,6 +930,48 @@ def pv_gather(stash: torch.Tensor, lse: torch.Tensor, v_cache: torch.Tensor, idx
     return out
 
 
+_lv_ws_cache = _LRU(16)
+
+
+def _local_v_workspace(batch, heads, device) -> torch.Tensor:
+    key = (batch, heads, device, _stream())
+    ws = _lv_ws_cache.get(key)
+    if ws is None:
+        n = _lib.load().spatten_local_v_workspace_bytes(batch, heads)
+        ws = _lv_ws_cache.put(key, torch.zeros(n, dtype=torch.uint8, device=device))
+    return _pin(ws)
+
+
+def attn_decode_local_v(q: torch.Tensor, kr_cache: torch.Tensor, v_cache: torch.Tensor, kv_len: int, cos: torch.Tensor,
+                        sin: torch.Tensor, pos_q: int, keep: int, scores: torch.Tensor, out: Optional[torch.Tensor] = None,
+                        lse: Optional[torch.Tensor] = None, keep_fraction: float = 0.0, step: Optional["StepState"] = None,
+                        layout: int = 0, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The decode step with local V pruning as ONE launch (spatten_attn_decode_local_v): stash + (max, sum), exact per-head
+    top-``keep`` of the logits, P.V over the kept V rows with the full denominator.  q [B,H,d]; kr_cache / v_cache
+    [B,Hkv,cap,d]; scores [B,H,>=kv_len] (written).  With ``step`` the kept count is ceil(keep_fraction * device length)."""
+    _dev(q, kr_cache, v_cache, cos, sin, scores, out, lse)
+    B, H, d = q.shape
+    Hkv, cap = v_cache.shape[1], v_cache.shape[2]
+    if q.stride(2) != 1 or v_cache.stride(3) != 1 or v_cache.stride(2) != d or kr_cache.stride() != v_cache.stride() \
+            or scores.stride(2) != 1 or scores.shape[2] < kv_len:
+        raise ValueError("q / caches / scores need contiguous rows; scores [B,H,>=kv_len]")
+    if kv_len > cap or (step is None and max(kv_len, pos_q + 1) > cos.shape[0]) or cos.shape[1] * 2 != d or layout > cap:
+        raise ValueError("kv_len exceeds cache capacity or rotary table")
+    if out is None:
+        out = torch.empty(B, H * d, dtype=q.dtype, device=q.device)
+    ws = workspace if workspace is not None else _local_v_workspace(B, H, q.device)
+    rc = _lib.load().spatten_attn_decode_local_v(
+        _dt(q), q.data_ptr(), (H * d if B == 1 else q.stride(0)), q.stride(1), kr_cache.data_ptr(), v_cache.data_ptr(),
+        v_cache.stride(0), v_cache.stride(1), cos.data_ptr(), sin.data_ptr(), cos.shape[0], int(pos_q), out.data_ptr(),
+        out.stride(0), scores.data_ptr(), scores.stride(0), scores.stride(1), _ptr(lse), ws.data_ptr(), B, H, Hkv, d,
+        int(kv_len), int(keep), float(keep_fraction), int(layout), None if step is None else step.data_ptr(), _stream())
+    if rc == -2:
+        raise NotImplementedError("spatten_attn_decode_local_v: split longer than 16384 rows — use cascade.local_v_decode's "
+                                  "three-launch form")
+    _lib.check(rc, "spatten_attn_decode_local_v")
+    return out
+
+
 class PQPlanes:
     """Progressive-quantisation planes of a rotated key cache: msb / lsb [B,Hkv,cap,d/2] uint8 (two 4-bit fields
     per byte), scale [B,Hkv,cap] fp32;  q8 = msb*16 + lsb,  x ~ q8 * scale."""

@@ -217,8 +217,8 @@ def llama_pos_shift_attention_forward(
         projected = None
         if ext is not None and gctx is not None:
             if not ext[0].graph_capable():
-                raise RuntimeError("DecodeGraph captures the plain decode step, the cascade-importance / head-pruning modes "
-                                   "the layer cascade and progressive quantisation; local V pruning runs eagerly")
+                raise RuntimeError("DecodeGraph captures every mode but local V pruning COMBINED with cascade importance "
+                                   "(its accumulation runs on host lengths)")
             attn_output, stash = ext[0].decode_step_graph(ext[1], q3, k3, v3, slab, kv_seq_len, cos, sin, gctx)
             gctx.touched.append((self, slab, ext))
         elif ext is not None:

@@ -359,6 +359,7 @@ def test_decode_graph_holds_the_head_parallel_exchange():
                                 dict(pq_threshold=0.05, importance_mode="cascade"),
                                 dict(pq_threshold=0.05, pq_profile=(4, 8)), dict(pq_threshold=0.02, pq_profile=(8, 8), head_keep=6),
                                 dict(pq_threshold=0.05, pq_profile=(6, 6), fuse_qkv=True),
+                                dict(local_v_keep=0.4), dict(local_v_keep=0.3, head_keep=6),
                                 dict(layer_keep=[36, 30, 24]), dict(layer_keep=[36, 30, 30], importance_mode="cascade", head_keep=7)])
 def test_decode_graph_covers_cascade_importance_and_head_pruning(kw):
     """The SpAtten modes whose decode step is ONE fused launch — cumulative importance (the previous step's probabilities
