@@ -170,8 +170,20 @@ typedef struct spatten_decode_args {
      spatten_gemv(out)) issued by the same call — one host call per layer-step instead of two. */
   const void* proj_weight; int64_t proj_w_sn; const void* proj_bias; void* proj_out; int64_t proj_out_sb; int32_t proj_n;
   int32_t pad4_;
+  /* ABI 4: the step's q / k / v projections (modify_llama.py:72-74) INSIDE the attention launch: qkv_x [hidden] = the
+     layer's input row, qkv_weight [3*heads*head_dim, hidden] = q_proj / k_proj / v_proj stacked (row stride qkv_w_sn),
+     qkv_bias optional [3*heads*head_dim], qkv_exchange = spatten_decode_qkv_exchange_bytes() of device scratch (zero-filled
+     once, one per workspace).  q, k_new, v_new must then be NULL: each workgroup projects its share of the head's q / k / v
+     while the K/V stream of the step is already in flight (the values equal spatten_gemv's bit for bit).  Only where
+     spatten_decode_qkv_supported() says so; SPATTEN_ERR_UNSUPPORTED otherwise (launch spatten_gemv + the plain step). */
+  const void* qkv_x; const void* qkv_weight; int64_t qkv_w_sn; const void* qkv_bias; void* qkv_exchange; int32_t qkv_hidden;
+  int32_t pad5_;
 } spatten_decode_args_t;
 int spatten_attn_decode_args(const spatten_decode_args_t* args, void* stream);
+/* the fused q/k/v projection + attention launch (spatten_decode_args_t::qkv_*): scratch size, and whether a step of this
+ * shape runs it (lean MHA step, bf16 / f16, head_dim 128, batch 1, <= 320 rows per split of the layout length) */
+size_t spatten_decode_qkv_exchange_bytes(int batch, int heads, int head_dim);
+int spatten_decode_qkv_supported(int dtype, int batch, int heads, int kv_heads, int head_dim, int kv_len_layout);
 
 /* ------------------------------------------------------------------------------------------------
  * Device-resident step state (ABI 3) — what makes a decode step capturable ONCE and replayable for every token of a

@@ -41,6 +41,8 @@ class DecodeArgs(ctypes.Structure):
         ("step_state", c_void_p), ("kv_len_layout", c_int32), ("pad3_", c_int32),
         ("proj_weight", c_void_p), ("proj_w_sn", c_int64), ("proj_bias", c_void_p), ("proj_out", c_void_p),
         ("proj_out_sb", c_int64), ("proj_n", c_int32), ("pad4_", c_int32),
+        ("qkv_x", c_void_p), ("qkv_weight", c_void_p), ("qkv_w_sn", c_int64), ("qkv_bias", c_void_p),
+        ("qkv_exchange", c_void_p), ("qkv_hidden", c_int32), ("pad5_", c_int32),
     ]
 
 class PQPlanesDesc(ctypes.Structure):
@@ -105,6 +107,10 @@ def _declare(lib):
         i, i, i, i, i, i, i, p]
     lib.spatten_attn_decode_args.restype = c_int
     lib.spatten_attn_decode_args.argtypes = [POINTER(DecodeArgs), p]
+    lib.spatten_decode_qkv_exchange_bytes.restype = c_size_t
+    lib.spatten_decode_qkv_exchange_bytes.argtypes = [i, i, i]
+    lib.spatten_decode_qkv_supported.restype = c_int
+    lib.spatten_decode_qkv_supported.argtypes = [i, i, i, i, i, i]
     lib.spatten_decode_workspace_status.restype = c_int
     lib.spatten_decode_workspace_status.argtypes = [p, p]
     lib.spatten_step_state_bytes.restype = c_size_t

@@ -431,6 +431,9 @@ struct DecodeCall {
   // fused / trailing output projection (spatten_decode_args_t::proj_*)
   const void* proj_w = nullptr; int64_t proj_w_sn = 0; const void* proj_bias = nullptr; void* proj_out = nullptr;
   int64_t proj_out_sb = 0; int proj_n = 0;
+  // the step's q / k / v projections fused into the launch (spatten_decode_args_t::qkv_*)
+  const void* qkv_x = nullptr; const void* qkv_w = nullptr; int64_t qkv_w_sn = 0; const void* qkv_bias = nullptr;
+  void* qkv_xch = nullptr; int qkv_hidden = 0;
 };
 int decode_rows(const DecodeCall& c, hipStream_t stream);
 // y[m, n] = sum_k x[m, k] W[n, k] (+ bias): the weight-streaming kernel of gemv.hip (C++ linkage for the other units)

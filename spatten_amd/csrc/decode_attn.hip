@@ -41,14 +41,19 @@
 
 #ifdef SPATTEN_TRACE   // developer instrumentation: per-workgroup phase timestamps (tools/mb/decode_trace.cpp)
 __device__ unsigned long long* g_spatten_trace = nullptr;
-#define SPATTEN_TSTAMP(slot)                                                                         \
+#ifndef SPATTEN_TRACE_SLOTS
+#define SPATTEN_TRACE_SLOTS 8
+#endif
+#define SPATTEN_TSTAMP_T(slot, thread)                                                               \
   do {                                                                                               \
-    if (g_spatten_trace && threadIdx.x == 0)                                                         \
-      g_spatten_trace[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = \
+    if (g_spatten_trace && threadIdx.x == (thread))                                                  \
+      g_spatten_trace[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * SPATTEN_TRACE_SLOTS + (slot)] = \
           __builtin_readcyclecounter();                                                              \
   } while (0)
+#define SPATTEN_TSTAMP(slot) SPATTEN_TSTAMP_T(slot, 0)
 #else
 #define SPATTEN_TSTAMP(slot)
+#define SPATTEN_TSTAMP_T(slot, thread)
 #endif
 
 namespace spatten {
@@ -82,12 +87,18 @@ struct DecodeParams {
                         // different split counts / head subsets / key sources never alias another unit's partials
   int B, H, Hkv, N, pos_q, S, chunk, n_q, causal, vis0, append, poll_merge;   // causal: query row qi sees keys [0, vis0 + qi)
   float sqrt_d;
+  // FUSED (decode_qkv_kernel): the step's q / k / v projections are computed by the launch itself — x [hidden] (the layer's
+  // input row), wqkv [3 * H * D, hidden] the stacked projection weight (rows: all q heads, all k heads, all v heads; row
+  // stride w_sn), optional bias [3 * H * D]; xch [units][3 * D] {value, tag} granules: the exchange of a head's q / k / v
+  // elements between its splits
+  const T* x; const T* wqkv; int64_t w_sn; const T* qkv_bias; unsigned long long* xch; int hidden;
 };
 
 #ifndef SPATTEN_PQ_UP
 #define SPATTEN_PQ_UP 4          // row-groups per pipelined tile of the MSB-plane pass (A/B switch, see launch_decode)
 #endif
 constexpr int kDecodeThreads = 256;
+constexpr int kGemvChunksFused = 8;      // = gemv.hip's kGemvChunks: the fused projection keeps its summation order
 constexpr int kDecodeCoResident = 256;   // workgroups the chip starts without waiting for another to finish: one per CU
 
 // one 8-byte {value, tag} granule of a published partial (tag != 0 <=> the value has landed)
@@ -117,9 +128,15 @@ __device__ inline void store_granule(unsigned long long* g, float v, unsigned ta
 // live, where the appended row goes): the loads are issued exactly as in the static kernel, nothing waits for the
 // length.  Rows [length, bound) of the planes are read and discarded (weight 0), so they must hold finite values
 // (include/spatten.h: zero-fill the planes once).
+// FUSED: the attention half of decode_qkv_kernel (below): the query and the appended token's key / value do not come from
+// memory but from LDS (`s_x`: q | k | v of this head, 3 * D floats holding model-dtype values), filled by the projection
+// waves of the same workgroup; two workgroup barriers are added — B1 in front of the tile loads (the projection waves have
+// issued their last weight pass: the K/V stream follows the weight stream through the memory pipe), B2 behind them (the
+// projections of the whole head have been exchanged).  The rest — tile arithmetic, reduction, publication, merge — is the
+// plain step's, bit for bit.
 template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0, bool NT = LEAN, bool CASC = false,
-          bool PIPE = false, bool DYN = false>
-__device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
+          bool PIPE = false, bool DYN = false, bool FUSED = false>
+__device__ __forceinline__ void decode_body(const DecodeParams<T>& p, const float* s_x = nullptr) {
   constexpr bool SCORES_ONLY = (MODE == 1);
   constexpr bool PQ = (KSRC != 0);
   constexpr int LPR = D / 16;                    // lanes per row
@@ -252,13 +269,26 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
     const T* qp = p.q + b * p.q_sb + h * p.q_sh + (LEAN ? 0 : qi * p.q_sq);
     int pq = (!LEAN && p.pos_ids) ? (int)p.pos_ids[b * p.pos_sb + qi] : p.pos_q + qi;
     pq = min(max(pq, 0), p.table_rows - 1);
-    q_raw[0] = V8::ldg(qp + 8 * c);
-    q_raw[1] = V8::ldg(qp + HALF + 8 * c);
+    if (!FUSED) {
+      q_raw[0] = V8::ldg(qp + 8 * c);
+      q_raw[1] = V8::ldg(qp + HALF + 8 * c);
+    }
     q_raw[2] = V8::ldg(p.cos + (int64_t)pq * HALF + 8 * c);
     q_raw[3] = V8::ldg(p.sin + (int64_t)pq * HALF + 8 * c);
   }
+  unsigned gen_f = 0;
+  if (FUSED) {      // what does not depend on the projections goes out first; then B1: the projection waves are on their last pass
+    n_raw[0] = V8::ldg(p.cos + (int64_t)p.nr_row * HALF + 8 * c);
+    n_raw[1] = V8::ldg(p.sin + (int64_t)p.nr_row * HALF + 8 * c);
+    gen_f = p.ws_cnt[(p.S > 1 ? 2 * unit + 1 : 0) + opaque_lane(0)];
+#if !(defined(SPATTEN_FUSED_EXP) && SPATTEN_FUSED_EXP == 2)
+    // B1 — a bare s_barrier: __syncthreads() carries a fence, i.e. `s_waitcnt vmcnt(0)`, and the projection waves would
+    // drain their in-flight weight passes in front of it (r04: the fused launch then took 29.5 us, the two launches 29.0)
+    __builtin_amdgcn_s_barrier();
+#endif
+  }
   issue_keys(tile_a, lo);
-  {   // the new token's un-rotated key and the rotary row of its slot N-1 (modify_llama.py:103-104)
+  if (!FUSED) {   // the new token's un-rotated key and the rotary row of its slot N-1 (modify_llama.py:103-104)
     const T* kp = p.k_new + b * p.new_sb + hkv * p.new_sh;      // (always readable: see `append`)
     nk_raw[0] = V8::ldg(kp + 8 * c);
     nk_raw[1] = V8::ldg(kp + HALF + 8 * c);
@@ -266,7 +296,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
     n_raw[1] = V8::ldg(p.sin + (int64_t)p.nr_row * HALF + 8 * c);
   }
   issue_values(tile_a, lo);
-  {
+  if (!FUSED) {
     const T* vp = p.v_new + b * p.new_sb + hkv * p.new_sh;
     nv_raw[0] = V8::ldg(vp + 8 * c);
     nv_raw[1] = V8::ldg(vp + HALF + 8 * c);
@@ -274,10 +304,32 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   // this unit's launch generation (tags of the published partials, see below): written by the previous launch's merger,
   // so it comes from memory — a VECTOR load queued behind the tile (a scalar load would be waited for with the kernel
   // arguments, before anything else happens).  (No workspace: ws_cnt points at the rotary table.)
-  const unsigned gen = p.ws_cnt[(p.S > 1 ? 2 * unit + 1 : 0) + opaque_lane(0)];
+  const unsigned gen = FUSED ? gen_f : p.ws_cnt[(p.S > 1 ? 2 * unit + 1 : 0) + opaque_lane(0)];
   // nothing that consumes a load may be scheduled above this point: left alone, the scheduler hoists the query
   // rotation (and the wait for the query) in front of the tile loads, which then leave one memory latency late
   __builtin_amdgcn_sched_barrier(0);
+  if (FUSED) {
+#if defined(SPATTEN_FUSED_EXP) && SPATTEN_FUSED_EXP == 2      // A/B harness only: the tile goes out at kernel start
+    __builtin_amdgcn_s_barrier();
+#endif
+    // B2: s_x holds the head's q | k | v (the writing wave drained its LDS stores in front of its s_barrier).  Bare again: the
+    // tile loads of this wave stay in flight across it and are waited for one row-group at a time below
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    float t8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t8[i] = s_x[D + 8 * c + i];
+    nk_raw[0] = V8::pack(t8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t8[i] = s_x[D + HALF + 8 * c + i];
+    nk_raw[1] = V8::pack(t8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t8[i] = s_x[2 * D + 8 * c + i];
+    nv_raw[0] = V8::pack(t8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t8[i] = s_x[2 * D + HALF + 8 * c + i];
+    nv_raw[1] = V8::pack(t8);
+  }
   SPATTEN_TSTAMP(5);
   // ---- the live rows of this split ------------------------------------------------------------------------------
   const int N = DYN ? __builtin_amdgcn_readfirstlane(n_dyn) : p.N;
@@ -300,8 +352,13 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p) {
   typename NibbleDot<T>::packed qn[4];           // PQ: the same rotated query, arranged for the nibble dot product
   {
     float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8];
-    V8::unpack(q_raw[0], xlo);
-    V8::unpack(q_raw[1], xhi);
+    if (FUSED) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { xlo[i] = s_x[8 * c + i]; xhi[i] = s_x[HALF + 8 * c + i]; }
+    } else {
+      V8::unpack(q_raw[0], xlo);
+      V8::unpack(q_raw[1], xhi);
+    }
     V8::unpack(q_raw[2], cc);
     V8::unpack(q_raw[3], ss);
     rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
@@ -740,6 +797,168 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_lean_kernel(T* krc, T* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// decode_qkv_kernel — the layer-step's q / k / v projections AND its attention in ONE launch (round 4).
+//
+// modify_llama.py:72-74 (q_proj / k_proj / v_proj of the single-token row) + :86-147.  As separate launches the step is
+// [stacked q/k/v GEMV 17.3 us] -> [attention 11.7 us]: the attention launch is latency-bound (5.4 us of bytes, 3.8 us of
+// launch / first-byte latency, 2.4 us of reduction + merge) and its K/V stream does not depend on the query at all.  Here a
+// workgroup (split s of head h, 512 threads) is two teams:
+//   waves 4-7  project the 3 * D / S elements of q_h, k_h, v_h that fall to this split — rows of the stacked weight, streamed
+//              exactly like gemv.hip (lane = 8 columns of a 512-column chunk, 16-byte loads, packed dots, the SAME summation
+//              order: bit-identical values), two rows per pass, double buffered — publish them as {value, tag} granules and
+//              one wave gathers the head's 3 * D elements from its S splits (one memory hop) into LDS;
+//   waves 0-3  are the plain decode step (decode_body<FUSED>): they wait (B1) until the projection waves have ISSUED their
+//              last weight pass, issue their whole K/V tile behind it — the memory pipe never drains between the two
+//              streams, and the q hand-over happens while the tile is in flight — then (B2) take q / k / v from LDS and run
+//              the step's arithmetic, reduction, publication and merge unchanged.
+// One kernel boundary and one launch + first-byte latency per layer-step disappear; the K/V bytes travel at the streaming
+// rate instead of the latency-bound one.  Requirements (else SPATTEN_ERR_UNSUPPORTED and the caller launches the two
+// kernels): the lean step (MHA, one query row, no mask / position tensor / head list / head importance), 16-bit dtype,
+// d = 128, a single-shot tile (<= 320 rows per split), S in {1, 2, 4, 8} with the polling merge (the barrier count of the
+// two teams must match: B1, B2 and the reduction's one LDS hop).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D>
+__device__ __forceinline__ void qkv_projection_waves(const DecodeParams<T>& p, float* s_x) {
+  using V8 = Vec8<T>;
+  using raw_t = typename V8::raw;
+  using D8 = Dot8<T>;
+  constexpr int C = kGemvChunksFused;            // 512-column chunks per pass (gemv.hip: 8)
+  const int tid = (int)threadIdx.x - kDecodeThreads;
+  const int lane = tid & 63, g = tid >> 6;
+  const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int unit = b * p.H + h;
+  const int eps = D / p.S;                       // elements of each of q, k, v projected by this split
+  const int rpw = 3 * eps / 4;                   // weight rows per wave (12 at S = 8): a multiple of 2
+  const int K = p.hidden, n_kb = (K + C * 512 - 1) / (C * 512);
+  const int n_units = (rpw / 2) * n_kb;          // (row pair, column block) passes: even
+  unsigned long long* xch = p.xch + (int64_t)unit * (3 * D);
+  const unsigned gen = p.ws_cnt[(p.S > 1 ? 2 * unit + 1 : 0) + opaque_lane(0)];
+  const unsigned tag = (gen & 0x7FFFFFFFu) + 1u;
+
+  // passes of two weight rows x one 4096-column block, two in flight (r04 A/B: a third pass in flight changes nothing —
+  // the projection team alone streams at the stand-alone spatten_gemv rate; what its 18.9 us against 17.3 hold is the
+  // exchange hop); x is loaded once when the hidden size is one column block (Llama-2-7B), per pass otherwise
+  struct Pass { raw_t w[2][C]; };
+  Pass pa, pb;
+  raw_t xr[C];
+  auto row_of = [&](int rho) {                   // local row -> (which projection, element of the head)
+    const int m = rho / eps, e = eps * split + rho % eps;
+    return m * D + e;                            // index into the head's q | k | v
+  };
+  auto load_x = [&](int k0) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      xr[c] = V8::ldg(p.x + b * (int64_t)K + min(k0 + c * 512 + lane * 8, K - 8));
+    }
+  };
+  auto issue = [&](Pass& ps, int u) {
+    const int rp = u / n_kb, k0 = (u % n_kb) * (C * 512);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int idx = row_of(rpw * g + 2 * rp + r);
+      const T* wrow = p.wqkv + ((int64_t)(idx / D) * p.H * D + (int64_t)h * D + idx % D) * p.w_sn;
+#pragma unroll
+      for (int c = 0; c < C; ++c) ps.w[r][c] = V8::ldg_stream(wrow + min(k0 + c * 512 + lane * 8, K - 8));
+    }
+  };
+  float acc[2] = {0.f, 0.f};
+  auto compute = [&](Pass& ps, int u) {
+    const int rp = u / n_kb, kb = u % n_kb, k0 = kb * (C * 512);
+    if (n_kb > 1 || K % 8 != 0 || K < C * 512) {
+      if (n_kb > 1) load_x(k0);                  // (L2 hits; the wave waits for them here)
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        if (k0 + c * 512 + lane * 8 >= K) {      // columns past K: the x piece is zeroed (gemv.hip)
+          float z[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) z[i] = 0.f;
+          xr[c] = V8::pack(z);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < C; ++c) acc[r] = D8::dot(xr[c], ps.w[r][c], acc[r]);
+    if (kb == n_kb - 1) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int idx = row_of(rpw * g + 2 * rp + r);
+        float v = wave_sum(acc[r]);
+        if (p.qkv_bias) v += DT<T>::to_f32(p.qkv_bias[(int64_t)(idx / D) * p.H * D + (int64_t)h * D + idx % D]);
+        v = DT<T>::round(v);                     // nn.Linear's one rounding to the model dtype
+        if (lane == 0) store_granule(xch + idx, v, tag);
+        acc[r] = 0.f;
+      }
+    }
+  };
+#ifndef SPATTEN_FUSED_B1
+#define SPATTEN_FUSED_B1 0
+#endif
+  // B1 (a bare s_barrier: no vmcnt drain) tells the attention waves to issue their K/V tile.  Where: 0 = when the LAST weight
+  // pass has been issued (the tile queues behind two passes in flight), 1 = when only the last pass is still in flight,
+  // 2 = when every weight has landed (the memory pipe drains for one round trip, but the tile takes no bandwidth from the
+  // weights the query waits for)
+  SPATTEN_TSTAMP_T(8, kDecodeThreads);
+  if (n_kb == 1) load_x(0);
+  issue(pa, 0);
+  for (int u = 0; u < n_units; u += 2) {         // n_units is even
+    issue(pb, u + 1);
+    if (SPATTEN_FUSED_B1 == 0 && u + 2 >= n_units) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    compute(pa, u);
+    if (u + 2 < n_units) issue(pa, u + 2);
+    if (SPATTEN_FUSED_B1 == 1 && u + 2 >= n_units) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    compute(pb, u + 1);
+  }
+  if (SPATTEN_FUSED_B1 == 2) __builtin_amdgcn_s_barrier();
+  SPATTEN_TSTAMP_T(9, kDecodeThreads);           // every weight consumed, the split's elements published
+  if (g == 0) {       // gather the head's q | k | v from its splits: 3 * D granules, 3 * D / 64 per lane, one round trip
+    constexpr int PER = 3 * D / kWave;
+    unsigned long long gr[PER];
+    int spins = 0;
+    bool landed;
+    do {
+      unsigned diff = 0u;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        gr[k] = __hip_atomic_load(xch + lane + kWave * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        diff |= (unsigned)(gr[k] >> 32) ^ tag;
+      }
+      landed = __all(diff == 0u);
+    } while (!landed && ++spins < (1 << 16));
+    if (!landed) atomicOr(p.ws_err, 1u);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) s_x[lane + kWave * k] = landed ? __uint_as_float((unsigned)gr[k]) : __builtin_nanf("");
+  }
+  SPATTEN_TSTAMP_T(10, kDecodeThreads);          // the head's q | k | v gathered
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS stores above have completed
+  __builtin_amdgcn_s_barrier();                  // B2: q | k | v of the head are in LDS
+  __builtin_amdgcn_s_barrier();                  // B3: the reduction's LDS hop of the attention waves (decode_body)
+}
+
+template <typename T, int D, int UNR, bool DYN>
+__global__ __launch_bounds__(2 * kDecodeThreads) void decode_qkv_kernel(T* krc, T* vc, const T* cos, const T* sin, int kv_sb,
+                                                                        int kv_sh, int N, int chunk, int H, int pos_q,
+                                                                        const DecodeParams<T> rest) {
+  __shared__ float s_x[3 * D];
+  DecodeParams<T> p = rest;
+  p.krc = krc; p.vc = vc; p.cos = cos; p.sin = sin;
+  p.kv_sb = kv_sb; p.kv_sh = kv_sh; p.q_sb = (int64_t)H * D; p.q_sh = D;
+  p.N = N; p.chunk = chunk; p.H = H; p.pos_q = pos_q;
+  if (threadIdx.x >= kDecodeThreads) {
+    qkv_projection_waves<T, D>(p, s_x);
+    return;
+  }
+#if defined(SPATTEN_FUSED_EXP) && SPATTEN_FUSED_EXP == 1     // A/B harness only: what does the projection team alone take?
+  __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier();
+  return;
+#endif
+  decode_body<T, D, UNR, 0, true, 0, true, false, false, DYN, true>(p, s_x);
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 // row-groups per tile.  Single-shot instantiation: 16-bit dtypes 10 (d = 128: 320 rows — a whole Llama-2-7B split — in
@@ -769,6 +988,14 @@ static int auto_splits(int units, int d, int kv_len) {
   if (s < 1) s = 1;
   if (s > kDecodeMaxSplits) s = kDecodeMaxSplits;
   return s;
+}
+
+// the fused projection + attention launch: the two teams of a workgroup must meet the same number of barriers (S <= 8 with the
+// polling merge, or one split), and a split projects a whole number of row pairs per wave
+static inline bool decode_qkv_shape_ok(int d, int S, int poll_merge) {
+  if (S != 1 && S != 2 && S != 4 && S != 8) return false;
+  if (S > 1 && !poll_merge) return false;
+  return d % S == 0 && (3 * (d / S)) % 8 == 0;
 }
 
 template <typename T, int D>
@@ -812,9 +1039,23 @@ static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_onl
     }
   } else {
     const bool lean = p.n_q == 1 && p.Hkv == p.H && !p.mask && !p.pos_ids && !p.head_ids && !p.causal &&
-                      p.q_sh == D && p.q_sb == (int64_t)p.H * D;
+                      (p.x != nullptr || (p.q_sh == D && p.q_sb == (int64_t)p.H * D));
     const int64_t lim = 0x7FFFFFFF;
     const bool small = p.kv_sb <= lim && p.kv_sh <= lim;
+    if (p.x != nullptr) {   // the step's projections fused into the launch (decode_qkv_kernel)
+      if constexpr (sizeof(T) == 2 && D == 128) {
+        if (!decode_qkv_shape_ok(D, p.S, p.poll_merge) || !lean || !small || pipe || casc || !p.append || p.head_abs || !p.xch)
+          return SPATTEN_ERR_UNSUPPORTED;
+        const dim3 blk2(2 * kDecodeThreads);
+        if (dyn) hipLaunchKernelGGL((decode_qkv_kernel<T, D, U, true>), grid, blk2, 0, stream, p.krc, p.vc, p.cos, p.sin,
+                                    (int)p.kv_sb, (int)p.kv_sh, p.N, p.chunk, p.H, p.pos_q, p);
+        else hipLaunchKernelGGL((decode_qkv_kernel<T, D, U, false>), grid, blk2, 0, stream, p.krc, p.vc, p.cos, p.sin,
+                                (int)p.kv_sb, (int)p.kv_sh, p.N, p.chunk, p.H, p.pos_q, p);
+        return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+      } else {
+        return SPATTEN_ERR_UNSUPPORTED;
+      }
+    }
     if (lean && small) {
 #define SPATTEN_LEAN(UU, CC, PP, DD)                                                                                    \
   hipLaunchKernelGGL((decode_lean_kernel<T, D, UU, CC, PP, DD>), grid, blk, 0, stream, p.krc, p.vc, p.q, p.cos, p.sin,   \
@@ -851,7 +1092,10 @@ static int dispatch_decode(DecodeParams<T>& p, int d, int n_active, bool scores_
 int decode_rows(const DecodeCall& c, hipStream_t stream) {
   const bool scores_only = (c.flags & SPATTEN_DECODE_SCORES_ONLY) != 0;
   const PQKeys* pq = c.pq;
-  if (!c.q || (!c.kr_cache && !pq) || !c.cos || !c.sin || (!scores_only && (!c.out || !c.v_cache))) return SPATTEN_ERR_INVALID;
+  if ((!c.q && !c.qkv_x) || (!c.kr_cache && !pq) || !c.cos || !c.sin || (!scores_only && (!c.out || !c.v_cache))) return SPATTEN_ERR_INVALID;
+  if (c.qkv_x && (!c.qkv_w || !c.qkv_xch || c.qkv_hidden <= 0 || c.qkv_hidden % 8 != 0 || c.qkv_w_sn < c.qkv_hidden || c.qkv_w_sn % 8 != 0 ||
+                  c.k_new || c.n_q != 1 || !c.k_cache || pq || scores_only || c.batch != 1))
+    return SPATTEN_ERR_INVALID;
   if (scores_only && (!c.scores || !c.lse || c.k_new)) return SPATTEN_ERR_INVALID;
   int n_active = c.head_ids ? c.n_active : c.heads;
   if (n_active <= 0 || n_active > c.heads) return SPATTEN_ERR_INVALID;
@@ -905,8 +1149,10 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   DecodeParams<T> p;                                                                                     \
   p.q = (const T*)c.q; p.q_sb = c.q_sb; p.q_sh = c.q_sh; p.q_sq = c.q_sq;                                \
   p.kc = (T*)c.k_cache; p.krc = (T*)c.kr_cache; p.vc = (T*)c.v_cache; p.kv_sb = c.kv_sb; p.kv_sh = c.kv_sh; \
-  p.append = c.k_new != nullptr;                                                                         \
-  p.k_new = (const T*)(c.k_new ? c.k_new : c.q); p.v_new = (const T*)(c.k_new ? c.v_new : c.q);           \
+  p.append = c.k_new != nullptr || c.qkv_x != nullptr;                                                   \
+  p.x = (const T*)c.qkv_x; p.wqkv = (const T*)c.qkv_w; p.w_sn = c.qkv_w_sn; p.qkv_bias = (const T*)c.qkv_bias;  \
+  p.xch = (unsigned long long*)c.qkv_xch; p.hidden = c.qkv_hidden;                                       \
+  p.k_new = (const T*)(c.k_new ? c.k_new : (c.q ? c.q : c.cos)); p.v_new = (const T*)(c.k_new ? c.v_new : (c.q ? c.q : c.cos)); \
   p.new_sb = c.k_new ? c.new_sb : c.q_sb; p.new_sh = c.k_new ? c.new_sh : c.q_sh;                        \
   p.cos = (const T*)c.cos; p.sin = (const T*)c.sin; p.table_rows = c.table_rows;                         \
   p.step = (const int32_t*)c.step; p.nr_row = (c.kv_len < c.table_rows ? c.kv_len : c.table_rows) - 1;   \
@@ -963,6 +1209,25 @@ extern "C" int spatten_decode_auto_splits(int batch, int heads, int head_dim, in
   return auto_splits(batch * heads, head_dim, kv_len);
 }
 
+extern "C" size_t spatten_decode_qkv_exchange_bytes(int batch, int heads, int head_dim) {
+  if (batch <= 0 || heads <= 0 || head_dim <= 0) return 0;
+  return (size_t)batch * heads * 3 * head_dim * sizeof(unsigned long long);
+}
+
+extern "C" int spatten_decode_qkv_supported(int dtype, int batch, int heads, int kv_heads, int head_dim, int kv_len_layout) {
+  if (dtype != SPATTEN_F16 && dtype != SPATTEN_BF16) return 0;
+  if (batch != 1 || heads <= 0 || heads != kv_heads || head_dim != 128 || kv_len_layout <= 0) return 0;
+  int S = auto_splits(batch * heads, head_dim, kv_len_layout);
+  if (S > kv_len_layout) S = kv_len_layout;
+  const int chunk = ceil_div(ceil_div(kv_len_layout, S), 8) * 8;
+  S = ceil_div(kv_len_layout, chunk);
+  static int env_poll = -1;
+  if (env_poll < 0) { const char* e = getenv("SPATTEN_DECODE_POLL"); env_poll = e ? atoi(e) : 1; }
+  const int poll = (env_poll != 0 && S > 1 && (long long)S * heads * batch <= kDecodeCoResident) ? 1 : 0;
+  if (!decode_qkv_shape_ok(head_dim, S, poll)) return 0;
+  return chunk <= 10 * decode_group_rows(head_dim) ? 1 : 0;      // a single-shot tile per split
+}
+
 extern "C" int spatten_decode_workspace_status(void* workspace, void* stream) {
   if (!workspace) return SPATTEN_ERR_INVALID;
   unsigned flag = 0;
@@ -998,6 +1263,8 @@ extern "C" int spatten_attn_decode_args(const spatten_decode_args_t* a, void* st
   c.step = a->step_state; c.layout_len = a->kv_len_layout;
   c.proj_w = a->proj_weight; c.proj_w_sn = a->proj_w_sn; c.proj_bias = a->proj_bias; c.proj_out = a->proj_out;
   c.proj_out_sb = a->proj_out_sb; c.proj_n = a->proj_n;
+  c.qkv_x = a->qkv_x; c.qkv_w = a->qkv_weight; c.qkv_w_sn = a->qkv_w_sn; c.qkv_bias = a->qkv_bias; c.qkv_xch = a->qkv_exchange;
+  c.qkv_hidden = a->qkv_hidden;
   PQKeys keys;
   if (a->pq_msb) {
     if (!a->pq_lsb || !a->pq_scale || !a->pq_need_lsb) return SPATTEN_ERR_INVALID;

@@ -26,7 +26,7 @@ _FAMILIES: Dict[str, Callable] = {"llama": _patch_llama}
 def enable_spatten_llm(model, start_size, important_size, recent_size, importance_mode="reference",
                        prefill_stash=True, assume_causal=False, head_keep=None, pq_threshold=None, local_v_keep=None,
                        layer_keep=None, fuse_qkv=False, native_gemv=False, head_parallel=None, numerics="reference",
-                       auto_graph=False, pq_profile=None):
+                       auto_graph=False, pq_profile=None, fused_step=False):
     """The reference's four positional arguments (enable_spatten_llm.py:5) plus opt-in extensions:
 
     ``prefill_stash=False``: forwards with ``q_len > 1`` do not materialise ``self.attn_scores`` ([B,H,q,N]: 4 GiB per
@@ -43,6 +43,12 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     (``spatten_gemv``) instead of torch's GEMM library — at q_len = 1 they are HBM-bound streams that make up four fifths
     of the decode step's bytes (same fp32 accumulation and single rounding as ``nn.Linear``; a different summation order,
     so the last bit can differ).  Multi-token forwards keep torch's GEMMs.
+
+    ``fused_step=True`` (needs ``fuse_qkv`` and ``native_gemv``): the q / k / v projections of a single-token step run INSIDE
+    the attention launch (spatten_decode_args_t::qkv_*: every workgroup projects its share of its head's q / k / v while the
+    step's K/V stream is already in flight; the values equal ``spatten_gemv``'s bit for bit) — one launch and one
+    launch-latency fewer per layer-step.  Applies to the plain step on MHA stacks at head_dim 128 in bf16 / f16, batch 1,
+    up to 320 cache rows per split; other steps run the separate launches.
 
     ``auto_graph=True`` (or a token horizon; True = 64, the reference's max_gen_len — run_spatten_llama.py:61): ``model.forward`` is wrapped so that the reference's per-token loop
     (run_spatten_llama.py:27-35), unchanged, replays one captured HIP graph of the whole patched stack per token
@@ -75,6 +81,8 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     from .pos_shift.modify_llama import attention_modules
 
     mods = attention_modules(model)                                # model.modules() order = layer order (:74-77)
+    if fused_step and not (fuse_qkv and native_gemv):
+        raise ValueError("fused_step needs fuse_qkv=True and native_gemv=True (it reads the stacked weight the way spatten_gemv does)")
     if pq_profile is not None and pq_threshold is None:
         raise ValueError("pq_profile needs pq_threshold")
     extended = (importance_mode == "cascade" or head_keep is not None or pq_threshold is not None or local_v_keep is not None
@@ -87,6 +95,7 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
         m.__dict__.pop("_spatten_geom", None)       # geometry cache of the patched forward: re-read on the next call
         m._spatten_qkv = None
         m.__dict__["_spatten_gemv"] = bool(native_gemv)
+        m.__dict__["_spatten_fused_step"] = bool(fused_step)
         if numerics not in ("reference", "fast"):
             raise ValueError("numerics must be 'reference' or 'fast'")
         m.__dict__["_spatten_numerics"] = numerics

@@ -98,6 +98,20 @@ class KVSlab:
             t = self._tab = rope_tables(max(cap, rows or 0), d, self.k.dtype, self.k.device, self.base, self.scaling)
         return t
 
+    def decode_step_qkv(self, x, qkv_w, qkv_b, heads: int, kv_len: int, pos_q: int, cos, sin, scores, step=None, proj=None):
+        """The plain step with its q / k / v projections fused into the attention launch (ops.SlabDecodeCall._run_qkv), or
+        None when this slab's shape does not run it (the caller projects and calls ``decode_step``)."""
+        B, Hkv, cap, d = self.k.shape
+        key = ((B, heads, d), x.dtype, cos.data_ptr())
+        dec = self.dec
+        if dec is None or dec.key != key:
+            dec = self.dec = ops.SlabDecodeCall(self.k, self.kr, self.v, cos, sin, x.new_empty(B, heads, d))
+        if not dec.qkv_supported(cap):
+            return None
+        if step is not None:
+            return dec.run(None, None, None, cap, 0, scores, step=step, proj=proj, qkv=(x, qkv_w, qkv_b))
+        return dec.run(None, None, None, kv_len, pos_q, scores, layout=cap, proj=proj, qkv=(x, qkv_w, qkv_b))
+
     def decode_step(self, q, k_new, v_new, kv_len: int, pos_q: int, cos, sin, scores, position_ids=None, mask=None,
                     step=None, proj=None):
         """The plain fused decode step on this slab through its prefilled argument block (ops.SlabDecodeCall).

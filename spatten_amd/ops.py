@@ -98,6 +98,15 @@ class DecodeWorkspace:
         self.key = (batch, heads, head_dim)
         nbytes = lib.spatten_decode_workspace_bytes(batch, heads, head_dim, max_splits)
         self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        self._xch = None            # exchange scratch of the fused projection + attention launch, allocated on first use
+
+    @property
+    def xch(self) -> torch.Tensor:
+        if self._xch is None:
+            b, h, d = self.key
+            n = _lib.load().spatten_decode_qkv_exchange_bytes(b, h, d)
+            self._xch = torch.zeros(n, dtype=torch.uint8, device=self.buf.device)
+        return self._xch
 
     def check(self):
         """Synchronises the current stream; raises SpattenDeviceTimeout if a split-N merge of an earlier launch gave
@@ -250,6 +259,51 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: Opti
     return out
 
 
+def attn_decode_qkv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], heads: int, k_cache: torch.Tensor,
+                    kr_cache: torch.Tensor, v_cache: torch.Tensor, kv_len: int, cos: torch.Tensor, sin: torch.Tensor, pos_q: int,
+                    scores: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, n_splits: int = 0,
+                    step: Optional["StepState"] = None, layout: int = 0,
+                    workspace: Optional[DecodeWorkspace] = None) -> torch.Tensor:
+    """The plain decode step with its q / k / v projections INSIDE the launch (spatten_decode_args_t::qkv_*,
+    modify_llama.py:72-74 + :86-147): x [hidden] (or [1, 1, hidden]) the layer's input row, weight [3*H*d, hidden] = q_proj /
+    k_proj / v_proj stacked, bias or None; the new token's K / V rows are appended at row kv_len - 1.  Raises
+    NotImplementedError where the fused launch does not apply (spatten_decode_qkv_supported).  Returns out [1, H*d]."""
+    _dev(x, weight, bias, k_cache, kr_cache, v_cache, cos, sin, scores, out)
+    Hkv, cap, d = v_cache.shape[1], v_cache.shape[2], v_cache.shape[3]
+    K = weight.shape[1]
+    if v_cache.shape[0] != 1 or Hkv != heads or x.numel() != K or x.stride(-1) != 1 or weight.stride(1) != 1 \
+            or weight.shape[0] != 3 * heads * d or weight.dtype != x.dtype or v_cache.stride(3) != 1 or v_cache.stride(2) != d \
+            or kr_cache.stride() != v_cache.stride() or k_cache.stride() != v_cache.stride():
+        raise ValueError("fused projection step: batch 1, MHA, x [hidden], weight [3*H*d, hidden], slab planes with contiguous rows")
+    if kv_len > cap or (step is None and max(kv_len, pos_q + 1) > cos.shape[0]) or layout > cap:
+        raise ValueError("kv_len exceeds cache capacity or rotary table")
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(1, heads * d, dtype=x.dtype, device=x.device)
+    stream = _stream()
+    ws = _pin(workspace) if workspace is not None else _workspace(1, heads, d, x.device, stream)
+    a = _lib.DecodeArgs()
+    a.struct_size = ctypes.sizeof(_lib.DecodeArgs)
+    a.dtype = _dt(x)
+    a.k_cache, a.kr_cache, a.v_cache = k_cache.data_ptr(), kr_cache.data_ptr(), v_cache.data_ptr()
+    a.kv_sb, a.kv_sh = v_cache.stride(0), v_cache.stride(1)
+    a.cos, a.sin, a.table_rows = cos.data_ptr(), sin.data_ptr(), cos.shape[0]
+    a.out, a.out_sb = out.data_ptr(), out.stride(0)
+    if scores is not None:
+        a.scores, a.sc_sb, a.sc_sh = scores.data_ptr(), scores.stride(0), scores.stride(1)
+    a.workspace, a.workspace_splits = ws.buf.data_ptr(), ws.max_splits
+    a.batch, a.heads, a.kv_heads, a.head_dim, a.kv_len, a.pos_q, a.n_splits = 1, heads, Hkv, d, int(kv_len), int(pos_q), int(n_splits)
+    a.kv_len_layout = int(layout)
+    a.step_state = None if step is None else step.data_ptr()
+    a.qkv_x, a.qkv_weight, a.qkv_w_sn, a.qkv_bias = x.data_ptr(), weight.data_ptr(), weight.stride(0), _ptr(bias)
+    a.qkv_exchange, a.qkv_hidden = ws.xch.data_ptr(), K
+    rc = lib.spatten_attn_decode_args(ctypes.byref(a), stream)
+    if rc == -2:
+        raise NotImplementedError("the fused projection + attention launch does not cover this step (spatten_decode_qkv_supported)")
+    _lib.check(rc, "spatten_attn_decode (fused projections)")
+    return out
+
+
 def _fill_proj(a, proj, q, B, K):
     """proj = (weight [N, K], bias or None, out [B, N]) -> the proj_* fields of a decode argument block."""
     w, bias, y = proj
@@ -328,13 +382,21 @@ class SlabDecodeCall:
         a.batch, a.heads, a.kv_heads, a.head_dim = B, H, Hkv, d
         self.lib = _lib.load()
 
+    def qkv_supported(self, layout: int) -> bool:
+        """Does a plain step on this slab, laid out for ``layout`` rows, run the fused projection + attention launch?"""
+        a = self.a
+        return bool(self.lib.spatten_decode_qkv_supported(a.dtype, a.batch, a.heads, a.kv_heads, a.head_dim, int(layout)))
+
     def run(self, q, k_new, v_new, kv_len: int, pos_q: int, scores: torch.Tensor,
             position_ids: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
-            step: Optional[StepState] = None, layout: int = 0, proj: Optional[tuple] = None) -> torch.Tensor:
+            step: Optional[StepState] = None, layout: int = 0, proj: Optional[tuple] = None,
+            qkv: Optional[tuple] = None) -> torch.Tensor:
         """q [B,H,d], k_new / v_new [B,Hkv,d] (rows contiguous), scores [B,H,>=kv_len]; optional position_ids int64 [B]
         (device) and additive mask [B,kv_len] as in attn_decode; returns out [B, H*d].
         ``layout``: lay the split-N decomposition out for this length (>= kv_len) instead of kv_len.  ``step``: the
         device-resident length — ``kv_len`` is then the BOUND of the launch (= the layout) and ``pos_q`` is not read."""
+        if qkv is not None:
+            return self._run_qkv(qkv, kv_len, pos_q, scores, step, layout, proj)
         if kv_len > self.cap or max(kv_len, pos_q + 1) > self.table_rows or q.stride(2) != 1 or k_new.stride(2) != 1 \
                 or v_new.stride() != k_new.stride() or scores.stride(2) != 1 or layout > self.cap:
             raise ValueError("decode step outside the slab / rotary table, or operands without contiguous rows")
@@ -371,7 +433,45 @@ class SlabDecodeCall:
             a.mask, a.mask_sb = mask.data_ptr(), mask.stride(0)
         else:
             a.mask = None
+        a.qkv_x = None
         _lib.check(self.lib.spatten_attn_decode_args(ctypes.byref(a), stream), "spatten_attn_decode")
+        return out if proj is None else (out, y)
+
+    def _run_qkv(self, qkv, kv_len, pos_q, scores, step, layout, proj):
+        """The step with its q / k / v projections INSIDE the launch (spatten_decode_args_t::qkv_*): ``qkv`` = (x [1, hidden]
+        the layer's input row, weight [3*H*d, hidden] stacked q/k/v, bias or None)."""
+        x, w, bias = qkv
+        _dev(x, w, bias)
+        K = w.shape[1]
+        if x.numel() != K or x.stride(-1) != 1 or w.stride(1) != 1 or w.shape[0] != 3 * self.H * self.d or w.dtype != x.dtype \
+                or scores.stride(2) != 1 or kv_len > self.cap or max(kv_len, pos_q + 1) > self.table_rows or layout > self.cap \
+                or (bias is not None and (not bias.is_contiguous() or bias.numel() != w.shape[0] or bias.dtype != x.dtype)):
+            raise ValueError("fused projection step: x [hidden], weight [3*H*d, hidden] of one dtype with contiguous rows")
+        stream = _stream()
+        if stream != self.stream:
+            self.stream, self.ws = stream, _workspace(self.B, self.H, self.d, x.device, stream)
+            self.a.workspace = self.ws.buf.data_ptr()
+        _pin(self.ws)
+        out = torch.empty(self.B, self.H * self.d, dtype=x.dtype, device=x.device)
+        a = self.a
+        a.q = a.k_new = a.v_new = None
+        a.qkv_x, a.qkv_weight, a.qkv_w_sn, a.qkv_bias = x.data_ptr(), w.data_ptr(), w.stride(0), _ptr(bias)
+        a.qkv_exchange, a.qkv_hidden = self.ws.xch.data_ptr(), K
+        a.out, a.out_sb = out.data_ptr(), out.stride(0)
+        a.scores, a.sc_sb, a.sc_sh = scores.data_ptr(), scores.stride(0), scores.stride(1)
+        a.kv_len, a.pos_q = kv_len, pos_q
+        a.kv_len_layout = layout
+        a.step_state = None if step is None else step.data_ptr()
+        a.position_ids = a.mask = None
+        if proj is not None:
+            y = torch.empty(self.B, proj[0].shape[0], dtype=x.dtype, device=x.device)
+            _fill_proj(a, (proj[0], proj[1], y), out, self.B, self.H * self.d)
+        else:
+            a.proj_weight = None
+        try:
+            _lib.check(self.lib.spatten_attn_decode_args(ctypes.byref(a), stream), "spatten_attn_decode (fused projections)")
+        finally:
+            a.qkv_x = None
         return out if proj is None else (out, y)
 
 

@@ -110,7 +110,19 @@ def llama_pos_shift_attention_forward(
     #  would skip the forward of a wrapped projection (LoRA, a quantised linear exposing .weight) on single-token steps only)
     native_rows = (tp == 1 and bsz * q_len <= 4 and bool(self.__dict__.get("_spatten_gemv", False))
                    and hidden_states.is_cuda and _plain_linears(self, hidden_states.dtype))
-    if tp > 1:                                                                    # :43-69
+    # opt-in (enable_spatten_llm(..., fused_step=True), with fuse_qkv + native_gemv): the single-token step's q / k / v
+    # projections run INSIDE the attention launch (include/spatten.h: spatten_decode_args_t::qkv_*) — decided below, once the
+    # slab is known; until then nothing is projected
+    fused_qkv = None
+    if (native_rows and q_len == 1 and bsz == 1 and hp is None and self.__dict__.get("_spatten_fused_step", False)
+            and getattr(self, "_spatten_ext", None) is None and getattr(self, "_spatten_qkv", None) is not None
+            and num_heads == num_kv_heads and past_key_value is not None):
+        w, bias, nq, nk = self._spatten_qkv
+        if self.q_proj.weight.data_ptr() == w.data_ptr() and w.dtype == hidden_states.dtype:
+            fused_qkv = (w, bias)
+    if fused_qkv is not None:
+        query_states = key_states = value_states = None
+    elif tp > 1:                                                                    # :43-69
         kv_slicing = (num_kv_heads * head_dim) // tp
         q_slices = self.q_proj.weight.split((num_heads * head_dim) // tp, dim=0)
         k_slices = self.k_proj.weight.split(kv_slicing, dim=0)
@@ -151,7 +163,7 @@ def llama_pos_shift_attention_forward(
         key_states = self.k_proj(hidden_states)
         value_states = self.v_proj(hidden_states)
 
-    dtype, device = query_states.dtype, query_states.device
+    dtype, device = hidden_states.dtype if query_states is None else query_states.dtype, hidden_states.device
     past_len = 0 if past_key_value is None else past_key_value[0].shape[-2]       # :86-88
     kv_seq_len = past_len + q_len
     ext = getattr(self, "_spatten_ext", None)         # (SpattenExtensions, layer index) — opt-in SpAtten semantics
@@ -203,9 +215,29 @@ def llama_pos_shift_attention_forward(
         attention_mask = attention_mask.to(dtype)
     slab.ensure_shadow(past_len)                     # a foreign past: its rows get their rotation now (:103-104)
     if q_len == 1:
-        q3 = query_states.view(bsz, num_heads, head_dim)
-        k3, v3 = key_states.view(bsz, num_kv_heads, head_dim), value_states.view(bsz, num_kv_heads, head_dim)
         gctx = kv_slab.graph_ctx_for(slab)     # this thread's tracing DecodeGraph, if THIS cache is one it is bound to
+        fused_out = None
+        if fused_qkv is not None:
+            # the projections inside the attention launch — where the slab's shape runs it (else: project now, as usual)
+            fproj = (self.o_proj.weight, self.o_proj.bias)
+            if gctx is not None:
+                row = slab.stash_row(num_heads)
+                fused_out = slab.decode_step_qkv(hidden_states, fused_qkv[0], fused_qkv[1], num_heads, kv_seq_len, past_len, cos,
+                                                 sin, row, step=gctx.state_for(slab, cos, sin), proj=fproj)
+                if fused_out is not None:
+                    stash = row[:, :, None, :kv_seq_len]
+                    gctx.touched.append((self, slab, None))
+            elif position_ids is None and (attention_mask is None or assume_causal):
+                stash = torch.empty(bsz, num_heads, 1, kv_seq_len, dtype=dtype, device=device)
+                fused_out = slab.decode_step_qkv(hidden_states, fused_qkv[0], fused_qkv[1], num_heads, kv_seq_len, past_len, cos,
+                                                 sin, stash.view(bsz, num_heads, kv_seq_len), proj=fproj)
+            if fused_out is None:
+                qkv = ops.gemv(hidden_states, fused_qkv[0], fused_qkv[1])
+                nq = num_heads * head_dim
+                query_states, key_states, value_states = qkv[..., :nq], qkv[..., nq:2 * nq], qkv[..., 2 * nq:]
+        if fused_out is None:
+            q3 = query_states.view(bsz, num_heads, head_dim)
+            k3, v3 = key_states.view(bsz, num_kv_heads, head_dim), value_states.view(bsz, num_kv_heads, head_dim)
         if gctx is not None and attention_mask is not None and attention_mask.numel() \
                 and not torch.cuda.is_current_stream_capturing() and bool((attention_mask != 0).any().item()):
             # the captured step does not read the mask (device-length causal rule); checked on the eager warm-up step
@@ -215,7 +247,9 @@ def llama_pos_shift_attention_forward(
         # library issues both launches: one host call per layer-step)
         fused_proj = (self.o_proj.weight, self.o_proj.bias) if (native_rows and hp is None and ext is None) else None
         projected = None
-        if ext is not None and gctx is not None:
+        if fused_out is not None:
+            attn_output = fused_out
+        elif ext is not None and gctx is not None:
             if not ext[0].graph_capable():
                 raise RuntimeError("DecodeGraph captures every mode but local V pruning COMBINED with cascade importance "
                                    "(its accumulation runs on host lengths)")
