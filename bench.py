@@ -59,6 +59,15 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the dense / eager comparison legs")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL path even with one rank (testing)")
+    ap.add_argument("--exchange", choices=["per-layer", "flat"], default="per-layer",
+                    help="N>1 with the library-owned communicator (--gather native): 'per-layer' (default) = one all-gather of "
+                         "[B, H/N*d] after EVERY layer's attention launch, captured inside the token's graph — the dependency a "
+                         "real decoder has (layer l+1's projections consume layer l's gathered output; the plugin's "
+                         "head-parallel mode gathers in front of o_proj, modify_llama.py:146-163); 'flat' = ONE all-gather of the "
+                         "32 layers' slices per token: a lower bound on the communication, not a schedule a model can run")
+    ap.add_argument("--peer-store", action="store_true",
+                    help="N>1: the exchange through the library's peer-store all-gather (hipIpc-mapped receive buffers, every "
+                         "rank writes its slice straight into all peers: SURVEY 8e 'single-shot direct writes') instead of RCCL")
     ap.add_argument("--gather", choices=["native", "flat", "grouped", "per-layer"], default="native",
                     help="N>1, the exchange of a token's attention outputs: 'native' = ONE all-gather of the 32 layers' "
                          "slices on the library-owned RCCL communicator (spatten_comm_*), captured INSIDE the token's HIP "
@@ -213,7 +222,7 @@ def cpu_baseline(L, new_len, lo, hi):
 
 
 def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False, False), (True, False, False), (True, True, False),
-                                                              (True, True, True))):
+                                                              (True, True, True), (True, True, "fused"))):
     """The DROP-IN number: tokens/s through the patched HF forward itself (`llama_pos_shift_attention_forward`, called per
     layer with the arguments transformers 4.33 passes — hidden states, a zero mask, position_ids, the layer's (K, V)
     pair — including the module's q/k/v/o projections and every per-call host step), eager launches, Llama-2-7B geometry,
@@ -249,9 +258,11 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False, Fals
         for flag, fuse, gemv in variants:
             import contextlib
             import io
+            fused_step = gemv == "fused"        # round 4: the q/k/v projections inside the attention launch (65 launches per token)
+            gemv = bool(gemv)
             with contextlib.redirect_stdout(io.StringIO()):       # the constructor prints the reference's banner
                 cache = enable_spatten_llm(model, START, IMPORTANT, RECENT, prefill_stash=False, assume_causal=flag, fuse_qkv=fuse,
-                                   native_gemv=gemv)
+                                   native_gemv=gemv, fused_step=fused_step)
             hid = HEADS * HEAD_DIM
             x = torch.randn(1, P, hid, device=dev, dtype=torch.float32).to(dt)
             mask = torch.zeros(1, 1, P, P, dtype=dt, device=dev).masked_fill_(
@@ -277,7 +288,7 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False, Fals
             for t in range(n_tokens):
                 token(t)
             torch.cuda.synchronize()
-            key = "plugin_path_assume_causal_fused_qkv_native_gemv_tokens_per_s" if gemv else (
+            key = "plugin_path_assume_causal_fused_step_tokens_per_s" if fused_step else "plugin_path_assume_causal_fused_qkv_native_gemv_tokens_per_s" if gemv else (
                 "plugin_path_assume_causal_fused_qkv_tokens_per_s" if fuse else (
                     "plugin_path_assume_causal_tokens_per_s" if flag else "plugin_path_eager_tokens_per_s"))
             out[key] = round(n_tokens / (time.perf_counter() - t0), 2)
@@ -313,10 +324,11 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False, Fals
                 graph.step(xt)
             torch.cuda.synchronize()
             t_rep = time.perf_counter() - t0
-            sfx = "_fused_qkv_native_gemv" if gemv else ("_fused_qkv" if fuse else "")
+            sfx = "_fused_step" if fused_step else "_fused_qkv_native_gemv" if gemv else ("_fused_qkv" if fuse else "")
             out[f"plugin_path_graph{sfx}_tokens_per_s"] = round(n_rep / t_rep, 2)
             out[f"plugin_path_graph{sfx}_turn_incl_capture_tokens_per_s"] = round(TURN / t_turn, 2)
-            if gemv:
+            out[f"plugin_path_graph{sfx}_recaptures_in_timed_replays"] = graph.n_binds - 1      # (none — the slabs hold them)
+            if gemv and not fused_step:
                 # the reference's whole caller protocol through the plugin (run_spatten_llama.py:60-87), two timed chat turns:
                 # prune event from the last decode step's stashes -> prefill of a 64-token prompt through the patched
                 # forward -> 63 greedy-decode steps under ONE captured graph (re-captured per turn: the prune moves the cache)
@@ -600,12 +612,39 @@ def main():
             except Exception:
                 rccl_ranks = None
 
-    def run_slot(slot):
+    peer = None
+    if dist_on and native and args.peer_store:
+        try:
+            peer = hp.init_peer_store(max(staging2[0][0].numel() * 2 // world_eff, staging_flat[0].numel() * 2 // world_eff))
+        except Exception as e:      # noqa: BLE001
+            if rank == 0:
+                print(f"peer-store all-gather unavailable ({type(e).__name__}: {e}); using RCCL", file=sys.stderr)
+            peer = None
+        okp = torch.tensor([1 if peer is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(okp, op=dist.ReduceOp.MIN)
+        if int(okp.item()) == 0:
+            peer = None
+
+    def exchange(send, recv):
+        if peer is not None:
+            hp.allgather_peer(send, recv)
+        else:
+            hp.allgather_native(send, recv)
+
+    def run_slot(slot, with_exchange=True):
         if slot == 0:
             prune()
-        decode_token(new_len + slot + 1, slot & 1)
-        if native:      # the exchange is part of the token: same stream, same graph
-            hp.allgather_native(outs_flat[slot & 1].view(-1), staging_flat[slot & 1])
+        n, par = new_len + slot + 1, slot & 1
+        if native and with_exchange and args.exchange == "per-layer":
+            # dependency-faithful: layer l's gathered output exists before layer l + 1 is launched (same stream, same graph)
+            for l in range(L):
+                ops.attn_decode(q[l], Kd[l], Krd[l], Vd[l], n, cos, sin, n - 1, k_new=kn[l], v_new=vn[l],
+                                scores=stash[l], out=outs2[par][l], workspace=ws)
+                exchange(outs2[par][l].view(-1), staging2[par][l].view(-1))
+            return
+        decode_token(n, par)
+        if native and with_exchange:      # 'flat': the exchange is part of the token — same stream, same graph — but ONE per token
+            exchange(outs_flat[par].view(-1), staging_flat[par])
 
     # ---- HIP graphs: one per position in the turn (kv_len is a launch parameter) -------------------------
     graphs = None
@@ -657,18 +696,73 @@ def main():
     elapsed = time_region(lambda n: run_steps(n, args.warmup), args.steps, dist_on)
     tokens_per_s = B * args.steps / elapsed
 
+    # ---- what the exchange costs per token (round 4): the same decode-only slots replayed with and without the collectives,
+    # as graphs, over the same number of tokens; and — native communicator — the OTHER schedule (flat / per-layer) beside the
+    # one the headline number ran, so that both are on every line (also at one rank with --force-dist)
+    comm = None
+    if dist_on and native and graphs is not None:
+        try:
+            def capture(fn, slots):
+                gs = []
+                for sl in slots:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        fn(sl)
+                    gs.append(g)
+                return gs
+
+            def time_graphs(gs, reps=4):
+                for g in gs:
+                    g.replay()
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    for g in gs:
+                        g.replay()
+                torch.cuda.synchronize()
+                dt_ = torch.tensor([(time.perf_counter() - t0) / (reps * len(gs))], dtype=torch.float64, device=dev)
+                dist.all_reduce(dt_, op=dist.ReduceOp.MAX)
+                return float(dt_.item()) * 1e6
+
+            slots = list(range(1, 17))                     # decode-only slots (slot 0 carries the prune event)
+            run_slot(1, False); run_slot(2, False)
+            torch.cuda.synchronize()
+            t_none = time_graphs(capture(lambda sl: run_slot(sl, False), slots))
+            t_this = time_graphs([graphs[sl] for sl in slots])
+            other = "flat" if args.exchange == "per-layer" else "per-layer"
+            keep = args.exchange
+            args.exchange = other
+            run_slot(1); run_slot(2)
+            torch.cuda.synchronize()
+            t_other = time_graphs(capture(run_slot, slots))
+            args.exchange = keep
+            comm = {"exchange": keep, "us_per_token_no_exchange": round(t_none, 1), "us_per_token": round(t_this, 1),
+                    "comm_us_per_token": round(t_this - t_none, 1),
+                    f"us_per_token_{other.replace('-', '_')}": round(t_other, 1),
+                    f"comm_us_per_token_{other.replace('-', '_')}": round(t_other - t_none, 1),
+                    "collectives_per_token": L if keep == "per-layer" else 1,
+                    "bytes_per_rank_per_collective": (B * Hl * d * 2) if keep == "per-layer" else (L * B * Hl * d * 2),
+                    "transport": "peer-store (hipIpc direct writes)" if peer is not None else "RCCL all-gather"}
+        except Exception as e:      # noqa: BLE001 - the headline number must not depend on this side measurement
+            comm = {"error": f"{type(e).__name__}: {e}"}
+
     result = {
         "metric": "decode tokens/sec (attention path), Llama-2-7B N=4k, 50% token prune",
         "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "comm": comm,
         "config": {"workload": "llama2-7b attention path: 4096-token KV cache -> per-head top-k prune to 2048 "
                                "(start 4 / important 1020 / recent 1024) -> decode, 64-token turns",
                    "layers": L, "heads": HEADS, "head_dim": d, "batch": B, "kv_len_before_prune": CTX,
                    "kv_len_after_prune": new_len, "turn_tokens": TURN,
                    "prune_events_in_timed_region": -(-args.steps // TURN),
-                   "parallelism": (f"head-parallel x{world}, {args.scaling} scaling (B = {B}, H/{world} heads per rank; RCCL "
-                                   f"all-gather of every layer's output, {args.gather})") if dist_on else "single GPU",
+                   "parallelism": (f"head-parallel x{world}, {args.scaling} scaling (B = {B}, H/{world} heads per rank; "
+                                   f"all-gather of every layer's output, {args.gather}"
+                                   f"{', ' + args.exchange if native else ''})") if dist_on else "single GPU",
+                   "exchange": (args.exchange if native else args.gather) if dist_on else None,
+                   "comm_us_per_token": None if not comm else comm.get("comm_us_per_token"),
                    "rccl_ranks": rccl_ranks if native else (world if dist_on else None),
                    "launch": "hip-graph" if graphs is not None else "eager"},
     }
@@ -898,6 +992,19 @@ def main():
                 extras["decode_8192_bf16_keys_us"] = round(_time(lambda i: ops.attn_decode(q1, None, Krc[i % NC], Vc[i % NC], Np, cp, sp, Np - 1, out=o1, workspace=ws)), 2)
                 extras["decode_8192_pq_msb_only_us"] = round(_time(lambda i: ops.attn_decode_pq(q1, plc[i % NC], Vc[i % NC], Np, cp, sp, Np - 1, 0.0, out=o1, workspace=ws)), 2)
                 extras["decode_8192_pq_refetch_all_us"] = round(_time(lambda i: ops.attn_decode_pq(q1, plc[i % NC], Vc[i % NC], Np, cp, sp, Np - 1, 2.0, out=o1, workspace=ws)), 2)
+                # round 4 (ABI 4): the bit profiles — quantised VALUE plane + LSB-only refetch (spatten_attn_decode_pq); same rows
+                for kb_, vb_ in ops.PQ_PROFILES:
+                    ppl = []
+                    for kc_, vc_ in zip(Krc, Vc):
+                        pp_ = ops.PQProfilePlanes(1, HEADS, HEADS, Np, d, dev, key_bits=kb_, value_bits=vb_)
+                        ops.pq_pack_planes(kc_, vc_, pp_, 0, Np)
+                        ppl.append(pp_)
+                    need_ = torch.zeros(HEADS, dtype=torch.int32, device=dev)
+                    tag_ = f"decode_8192_pq_k{kb_}v{vb_}"
+                    extras[tag_ + "_msb_only_us"] = round(_time(lambda i: ops.attn_decode_pqv(q1, ppl[i % NC], Np, cp, sp, Np - 1, 0.0, out=o1, need_lsb=need_, workspace=ws)), 2)
+                    extras[tag_ + "_refetch_all_us"] = round(_time(lambda i: ops.attn_decode_pqv(q1, ppl[i % NC], Np, cp, sp, Np - 1, 2.0, out=o1, need_lsb=need_, workspace=ws)), 2)
+                    del ppl
+                extras["decode_8192_pq_refetch_all_vs_bf16_decode"] = round(extras["decode_8192_pq_k4v8_refetch_all_us"] / extras["decode_8192_bf16_keys_us"], 3)
                 # configs[2] (C3): the pruned 2048-row cache with 25 % of the heads pruned (24 of 32 launched);
                 # rotating over the 32 layers' slabs (1.1 GB)
                 hid = torch.arange(0, HEADS, dtype=torch.int32, device=dev)[torch.arange(HEADS, device=dev) % 4 != 3].contiguous()
@@ -950,6 +1057,22 @@ def main():
                 extras["c5_decode_13b_8192_kept_bf16_keys_us"] = round(_time(lambda i: ops.attn_decode(q5, None, K5[i % 4], V5[i % 4], N5, c5, s5, N5 - 1, out=o5, workspace=ws5)), 2)
                 extras["c5_decode_13b_8192_kept_pq_msb_only_us"] = round(_time(lambda i: ops.attn_decode_pq(q5, pl5[i % 4], V5[i % 4], N5, c5, s5, N5 - 1, 0.0, out=o5, workspace=ws5)), 2)
                 extras["c5_decode_13b_16384_dense_bf16_keys_us"] = round(_time(lambda i: ops.attn_decode(q5, None, K6[i % 2], V6[i % 2], 2 * N5, c5, s5, 2 * N5 - 1, out=o5, workspace=ws5)), 2)
+                # round 4: the (8, 8) profile — the RTL harness default — on the kept 8192 rows
+                pp5 = []
+                for kc_, vc_ in zip(K5, V5):
+                    pp_ = ops.PQProfilePlanes(1, H5, H5, N5, d, dev, key_bits=8, value_bits=8)
+                    ops.pq_pack_planes(kc_, vc_, pp_, 0, N5)
+                    pp5.append(pp_)
+                need5 = torch.zeros(H5, dtype=torch.int32, device=dev)
+                extras["c5_decode_13b_8192_kept_pq_k8v8_msb_only_us"] = round(_time(lambda i: ops.attn_decode_pqv(q5, pp5[i % 4], N5, c5, s5, N5 - 1, 0.0, out=o5, need_lsb=need5, workspace=ws5)), 2)
+                del pp5, pl5
+                # round 4: local V pruning as ONE launch on the dense 16384-row cache, 30 % of the V rows fetched
+                # (SpAttenController.scala:546-558,591-612) beside the plain step over the same rows (above)
+                st5 = torch.empty(1, H5, 2 * N5, dtype=dt, device=dev)
+                keep5 = int(0.3 * 2 * N5)
+                extras["c5_decode_13b_16384_local_v_30pct_us"] = round(_time(lambda i: ops.attn_decode_local_v(
+                    q5, K6[i % 2], V6[i % 2], 2 * N5, c5, s5, 2 * N5 - 1, keep5, st5, out=o5)), 2)
+                extras["c5_local_v_30pct_vs_plain_decode"] = round(extras["c5_decode_13b_16384_local_v_30pct_us"] / extras["c5_decode_13b_16384_dense_bf16_keys_us"], 3)
             except Exception as e:  # the headline number must not depend on the side measurements
                 extras["side_measurements_error"] = f"{type(e).__name__}: {e}"
             result["extras"] = extras

@@ -581,6 +581,24 @@ int spatten_comm_destroy(void* comm);
 int spatten_comm_info(void* comm, int* nranks_out, int* rank_out);
 int spatten_allgather(void* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
 
+/* Peer-store all-gather (ABI 4; SURVEY 8e: the decode step's exchange is latency-bound — 1 KiB per rank per layer at 8 GPUs —
+ * so "single-shot direct writes to all peers, all links concurrently" instead of a collective library's ring / tree steps).
+ * Every rank owns a receive window in its own HBM, mapped into every peer through hipIpc; ONE launch per all-gather writes
+ * this rank's slice into slot `rank` of every peer's window, publishes an epoch flag there, waits for the peers' flags in its
+ * own window and copies their slices out: recv[r*bytes .. ) = rank r's send.  A stream operation (capturable: the epoch lives
+ * in device memory).  Messages up to max_bytes_per_rank (a multiple of 8 bytes); larger exchanges (prefill) use spatten_allgather.
+ *   every rank:  spatten_peer_create(&peer, rank, nranks, max_bytes, my_handle)      my_handle: SPATTEN_PEER_HANDLE_BYTES
+ *   out of band: all-gather the handles (rank-major);   every rank: spatten_peer_connect(peer, all_handles)
+ *   per step:    spatten_peer_allgather(peer, send, recv, bytes, stream);   spatten_peer_status(peer, stream) at sync points
+ * (SPATTEN_ERR_TIMEOUT: a peer's flag did not arrive within the bounded wait — its slice was filled with 0xFF).
+ * nranks <= 16.  One process per GPU; HSA_ENABLE_IPC_MODE_LEGACY=0 where the driver only offers dmabuf IPC. */
+#define SPATTEN_PEER_HANDLE_BYTES 64
+int spatten_peer_create(void** peer_out, int rank, int nranks, size_t max_bytes_per_rank, void* handle_out);
+int spatten_peer_connect(void* peer, const void* handles);
+int spatten_peer_allgather(void* peer, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+int spatten_peer_status(void* peer, void* stream);
+int spatten_peer_destroy(void* peer);
+
 #ifdef __cplusplus
 }
 #endif

@@ -179,6 +179,16 @@ def _declare(lib):
     lib.spatten_comm_destroy.argtypes = [p]
     lib.spatten_allgather.restype = c_int
     lib.spatten_allgather.argtypes = [p, p, p, c_size_t, p]
+    lib.spatten_peer_create.restype = c_int
+    lib.spatten_peer_create.argtypes = [POINTER(c_void_p), i, i, c_size_t, p]
+    lib.spatten_peer_connect.restype = c_int
+    lib.spatten_peer_connect.argtypes = [p, p]
+    lib.spatten_peer_allgather.restype = c_int
+    lib.spatten_peer_allgather.argtypes = [p, p, p, c_size_t, p]
+    lib.spatten_peer_status.restype = c_int
+    lib.spatten_peer_status.argtypes = [p, p]
+    lib.spatten_peer_destroy.restype = c_int
+    lib.spatten_peer_destroy.argtypes = [p]
     lib.spatten_rope_single.restype = c_int
     lib.spatten_rope_single.argtypes = [i, p, i64, i64, i64, p, i64, i64, i64, p, p, i, p, i64, i,
                                         i, i, i, i, p]

@@ -80,6 +80,7 @@ class DecodeGraph:
         self.static_in: Optional[List[torch.Tensor]] = None
         self.static_out = None
         self.n_replays = 0
+        self.n_binds = 0                        # bindings so far (> 1: the graph outgrew its slabs and was re-captured)
         self.steps_traced = 0                   # device-length steps since the state was set (= state word 2 before a step)
         self._ext = None                        # SpattenExtensions of the patched modules, once a traced step met them
         self._past = None
@@ -98,6 +99,7 @@ class DecodeGraph:
         self.touched = []
         self.steps_traced = 0
         self.bind_id = object()                 # identity of this binding: the extensions restart their buffers with it
+        self.n_binds += 1
 
     def length_of(self, slab) -> int:
         return self.length + self._offset_of.get(id(slab), 0)

@@ -163,6 +163,64 @@ class HeadParallel:
             _lib.load().spatten_comm_destroy(self._comm)
             self._comm = None
 
+    # ---- the peer-store all-gather (include/spatten.h: spatten_peer_*): direct writes into every peer's receive window ----
+    def init_peer_store(self, max_bytes_per_rank: int, exchange_handles=None):
+        """Create this rank's receive window (on its CURRENT device), exchange the 64-byte hipIpc handles — through
+        torch.distributed (any backend), or through ``exchange_handles(my_handle: bytes) -> list[bytes]`` (rank-major) — and
+        map every peer's window.  Collective.  With one rank nothing is exchanged (loopback)."""
+        import ctypes
+
+        from . import _lib
+        lib = _lib.load()
+        peer = ctypes.c_void_p()
+        mine = ctypes.create_string_buffer(64)
+        _lib.check(lib.spatten_peer_create(ctypes.byref(peer), self.rank, self.world, int(max_bytes_per_rank), mine), "spatten_peer_create")
+        handles = list(exchange_handles(mine.raw)) if exchange_handles is not None else self.gather_handles(mine.raw)
+        if len(handles) != self.world or any(len(h) != 64 for h in handles):
+            lib.spatten_peer_destroy(peer)
+            raise ValueError("peer-store: the handle exchange must return one 64-byte handle per rank, rank-major")
+        blob = ctypes.create_string_buffer(b"".join(handles), 64 * self.world)
+        try:
+            _lib.check(lib.spatten_peer_connect(peer, blob), "spatten_peer_connect")
+        except Exception:
+            lib.spatten_peer_destroy(peer)
+            raise
+        self._peer = peer
+        return peer
+
+    def gather_handles(self, mine: bytes):
+        """Every rank's 64-byte window handle, rank-major, through torch.distributed (any backend; objects, not tensors:
+        the handles are host bytes)."""
+        if self.world == 1:
+            return [mine]
+        handles = [None] * self.world
+        dist.all_gather_object(handles, mine, group=self.group)
+        return handles
+
+    def allgather_peer(self, send: torch.Tensor, recv: torch.Tensor):
+        """recv[r * n : (r + 1) * n] = rank r's ``send`` through the peer windows — one launch on the current stream."""
+        from . import _lib
+        if getattr(self, "_peer", None) is None:
+            raise RuntimeError("init_peer_store() first")
+        if not (send.is_contiguous() and recv.is_contiguous()) or recv.numel() != self.world * send.numel() or recv.dtype != send.dtype:
+            raise ValueError("send / recv must be contiguous, recv = world x send")
+        rc = _lib.load().spatten_peer_allgather(self._peer, send.data_ptr(), recv.data_ptr(), send.numel() * send.element_size(),
+                                                torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "spatten_peer_allgather")
+        return recv
+
+    def peer_status(self):
+        """Synchronises the current stream; raises SpattenDeviceTimeout if a peer's slice did not arrive in an earlier call."""
+        from . import _lib
+        if getattr(self, "_peer", None) is not None:
+            _lib.check(_lib.load().spatten_peer_status(self._peer, torch.cuda.current_stream().cuda_stream), "spatten_peer_allgather")
+
+    def close_peer_store(self):
+        from . import _lib
+        if getattr(self, "_peer", None) is not None:
+            _lib.load().spatten_peer_destroy(self._peer)
+            self._peer = None
+
     def gather_head_scores(self, local_scores: torch.Tensor) -> torch.Tensor:
         """[H/G] fp32 -> [H] on every rank (head pruning: every rank then runs the same top-k)."""
         if self.gather_fn is not None:

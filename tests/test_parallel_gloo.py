@@ -167,3 +167,33 @@ print("ok")
     env = dict(os.environ, SPATTEN_RCCL_LIB="/nonexistent/librccl.so")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def _handles_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from spatten_amd.parallel import HeadParallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        hp = HeadParallel(8)
+        mine = bytes([rank + 1]) * 64                       # stands in for this rank's hipIpc window handle
+        got = hp.gather_handles(mine)
+        q.put((rank, [h[0] for h in got], all(len(h) == 64 for h in got)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_store_handle_exchange_is_rank_major_world2_gloo():
+    """The out-of-band step of the peer-store all-gather (include/spatten.h: spatten_peer_connect takes the handles rank-major):
+    every rank's 64-byte handle reaches every rank in rank order through torch.distributed (CPU, two processes)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_handles_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert res == [(0, [1, 2], True), (1, [1, 2], True)]
