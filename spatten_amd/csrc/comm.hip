@@ -152,10 +152,12 @@ __global__ __launch_bounds__(256) void peer_allgather_kernel(const PeerArgs a) {
     u64* dst = reinterpret_cast<u64*>(a.peers[p] + kPeerFlagBytes + ((size_t)half * a.nranks + a.rank) * a.slot);
     const u64* src = reinterpret_cast<const u64*>(a.send);
     for (size_t i = tid; i < words; i += blockDim.x) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __threadfence_system();
+    // the payload went out write-through (system-scope stores): every storing wave drains its own stores, then ONE lane
+    // raises the flag — no cache-wide release fence (a system-scope fence writes back the whole L2: several us per launch)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0)
-      __hip_atomic_store(reinterpret_cast<unsigned*>(a.peers[p] + (half * kPeerMaxRanks + a.rank) * 64), epoch, __ATOMIC_RELEASE,
+      __hip_atomic_store(reinterpret_cast<unsigned*>(a.peers[p] + (half * kPeerMaxRanks + a.rank) * 64), epoch, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
   }
   // 2. peer p's slice out of MY window
@@ -167,8 +169,8 @@ __global__ __launch_bounds__(256) void peer_allgather_kernel(const PeerArgs a) {
       int spins = 0;
       unsigned seen;
       do {
-        seen = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (seen != epoch) __builtin_amdgcn_s_sleep(8);
+        seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // (the slices are read with
+        if (seen != epoch) __builtin_amdgcn_s_sleep(2);                                   //  system-scope loads: no acquire fence)
       } while (seen != epoch && ++spins < (1 << 22));
       ok = seen == epoch;
       if (!ok) atomicOr(a.state + 2, 1u);
@@ -182,7 +184,6 @@ __global__ __launch_bounds__(256) void peer_allgather_kernel(const PeerArgs a) {
   // 3. the last block of the launch advances the epoch (the launch is its own epoch source: replayable)
   __syncthreads();
   if (tid == 0) {
-    __threadfence();
     const unsigned done = atomicAdd(a.state + 1, 1u);
     if (done == (unsigned)a.nranks - 1u) {
       __hip_atomic_store(a.state + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -60,9 +60,17 @@ def test_extension_arguments_are_validated(hf_llama):
         enable_spatten_llm(hf_llama, 4, 8, 8, pq_threshold=0.1, local_v_keep=0.5)
     with pytest.raises(ValueError, match="fraction"):
         enable_spatten_llm(hf_llama, 4, 8, 8, local_v_keep=1.5)
-    with pytest.raises(ValueError, match="auto_graph"):                 # modes whose decode step is not capturable
-        enable_spatten_llm(hf_llama, 4, 8, 8, local_v_keep=0.5, auto_graph=True)
+    with pytest.raises(ValueError, match="auto_graph"):                 # the one mode whose decode step is not capturable
+        enable_spatten_llm(hf_llama, 4, 8, 8, local_v_keep=0.5, importance_mode="cascade", auto_graph=True)
     assert not hasattr(hf_llama, "_spatten_auto_graph")
+    with pytest.raises(ValueError, match="pq_threshold"):               # round 4: bit profiles, fused step
+        enable_spatten_llm(hf_llama, 4, 8, 8, pq_profile=(4, 8))
+    with pytest.raises(ValueError, match="one of"):
+        enable_spatten_llm(hf_llama, 4, 8, 8, pq_threshold=0.1, pq_profile=(5, 8))
+    with pytest.raises(ValueError, match="cascade"):
+        enable_spatten_llm(hf_llama, 4, 8, 8, pq_threshold=0.1, pq_profile=(4, 8), importance_mode="cascade")
+    with pytest.raises(ValueError, match="fused_step"):
+        enable_spatten_llm(hf_llama, 4, 8, 8, fused_step=True)
     c = enable_spatten_llm(hf_llama, 4, 8, 8, importance_mode="cascade", prefill_stash=False)     # stash-free cascade
     assert c.ext.cascade and c.ext.prefill_wants_lse(torch.bfloat16, 128, 64, False)
     assert not c.ext.prefill_wants_lse(torch.float32, 128, 64, False) and not c.ext.prefill_wants_lse(torch.bfloat16, 128, 64, True)
