@@ -857,7 +857,24 @@ def main():
                 lc()
             torch.cuda.synchronize()
             result["prune_event"]["layer_cascade_prune_event_us_incl_allocation"] = round((time.perf_counter() - t0) / 3 * 1e6, 1)
-            del accs, acc_new, plan3
+            # round 4: like the plain event above, into PRE-ALLOCATED destination planes, by device events
+            nl_ = [START + k_ + (CTX - hi) for k_ in keeps_lc]
+            Kd_lc = [torch.empty(B, Hl, cap, d, dtype=dt, device=dev) for _ in range(L)]
+            Vd_lc = [torch.empty_like(x) for x in Kd_lc]
+            Krd_lc = [torch.empty_like(x) for x in Kd_lc]
+            for tag_ in ("layer_cascade_prune_event_us",):
+                lc2 = lambda: ops.prune_layer_cascade(importance, [None] * L, 0, Kp, Vp, [CTX] * L, [hi] * L, keeps_lc, START,
+                                                      [cap] * L, (cos, sin), accs, dst=(Kd_lc, Vd_lc, Krd_lc))
+                lc2()
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(5):
+                    lc2()
+                e1.record()
+                torch.cuda.synchronize()
+                result["prune_event"][tag_] = round(e0.elapsed_time(e1) * 1e3 / 5, 1)
+            result["prune_event"]["layer_cascade_vs_plain_event"] = round(result["prune_event"]["layer_cascade_prune_event_us"] / result["prune_event"]["us_all_layers"], 3)
+            del accs, acc_new, plan3, Kd_lc, Vd_lc, Krd_lc
             prune()   # restore the shadow planes for whatever runs next
 
         # ---- dense comparison legs ---------------------------------------------------------------------

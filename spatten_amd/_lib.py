@@ -210,8 +210,6 @@ def _declare(lib):
 
     lib.spatten_prune_layer_cascade.restype = c_int
     lib.spatten_prune_layer_cascade.argtypes = [i, i, i, p, p, p, p, p, p, p, p, p, p, p, p, i, p, i, p, i64, p, p, i, i, i, i, p]
-
-
 def load():
     """Load (once) and return the ctypes handle.  Raises SpattenLibraryError if the .so is missing."""
     global _lib

@@ -30,10 +30,11 @@ struct ChainParams {
   int32_t* const* new_ids_ptrs;        // [layers] -> int32 [H, new_len] out: ids of the new cache's slots
   int32_t* idx; int64_t idx_sl, idx_sh;   // [layers, H, kmax] out: kept window positions, ascending
   uint32_t* keys; int64_t keys_sh;     // [H, >= max window] scratch (windows that do not fit the LDS copy)
-  int layers, start, lds_keys;         // windows up to lds_keys entries keep their keys in LDS
+  int layers, start, lds_keys, heads;  // windows up to lds_keys entries keep their keys in LDS
   int lds_ids;                         // ... and new-id rows up to lds_ids entries stay in LDS for the next layer's membership test
 };
 
+__device__ inline int gridDim_heads(const ChainParams& p) { return p.heads; }
 constexpr int kChainThreads = 1024;    // the chain is latency-bound on ONE workgroup per head: many threads, few iterations
 constexpr int kChainWaves = kChainThreads / 64;
 
@@ -44,8 +45,14 @@ __device__ inline int32_t slot_id(const LayerPrune& L, const int32_t* known, int
 // one workgroup per head walks the layers: rank (membership in the previous layer's kept ids -> score or -inf), exact top-k
 // of the window (radix select, ties: lowest position), the new slot ids.  Same keys, tie rule and output order as
 // cascade_rank_kernel + topk_select_kernel<float> + the id gather of round 2.
-template <typename T>
-__global__ __launch_bounds__(kChainThreads) void layer_cascade_select_kernel(const ChainParams p) {
+// PUBLISH: the kept positions go out write-through and a per-(layer, head) word is raised when they are complete.  (Round 4
+// built the event as ONE launch on it — 32 chain workgroups + 224 persistent gather workers waiting on those words, the
+// gather of layer l under the chain's layer l + 1 — bit-identical, and SLOWER: 1,061 us against 970 for the launches below at
+// Llama-2-7B geometry: the chain's LDS / barrier path does not get shorter, its global accesses get slower under the
+// gather's 5 TB/s, and 224 one-item-at-a-time workers gather more slowly than the free-running grid.  Removed again; the
+// flag is kept for the record and instantiated false.)
+template <typename T, bool PUBLISH>
+__device__ __forceinline__ void chain_body(const ChainParams& p, const int h, unsigned* ready, const unsigned gen) {
   // kHistCopies private histograms (wave w counts into copy w % kHistCopies): real score windows fall into a handful of
   // exponent bins, and same-address LDS atomics serialise (r03: one shared histogram was most of the chain's time)
   constexpr int kHistCopies = 8;
@@ -57,12 +64,36 @@ __global__ __launch_bounds__(kChainThreads) void layer_cascade_select_kernel(con
   // negative values, -inf of a non-member included), so the digits below them cannot separate two keys: skipped
   constexpr int kPasses = sizeof(T) == 4 ? 4 : (DT<T>::kId == SPATTEN_BF16 ? 2 : 3);
   constexpr unsigned kKeyMask = kPasses == 4 ? 0xFFFFFFFFu : (kPasses == 3 ? 0xFFFFFF00u : 0xFFFF0000u);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // the previous layer's new slot ids: the membership test is a binary search — 11 DEPENDENT loads per key — so the row is
   // kept in LDS when it fits (539 -> 438 us for the 32-layer chain at 3068-entry windows)
   int32_t* s_prev = reinterpret_cast<int32_t*>(s_keys + p.lds_keys);
   const int32_t* prev = nullptr;
   int n_prev = 0;
+  // Everything a layer reads from global memory — its scores, the token ids of its slots — does NOT depend on what the
+  // previous layer selected, so it is requested ONE LAYER AHEAD into registers (round 4): the per-layer critical path is then
+  // LDS traffic and barriers only (r03: 3-4 dependent global round trips per layer, 12 us per layer on one workgroup; under
+  // the overlapped event's gather traffic those round trips are 2-3x longer).  Thread t holds window positions t + 1024 q,
+  // q < kPf, the tail rows t + 1024 q, q < kPt, and the head row t; longer windows / tails load the rest in place.
+  constexpr int kPf = 4, kPt = 2;
+  T pf_sc[kPf];
+  int32_t pf_id[kPf], pf_tail[kPt], pf_head = 0;
+  auto prefetch = [&](int l) {
+    const LayerPrune L = p.lay[l];
+    const T* score = (const T*)p.score_ptrs[l] + h * L.score_sh;
+    const int32_t* known = p.known_ptrs[l] ? p.known_ptrs[l] + h * L.known_sh : nullptr;
+    const int W = (int)L.hi - p.start, tail = (int)(L.len - L.hi);
+#pragma unroll
+    for (int q = 0; q < kPf; ++q) {
+      const int i = min(tid + q * kChainThreads, max(W - 1, 0)), j = p.start + i;
+      pf_sc[q] = score[j];
+      pf_id[q] = slot_id(L, known, j);
+    }
+#pragma unroll
+    for (int q = 0; q < kPt; ++q) pf_tail[q] = slot_id(L, known, (int)L.hi + min(tid + q * kChainThreads, max(tail - 1, 0)));
+    pf_head = slot_id(L, known, min(tid, max(p.start - 1, 0)));
+  };
+  prefetch(0);
   for (int l = 0; l < p.layers; ++l) {
     const LayerPrune L = p.lay[l];
     const T* score = (const T*)p.score_ptrs[l] + h * L.score_sh;
@@ -70,17 +101,37 @@ __global__ __launch_bounds__(kChainThreads) void layer_cascade_select_kernel(con
     const int W = (int)L.hi - p.start, k = (int)L.k;
     int32_t* out = p.idx + l * p.idx_sl + h * p.idx_sh;
     uint32_t* keys = W <= p.lds_keys ? s_keys : p.keys + h * p.keys_sh;
+    // this layer's prefetched values move to their own registers: the prefetch of layer l + 1 reuses pf_*
+    T my_sc[kPf];
+    int32_t my_id[kPf], my_tail[kPt];
+    const int32_t my_head = pf_head;
+#pragma unroll
+    for (int q = 0; q < kPf; ++q) { my_sc[q] = pf_sc[q]; my_id[q] = pf_id[q]; }
+#pragma unroll
+    for (int q = 0; q < kPt; ++q) my_tail[q] = pf_tail[q];
+    if (l + 1 < p.layers) prefetch(l + 1);
     // ---- keys of the window
-    for (int i = tid; i < W; i += kChainThreads) {
-      const int j = p.start + i;
-      bool member = true;
-      if (prev) {
-        const int32_t want = slot_id(L, known, j);
-        int lo = 0, hi = n_prev;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (prev[mid] < want) lo = mid + 1; else hi = mid; }
-        member = lo < n_prev && prev[lo] == want;
+    {
+      int q = 0;
+      for (int i = tid; i < W; i += kChainThreads, ++q) {
+        const int j = p.start + i;
+        bool member = true;
+        T scv = my_sc[0];
+        int32_t want = 0;
+        if (q < kPf) {
+#pragma unroll
+          for (int qq = 0; qq < kPf; ++qq) if (qq == q) { scv = my_sc[qq]; want = my_id[qq]; }
+        } else {
+          scv = score[j];
+          want = slot_id(L, known, j);
+        }
+        if (prev) {
+          int lo = 0, hi = n_prev;
+          while (lo < hi) { const int mid = (lo + hi) >> 1; if (prev[mid] < want) lo = mid + 1; else hi = mid; }
+          member = lo < n_prev && prev[lo] == want;
+        }
+        keys[i] = ordered_key(member ? DT<T>::to_f32(scv) : -INFINITY) & kKeyMask;
       }
-      keys[i] = ordered_key(member ? DT<T>::to_f32(score[j]) : -INFINITY) & kKeyMask;
     }
     __threadfence_block();
     __syncthreads();
@@ -127,10 +178,14 @@ __global__ __launch_bounds__(kChainThreads) void layer_cascade_select_kernel(con
       k_rem -= s_sel[1];
     }
     const unsigned thr = prefix, need_eq = k_rem;
-    // ---- order-preserving compaction: everything above the threshold, the first need_eq at it
+    // ---- order-preserving compaction: everything above the threshold, the first need_eq at it.  The thread that keeps
+    // window position i also knows that slot's token id (prefetched): the new cache's id row is written here, not gathered
+    int32_t* nid = p.new_ids_ptrs[l] + h * L.new_ids_sh;
+    const int lp = (int)L.new_len;
+    const bool in_lds = lp <= p.lds_ids;
     unsigned run_eq = 0, run_kept = 0;
-    int parity = 0;
-    for (int base = 0; base < W; base += kChainThreads, parity ^= 1) {
+    int parity = 0, q = 0;
+    for (int base = 0; base < W; base += kChainThreads, parity ^= 1, ++q) {
       const int i = base + tid;
       const bool in = i < W;
       const unsigned key = in ? keys[i] : 0u;
@@ -151,27 +206,57 @@ __global__ __launch_bounds__(kChainThreads) void layer_cascade_select_kernel(con
       const unsigned long long lt = (1ull << lane) - 1ull;
       const bool keep = gt || (eq && eq_base + __popcll(m_eq & lt) < need_eq);
       const unsigned pos = kept_base + __popcll(__ballot(keep) & lt);
-      if (keep && pos < (unsigned)k) out[pos] = p.start + i;
+      if (keep && pos < (unsigned)k) {
+        if (PUBLISH) __hip_atomic_store(out + pos, p.start + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
+        else out[pos] = p.start + i;
+        int32_t id = 0;
+        if (q < kPf) {
+#pragma unroll
+          for (int qq = 0; qq < kPf; ++qq) if (qq == q) id = my_id[qq];
+        } else {
+          id = slot_id(L, known, p.start + i);
+        }
+        nid[p.start + pos] = id;
+        if (in_lds) s_prev[p.start + pos] = id;
+      }
       run_eq = tot_eq;
       run_kept = tot_kept;
     }
-    __threadfence_block();
-    __syncthreads();
-    // ---- the ids of the new cache's slots (start | kept | tail): what the next layer tests membership against
-    int32_t* nid = p.new_ids_ptrs[l] + h * L.new_ids_sh;
-    const int lp = (int)L.new_len;
-    const bool in_lds = lp <= p.lds_ids;
-    for (int r = tid; r < lp; r += kChainThreads) {
-      const int src = r < p.start ? r : (r < p.start + k ? out[r - p.start] : (int)L.hi + (r - p.start - k));
-      const int32_t id = slot_id(L, known, src);
-      nid[r] = id;
-      if (in_lds) s_prev[r] = id;
+    // ---- the ids of the head rows [0, start) and of the tail rows [hi, len) of the new cache (prefetched)
+    if (tid < p.start) { nid[tid] = my_head; if (in_lds) s_prev[tid] = my_head; }
+    for (int r = kChainThreads; r + tid < p.start; r += kChainThreads) {      // (start > 1024: not prefetched)
+      const int32_t id = slot_id(L, known, r + tid);
+      nid[r + tid] = id; if (in_lds) s_prev[r + tid] = id;
     }
+    {
+      const int tail = (int)(L.len - L.hi);
+      int qt = 0;
+      for (int t = tid; t < tail; t += kChainThreads, ++qt) {
+        int32_t id = 0;
+        if (qt < kPt) {
+#pragma unroll
+          for (int qq = 0; qq < kPt; ++qq) if (qq == qt) id = my_tail[qq];
+        } else {
+          id = slot_id(L, known, (int)L.hi + t);
+        }
+        const int r = p.start + k + t;
+        nid[r] = id;
+        if (in_lds) s_prev[r] = id;
+      }
+    }
+    if (PUBLISH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its own stores ...
     __threadfence_block();
     __syncthreads();
+    if (PUBLISH && tid == 0)                                            // ... then ONE lane raises the layer's word
+      __hip_atomic_store(ready + (size_t)l * gridDim_heads(p) + h, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     prev = in_lds ? s_prev : nid;
     n_prev = lp;
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kChainThreads) void layer_cascade_select_kernel(const ChainParams p) {
+  chain_body<T, false>(p, (int)blockIdx.x, nullptr, 0u);
 }
 
 struct RaggedParams {
@@ -184,25 +269,43 @@ struct RaggedParams {
 };
 
 // the fused gather + concat (+ rotated shadow) of kv_compact_kernel with every layer's own lengths and strides
-template <typename T>
-__global__ __launch_bounds__(256) void kv_compact_ragged_kernel(const RaggedParams p) {
-  const int layer = blockIdx.z >> 1, t = blockIdx.z & 1;
-  const LayerPrune L = p.lay[layer];
-  const int rloc = threadIdx.x / p.half_ppr, piece = threadIdx.x - rloc * p.half_ppr;
-  const int r = blockIdx.x * p.rows_per_block + rloc;
-  if (rloc >= p.rows_per_block || r >= (int)L.new_len) return;
-  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+// one 256-thread item: rows [rb * rows_per_block, +rows_per_block) of plane t (0 = K + shadow, 1 = V) of (b, h) of `layer`, in
+// two halves so that a caller can put several items' loads in flight before the first store.
+// FRESH: the kept positions were published by another workgroup of the SAME launch -> agent-scope loads
+struct RaggedRow { u32x4 lo_v, hi_v; int64_t doff; int r; bool live; };
+template <typename T, bool FRESH>
+__device__ __forceinline__ RaggedRow ragged_load(const RaggedParams& p, const LayerPrune& L, const int layer, const int t, const int bh,
+                                                 const int rb, const int tid) {
+  RaggedRow o;
+  const int rloc = tid / p.half_ppr, piece = tid - rloc * p.half_ppr;
+  const int r = rb * p.rows_per_block + rloc;
+  o.r = r;
+  o.live = rloc < p.rows_per_block && r < (int)L.new_len && rb >= 0;
+  o.doff = 0;
+  if (!o.live) return o;
+  const int b = bh / p.H, h = bh - b * p.H;
   const int k = (int)L.k, half_bytes = p.row_bytes >> 1;
   int src_row;
   if (r < p.start) src_row = r;
-  else if (r < p.start + k) src_row = p.idx[layer * p.idx_sl + h * p.idx_sh + (r - p.start)];
-  else src_row = (int)L.hi + (r - p.start - k);
+  else if (r < p.start + k) {
+    const int32_t* ip = p.idx + layer * p.idx_sl + h * p.idx_sh + (r - p.start);
+    src_row = FRESH ? __hip_atomic_load(ip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *ip;
+  } else src_row = (int)L.hi + (r - p.start - k);
   const char* sbase = (const char*)(t == 0 ? p.k_src_ptrs[layer] : p.v_src_ptrs[layer]);
-  char* dbase = (char*)(t == 0 ? p.k_dst_ptrs[layer] : p.v_dst_ptrs[layer]);
   const char* sp = sbase + (b * L.src_sb + h * L.src_sh) * p.es + (int64_t)src_row * p.row_bytes + piece * 16;
-  const int64_t doff = (b * L.dst_sb + h * L.dst_sh) * p.es + (int64_t)r * p.row_bytes + piece * 16;
-  const u32x4 lo_v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp));
-  const u32x4 hi_v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp + half_bytes));
+  o.doff = (b * L.dst_sb + h * L.dst_sh) * p.es + (int64_t)r * p.row_bytes + piece * 16;
+  o.lo_v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp));
+  o.hi_v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp + half_bytes));
+  return o;
+}
+template <typename T>
+__device__ __forceinline__ void ragged_store(const RaggedParams& p, const int layer, const int t, const int tid, const RaggedRow& o) {
+  if (!o.live) return;
+  const int rloc = tid / p.half_ppr, piece = tid - rloc * p.half_ppr;
+  const int half_bytes = p.row_bytes >> 1, r = o.r;
+  const int64_t doff = o.doff;
+  const u32x4 lo_v = o.lo_v, hi_v = o.hi_v;
+  char* dbase = (char*)(t == 0 ? p.k_dst_ptrs[layer] : p.v_dst_ptrs[layer]);
   __builtin_nontemporal_store(lo_v, reinterpret_cast<u32x4*>(dbase + doff));
   __builtin_nontemporal_store(hi_v, reinterpret_cast<u32x4*>(dbase + doff + half_bytes));
   if (t == 0 && p.kr_dst_ptrs) {       // the rotated shadow of the new cache: row r at position r (modify_llama.py:103-104)
@@ -234,6 +337,14 @@ __global__ __launch_bounds__(256) void kv_compact_ragged_kernel(const RaggedPara
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void kv_compact_ragged_kernel(const RaggedParams p) {
+  const int layer = blockIdx.z >> 1, t = blockIdx.z & 1;
+  const LayerPrune L = p.lay[layer];
+  const RaggedRow row = ragged_load<T, false>(p, L, layer, t, (int)blockIdx.y, (int)blockIdx.x, (int)threadIdx.x);
+  ragged_store<T>(p, layer, t, (int)threadIdx.x, row);
+}
+
 __global__ __launch_bounds__(256) void acc_compact_ragged_kernel(const LayerPrune* __restrict__ lay,
                                                                  const float* const* __restrict__ src_ptrs,
                                                                  float* const* __restrict__ dst_ptrs,
@@ -251,6 +362,15 @@ __global__ __launch_bounds__(256) void acc_compact_ragged_kernel(const LayerPrun
 
 using namespace spatten;
 
+static int prune_layer_cascade_impl(int score_dtype, int kv_dtype, int layers, const void* lay_dev, const void* lay_host,
+                                    const void* const* score_ptrs, const int32_t* const* known_ptrs,
+                                    int32_t* const* new_ids_ptrs, const void* const* k_src_ptrs,
+                                    const void* const* v_src_ptrs, void* const* k_dst_ptrs, void* const* v_dst_ptrs,
+                                    void* const* kr_dst_ptrs, const void* cos, const void* sin, int table_rows,
+                                    int32_t* idx, int kmax, uint32_t* key_scratch, int64_t key_scratch_sh,
+                                    const float* const* acc_src_ptrs, float* const* acc_dst_ptrs, int batch, int heads,
+                                    int head_dim, int start, unsigned* sync_words, unsigned generation, void* stream);
+
 extern "C" int spatten_prune_layer_cascade(int score_dtype, int kv_dtype, int layers, const void* lay_dev, const void* lay_host,
                                            const void* const* score_ptrs, const int32_t* const* known_ptrs,
                                            int32_t* const* new_ids_ptrs, const void* const* k_src_ptrs,
@@ -259,6 +379,19 @@ extern "C" int spatten_prune_layer_cascade(int score_dtype, int kv_dtype, int la
                                            int32_t* idx, int kmax, uint32_t* key_scratch, int64_t key_scratch_sh,
                                            const float* const* acc_src_ptrs, float* const* acc_dst_ptrs, int batch, int heads,
                                            int head_dim, int start, void* stream) {
+  return prune_layer_cascade_impl(score_dtype, kv_dtype, layers, lay_dev, lay_host, score_ptrs, known_ptrs, new_ids_ptrs, k_src_ptrs,
+                                  v_src_ptrs, k_dst_ptrs, v_dst_ptrs, kr_dst_ptrs, cos, sin, table_rows, idx, kmax, key_scratch,
+                                  key_scratch_sh, acc_src_ptrs, acc_dst_ptrs, batch, heads, head_dim, start, nullptr, 0u, stream);
+}
+
+static int prune_layer_cascade_impl(int score_dtype, int kv_dtype, int layers, const void* lay_dev, const void* lay_host,
+                                           const void* const* score_ptrs, const int32_t* const* known_ptrs,
+                                           int32_t* const* new_ids_ptrs, const void* const* k_src_ptrs,
+                                           const void* const* v_src_ptrs, void* const* k_dst_ptrs, void* const* v_dst_ptrs,
+                                           void* const* kr_dst_ptrs, const void* cos, const void* sin, int table_rows,
+                                           int32_t* idx, int kmax, uint32_t* key_scratch, int64_t key_scratch_sh,
+                                    const float* const* acc_src_ptrs, float* const* acc_dst_ptrs, int batch, int heads,
+                                    int head_dim, int start, unsigned* sync_words, unsigned generation, void* stream) {
   if (!ok_dtype(score_dtype) || !ok_dtype(kv_dtype) || layers <= 0 || !lay_dev || !lay_host || !score_ptrs || !known_ptrs ||
       !new_ids_ptrs || !k_src_ptrs || !v_src_ptrs || !k_dst_ptrs || !v_dst_ptrs || !idx || !key_scratch || batch <= 0 ||
       heads <= 0 || start < 0 || kmax <= 0)
@@ -283,16 +416,14 @@ extern "C" int spatten_prune_layer_cascade(int score_dtype, int kv_dtype, int la
   ChainParams c{};
   c.lay = (const LayerPrune*)lay_dev; c.score_ptrs = score_ptrs; c.known_ptrs = known_ptrs; c.new_ids_ptrs = new_ids_ptrs;
   c.idx = idx; c.idx_sl = (int64_t)heads * kmax; c.idx_sh = kmax; c.keys = key_scratch; c.keys_sh = key_scratch_sh;
-  c.layers = layers; c.start = start;
+  c.layers = layers; c.start = start; c.heads = heads;
   int64_t max_w = 0;
   for (int l = 0; l < layers; ++l) max_w = std::max(max_w, H_[l].hi - start);
   // 60 KB of dynamic LDS (+ the histogram): the window's keys first, the previous layer's ids in what is left; longer
   // windows / rows fall back to the global scratch / the global id rows
   c.lds_keys = (int)std::min<int64_t>(max_w, 15360);
   c.lds_ids = (int)std::min<int64_t>(max_new, 15360 - c.lds_keys);
-  SPATTEN_BY_DTYPE(score_dtype, hipLaunchKernelGGL((layer_cascade_select_kernel<T>), dim3((unsigned)heads), dim3(kChainThreads),
-                                                   (size_t)(c.lds_keys + c.lds_ids) * sizeof(uint32_t), st, c));
-  if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
+  const size_t lds = (size_t)(c.lds_keys + c.lds_ids) * sizeof(uint32_t);
   const int es = kv_dtype == SPATTEN_F32 ? 4 : 2;
   RaggedParams r{};
   r.lay = (const LayerPrune*)lay_dev; r.k_src_ptrs = k_src_ptrs; r.v_src_ptrs = v_src_ptrs; r.k_dst_ptrs = k_dst_ptrs;
@@ -304,9 +435,15 @@ extern "C" int spatten_prune_layer_cascade(int score_dtype, int kv_dtype, int la
   if (r.half_ppr > 256) return SPATTEN_ERR_UNSUPPORTED;
   r.rows_per_block = 256 / r.half_ppr;
   if ((long long)batch * heads > 65535 || 2 * layers > 65535) return SPATTEN_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)ceil_div((int)max_new, r.rows_per_block), (unsigned)(batch * heads), (unsigned)(2 * layers));
-  SPATTEN_BY_DTYPE(kv_dtype, hipLaunchKernelGGL((kv_compact_ragged_kernel<T>), grid, dim3(256), 0, st, r));
-  if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
+  (void)sync_words; (void)generation;
+  {
+    SPATTEN_BY_DTYPE(score_dtype, hipLaunchKernelGGL((layer_cascade_select_kernel<T>), dim3((unsigned)heads), dim3(kChainThreads),
+                                                     lds, st, c));
+    if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
+    const dim3 grid((unsigned)ceil_div((int)max_new, r.rows_per_block), (unsigned)(batch * heads), (unsigned)(2 * layers));
+    SPATTEN_BY_DTYPE(kv_dtype, hipLaunchKernelGGL((kv_compact_ragged_kernel<T>), grid, dim3(256), 0, st, r));
+    if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
+  }
   if (acc_src_ptrs) {
     hipLaunchKernelGGL(acc_compact_ragged_kernel, dim3((unsigned)ceil_div((int)max_new, 256), (unsigned)heads, (unsigned)layers),
                        dim3(256), 0, st, (const LayerPrune*)lay_dev, acc_src_ptrs, acc_dst_ptrs, idx, (int64_t)heads * kmax,

@@ -821,9 +821,10 @@ def prune_layer_cascade(scores: Sequence[torch.Tensor], known_ids: Sequence[Opti
                         Ks: Sequence[torch.Tensor], Vs: Sequence[torch.Tensor], lens: Sequence[int], his: Sequence[int],
                         keeps: Sequence[int], start: int, capacities: Sequence[int],
                         rope: Tuple[torch.Tensor, torch.Tensor],
-                        accs: Optional[Sequence[torch.Tensor]] = None):
+                        accs: Optional[Sequence[torch.Tensor]] = None, dst: Optional[tuple] = None):
     """The layer-to-layer cascade's prune event for all layers in three launches (include/spatten.h:
-    spatten_prune_layer_cascade).  scores[l] [H, >= len_l] (one dtype; rows contiguous); known_ids[l] int32 [H, n_known_l] or
+    spatten_prune_layer_cascade).  ``dst`` = (Kd, Vd, Krd) lists of pre-allocated destination planes [B, H, >= new_len_l, d]
+    (default: allocated here).  scores[l] [H, >= len_l] (one dtype; rows contiguous); known_ids[l] int32 [H, n_known_l] or
     None; Ks[l] / Vs[l] [B, H, >= len_l, d] (rows contiguous, K and V of a layer with equal strides); his[l] = window end;
     keeps[l] = tokens kept in the window (non-increasing); accs[l] fp32 [H, >= len_l] cascade accumulators (optional).
     Returns (K' list, V' list, Kr' list, idx list [H, k_l], new_ids list [H, new_len_l], new accs or None)."""
@@ -835,9 +836,15 @@ def prune_layer_cascade(scores: Sequence[torch.Tensor], known_ids: Sequence[Opti
     cos, sin = rope
     new_lens = [start + keeps[l] + (lens[l] - his[l]) for l in range(nl)]
     kmax = max(keeps)
-    Kd = [torch.empty(B, H, max(capacities[l], new_lens[l]), d, dtype=dt, device=dev) for l in range(nl)]
-    Vd = [torch.empty_like(x) for x in Kd]
-    Krd = [torch.empty_like(x) for x in Kd]
+    if dst is not None:
+        Kd, Vd, Krd = (list(x) for x in dst)
+        if any(Kd[l].shape[2] < new_lens[l] or Kd[l].stride() != Vd[l].stride() or Kd[l].stride() != Krd[l].stride()
+               or Kd[l].stride(3) != 1 or Kd[l].stride(2) != d for l in range(nl)):
+            raise ValueError("layer cascade: destination planes too small or not row-contiguous with equal strides")
+    else:
+        Kd = [torch.empty(B, H, max(capacities[l], new_lens[l]), d, dtype=dt, device=dev) for l in range(nl)]
+        Vd = [torch.empty_like(x) for x in Kd]
+        Krd = [torch.empty_like(x) for x in Kd]
     new_ids = [torch.empty(H, new_lens[l], dtype=torch.int32, device=dev) for l in range(nl)]
     new_accs = None
     if accs is not None:
@@ -863,10 +870,10 @@ def prune_layer_cascade(scores: Sequence[torch.Tensor], known_ids: Sequence[Opti
     flat = torch.tensor([0 if t is None else t.data_ptr() for g in groups for t in g], dtype=torch.int64).to(dev)
     ptr = lambda i: flat[i * nl:(i + 1) * nl].data_ptr()
     tab_dev = tab.to(dev)
-    rc = lib.spatten_prune_layer_cascade(
-        _dt(scores[0]), _dt(Ks[0]), nl, tab_dev.data_ptr(), tab.data_ptr(), ptr(0), ptr(1), ptr(2), ptr(3), ptr(4), ptr(5), ptr(6),
-        ptr(7), cos.data_ptr(), sin.data_ptr(), cos.shape[0], idx.data_ptr(), kmax, scratch.data_ptr(), scratch.stride(0),
-        ptr(8) if accs is not None else None, ptr(9) if accs is not None else None, B, H, d, start, _stream())
+    args = (_dt(scores[0]), _dt(Ks[0]), nl, tab_dev.data_ptr(), tab.data_ptr(), ptr(0), ptr(1), ptr(2), ptr(3), ptr(4), ptr(5), ptr(6),
+            ptr(7), cos.data_ptr(), sin.data_ptr(), cos.shape[0], idx.data_ptr(), kmax, scratch.data_ptr(), scratch.stride(0),
+            ptr(8) if accs is not None else None, ptr(9) if accs is not None else None, B, H, d, start)
+    rc = lib.spatten_prune_layer_cascade(*args, _stream())
     _lib.check(rc, "spatten_prune_layer_cascade")
     keep_alive = (flat, tab_dev, scratch)            # referenced until the launches were issued
     del keep_alive
