@@ -196,6 +196,41 @@ def cpu_baseline(L, new_len, lo, hi):
            "cpu_model": _cpu_model(), "logical_cpus": os.cpu_count(), "physical_cores": phys,
            "accepted_vs_reference": "profiles/r02_cpu_port_vs_reference.json (mirror / imported reference = 0.87-0.97 decode, "
                                     "0.89-0.98 prune, build container, 1 and 8 threads)"}
+    try:
+        # ---- how often does the KEPT SET differ from the reference's at C2 scale?  One decode step on
+        # a 4095-token cache: the mirror's stash (the reference's op sequence, bf16 on the host) -> the reference's top-k
+        # (kv_cache_token_pruning.py:59-63) against the HIP kernel's stash -> the HIP select, per head
+        if torch.cuda.is_available():
+            from spatten_amd import ops
+            with torch.no_grad():
+                qc, kcn, vcn = (torch.randn(1, H, 1, d, generator=g).to(dt) for _ in range(3))
+                pkc = (torch.randn(1, H, CTX - 1, d, generator=g) * d ** -0.5).to(dt)
+                pvc = torch.randn(1, H, CTX - 1, d, generator=g).to(dt)
+                cosf, sinf = tm.rotary_table(CTX, d, dt)
+                _, st_ref, _ = tm.decode_core(qc, kcn, vcn, pkc, pvc, cosf, sinf)
+                sel = st_ref.sum(0).sum(1)[:, START:CTX - RECENT]
+                idx_ref = torch.topk(sel, IMPORTANT, dim=-1).indices.sort().values + START
+                dev_ = torch.device("cuda", torch.cuda.current_device())
+                cg, sg = ops.rope_table(CTX, d, dt, dev_)
+                kd = torch.zeros(1, H, CTX, d, dtype=dt, device=dev_)
+                vd, krd = torch.zeros_like(kd), torch.zeros_like(kd)
+                kd[:, :, :CTX - 1], vd[:, :, :CTX - 1] = pkc.to(dev_), pvc.to(dev_)
+                ops.build_shadow(kd, krd, 0, CTX - 1, cg, sg)
+                st_gpu = torch.empty(1, H, CTX, dtype=dt, device=dev_)
+                ops.attn_decode(qc[:, :, 0].to(dev_), kd, krd, vd, CTX, cg, sg, CTX - 1, k_new=kcn[:, :, 0].to(dev_),
+                                v_new=vcn[:, :, 0].to(dev_), scores=st_gpu)
+                idx_gpu = ops.topk_select(st_gpu[0], START, CTX - RECENT, IMPORTANT).cpu()
+                st_g = st_gpu.cpu()[:, :, None, :]
+                same = [len(set(idx_ref[h].tolist()) & set(idx_gpu[h].tolist())) for h in range(H)]
+                out["kept_set_vs_reference_c2"] = {
+                    "heads": H, "heads_with_identical_kept_set": int(sum(x == IMPORTANT for x in same)),
+                    "min_overlap": int(min(same)), "of": IMPORTANT,
+                    "stash_entries_differing": round(float((st_g != st_ref).float().mean()), 6),
+                    "how": "one decode step on a 4095-token cache, bf16: reference op sequence (oracle/torch_mirror.py) -> torch.topk "
+                           "against the HIP stash -> spatten_topk_select; a differing stash entry (<= 2 ulp) can only swap tokens "
+                           "that sit AT the threshold, where torch.topk's own choice among equal scores is unspecified"}
+    except Exception as e:      # noqa: BLE001 - informative only
+        out["kept_set_vs_reference_c2"] = {"error": f"{type(e).__name__}: {e}"}
     try:      # the C port beside it (-march=native build on this host when gcc is there)
         co.load(native=True)
         rs = np.random.default_rng(0)
