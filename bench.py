@@ -329,8 +329,9 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False, Fals
             out[key] = round(n_tokens / (time.perf_counter() - t0), 2)
             # ---- the same decode step as ONE captured HIP graph of the whole layer stack (spatten_amd/graph.py): the
             # device-resident step state (ABI 3) lets a single graph replay for every token of the turn
-            if flag and not fuse:
-                continue                # (assume_causal is implied under capture: graph legs for the plain and the fused form)
+            if (flag and not fuse) or fused_step:
+                continue                # (assume_causal is implied under capture: graph legs for the plain and the fused form;
+                                        #  fused_step applies to eager calls only — a traced step runs the separate launches)
             from spatten_amd.graph import DecodeGraph
 
             def step_fn(pst, xin):

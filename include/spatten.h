@@ -175,7 +175,10 @@ typedef struct spatten_decode_args {
      qkv_bias optional [3*heads*head_dim], qkv_exchange = spatten_decode_qkv_exchange_bytes() of device scratch (zero-filled
      once, one per workspace).  q, k_new, v_new must then be NULL: each workgroup projects its share of the head's q / k / v
      while the K/V stream of the step is already in flight (the values equal spatten_gemv's bit for bit).  Only where
-     spatten_decode_qkv_supported() says so; SPATTEN_ERR_UNSUPPORTED otherwise (launch spatten_gemv + the plain step). */
+     spatten_decode_qkv_supported() says so; SPATTEN_ERR_UNSUPPORTED otherwise (launch spatten_gemv + the plain step).
+     With proj_* set as well, the output projection runs inside the SAME launch when proj_n = 16 x the launch's workgroups
+     and heads*head_dim = 4096 (Llama-2-7B: the whole attention module of a decode step is one launch; same bits as
+     spatten_gemv(out)), as the second launch of the call otherwise. */
   const void* qkv_x; const void* qkv_weight; int64_t qkv_w_sn; const void* qkv_bias; void* qkv_exchange; int32_t qkv_hidden;
   int32_t pad5_;
 } spatten_decode_args_t;

@@ -434,6 +434,7 @@ struct DecodeCall {
   // the step's q / k / v projections fused into the launch (spatten_decode_args_t::qkv_*)
   const void* qkv_x = nullptr; const void* qkv_w = nullptr; int64_t qkv_w_sn = 0; const void* qkv_bias = nullptr;
   void* qkv_xch = nullptr; int qkv_hidden = 0;
+  bool step_oproj_off = false;   // (reserved: keep the output projection a separate launch)
 };
 int decode_rows(const DecodeCall& c, hipStream_t stream);
 // y[m, n] = sum_k x[m, k] W[n, k] (+ bias): the weight-streaming kernel of gemv.hip (C++ linkage for the other units)

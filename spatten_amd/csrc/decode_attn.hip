@@ -92,6 +92,10 @@ struct DecodeParams {
   // stride w_sn), optional bias [3 * H * D]; xch [units][3 * D] {value, tag} granules: the exchange of a head's q / k / v
   // elements between its splits
   const T* x; const T* wqkv; int64_t w_sn; const T* qkv_bias; unsigned long long* xch; int hidden;
+  // ... and (OPROJ) the step's OUTPUT projection (modify_llama.py:163): ow [n_out, H * D] row stride ow_sn, optional bias, y [n_out];
+  // ych [B * H * D] granules: the merged attention outputs of all heads, gathered by every workgroup; ych_gen: that
+  // exchange's own generation word (the per-head generations above may differ between heads)
+  const T* ow; int64_t ow_sn; const T* o_bias; T* y; unsigned long long* ych; unsigned* ych_gen; int n_out;
 };
 
 #ifndef SPATTEN_PQ_UP
@@ -135,7 +139,7 @@ __device__ inline void store_granule(unsigned long long* g, float v, unsigned ta
 // projections of the whole head have been exchanged).  The rest — tile arithmetic, reduction, publication, merge — is the
 // plain step's, bit for bit.
 template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0, bool NT = LEAN, bool CASC = false,
-          bool PIPE = false, bool DYN = false, bool FUSED = false>
+          bool PIPE = false, bool DYN = false, bool FUSED = false, bool OPROJ = false>
 __device__ __forceinline__ void decode_body(const DecodeParams<T>& p, const float* s_x = nullptr) {
   constexpr bool SCORES_ONLY = (MODE == 1);
   constexpr bool PQ = (KSRC != 0);
@@ -276,11 +280,12 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p, const floa
     q_raw[2] = V8::ldg(p.cos + (int64_t)pq * HALF + 8 * c);
     q_raw[3] = V8::ldg(p.sin + (int64_t)pq * HALF + 8 * c);
   }
-  unsigned gen_f = 0;
+  unsigned gen_f = 0, gen_y = 0;
   if (FUSED) {      // what does not depend on the projections goes out first; then B1: the projection waves are on their last pass
     n_raw[0] = V8::ldg(p.cos + (int64_t)p.nr_row * HALF + 8 * c);
     n_raw[1] = V8::ldg(p.sin + (int64_t)p.nr_row * HALF + 8 * c);
     gen_f = p.ws_cnt[(p.S > 1 ? 2 * unit + 1 : 0) + opaque_lane(0)];
+    if (OPROJ) gen_y = p.ych_gen[opaque_lane(0)];
 #if !(defined(SPATTEN_FUSED_EXP) && SPATTEN_FUSED_EXP == 2)
     // B1 — a bare s_barrier: __syncthreads() carries a fence, i.e. `s_waitcnt vmcnt(0)`, and the projection waves would
     // drain their in-flight weight passes in front of it (r04: the fused launch then took 29.5 us, the two launches 29.0)
@@ -640,6 +645,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p, const floa
   };
   if (p.S == 1) {
     if (!SCORES_ONLY && tid < D) outp[tid] = DT<T>::from_f32(o_tot / l_tot);
+    if (OPROJ && tid < D) store_granule(p.ych + (int64_t)unit * D + tid, DT<T>::round(o_tot / l_tot), (gen_y & 0x7FFFFFFFu) + 1u);
     if (lse_cur != nullptr && tid == 0) { float* ls = lse_cur + ((int64_t)(b * p.H + h) * p.lse_q + qi) * 2; ls[0] = m_run; ls[1] = l_tot; }
     const bool need1 = KSRC == 1 && (1.0f / l_tot) < p.pq_thr;                          // max prob = exp(0) / sum
     if (KSRC == 1 && tid == 0) p.pq_need[unit] = need1 ? 1 : 0;
@@ -761,6 +767,8 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p, const floa
     }
   }
   if (!SCORES_ONLY && g == 0) outp[e] = DT<T>::from_f32(og / lg);
+  // OPROJ: the merged head goes out to every workgroup's projection team as well (value = what `out` holds)
+  if (OPROJ && g == 0) store_granule(p.ych + (int64_t)unit * D + e, DT<T>::round(og / lg), (gen_y & 0x7FFFFFFFu) + 1u);
   if (!SCORES_ONLY && p.head_abs != nullptr) {
     if (KSRC == 1 && tid == 0) s_ticket = (1.0f / lg) < p.pq_thr ? 1u : 0u;               // reuse the ticket word
     if (KSRC == 1) __syncthreads();
@@ -817,8 +825,8 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_lean_kernel(T* krc, T* 
 // d = 128, a single-shot tile (<= 320 rows per split), S in {1, 2, 4, 8} with the polling merge (the barrier count of the
 // two teams must match: B1, B2 and the reduction's one LDS hop).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int D>
-__device__ __forceinline__ void qkv_projection_waves(const DecodeParams<T>& p, float* s_x) {
+template <typename T, int D, bool OPROJ>
+__device__ __forceinline__ void qkv_projection_waves(const DecodeParams<T>& p, float* s_x, T* s_y) {
   using V8 = Vec8<T>;
   using raw_t = typename V8::raw;
   using D8 = Dot8<T>;
@@ -935,27 +943,102 @@ __device__ __forceinline__ void qkv_projection_waves(const DecodeParams<T>& p, f
   SPATTEN_TSTAMP_T(10, kDecodeThreads);          // the head's q | k | v gathered
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS stores above have completed
   __builtin_amdgcn_s_barrier();                  // B2: q | k | v of the head are in LDS
+  if (!OPROJ) {
+    __builtin_amdgcn_s_barrier();                // B3: the reduction's LDS hop of the attention waves (decode_body)
+    return;
+  }
+  // ---- the output projection of the step (modify_llama.py:163; gemv.hip's mapping: this workgroup's 16 rows, 4 per wave, one
+  // pass over the H * D columns).  The weights do not depend on anything: they are requested NOW — the attention team is busy
+  // with its tile, reduction and merge for the next ~5 us, during which they stream — and wait in registers for the merged
+  // heads of ALL workgroups.
+  const int wg = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+  const int n0 = (wg * 4 + g) * 4;               // first of this wave's 4 output rows
+  const int Ko = p.H * D;                        // = C * 512 (checked on the host)
+  raw_t ow[4][C];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const T* wrow = p.ow + (int64_t)min(n0 + r, p.n_out - 1) * p.ow_sn;
+#pragma unroll
+    for (int c = 0; c < C; ++c) ow[r][c] = V8::ldg_stream(wrow + c * 512 + lane * 8);
+  }
+  const unsigned gy = p.ych_gen[opaque_lane(0)];
+  __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();                  // B3: the reduction's LDS hop of the attention waves (decode_body)
+  const unsigned tagy = (gy & 0x7FFFFFFFu) + 1u;
+  SPATTEN_TSTAMP_T(11, kDecodeThreads);          // B3 passed (the o_proj weights were requested before it)
+  if (g == 0) {       // gather the merged attention outputs of ALL heads: H * D granules, 16 per lane and sweep (r04 A/B: a quarter
+                      // per wave of the team is SLOWER, 37.5 against 36.4 us per layer — four times the polls in front of the merge)
+    bool fail = false;
+    for (int base = 0; base < Ko; base += 16 * kWave) {
+      unsigned long long gr[16];
+      int spins = 0;
+      bool landed;
+      do {
+        unsigned diff = 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          gr[k] = __hip_atomic_load(p.ych + base + lane + kWave * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          diff |= (unsigned)(gr[k] >> 32) ^ tagy;
+        }
+        landed = __all(diff == 0u);
+        if (!landed) __builtin_amdgcn_s_sleep(1);
+      } while (!landed && ++spins < (1 << 18));
+      fail |= !landed;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        s_y[base + lane + kWave * k] = DT<T>::from_f32(landed ? __uint_as_float((unsigned)gr[k]) : __builtin_nanf(""));
+    }
+    if (fail) atomicOr(p.ws_err, 1u);
+  }
+  SPATTEN_TSTAMP_T(12, kDecodeThreads);          // the merged heads of every workgroup are in LDS
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                  // B4 (the attention waves have terminated by now: only this team is counted)
+  asm volatile("" ::: "memory");
+  {
+    raw_t xo[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) xo[c] = *reinterpret_cast<const raw_t*>(s_y + c * 512 + lane * 8);
+    float oacc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      oacc[r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) oacc[r] = D8::dot(xo[c], ow[r][c], oacc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) oacc[r] = wave_sum(oacc[r]);
+    if (lane < 4 && n0 + lane < p.n_out) {
+      float v = oacc[0];
+#pragma unroll
+      for (int r = 1; r < 4; ++r) v = (lane == r) ? oacc[r] : v;
+      if (p.o_bias) v += DT<T>::to_f32(p.o_bias[n0 + lane]);
+      p.y[n0 + lane] = DT<T>::from_f32(v);
+    }
+  }
+  SPATTEN_TSTAMP_T(13, kDecodeThreads);          // this workgroup's 16 output rows are stored
+  // every workgroup has read this launch's generation before any head could be merged: advance it for the next launch
+  if (wg == 0 && tid == 0) p.ych_gen[0] = gy + 1u;
 }
 
-template <typename T, int D, int UNR, bool DYN>
+template <typename T, int D, int UNR, bool DYN, bool OPROJ>
 __global__ __launch_bounds__(2 * kDecodeThreads) void decode_qkv_kernel(T* krc, T* vc, const T* cos, const T* sin, int kv_sb,
                                                                         int kv_sh, int N, int chunk, int H, int pos_q,
                                                                         const DecodeParams<T> rest) {
   __shared__ float s_x[3 * D];
+  __shared__ __attribute__((aligned(16))) T s_y[OPROJ ? kGemvChunksFused * 512 : 8];
   DecodeParams<T> p = rest;
   p.krc = krc; p.vc = vc; p.cos = cos; p.sin = sin;
   p.kv_sb = kv_sb; p.kv_sh = kv_sh; p.q_sb = (int64_t)H * D; p.q_sh = D;
   p.N = N; p.chunk = chunk; p.H = H; p.pos_q = pos_q;
   if (threadIdx.x >= kDecodeThreads) {
-    qkv_projection_waves<T, D>(p, s_x);
+    qkv_projection_waves<T, D, OPROJ>(p, s_x, s_y);
     return;
   }
 #if defined(SPATTEN_FUSED_EXP) && SPATTEN_FUSED_EXP == 1     // A/B harness only: what does the projection team alone take?
   __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier();
   return;
 #endif
-  decode_body<T, D, UNR, 0, true, 0, true, false, false, DYN, true>(p, s_x);
+  decode_body<T, D, UNR, 0, true, 0, true, false, false, DYN, true, OPROJ>(p, s_x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1047,10 +1130,11 @@ static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_onl
         if (!decode_qkv_shape_ok(D, p.S, p.poll_merge) || !lean || !small || pipe || casc || !p.append || p.head_abs || !p.xch)
           return SPATTEN_ERR_UNSUPPORTED;
         const dim3 blk2(2 * kDecodeThreads);
-        if (dyn) hipLaunchKernelGGL((decode_qkv_kernel<T, D, U, true>), grid, blk2, 0, stream, p.krc, p.vc, p.cos, p.sin,
-                                    (int)p.kv_sb, (int)p.kv_sh, p.N, p.chunk, p.H, p.pos_q, p);
-        else hipLaunchKernelGGL((decode_qkv_kernel<T, D, U, false>), grid, blk2, 0, stream, p.krc, p.vc, p.cos, p.sin,
-                                (int)p.kv_sb, (int)p.kv_sh, p.N, p.chunk, p.H, p.pos_q, p);
+#define SPATTEN_QKV(DY, OP) hipLaunchKernelGGL((decode_qkv_kernel<T, D, U, DY, OP>), grid, blk2, 0, stream, p.krc, p.vc, p.cos, p.sin, \
+                                               (int)p.kv_sb, (int)p.kv_sh, p.N, p.chunk, p.H, p.pos_q, p)
+        if (p.ow != nullptr) { if (dyn) SPATTEN_QKV(true, true); else SPATTEN_QKV(false, true); }
+        else { if (dyn) SPATTEN_QKV(true, false); else SPATTEN_QKV(false, false); }
+#undef SPATTEN_QKV
         return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
       } else {
         return SPATTEN_ERR_UNSUPPORTED;
@@ -1145,6 +1229,13 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   const bool want_proj = c.proj_w != nullptr;
   if (want_proj && (!c.proj_out || c.proj_n <= 0 || c.n_q != 1 || scores_only || c.proj_w_sn < (int64_t)c.heads * c.head_dim))
     return SPATTEN_ERR_INVALID;
+  // the output projection INSIDE the fused projection + attention launch (round 4): when that launch runs at all, its grid has
+  // one workgroup per 16 output rows (gemv.hip's mapping) and the contraction is one 4096-column pass
+  static int env_oproj = -1;
+  if (env_oproj < 0) { const char* e = getenv("SPATTEN_FUSED_OPROJ"); env_oproj = e ? atoi(e) : 1; }
+  const bool proj_inside = want_proj && c.qkv_x && env_oproj != 0 && c.dtype != SPATTEN_F32 && c.head_dim == 128 && !c.step_oproj_off &&
+                           c.heads * c.head_dim == kGemvChunksFused * 512 && c.proj_n == 16 * S * n_active * c.batch &&
+                           c.proj_w_sn % 8 == 0 && c.proj_out_sb >= 0;
 #define SPATTEN_FILL(T)                                                                                  \
   DecodeParams<T> p;                                                                                     \
   p.q = (const T*)c.q; p.q_sb = c.q_sb; p.q_sh = c.q_sh; p.q_sq = c.q_sq;                                \
@@ -1152,6 +1243,12 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   p.append = c.k_new != nullptr || c.qkv_x != nullptr;                                                   \
   p.x = (const T*)c.qkv_x; p.wqkv = (const T*)c.qkv_w; p.w_sn = c.qkv_w_sn; p.qkv_bias = (const T*)c.qkv_bias;  \
   p.xch = (unsigned long long*)c.qkv_xch; p.hidden = c.qkv_hidden;                                       \
+  p.ow = nullptr; p.ow_sn = 0; p.o_bias = nullptr; p.y = nullptr; p.ych = nullptr; p.ych_gen = nullptr; p.n_out = 0; \
+  if (proj_inside) {                                                                                     \
+    p.ow = (const T*)c.proj_w; p.ow_sn = c.proj_w_sn; p.o_bias = (const T*)c.proj_bias; p.y = (T*)c.proj_out; p.n_out = c.proj_n; \
+    p.ych_gen = (unsigned*)((char*)c.qkv_xch + (size_t)units * 3 * c.head_dim * sizeof(unsigned long long)); \
+    p.ych = (unsigned long long*)((char*)p.ych_gen + 256);                                                \
+  }                                                                                                      \
   p.k_new = (const T*)(c.k_new ? c.k_new : (c.q ? c.q : c.cos)); p.v_new = (const T*)(c.k_new ? c.v_new : (c.q ? c.q : c.cos)); \
   p.new_sb = c.k_new ? c.new_sb : c.q_sb; p.new_sh = c.k_new ? c.new_sh : c.q_sh;                        \
   p.cos = (const T*)c.cos; p.sin = (const T*)c.sin; p.table_rows = c.table_rows;                         \
@@ -1181,7 +1278,7 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   p.sqrt_d = sqrtf((float)c.head_dim);                                                                   \
   {                                                                                                      \
     const int rc_ = dispatch_decode<T>(p, c.head_dim, n_active, scores_only, stream);                    \
-    if (rc_ != SPATTEN_OK || !want_proj) return rc_;                                                     \
+    if (rc_ != SPATTEN_OK || !want_proj || proj_inside) return rc_;                                      \
     return gemv_rows(c.dtype, c.out, c.out_sb, c.proj_w, c.proj_w_sn, c.proj_bias, c.proj_out, c.proj_out_sb, c.batch, \
                      c.proj_n, c.heads * c.head_dim, stream);                                            \
   }
@@ -1211,7 +1308,9 @@ extern "C" int spatten_decode_auto_splits(int batch, int heads, int head_dim, in
 
 extern "C" size_t spatten_decode_qkv_exchange_bytes(int batch, int heads, int head_dim) {
   if (batch <= 0 || heads <= 0 || head_dim <= 0) return 0;
-  return (size_t)batch * heads * 3 * head_dim * sizeof(unsigned long long);
+  // [units][3 d] granules: a head's q | k | v between its splits; then a 256-byte header (word 0: the generation of the
+  // output exchange) and [units][d] granules: the merged heads to every workgroup (the output projection inside the launch)
+  return (size_t)batch * heads * 3 * head_dim * sizeof(unsigned long long) + 256 + (size_t)batch * heads * head_dim * sizeof(unsigned long long);
 }
 
 extern "C" int spatten_decode_qkv_supported(int dtype, int batch, int heads, int kv_heads, int head_dim, int kv_len_layout) {

@@ -47,8 +47,10 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     ``fused_step=True`` (needs ``fuse_qkv`` and ``native_gemv``): the q / k / v projections of a single-token step run INSIDE
     the attention launch (spatten_decode_args_t::qkv_*: every workgroup projects its share of its head's q / k / v while the
     step's K/V stream is already in flight; the values equal ``spatten_gemv``'s bit for bit) — one launch and one
-    launch-latency fewer per layer-step.  Applies to the plain step on MHA stacks at head_dim 128 in bf16 / f16, batch 1,
-    up to 320 cache rows per split; other steps run the separate launches.
+    host call per layer-step — for the EAGER per-call loop, which is host-bound (673 -> 841 tokens/s at Llama-2-7B geometry);
+    a step traced by ``DecodeGraph`` / ``auto_graph`` runs the separate launches (2 % faster there, bit-identical).  Applies
+    to the plain step on MHA stacks at head_dim 128 in bf16 / f16, batch 1, up to 320 cache rows per split; other steps run
+    the separate launches.
 
     ``auto_graph=True`` (or a token horizon; True = 64, the reference's max_gen_len — run_spatten_llama.py:61): ``model.forward`` is wrapped so that the reference's per-token loop
     (run_spatten_llama.py:27-35), unchanged, replays one captured HIP graph of the whole patched stack per token

@@ -263,11 +263,14 @@ def attn_decode_qkv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
                     kr_cache: torch.Tensor, v_cache: torch.Tensor, kv_len: int, cos: torch.Tensor, sin: torch.Tensor, pos_q: int,
                     scores: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, n_splits: int = 0,
                     step: Optional["StepState"] = None, layout: int = 0,
-                    workspace: Optional[DecodeWorkspace] = None) -> torch.Tensor:
+                    workspace: Optional[DecodeWorkspace] = None, proj=None):
     """The plain decode step with its q / k / v projections INSIDE the launch (spatten_decode_args_t::qkv_*,
     modify_llama.py:72-74 + :86-147): x [hidden] (or [1, 1, hidden]) the layer's input row, weight [3*H*d, hidden] = q_proj /
     k_proj / v_proj stacked, bias or None; the new token's K / V rows are appended at row kv_len - 1.  Raises
-    NotImplementedError where the fused launch does not apply (spatten_decode_qkv_supported).  Returns out [1, H*d]."""
+    NotImplementedError where the fused launch does not apply (spatten_decode_qkv_supported).  Returns out [1, H*d].
+    ``proj`` = (o_proj weight [N, H*d], bias or None[, y [1, N]]): the step's output projection too (modify_llama.py:163) —
+    inside the same launch when N = 16 x its workgroups and H*d = 4096 (Llama-2-7B), one spatten_gemv launch behind it
+    otherwise, the same bits either way; returns (out, y)."""
     _dev(x, weight, bias, k_cache, kr_cache, v_cache, cos, sin, scores, out)
     Hkv, cap, d = v_cache.shape[1], v_cache.shape[2], v_cache.shape[3]
     K = weight.shape[1]
@@ -297,11 +300,15 @@ def attn_decode_qkv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
     a.step_state = None if step is None else step.data_ptr()
     a.qkv_x, a.qkv_weight, a.qkv_w_sn, a.qkv_bias = x.data_ptr(), weight.data_ptr(), weight.stride(0), _ptr(bias)
     a.qkv_exchange, a.qkv_hidden = ws.xch.data_ptr(), K
+    y = None
+    if proj is not None:
+        y = proj[2] if len(proj) > 2 and proj[2] is not None else torch.empty(1, proj[0].shape[0], dtype=x.dtype, device=x.device)
+        _fill_proj(a, (proj[0], proj[1], y.view(1, -1)), out, 1, heads * d)
     rc = lib.spatten_attn_decode_args(ctypes.byref(a), stream)
     if rc == -2:
         raise NotImplementedError("the fused projection + attention launch does not cover this step (spatten_decode_qkv_supported)")
     _lib.check(rc, "spatten_attn_decode (fused projections)")
-    return out
+    return out if proj is None else (out, y)
 
 
 def _fill_proj(a, proj, q, B, K):

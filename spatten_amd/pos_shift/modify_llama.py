@@ -220,13 +220,10 @@ def llama_pos_shift_attention_forward(
         if fused_qkv is not None:
             # the projections inside the attention launch — where the slab's shape runs it (else: project now, as usual)
             fproj = (self.o_proj.weight, self.o_proj.bias)
+            # (only for EAGER calls: under a captured graph the separate launches are 2 % faster — DESIGN 3.13 — and the two
+            #  forms are bit-identical, so a traced step simply projects first)
             if gctx is not None:
-                row = slab.stash_row(num_heads)
-                fused_out = slab.decode_step_qkv(hidden_states, fused_qkv[0], fused_qkv[1], num_heads, kv_seq_len, past_len, cos,
-                                                 sin, row, step=gctx.state_for(slab, cos, sin), proj=fproj)
-                if fused_out is not None:
-                    stash = row[:, :, None, :kv_seq_len]
-                    gctx.touched.append((self, slab, None))
+                pass
             elif position_ids is None and (attention_mask is None or assume_causal):
                 stash = torch.empty(bsz, num_heads, 1, kv_seq_len, dtype=dtype, device=device)
                 fused_out = slab.decode_step_qkv(hidden_states, fused_qkv[0], fused_qkv[1], num_heads, kv_seq_len, past_len, cos,

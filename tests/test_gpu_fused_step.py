@@ -1,7 +1,8 @@
 """The layer-step's q / k / v projections INSIDE the attention launch (decode_qkv_kernel, round 4; modify_llama.py:72-74 +
 :86-147): bit-identical to spatten_gemv + the plain fused decode step — output, stash, appended cache rows (un-rotated key,
 rotated shadow, value) — in the static and the device-length form, at several split counts and hidden sizes; and through the
-plugin (enable_spatten_llm(fused_step=True)): the eager loop and DecodeGraph replays equal the unfused plugin bit for bit."""
+plugin (enable_spatten_llm(fused_step=True)): the eager loop runs the fused launch and equals the unfused plugin bit for bit,
+DecodeGraph replays on the same model too (the device-length form of the fused launch is covered at the op level above)."""
 import contextlib
 import io
 from types import SimpleNamespace
@@ -69,6 +70,60 @@ def test_fused_projection_step_equals_gemv_plus_the_plain_step_bitwise(dt, H, hi
     torch.cuda.synchronize()
     assert torch.equal(oa2, ob2) and torch.equal(sa[:, :, :N + 1], sb[:, :, :N + 1])
     assert torch.equal(ka, kb) and torch.equal(kra, krb) and torch.equal(va, vb)
+
+
+@pytest.mark.parametrize("dt,with_bias", [("bf16", False), ("f16", True)])
+def test_output_projection_inside_the_fused_launch_equals_spatten_gemv_bitwise(dt, with_bias):
+    """Llama-2-7B geometry (32 heads x 128, 8 splits = 256 workgroups x 16 o_proj rows): the whole attention module of a decode
+    step as ONE launch; y equals spatten_gemv(o_proj) on the separate step's output, over several steps on one workspace (the
+    output exchange has its own generation word), static and device-length form."""
+    from spatten_amd import ops
+    H, d, hidden, P, tdt = 32, 128, 4096, 2047, TORCH_DT[dt]
+    g = torch.Generator(device="cuda").manual_seed(11)
+    cap = P + 1 + 60
+    c, s = orc.rope_table(cap, d, dt)
+    cos, sin = dev(c[:, : d // 2], dt), dev(s[:, : d // 2], dt)
+    ka, kra, va = _planes(H, cap, d, P, tdt, g)
+    ops.build_shadow(ka, kra, 0, P, cos, sin)
+    kb, krb, vb = ka.clone(), kra.clone(), va.clone()
+    w = (torch.randn(3 * H * d, hidden, device="cuda", generator=g) * hidden ** -0.5).to(tdt)
+    wo = (torch.randn(hidden, H * d, device="cuda", generator=g) * hidden ** -0.5).to(tdt)
+    bo = (torch.randn(hidden, device="cuda", generator=g) * 0.1).to(tdt) if with_bias else None
+    wsa, wsb = ops.DecodeWorkspace(1, H, d, "cuda"), ops.DecodeWorkspace(1, H, d, "cuda")
+    sa = torch.zeros(1, H, cap, dtype=tdt, device="cuda")
+    sb = torch.zeros_like(sa)
+    st = ops.StepState(cos, sin)
+    st.set(P, P - 1)
+    for t in range(4):
+        N = P + 1 + t
+        x = torch.randn(1, 1, hidden, device="cuda", generator=g).to(tdt)
+        qkv = ops.gemv(x, w, None).view(3, H, d)
+        oa = ops.attn_decode(qkv[0][None], ka, kra, va, N, cos, sin, N - 1, k_new=qkv[1][None], v_new=qkv[2][None], scores=sa,
+                             workspace=wsa, layout=cap)
+        ya = ops.gemv(oa.view(1, 1, H * d), wo, bo)
+        st.advance()
+        if t % 2 == 0:
+            ob, yb = ops.attn_decode_qkv(x, w, None, H, kb, krb, vb, N, cos, sin, N - 1, scores=sb, workspace=wsb, layout=cap,
+                                         proj=(wo, bo))
+        else:
+            ob, yb = ops.attn_decode_qkv(x, w, None, H, kb, krb, vb, cap, cos, sin, 0, scores=sb, workspace=wsb, step=st,
+                                         proj=(wo, bo))
+        torch.cuda.synchronize()
+        assert torch.equal(oa, ob)
+        assert torch.equal(ya.view(-1), yb.view(-1)), (t, float((ya.float().view(-1) - yb.float().view(-1)).abs().max()))
+        assert torch.equal(sa[:, :, :N], sb[:, :, :N])
+        wsb.check()
+    # the same call with the in-launch projection switched off (SPATTEN_FUSED_OPROJ=0 is read once per process: compare
+    # against a geometry the in-launch form does not cover instead — 8 heads: one spatten_gemv launch behind the step)
+    H2 = 8
+    k2, kr2, v2 = _planes(H2, cap, d, 600, tdt, g)
+    ops.build_shadow(k2, kr2, 0, 600, cos, sin)
+    x2 = torch.randn(1, 1, 1024, device="cuda", generator=g).to(tdt)
+    w2 = (torch.randn(3 * H2 * d, 1024, device="cuda", generator=g) * 1024 ** -0.5).to(tdt)
+    wo2 = (torch.randn(1024, H2 * d, device="cuda", generator=g) * 1024 ** -0.5).to(tdt)
+    s2 = torch.zeros(1, H2, cap, dtype=tdt, device="cuda")
+    o2, y2 = ops.attn_decode_qkv(x2, w2, None, H2, k2, kr2, v2, 601, cos, sin, 600, scores=s2, n_splits=8, layout=cap, proj=(wo2, None))
+    assert torch.equal(y2.view(-1), ops.gemv(o2.view(1, 1, H2 * d), wo2).view(-1))
 
 
 def test_fused_step_refuses_the_shapes_it_does_not_cover():
@@ -157,14 +212,16 @@ def test_plugin_with_fused_step_equals_the_unfused_plugin_bitwise_eager_and_unde
         assert len(launches) == T * LAYERS            # the fused launch DID run
         for ma, mb in zip(a.layers, b.layers):
             assert torch.equal(ma.attn_scores, mb.attn_scores)
+        n_eager = len(launches)
         graph = DecodeGraph(lambda past, x: tuple(reversed(b(x, past))), pb, horizon=T)
-        for t in range(T):                            # graph replays of the fused step vs the eager unfused loop
+        for t in range(T):                            # graph replays (a traced step projects first: the separate launches are
+                                                      # the faster form under a graph, and bit-identical) vs the eager unfused loop
             x = torch.randn(1, 1, HID, device="cuda", generator=g).to(dt)
             ya, pa = a(x, pa)
             yb = graph.step(x)
             torch.cuda.synchronize()
             assert torch.equal(ya, yb), t
-        assert graph.n_replays == T - 1
+        assert graph.n_replays == T - 1 and len(launches) == n_eager
         pb = graph.past_key_values
     finally:
         ops.SlabDecodeCall._run_qkv = orig

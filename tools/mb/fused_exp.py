@@ -2,6 +2,7 @@
 the Infinity Cache from one replay to the next):
    A   spatten_gemv(stacked q/k/v) ; plain decode step ; spatten_gemv(o_proj)           (r03: 97 launches per token)
    B   fused projection + attention launch (decode_qkv_kernel) ; spatten_gemv(o_proj)    (65 launches per token)
+   C   the whole attention module in one launch (o_proj inside; SPATTEN_FUSED_OPROJ=0 -> B)  (33 launches per token)
 python tools/mb/fused_exp.py [rows]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -42,6 +43,14 @@ def token_b():
         h = ops.gemv(o.view(1, 1, hid), Wo[i], out=y)
 
 
+def token_c():
+    h = x
+    for i in range(L):
+        o, h = ops.attn_decode_qkv(h, Wqkv[i], None, H, K[i], KR[i], V[i], N, cos, sin, N - 1, scores=st, out=out, workspace=ws,
+                                   layout=cap, proj=(Wo[i], None, y.view(1, hid)))
+        h = h.view(1, 1, hid)
+
+
 def _time(fn, reps=20):
     side = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(side):
@@ -57,5 +66,6 @@ def _time(fn, reps=20):
 
 
 for rnd in range(2):
-    a, b = _time(token_a), _time(token_b)
-    print(f"rows {N}: separate {a:.1f} us/token ({a / L:.2f} us/layer, {1e6 / a:.0f} tok/s)   fused {b:.1f} us/token ({b / L:.2f} us/layer, {1e6 / b:.0f} tok/s)")
+    a, b, c = _time(token_a), _time(token_b), _time(token_c)
+    print(f"rows {N}: separate {a:.1f} us/token ({a / L:.2f} us/layer, {1e6 / a:.0f} tok/s)   fused qkv {b:.1f} us/token ({b / L:.2f} us/layer, {1e6 / b:.0f} tok/s)"
+          f"   whole module {c:.1f} us/token ({c / L:.2f} us/layer, {1e6 / c:.0f} tok/s)")
