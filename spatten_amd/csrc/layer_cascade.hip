@@ -12,6 +12,14 @@
 
 #include "common.h"
 
+#ifdef SPATTEN_LC_TRACE   // developer instrumentation: phase timestamps of head 0's chain, 8 slots per layer (tools/mb/lc_trace.py)
+__device__ unsigned long long* g_lc_trace = nullptr;
+#define LC_STAMP(layer, slot)                                                                         \
+  do { if (g_lc_trace && blockIdx.x == 0 && threadIdx.x == 0) g_lc_trace[(layer) * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LC_STAMP(layer, slot)
+#endif
+
 namespace spatten {
 
 // per-layer geometry, DEVICE array (all lengths in rows / elements)
@@ -31,12 +39,22 @@ struct ChainParams {
   int32_t* idx; int64_t idx_sl, idx_sh;   // [layers, H, kmax] out: kept window positions, ascending
   uint32_t* keys; int64_t keys_sh;     // [H, >= max window] scratch (windows that do not fit the LDS copy)
   int layers, start, lds_keys, heads;  // windows up to lds_keys entries keep their keys in LDS
-  int lds_ids;                         // ... and new-id rows up to lds_ids entries stay in LDS for the next layer's membership test
+  int l_begin, l_end;                  // this launch walks layers [l_begin, l_end) (the event = a few launches: see the host side)
+  int map_ids;                         // ... and behind them a byte per token id in [map_base, map_base + map_ids): the membership map
 };
 
 __device__ inline int gridDim_heads(const ChainParams& p) { return p.heads; }
 constexpr int kChainThreads = 1024;    // the chain is latency-bound on ONE workgroup per head: many threads, few iterations
 constexpr int kChainWaves = kChainThreads / 64;
+constexpr int kChainMaxLayers = 48;    // layers per launch whose tables live in LDS (the host cuts longer events into more legs)
+
+// the chain's barrier: LDS traffic only.  __syncthreads() carries a fence = s_waitcnt vmcnt(0), which would wait for the NEXT
+// layer's prefetch (a global round trip per layer: r04 stamps, 6k of 26k cycles) — a bare s_barrier behind the LDS counter does not.
+__device__ __forceinline__ void lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 
 __device__ inline int32_t slot_id(const LayerPrune& L, const int32_t* known, int j) {
   return j < (int)L.n_known ? known[j] : (int32_t)(L.id_base + (j - L.n_known));
@@ -65,10 +83,37 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int h, un
   constexpr int kPasses = sizeof(T) == 4 ? 4 : (DT<T>::kId == SPATTEN_BF16 ? 2 : 3);
   constexpr unsigned kKeyMask = kPasses == 4 ? 0xFFFFFFFFu : (kPasses == 3 ? 0xFFFFFF00u : 0xFFFF0000u);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // the previous layer's new slot ids: the membership test is a binary search — 11 DEPENDENT loads per key — so the row is
-  // kept in LDS when it fits (539 -> 438 us for the 32-layer chain at 3068-entry windows)
-  int32_t* s_prev = reinterpret_cast<int32_t*>(s_keys + p.lds_keys);
-  const int32_t* prev = nullptr;
+  // Membership of a slot's token in the previous layer's new cache.  r03 kept that layer's id row in LDS and binary-searched
+  // it: 11-12 DEPENDENT LDS loads per key, 3 keys per thread — 36 % of the chain (tools/mb/lc_trace.py: 11.3k of 31.4k cycles per
+  // layer).  Round 4: a byte per token id, s_map[id - base] = l + 1 once layer l keeps the token — written by the thread that
+  // writes the id row anyway, never cleared (the stamp of layer l - 1 is what layer l asks for), one LDS load per key.  Ids
+  // outside [base, base + map_ids) (a conversation of more than ~98k tokens) fall back to the binary search of the global row.
+  // the layers' tables and row pointers: copied into LDS once (a layer start was two dependent scalar-load round trips to global memory)
+  __shared__ LayerPrune s_lay[kChainMaxLayers];
+  __shared__ const void* s_score[kChainMaxLayers];
+  __shared__ const int32_t* s_known[kChainMaxLayers];
+  __shared__ int32_t* s_nid[kChainMaxLayers];
+  for (int i = tid; i < (p.l_end - p.l_begin) * (int)(sizeof(LayerPrune) / 8); i += kChainThreads)
+    reinterpret_cast<uint64_t*>(s_lay)[i] = reinterpret_cast<const uint64_t*>(p.lay + p.l_begin)[i];
+  if (tid < p.l_end - p.l_begin) {
+    s_score[tid] = p.score_ptrs[p.l_begin + tid];
+    s_known[tid] = p.known_ptrs[p.l_begin + tid];
+    s_nid[tid] = p.new_ids_ptrs[p.l_begin + tid];
+  }
+  uint8_t* s_map = reinterpret_cast<uint8_t*>(s_keys + p.lds_keys);
+  const int R = p.map_ids;
+  for (int i = tid * 4; i < R; i += kChainThreads * 4) *reinterpret_cast<uint32_t*>(s_map + i) = 0u;
+  int32_t map_base;
+  {
+    const LayerPrune L0 = p.lay[p.l_begin];
+    const int32_t* known0 = p.known_ptrs[p.l_begin] ? p.known_ptrs[p.l_begin] + h * L0.known_sh : nullptr;
+    map_base = slot_id(L0, known0, p.start);            // the oldest prunable token of this head (ids ascend along the slots)
+  }
+  auto stamp = [&](int32_t id, int l) {
+    const unsigned off = (unsigned)(id - map_base);
+    if (off < (unsigned)R) s_map[off] = (uint8_t)(l + 1);
+  };
+  const int32_t* prev = nullptr;       // the previous layer's id row in global memory (fallback; null: no previous layer)
   int n_prev = 0;
   // Everything a layer reads from global memory — its scores, the token ids of its slots — does NOT depend on what the
   // previous layer selected, so it is requested ONE LAYER AHEAD into registers (round 4): the per-layer critical path is then
@@ -78,10 +123,12 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int h, un
   constexpr int kPf = 4, kPt = 2;
   T pf_sc[kPf];
   int32_t pf_id[kPf], pf_tail[kPt], pf_head = 0;
-  auto prefetch = [&](int l) {
-    const LayerPrune L = p.lay[l];
-    const T* score = (const T*)p.score_ptrs[l] + h * L.score_sh;
-    const int32_t* known = p.known_ptrs[l] ? p.known_ptrs[l] + h * L.known_sh : nullptr;
+  auto prefetch = [&](int l, bool tables_in_lds) {
+    const LayerPrune L = tables_in_lds ? s_lay[l - p.l_begin] : p.lay[l];
+    const void* sp = tables_in_lds ? s_score[l - p.l_begin] : p.score_ptrs[l];
+    const int32_t* kp = tables_in_lds ? s_known[l - p.l_begin] : p.known_ptrs[l];
+    const T* score = (const T*)sp + h * L.score_sh;
+    const int32_t* known = kp ? kp + h * L.known_sh : nullptr;
     const int W = (int)L.hi - p.start, tail = (int)(L.len - L.hi);
 #pragma unroll
     for (int q = 0; q < kPf; ++q) {
@@ -93,11 +140,19 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int h, un
     for (int q = 0; q < kPt; ++q) pf_tail[q] = slot_id(L, known, (int)L.hi + min(tid + q * kChainThreads, max(tail - 1, 0)));
     pf_head = slot_id(L, known, min(tid, max(p.start - 1, 0)));
   };
-  prefetch(0);
-  for (int l = 0; l < p.layers; ++l) {
-    const LayerPrune L = p.lay[l];
-    const T* score = (const T*)p.score_ptrs[l] + h * L.score_sh;
-    const int32_t* known = p.known_ptrs[l] ? p.known_ptrs[l] + h * L.known_sh : nullptr;
+  prefetch(p.l_begin, false);
+  lds_sync();
+  if (p.l_begin > 0) {      // a later leg of the chain: the previous layer's id row was written by the launch before this one
+    const LayerPrune Lp = p.lay[p.l_begin - 1];
+    prev = p.new_ids_ptrs[p.l_begin - 1] + h * Lp.new_ids_sh;
+    n_prev = (int)Lp.new_len;
+    for (int i = tid; i < n_prev; i += kChainThreads) stamp(prev[i], p.l_begin - 1);
+    lds_sync();
+  }
+  for (int l = p.l_begin; l < p.l_end; ++l) {
+    const LayerPrune L = s_lay[l - p.l_begin];
+    const T* score = (const T*)s_score[l - p.l_begin] + h * L.score_sh;
+    const int32_t* known = s_known[l - p.l_begin] ? s_known[l - p.l_begin] + h * L.known_sh : nullptr;
     const int W = (int)L.hi - p.start, k = (int)L.k;
     int32_t* out = p.idx + l * p.idx_sl + h * p.idx_sh;
     uint32_t* keys = W <= p.lds_keys ? s_keys : p.keys + h * p.keys_sh;
@@ -109,7 +164,8 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int h, un
     for (int q = 0; q < kPf; ++q) { my_sc[q] = pf_sc[q]; my_id[q] = pf_id[q]; }
 #pragma unroll
     for (int q = 0; q < kPt; ++q) my_tail[q] = pf_tail[q];
-    if (l + 1 < p.layers) prefetch(l + 1);
+    LC_STAMP(l, 0);
+    if (l + 1 < p.l_end) prefetch(l + 1, true);
     // ---- keys of the window
     {
       int q = 0;
@@ -126,28 +182,33 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int h, un
           want = slot_id(L, known, j);
         }
         if (prev) {
-          int lo = 0, hi = n_prev;
-          while (lo < hi) { const int mid = (lo + hi) >> 1; if (prev[mid] < want) lo = mid + 1; else hi = mid; }
-          member = lo < n_prev && prev[lo] == want;
+          const unsigned off = (unsigned)(want - map_base);
+          if (off < (unsigned)R) {
+            member = s_map[off] == (uint8_t)l;           // the stamp of layer l - 1
+          } else {
+            int lo = 0, hi = n_prev;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (prev[mid] < want) lo = mid + 1; else hi = mid; }
+            member = lo < n_prev && prev[lo] == want;
+          }
         }
         keys[i] = ordered_key(member ? DT<T>::to_f32(scv) : -INFINITY) & kKeyMask;
       }
     }
-    __threadfence_block();
-    __syncthreads();
+    lds_sync();
+    LC_STAMP(l, 1);
     // ---- the key of the k-th largest (8-bit digits, most significant first)
     unsigned prefix = 0, pmask = 0, k_rem = (unsigned)k;
 #pragma unroll 1
     for (int pass = 0; pass < kPasses; ++pass) {
       const int shift = 24 - 8 * pass;
       for (int t = tid; t < kHistCopies * 256; t += kChainThreads) (&s_hist[0][0])[t] = 0;
-      __syncthreads();
+      lds_sync();
       unsigned* my_hist = s_hist[wave % kHistCopies];
       for (int i = tid; i < W; i += kChainThreads) {
         const unsigned key = keys[i];
         if ((key & pmask) == prefix) atomicAdd(&my_hist[(key >> shift) & 255u], 1u);
       }
-      __syncthreads();
+      lds_sync();
       if (wave == 0) {
         unsigned c[4], tot = 0;
 #pragma unroll
@@ -172,17 +233,17 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int h, un
           }
         }
       }
-      __syncthreads();
+      lds_sync();
       prefix |= s_sel[0] << shift;
       pmask |= 255u << shift;
       k_rem -= s_sel[1];
     }
     const unsigned thr = prefix, need_eq = k_rem;
+    LC_STAMP(l, 2);
     // ---- order-preserving compaction: everything above the threshold, the first need_eq at it.  The thread that keeps
     // window position i also knows that slot's token id (prefetched): the new cache's id row is written here, not gathered
-    int32_t* nid = p.new_ids_ptrs[l] + h * L.new_ids_sh;
+    int32_t* nid = s_nid[l - p.l_begin] + h * L.new_ids_sh;
     const int lp = (int)L.new_len;
-    const bool in_lds = lp <= p.lds_ids;
     unsigned run_eq = 0, run_kept = 0;
     int parity = 0, q = 0;
     for (int base = 0; base < W; base += kChainThreads, parity ^= 1, ++q) {
@@ -192,7 +253,7 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int h, un
       const bool gt = in && key > thr, eq = in && key == thr;
       const unsigned long long m_gt = __ballot(gt), m_eq = __ballot(eq);
       if (lane == 0) { s_cnt[parity][wave][0] = __popcll(m_gt); s_cnt[parity][wave][1] = __popcll(m_eq); }
-      __syncthreads();
+      lds_sync();
       unsigned eq_base = run_eq, kept_base = run_kept, tot_eq = run_eq, tot_kept = run_kept;
 #pragma unroll
       for (int w = 0; w < kChainWaves; ++w) {
@@ -217,16 +278,17 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int h, un
           id = slot_id(L, known, p.start + i);
         }
         nid[p.start + pos] = id;
-        if (in_lds) s_prev[p.start + pos] = id;
+        stamp(id, l);
       }
       run_eq = tot_eq;
       run_kept = tot_kept;
     }
+    LC_STAMP(l, 3);
     // ---- the ids of the head rows [0, start) and of the tail rows [hi, len) of the new cache (prefetched)
-    if (tid < p.start) { nid[tid] = my_head; if (in_lds) s_prev[tid] = my_head; }
+    if (tid < p.start) { nid[tid] = my_head; stamp(my_head, l); }
     for (int r = kChainThreads; r + tid < p.start; r += kChainThreads) {      // (start > 1024: not prefetched)
       const int32_t id = slot_id(L, known, r + tid);
-      nid[r + tid] = id; if (in_lds) s_prev[r + tid] = id;
+      nid[r + tid] = id; stamp(id, l);
     }
     {
       const int tail = (int)(L.len - L.hi);
@@ -241,16 +303,16 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int h, un
         }
         const int r = p.start + k + t;
         nid[r] = id;
-        if (in_lds) s_prev[r] = id;
+        stamp(id, l);
       }
     }
     if (PUBLISH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its own stores ...
-    __threadfence_block();
-    __syncthreads();
+    lds_sync();
     if (PUBLISH && tid == 0)                                            // ... then ONE lane raises the layer's word
       __hip_atomic_store(ready + (size_t)l * gridDim_heads(p) + h, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    prev = in_lds ? s_prev : nid;
+    prev = nid;
     n_prev = lp;
+    LC_STAMP(l, 4);
   }
 }
 
@@ -266,6 +328,7 @@ struct RaggedParams {
   const void* cos; const void* sin; int table_rows;
   const int32_t* idx; int64_t idx_sl, idx_sh;
   int B, H, start, row_bytes, es, half_ppr, rows_per_block;
+  int l0;                              // first layer of this launch (grid z counts from it)
 };
 
 // the fused gather + concat (+ rotated shadow) of kv_compact_kernel with every layer's own lengths and strides
@@ -339,7 +402,7 @@ __device__ __forceinline__ void ragged_store(const RaggedParams& p, const int la
 
 template <typename T>
 __global__ __launch_bounds__(256) void kv_compact_ragged_kernel(const RaggedParams p) {
-  const int layer = blockIdx.z >> 1, t = blockIdx.z & 1;
+  const int layer = p.l0 + (int)(blockIdx.z >> 1), t = blockIdx.z & 1;
   const LayerPrune L = p.lay[layer];
   const RaggedRow row = ragged_load<T, false>(p, L, layer, t, (int)blockIdx.y, (int)blockIdx.x, (int)threadIdx.x);
   ragged_store<T>(p, layer, t, (int)threadIdx.x, row);
@@ -349,8 +412,8 @@ __global__ __launch_bounds__(256) void acc_compact_ragged_kernel(const LayerPrun
                                                                  const float* const* __restrict__ src_ptrs,
                                                                  float* const* __restrict__ dst_ptrs,
                                                                  const int32_t* __restrict__ idx, int64_t idx_sl, int64_t idx_sh,
-                                                                 int start) {
-  const int r = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, l = blockIdx.z;
+                                                                 int start, int l0) {
+  const int r = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, l = l0 + (int)blockIdx.z;
   const LayerPrune L = lay[l];
   if (r >= (int)L.new_len) return;
   const int k = (int)L.k;
@@ -361,6 +424,36 @@ __global__ __launch_bounds__(256) void acc_compact_ragged_kernel(const LayerPrun
 }  // namespace spatten
 
 using namespace spatten;
+
+// the library-owned side stream of the layer-cascade event (one per device, created on first use, never destroyed: like the
+// communicator of comm.hip it lives as long as the process)
+struct SideStream {
+  static constexpr int kEvents = 16;
+  hipStream_t s = nullptr;
+  hipEvent_t ev[kEvents] = {};
+  hipEvent_t join = nullptr;
+};
+static SideStream* side_stream() {
+  static SideStream per_dev[16];
+  static bool failed[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || failed[dev]) return nullptr;
+  SideStream& S = per_dev[dev];
+  if (S.s) return &S;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)cs;
+  if (hipStreamCreateWithFlags(&S.s, hipStreamNonBlocking) != hipSuccess) { S.s = nullptr; failed[dev] = true; return nullptr; }
+  bool ok = hipEventCreateWithFlags(&S.join, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; i < SideStream::kEvents && ok; ++i) ok = hipEventCreateWithFlags(&S.ev[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) { failed[dev] = true; return nullptr; }
+  return &S;
+}
+
+#ifdef SPATTEN_LC_TRACE
+extern "C" int spatten_debug_set_lc_trace(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_lc_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 static int prune_layer_cascade_impl(int score_dtype, int kv_dtype, int layers, const void* lay_dev, const void* lay_host,
                                     const void* const* score_ptrs, const int32_t* const* known_ptrs,
@@ -419,11 +512,22 @@ static int prune_layer_cascade_impl(int score_dtype, int kv_dtype, int layers, c
   c.layers = layers; c.start = start; c.heads = heads;
   int64_t max_w = 0;
   for (int l = 0; l < layers; ++l) max_w = std::max(max_w, H_[l].hi - start);
-  // 60 KB of dynamic LDS (+ the histogram): the window's keys first, the previous layer's ids in what is left; longer
-  // windows / rows fall back to the global scratch / the global id rows
+  // dynamic LDS: the window's keys (up to 60 KB; longer windows use the global scratch), then the membership map — a byte per
+  // token id, up to 96 KB (the 160-KB LDS of a gfx950 CU is this one workgroup's: ~17 KB static + at most 140 KB here)
   c.lds_keys = (int)std::min<int64_t>(max_w, 15360);
-  c.lds_ids = (int)std::min<int64_t>(max_new, 15360 - c.lds_keys);
-  const size_t lds = (size_t)(c.lds_keys + c.lds_ids) * sizeof(uint32_t);
+  c.map_ids = layers <= 254 ? (int)std::min<int64_t>(96 * 1024, 140 * 1024 - (int64_t)c.lds_keys * 4) & ~3 : 0;
+  const size_t lds = (size_t)c.lds_keys * sizeof(uint32_t) + (size_t)c.map_ids;
+  {
+    static bool attr_set[4] = {};
+    const int di = score_dtype == SPATTEN_F32 ? 0 : (score_dtype == SPATTEN_BF16 ? 1 : 2);
+    if (!attr_set[di]) {
+      hipError_t e = hipSuccess;
+      SPATTEN_BY_DTYPE(score_dtype, e = hipFuncSetAttribute((const void*)layer_cascade_select_kernel<T>,
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+      if (e != hipSuccess) return SPATTEN_ERR_LAUNCH;
+      attr_set[di] = true;
+    }
+  }
   const int es = kv_dtype == SPATTEN_F32 ? 4 : 2;
   RaggedParams r{};
   r.lay = (const LayerPrune*)lay_dev; r.k_src_ptrs = k_src_ptrs; r.v_src_ptrs = v_src_ptrs; r.k_dst_ptrs = k_dst_ptrs;
@@ -436,19 +540,54 @@ static int prune_layer_cascade_impl(int score_dtype, int kv_dtype, int layers, c
   r.rows_per_block = 256 / r.half_ppr;
   if ((long long)batch * heads > 65535 || 2 * layers > 65535) return SPATTEN_ERR_UNSUPPORTED;
   (void)sync_words; (void)generation;
-  {
+  // The chain is ONE workgroup per head for the whole event and the gather cannot start before its layer's positions exist, but
+  // layer l's gather does not have to wait for layer l + 1's selection: the event is cut into kLegs legs of consecutive layers,
+  // the chain walks them as separate launches on the caller's stream and each leg's gather runs on a library-owned side stream
+  // behind an event — a full-speed, free-running grid UNDER the next leg's (latency-bound, 32-workgroup) chain; the caller's
+  // stream joins the side stream at the end (a fork / join that a stream capture follows as well).  r04: the same overlap
+  // inside one launch (persistent gather workers polling per-layer words) lost; as launches it wins because the gather
+  // keeps its own grid.  SPATTEN_LC_LEGS=1 is the serial form.
+  static int env_legs = -1;
+  if (env_legs < 0) { const char* e = getenv("SPATTEN_LC_LEGS"); env_legs = e ? std::max(1, atoi(e)) : 4; }
+  const int legs = std::min(std::max(env_legs, ceil_div(layers, kChainMaxLayers)), layers);
+  SideStream* side = legs > 1 ? side_stream() : nullptr;
+  const int n_legs = side ? legs : ceil_div(layers, kChainMaxLayers);
+  auto launch_gather = [&](int l0, int l1, hipStream_t s) -> int {
+    r.l0 = l0;
+    int64_t leg_new = 0;
+    for (int l = l0; l < l1; ++l) leg_new = std::max(leg_new, H_[l].new_len);
+    const dim3 grid((unsigned)ceil_div((int)leg_new, r.rows_per_block), (unsigned)(batch * heads), (unsigned)(2 * (l1 - l0)));
+    SPATTEN_BY_DTYPE(kv_dtype, hipLaunchKernelGGL((kv_compact_ragged_kernel<T>), grid, dim3(256), 0, s, r));
+    if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
+    if (acc_src_ptrs) {
+      hipLaunchKernelGGL(acc_compact_ragged_kernel, dim3((unsigned)ceil_div((int)leg_new, 256), (unsigned)heads, (unsigned)(l1 - l0)),
+                         dim3(256), 0, s, (const LayerPrune*)lay_dev, acc_src_ptrs, acc_dst_ptrs, idx, (int64_t)heads * kmax,
+                         (int64_t)kmax, start, l0);
+      if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
+    }
+    return SPATTEN_OK;
+  };
+  bool forked = false;
+  for (int g = 0; g < n_legs; ++g) {
+    const int l0 = (int)((int64_t)layers * g / n_legs), l1 = (int)((int64_t)layers * (g + 1) / n_legs);
+    c.l_begin = l0; c.l_end = l1;
     SPATTEN_BY_DTYPE(score_dtype, hipLaunchKernelGGL((layer_cascade_select_kernel<T>), dim3((unsigned)heads), dim3(kChainThreads),
                                                      lds, st, c));
     if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
-    const dim3 grid((unsigned)ceil_div((int)max_new, r.rows_per_block), (unsigned)(batch * heads), (unsigned)(2 * layers));
-    SPATTEN_BY_DTYPE(kv_dtype, hipLaunchKernelGGL((kv_compact_ragged_kernel<T>), grid, dim3(256), 0, st, r));
-    if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
+    if (g + 1 < n_legs) {       // this leg's gather goes to the side stream, behind the leg's chain
+      if (hipEventRecord(side->ev[g % SideStream::kEvents], st) != hipSuccess) return SPATTEN_ERR_LAUNCH;
+      if (hipStreamWaitEvent(side->s, side->ev[g % SideStream::kEvents], 0) != hipSuccess) return SPATTEN_ERR_LAUNCH;
+      forked = true;
+      const int rc = launch_gather(l0, l1, side->s);
+      if (rc != SPATTEN_OK) return rc;
+    } else {
+      const int rc = launch_gather(l0, l1, st);
+      if (rc != SPATTEN_OK) return rc;
+    }
   }
-  if (acc_src_ptrs) {
-    hipLaunchKernelGGL(acc_compact_ragged_kernel, dim3((unsigned)ceil_div((int)max_new, 256), (unsigned)heads, (unsigned)layers),
-                       dim3(256), 0, st, (const LayerPrune*)lay_dev, acc_src_ptrs, acc_dst_ptrs, idx, (int64_t)heads * kmax,
-                       (int64_t)kmax, start);
-    if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
+  if (forked) {                 // join: everything the side stream did is ordered before whatever follows on the caller's stream
+    if (hipEventRecord(side->join, side->s) != hipSuccess) return SPATTEN_ERR_LAUNCH;
+    if (hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return SPATTEN_ERR_LAUNCH;
   }
   return SPATTEN_OK;
 }

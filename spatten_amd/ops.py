@@ -852,37 +852,42 @@ def prune_layer_cascade(scores: Sequence[torch.Tensor], known_ids: Sequence[Opti
         Kd = [torch.empty(B, H, max(capacities[l], new_lens[l]), d, dtype=dt, device=dev) for l in range(nl)]
         Vd = [torch.empty_like(x) for x in Kd]
         Krd = [torch.empty_like(x) for x in Kd]
-    new_ids = [torch.empty(H, new_lens[l], dtype=torch.int32, device=dev) for l in range(nl)]
+    # one allocation per kind (32 layers x torch.empty / torch.zeros — 32 fill launches — were most of the event's host time)
+    ids_all = torch.empty(nl, H, max(new_lens), dtype=torch.int32, device=dev)
+    new_ids = [ids_all[l, :, :new_lens[l]] for l in range(nl)]
     new_accs = None
     if accs is not None:
-        new_accs = [torch.zeros(H, max(Kd[l].shape[2], accs[l].shape[1]), dtype=torch.float32, device=dev) for l in range(nl)]
+        widths = [max(Kd[l].shape[2], accs[l].shape[1]) for l in range(nl)]
+        acc_all = torch.zeros(nl, H, max(widths), dtype=torch.float32, device=dev)
+        new_accs = [acc_all[l, :, :widths[l]] for l in range(nl)]
     idx = torch.empty(nl, H, kmax, dtype=torch.int32, device=dev)
     wmax = max(his[l] - start for l in range(nl))
     scratch = torch.empty(H, wmax, dtype=torch.int32, device=dev)
-    tab = torch.zeros(nl, 16, dtype=torch.int64)
+    sdt = scores[0].dtype
+    rows = []
     for l in range(nl):
         K, V, sc = Ks[l], Vs[l], scores[l]
-        if K.stride(3) != 1 or K.stride(2) != d or V.stride() != K.stride() or sc.stride(1) != 1 or sc.dtype != scores[0].dtype:
+        if K.stride(3) != 1 or K.stride(2) != d or V.stride() != K.stride() or sc.stride(1) != 1 or sc.dtype != sdt:
             raise ValueError("layer cascade: K / V need contiguous rows and equal strides, scores contiguous rows of one dtype")
         kn = known_ids[l]
         if kn is not None and (kn.dtype != torch.int32 or kn.stride(1) != 1 or kn.shape[0] != H):
             raise ValueError("known ids must be int32 [H, n] with contiguous rows")
-        tab[l] = torch.tensor([lens[l], his[l], keeps[l], new_lens[l],
-                               sc.stride(0), 0 if kn is None else kn.shape[1], 0 if kn is None else kn.stride(0), new_ids[l].stride(0),
-                               K.stride(0), K.stride(1), Kd[l].stride(0), Kd[l].stride(1),
-                               0 if accs is None else accs[l].stride(0), 0 if accs is None else new_accs[l].stride(0),
-                               int(id_base), 0], dtype=torch.int64)
-    groups = [scores, [None if k is None else k for k in known_ids], new_ids, Ks, Vs, Kd, Vd, Krd] + \
-             ([list(accs), new_accs] if accs is not None else [])
-    flat = torch.tensor([0 if t is None else t.data_ptr() for g in groups for t in g], dtype=torch.int64).to(dev)
-    ptr = lambda i: flat[i * nl:(i + 1) * nl].data_ptr()
-    tab_dev = tab.to(dev)
-    args = (_dt(scores[0]), _dt(Ks[0]), nl, tab_dev.data_ptr(), tab.data_ptr(), ptr(0), ptr(1), ptr(2), ptr(3), ptr(4), ptr(5), ptr(6),
+        rows += [lens[l], his[l], keeps[l], new_lens[l],
+                 sc.stride(0), 0 if kn is None else kn.shape[1], 0 if kn is None else kn.stride(0), new_ids[l].stride(0),
+                 K.stride(0), K.stride(1), Kd[l].stride(0), Kd[l].stride(1),
+                 0 if accs is None else accs[l].stride(0), 0 if accs is None else new_accs[l].stride(0), int(id_base), 0]
+    groups = [scores, known_ids, new_ids, Ks, Vs, Kd, Vd, Krd] + ([list(accs), new_accs] if accs is not None else [])
+    # the per-layer table (16 int64 per layer: LayerPrune of layer_cascade.hip) and the pointer rows behind it: ONE host tensor,
+    # one copy to the device
+    host = torch.tensor(rows + [0 if t is None else t.data_ptr() for g in groups for t in g], dtype=torch.int64).pin_memory()
+    both = host.to(dev, non_blocking=True)      # (pinned: the copy does not block the host behind the stream's earlier work)
+    ptr = lambda i: both.data_ptr() + (nl * 16 + i * nl) * 8
+    args = (_dt(scores[0]), _dt(Ks[0]), nl, both.data_ptr(), host.data_ptr(), ptr(0), ptr(1), ptr(2), ptr(3), ptr(4), ptr(5), ptr(6),
             ptr(7), cos.data_ptr(), sin.data_ptr(), cos.shape[0], idx.data_ptr(), kmax, scratch.data_ptr(), scratch.stride(0),
             ptr(8) if accs is not None else None, ptr(9) if accs is not None else None, B, H, d, start)
     rc = lib.spatten_prune_layer_cascade(*args, _stream())
     _lib.check(rc, "spatten_prune_layer_cascade")
-    keep_alive = (flat, tab_dev, scratch)            # referenced until the launches were issued
+    keep_alive = (both, host, scratch)               # referenced until the launches were issued
     del keep_alive
     return ([Kd[l][:, :, :new_lens[l]] for l in range(nl)], [Vd[l][:, :, :new_lens[l]] for l in range(nl)],
             [Krd[l][:, :, :new_lens[l]] for l in range(nl)], [idx[l, :, :keeps[l]] for l in range(nl)], new_ids, new_accs)

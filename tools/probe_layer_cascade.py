@@ -32,4 +32,31 @@ def t_ms(fn, n=5):
 ref = t_ms(lambda: ops.prune_layers(sc, K, V, CTX, START, hi, IMP, capacity=cap, rope=(cos, sin)))
 lc = t_ms(lambda: ops.prune_layer_cascade(sc, [None] * L, 0, K, V, [CTX] * L, [hi] * L, keeps, START, [cap] * L, (cos, sin)))
 lc_same = t_ms(lambda: ops.prune_layer_cascade(sc, [None] * L, 0, K, V, [CTX] * L, [hi] * L, [IMP] * L, START, [cap] * L, (cos, sin)))
+# pre-allocated destinations: device time by events, host time per call without a synchronisation
+nl_ = [START + k_ + (CTX - hi) for k_ in keeps]
+Kd = [torch.empty(1, H, cap, d, device=dev, dtype=dt) for _ in range(L)]
+Vd = [torch.empty_like(x) for x in Kd]
+Krd = [torch.empty_like(x) for x in Kd]
+accs = [torch.rand(H, CTX, device=dev) for _ in range(L)]
+for with_acc in (False, True):
+    f = lambda: ops.prune_layer_cascade(sc, [None] * L, 0, K, V, [CTX] * L, [hi] * L, keeps, START, [cap] * L, (cos, sin),
+                                        accs if with_acc else None, dst=(Kd, Vd, Krd))
+    f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); t = time.perf_counter()
+    for _ in range(5):
+        f()
+    host_ms = (time.perf_counter() - t) / 5 * 1e3
+    e1.record(); torch.cuda.synchronize()
+    print(f"pre-allocated planes, accumulators {with_acc}: device {e0.elapsed_time(e1) / 5:.3f} ms per event, host {host_ms:.3f} ms per call")
+plan = ops.PrunePlan(sc, K, V, Kd, Vd, Krd)
+idxp = torch.empty(L, H, IMP, dtype=torch.int32, device=dev)
+g = lambda: ops.prune_layers(sc, K, V, CTX, START, hi, IMP, dst=(Kd, Vd, Krd), plan=plan, idx=idxp, rope=(cos, sin))
+g(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    g()
+e1.record(); torch.cuda.synchronize()
+print(f"reference-mode event, pre-allocated + plan: device {e0.elapsed_time(e1) / 5:.3f} ms")
 print(f"reference-mode event (incl. allocation) {ref:.3f} ms | layer cascade, keeps 1020->510 {lc:.3f} ms | layer cascade, keeps 1020 everywhere {lc_same:.3f} ms")
