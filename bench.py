@@ -1009,6 +1009,21 @@ def main():
                     ops.attn_prefill(Qp, Krp2, Vp2, Np, cp, sp, 0, causal=True, out=op, numerics="fast")
                 torch.cuda.synchronize()
                 extras["prefill_8192_causal_fast_numerics_TFLOPs"] = round(fl / ((time.perf_counter() - t0) / 20) / 1e12, 1)
+                # the first prompt of a C2 session: q = N = 2048 — one workgroup per CU, paired 128-row blocks (round 4)
+                N2 = 2048
+                c2, s2 = cp[:N2], sp[:N2]
+                o2 = torch.empty(1, N2, HEADS * d, dtype=dt, device=dev)
+                Q2, K2, V2 = Qp[:, :, :N2].contiguous(), Krp2[:, :, :N2].contiguous(), Vp2[:, :, :N2].contiguous()
+                run2 = lambda: ops.attn_prefill(Q2, K2, V2, N2, c2, s2, 0, causal=True, out=o2)
+                for _ in range(3):
+                    run2()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    run2()
+                torch.cuda.synchronize()
+                extras["prefill_2048_causal_TFLOPs"] = round(4 * HEADS * d * N2 * (N2 + 1) / 2 / ((time.perf_counter() - t0) / 20) / 1e12, 1)
+                del Q2, K2, V2, o2
                 # progressive-quant decode over the same 8192 keys: MSB-only vs always-refetch vs bf16 keys
                 planes = ops.PQPlanes(1, HEADS, Np, d, dev)
                 ops.pq_pack(Krp2, planes, 0, Np)

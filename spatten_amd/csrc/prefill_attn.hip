@@ -116,6 +116,7 @@ struct FlashParams {
   int32_t* need;      // [B,H,q_len]: pass 1 writes max prob < thr, pass 2 recomputes the flagged rows
   float pq_thr;
   int B, H, Hkv, q_len, N, Npad, causal, nqb;
+  int pair;           // prefill_pp128_kernel<..., PAIR>: a workgroup's halves take the 128-row blocks i and n - 1 - i (see the kernel)
   int vtr;     // this launch reads V through the transposing LDS reads (no Vt copy was made)
   int fast;    // SPATTEN_PREFILL_FAST_NUMERICS: fp32 logits, no reference roundings (plain causal / unmasked flash leg only)
   float sqrt_d;
@@ -149,6 +150,9 @@ struct FlashParams {
 // (use_vtr below); SPATTEN_PREFILL_VTR=0|1 forces it (A/B).
 #ifndef SPATTEN_PF_VTR_MAXQ
 #define SPATTEN_PF_VTR_MAXQ 512  // transposing reads for query blocks up to this length
+#endif
+#ifndef SPATTEN_PF_P1            // the reference roundings of S(t+1) behind the wave's own P.V MFMAs (prefill_pp128_kernel)
+#define SPATTEN_PF_P1 0
 #endif
 #ifndef SPATTEN_PF_ROWSUM_MFMA  // row sums of P on the matrix pipe instead of 64 VALU adds per lane and tile: MEASURED SLOWER
 #define SPATTEN_PF_ROWSUM_MFMA 0   // (713 vs 768): the 8 extra MFMAs per tile cost more than the adds they replace.  Off.
@@ -594,9 +598,10 @@ template <int ROWB> __device__ inline int swz_slot(int row, int p) {   // logica
   return ROWB == 256 ? (p ^ (row & 15)) : (p ^ ((row >> 1) & 7));
 }
 
-template <typename T, int D, bool MASK, int PQK = 0, bool FASTN = false, bool VTRP = false>
+template <typename T, int D, bool MASK, int PQK = 0, bool FASTN = false, bool VTRP = false, bool PAIR = false>
 __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams<T> p) {
   constexpr bool FAST = FASTN || (SPATTEN_PF_EXPMODE & 1);
+  constexpr bool P1 = SPATTEN_PF_P1 && !FAST && PQK == 0 && !MASK;
   constexpr int KT = 128, NKB = KT / 32;                      // keys per tile, 32-key blocks per tile
   constexpr int KK = D / 16, DB = D / 32, KROWB = D * 2;
   constexpr int KBYTES = KT * KROWB, VBYTES = D * 256, BUF = KBYTES + VBYTES;   // Vt row = 128 keys = 256 B
@@ -630,7 +635,19 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     }
   }
   const int hkv = p.Hkv == p.H ? h : h / (p.H / p.Hkv);
-  const int q0 = qblk * 256 + wave * 32;
+  // PAIR (round 4; causal, no more workgroups than CUs): a 256-row block of a causal prefill needs 2, 4, ... 2 nqb key tiles, and
+  // with B * H * nqb <= 256 workgroups nothing balances that — the launch lasts as long as its last block while the mean is half
+  // of it (q = N = 2048: 426-437 TFLOP/s against 800+ at 8192).  Here the two halves of a workgroup take DIFFERENT 128-row blocks
+  // of the same head, i and n128 - 1 - i: they walk the same key tiles in lock step (the K / V stream is shared as before), the
+  // short block's half simply runs out of tiles and from then on only serves DMA and barriers, and the other half — alone on its
+  // SIMDs — runs its remaining tiles without the partner's contention: q = N = 2048 437 -> 481 TFLOP/s (71.5 against 78.6 us
+  // with the V transpose), 1024 +9 %; with more workgroups than CUs the dispatch order balances better (8192: -15 % when forced) —
+  // the host enables it for batch x heads x q_len / 256 <= 256.  (r04 also built the second act — the finished half stores its
+  // rows and joins the other half's block on every second remaining tile, partials folded through LDS — correct and NOT faster
+  // (75.6 us): a step is bound by the 64-KB tile fill of its CU, not by the halves' arithmetic.  Removed.)
+  constexpr bool paired = PAIR;        // (its own instantiation: the plain kernel keeps its register allocation)
+  const int blk128 = paired ? (grp == 0 ? 2 * nqb - 1 - qblk : qblk) : 0;
+  const int q0 = paired ? blk128 * 128 + (wave & 3) * 32 : qblk * 256 + wave * 32;
   const int myq = q0 + qi;
   const bool qvalid = myq < p.q_len;
   const int P = p.N - p.q_len;
@@ -693,7 +710,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   for (int e = 0; e < 8; ++e) ones[e] = DT<T>::from_f32(qi == 0 ? 1.f : 0.f);
   float m_true = -INFINITY;   // PQK == 1: the row's TRUE running maximum (m_run may lag it: deferred rescale)
 
-  const int wg_q_end = min(p.q_len, qblk * 256 + 256);
+  const int wg_q_end = min(p.q_len, paired ? (2 * nqb - qblk) * 128 : qblk * 256 + 256);   // (paired: the end of the LATER block)
   const int att_keys = p.causal ? min(p.N, P + wg_q_end) : p.N;
   const int all_tiles = (att_keys + KT - 1) / KT;
   // this workgroup's tiles [T0, T1) (all of them without a key split); an empty range leaves an empty partial
@@ -805,7 +822,19 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     }
     __builtin_amdgcn_sched_group_barrier(0x008, RING, 0);
   };
-  auto pv = [&](const char* vbuf) {
+  // P1 (round 4): the two reference roundings of the NEXT tile's logits — 256 of the ~530 VALU instructions of a tile's softmax,
+  // and the only part of it that depends on nothing but S(t+1) — ride in the shadow of this wave's OWN P.V MFMAs (S(t+1) is
+  // computed first, then P(t).V(t) with eight rounding instructions behind each MFMA) instead of in the vector phase, where
+  // they compete with the partner wave's MFMAs for the SIMD's issue port (stripped builds, r04: the flash kernel without its
+  // softmax runs 1,454 TFLOP/s against 786 — the vector phase's VALU and the partner's matrix phase ADD rather than overlap).
+  auto round_pair = [&](int kb, int r) {
+    const f32x2 x = round2<T>(f32x2{s[kb][r], s[kb][r + 1]});
+    const f32x2 v = round2<T>(f32x2{logit_scale<T>(x[0], p.sqrt_d, rsqrt_d), logit_scale<T>(x[1], p.sqrt_d, rsqrt_d)});
+    s[kb][r] = v[0];
+    s[kb][r + 1] = v[1];
+  };
+  auto pv = [&](const char* vbuf, auto with_p1) {
+    constexpr bool WP1 = decltype(with_p1)::value;
     frag a[RING];
     const unsigned vu = (unsigned)(vbuf - lds) + qi * 256 + ((qi & 15) << 4);
     // VTR: lane (qi, hi) needs, for d = 32 db + qi, the 8 keys its P fragment holds — elements 0..3: keys k16 + 4 hi + 0..3,
@@ -839,17 +868,34 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 #if SPATTEN_PF_ROWSUM_MFMA
       if (db == DB - 1) osum = Mfma<T>::mma(ones, pf[kt >> 1][kt & 1], osum);
 #endif
+      if constexpr (WP1) {      // 2 * NKB * DB MFMAs, NKB * 8 logit pairs: pairs_per logit pairs behind each MFMA
+        constexpr int pairs_per = (NKB * 8) / (2 * NKB * DB) > 0 ? (NKB * 8) / (2 * NKB * DB) : 1;
+#pragma unroll
+        for (int j = 0; j < pairs_per; ++j) {
+          const int pi = i * pairs_per + j;
+          if (pi < NKB * 8) round_pair(pi >> 3, (pi & 7) * 2);
+        }
+      }
     }
     __builtin_amdgcn_sched_group_barrier(0x100, RING, 0);
 #pragma unroll
     for (int i = 0; i < 2 * NKB * DB - RING; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if constexpr (WP1) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, RING + (SPATTEN_PF_ROWSUM_MFMA ? 2 * NKB : 0), 0);
+    if constexpr (WP1) {
+#pragma unroll
+      for (int i = 0; i < RING; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+      }
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x008, RING + (SPATTEN_PF_ROWSUM_MFMA ? 2 * NKB : 0), 0);
+    }
   };
 
-  auto softmax_tile = [&](int tile) {
+  auto softmax_tile = [&](int tile, bool rounded = false) {
     const bool edge = tile * KT + KT > wave_full_keys;
     if (PQK) {
       // quantised keys: s holds q . q8 (exact integers times the query); the logit is that times the key's scale / sqrt(d)
@@ -867,7 +913,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     } else {
     // both reference roundings of every logit (matmul -> dtype, "/ sqrt(d)" -> dtype, modify_llama.py:111-113), two
     // scores at a time: at large logits a 16-bit ulp is a visible change of P
-    if (!(FAST && !MASK && !edge)) {
+    if (!(FAST && !MASK && !edge) && !rounded) {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -986,9 +1032,21 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     if (grp == 0 && t >= T0 + 1 && t + 1 < n_tiles) dma_stage(t + 1);
 #endif
     __builtin_amdgcn_sched_barrier(0);
-    if (t < wave_att_tiles) pv(v_area(t));
-    __builtin_amdgcn_sched_barrier(0);                   // P is dead from here on: keep S(t+1) out of its live range
-    if (t + 1 < wave_tiles) qk(k_area(t));
+    bool rounded = false;
+    if constexpr (P1) {
+      // S(t+1) first, then P(t).V(t) with the roundings of S(t+1) in its shadow
+      const bool nxt = t + 1 < wave_tiles;
+      if (nxt) qk(k_area(t));
+      __builtin_amdgcn_sched_barrier(0);
+      if (t < wave_att_tiles) {
+        if (nxt) { pv(v_area(t), std::true_type{}); rounded = true; }
+        else pv(v_area(t), std::false_type{});
+      }
+    } else {
+      if (t < wave_att_tiles) pv(v_area(t), std::false_type{});
+      __builtin_amdgcn_sched_barrier(0);                   // P is dead from here on: keep S(t+1) out of its live range
+      if (t + 1 < wave_tiles) qk(k_area(t));
+    }
     PF_STAMP(1);
 
     if (grp == 1) __builtin_amdgcn_s_waitcnt(0x0F70);    // half 1's pieces (issued one phase ago) have landed
@@ -1004,7 +1062,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     if (grp == 1 && t + 2 < n_tiles) dma_stage(t + 2);
 #endif
     PF_STAMP(3);
-    if (!(SPATTEN_PF_EXPMODE & 8) && t + 1 < wave_tiles) softmax_tile(t + 1);
+    if (!(SPATTEN_PF_EXPMODE & 8) && t + 1 < wave_tiles) softmax_tile(t + 1, rounded);
     PF_STAMP(4);
     if (grp == 0) __builtin_amdgcn_s_waitcnt(0x0F70);    // half 0's pieces (issued at the top of this iteration)
     __syncthreads();
@@ -1324,6 +1382,13 @@ static inline int flash_ksplit(int batch, int heads, int q_len, int kv_len) {
   const int per = ceil_div(tiles, ks);          // tiles per range ...
   return ceil_div(tiles, per);                  // ... and no empty ranges (17 tiles: 8 ranges of 3 would leave two empty)
 }
+// paired 128-row blocks (prefill_pp128_kernel<..., PAIR>): a causal block of whole 256-row groups whose workgroups all fit the chip at once
+static inline bool flash_pair(int batch, int heads, int q_len, int causal) {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("SPATTEN_PREFILL_PAIR"); env = e ? atoi(e) : 2; }   // 0 = off, 1 = forced (A/B), 2 = auto
+  if (!causal || q_len % 256 != 0 || q_len < 512 || env == 0) return false;
+  return env == 1 || (long long)batch * heads * (q_len / 256) <= 256;
+}
 static inline size_t flash_partial_bytes(int batch, int heads, int head_dim, int q_len, int ks) {
   if (ks <= 1) return 0;
   return (size_t)batch * heads * ceil_div(q_len, 256) * ks * 256 * (head_dim + 2) * sizeof(float);
@@ -1358,6 +1423,8 @@ static void launch_flash_m(const FlashParams<T>& p, hipStream_t st) {
       const dim3 gridk((unsigned)(p.nqb * p.H * p.B * (p.ksplit > 1 ? p.ksplit : 1)));
       if (p.mask) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, true>), gridk, dim3(512), 0, st, p);
       else if (p.fast) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, 0, true>), gridk, dim3(512), 0, st, p);
+      else if (p.pair && p.vtr) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, 0, false, true, true>), gridk, dim3(512), 0, st, p);
+      else if (p.pair) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, 0, false, false, true>), gridk, dim3(512), 0, st, p);
       else if (p.vtr) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, 0, false, true>), gridk, dim3(512), 0, st, p);
       else hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false>), gridk, dim3(512), 0, st, p);
       if (p.ksplit > 1) {
@@ -1495,6 +1562,7 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
     p.ksplit = (!scores && !col_importance && prefill_variant() == 0) ? flash_ksplit(batch, heads, q_len, kv_len) : 1; \
     p.part_o = (float*)(ws + align256((size_t)batch * kv_heads * head_dim * npad * 2));                \
     p.part_ml = p.part_o + (size_t)batch * heads * p.nqb * p.ksplit * 256 * head_dim;                   \
+    p.pair = flash_pair(batch, heads, q_len, causal & 1) && p.ksplit == 1 && !scores && !col_importance && !mask && !p.fast && prefill_variant() == 0; \
     return launch_flash<T, DD>(p, st);                                                                 \
   }
   if (dtype == SPATTEN_BF16) { if (head_dim == 128) SPATTEN_FLASH(bf16_t, 128) else SPATTEN_FLASH(bf16_t, 64) }
@@ -1604,7 +1672,7 @@ extern "C" int spatten_attn_prefill_pq(int dtype, const void* q, int64_t q_sb, i
     p.scores = nullptr; p.sc_sb = p.sc_sh = p.sc_sq = 0; p.col_imp = nullptr; p.lse = nullptr;         \
     p.kscale = kscale; p.ks_sb = (int64_t)kv_heads * kv_len; p.ks_sh = kv_len; p.need = need_lsb; p.pq_thr = (THR); \
     p.B = batch; p.H = heads; p.Hkv = kv_heads; p.q_len = q_len; p.N = kv_len; p.Npad = npad;          \
-    p.causal = causal & 1; p.fast = 0; p.sqrt_d = sqrtf((float)head_dim); p.nqb = ceil_div(q_len, 256);   \
+    p.causal = causal & 1; p.fast = 0; p.sqrt_d = sqrtf((float)head_dim); p.nqb = ceil_div(q_len, 256); p.pair = 0;   \
     p.ksplit = 1; p.part_o = nullptr; p.part_ml = nullptr;                                             \
     rc = launch_flash<T, DD>(p, st);                                                                   \
   }

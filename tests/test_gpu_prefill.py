@@ -100,10 +100,15 @@ def test_prefill_vs_oracle(dt, d, P, ql):
 
 
 @pytest.mark.parametrize("case", [("bf16", 128, 1, 4, 4, 0, 700), ("bf16", 128, 2, 4, 1, 411, 300), ("f16", 128, 1, 2, 2, 1000, 257),
-                                  ("bf16", 64, 1, 8, 2, 129, 520), ("f16", 64, 2, 2, 2, 0, 385), ("bf16", 128, 1, 2, 2, 255, 1)])
+                                  ("bf16", 64, 1, 8, 2, 129, 520), ("f16", 64, 2, 2, 2, 0, 385), ("bf16", 128, 1, 2, 2, 255, 1),
+                                  # whole 256-row groups, causal: the PAIRED form (a workgroup's halves take the 128-row blocks
+                                  # i and n - 1 - i) — with and without a cache in front, GQA, batch, d = 64, one and three pairs
+                                  ("bf16", 128, 1, 4, 4, 0, 1024), ("bf16", 128, 2, 4, 2, 300, 768), ("f16", 64, 1, 2, 2, 77, 512),
+                                  ("f16", 128, 1, 2, 1, 1000, 1536)])
 def test_prefill_multi_block_shapes_vs_oracle(case):
     """Several 256-query workgroups per head, ragged last blocks, tiles that straddle N, GQA, batch: the by-product-free
-    kernel (128-key tiles, LDS-DMA) and the stash kernel (64-key tiles) against the oracle."""
+    kernel (128-key tiles, LDS-DMA; paired 128-row blocks where the block is whole 256-row groups) and the stash kernel
+    (64-key tiles) against the oracle."""
     dt, d, B, H, Hkv, P, ql = case
     q, k, v, past = attn_inputs(B, H, Hkv, d, P, ql, dt, seed=900 + P + ql)
     N = P + ql

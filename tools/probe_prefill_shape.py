@@ -1,4 +1,4 @@
-"""ONE prefill shape, for per-shape rocprofv3 kernel stats:  probe_prefill_shape.py q_len kv_len [fast]
+"""ONE prefill shape, for per-shape rocprofv3 kernel stats:  [PF_HEADS=h] probe_prefill_shape.py q_len kv_len [fast]
 (causal flash leg, Llama-2-7B geometry, bf16; kv_len > q_len = a block appended to a cache)."""
 import os
 import sys
@@ -10,7 +10,7 @@ from spatten_amd import ops  # noqa: E402
 
 ql, N = int(sys.argv[1]), int(sys.argv[2])
 numerics = "fast" if len(sys.argv) > 3 and sys.argv[3] == "fast" else "reference"
-dt, B, H, d = torch.bfloat16, 1, 32, 128
+dt, B, H, d = torch.bfloat16, 1, int(os.environ.get("PF_HEADS", "32")), 128
 q = torch.randn(B, H, ql, d, device="cuda", dtype=dt)
 k = torch.randn(B, H, N, d, device="cuda", dtype=dt)
 v = torch.randn(B, H, N, d, device="cuda", dtype=dt)
