@@ -321,6 +321,224 @@ __global__ __launch_bounds__(kChainThreads) void layer_cascade_select_kernel(con
   chain_body<T, false>(p, (int)blockIdx.x, nullptr, 0u);
 }
 
+// ---- the BLOCKED chain (round 4): windows of up to 4 x 1024 positions, thread t owns the four CONSECUTIVE positions 4t .. 4t+3.
+// The phase stamps of chain_body (profiles/r04_layer_cascade_anatomy.txt) are barriers and LDS round trips: 11 workgroup barriers
+// of 16 waves per layer — three per radix pass (clear, count, wave 0's scan), three chunk rounds of the compaction.  Here the keys
+// stay in registers, every radix pass has its own histogram (cleared while the previous layer's rows are written), EVERY wave
+// scans the histogram itself (no broadcast round), and with a blocked layout the order-preserving compaction is one prefix over
+// threads (wave scan + the 16 wave totals): 4 barriers per layer.  Same keys, tie rule (lowest position first) and outputs as
+// chain_body, bit for bit (tests/test_gpu_cascade.py runs both).
+constexpr int kBlk = 4;                       // window positions per thread
+constexpr int kBlkCopies = 4;                 // private histograms per pass
+template <typename T>
+__global__ __launch_bounds__(kChainThreads) void layer_cascade_select_blocked_kernel(const ChainParams p) {
+  constexpr int kPasses = sizeof(T) == 4 ? 4 : (DT<T>::kId == SPATTEN_BF16 ? 2 : 3);
+  constexpr unsigned kKeyMask = kPasses == 4 ? 0xFFFFFFFFu : (kPasses == 3 ? 0xFFFFFF00u : 0xFFFF0000u);
+  __shared__ unsigned s_hist[kPasses][kBlkCopies][256];
+  __shared__ unsigned s_tot[kChainWaves][2];
+  __shared__ LayerPrune s_lay[kChainMaxLayers];
+  __shared__ const void* s_score[kChainMaxLayers];
+  __shared__ const int32_t* s_known[kChainMaxLayers];
+  __shared__ int32_t* s_nid[kChainMaxLayers];
+  extern __shared__ uint32_t s_dyn[];
+  uint8_t* s_map = reinterpret_cast<uint8_t*>(s_dyn);
+  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int R = p.map_ids;
+  const int nl = p.l_end - p.l_begin;
+  for (int i = tid; i < nl * (int)(sizeof(LayerPrune) / 8); i += kChainThreads)
+    reinterpret_cast<uint64_t*>(s_lay)[i] = reinterpret_cast<const uint64_t*>(p.lay + p.l_begin)[i];
+  if (tid < nl) {
+    s_score[tid] = p.score_ptrs[p.l_begin + tid];
+    s_known[tid] = p.known_ptrs[p.l_begin + tid];
+    s_nid[tid] = p.new_ids_ptrs[p.l_begin + tid];
+  }
+  for (int i = tid * 4; i < R; i += kChainThreads * 4) *reinterpret_cast<uint32_t*>(s_map + i) = 0u;
+  for (int i = tid; i < kPasses * kBlkCopies * 256; i += kChainThreads) (&s_hist[0][0][0])[i] = 0u;
+  int32_t map_base;
+  {
+    const LayerPrune L0 = p.lay[p.l_begin];
+    const int32_t* known0 = p.known_ptrs[p.l_begin] ? p.known_ptrs[p.l_begin] + h * L0.known_sh : nullptr;
+    map_base = slot_id(L0, known0, p.start);
+  }
+  auto stamp = [&](int32_t id, int l) {
+    const unsigned off = (unsigned)(id - map_base);
+    if (off < (unsigned)R) s_map[off] = (uint8_t)(l + 1);
+  };
+  const int32_t* prev = nullptr;
+  int n_prev = 0;
+  constexpr int kPt = 2;
+  T pf_sc[kBlk];
+  int32_t pf_id[kBlk], pf_tail[kPt], pf_head = 0;
+  auto prefetch = [&](int l, bool tables_in_lds) {
+    const LayerPrune L = tables_in_lds ? s_lay[l - p.l_begin] : p.lay[l];
+    const void* sp = tables_in_lds ? s_score[l - p.l_begin] : p.score_ptrs[l];
+    const int32_t* kp = tables_in_lds ? s_known[l - p.l_begin] : p.known_ptrs[l];
+    const T* score = (const T*)sp + h * L.score_sh;
+    const int32_t* known = kp ? kp + h * L.known_sh : nullptr;
+    const int W = (int)L.hi - p.start, tail = (int)(L.len - L.hi);
+#pragma unroll
+    for (int q = 0; q < kBlk; ++q) {
+      const int i = min(kBlk * tid + q, max(W - 1, 0)), j = p.start + i;
+      pf_sc[q] = score[j];
+      pf_id[q] = slot_id(L, known, j);
+    }
+#pragma unroll
+    for (int q = 0; q < kPt; ++q) pf_tail[q] = slot_id(L, known, (int)L.hi + min(tid + q * kChainThreads, max(tail - 1, 0)));
+    pf_head = slot_id(L, known, min(tid, max(p.start - 1, 0)));
+  };
+  prefetch(p.l_begin, false);
+  lds_sync();
+  if (p.l_begin > 0) {
+    const LayerPrune Lp = p.lay[p.l_begin - 1];
+    prev = p.new_ids_ptrs[p.l_begin - 1] + h * Lp.new_ids_sh;
+    n_prev = (int)Lp.new_len;
+    for (int i = tid; i < n_prev; i += kChainThreads) stamp(prev[i], p.l_begin - 1);
+    lds_sync();
+  }
+  for (int l = p.l_begin; l < p.l_end; ++l) {
+    const LayerPrune L = s_lay[l - p.l_begin];
+    const int32_t* known = s_known[l - p.l_begin] ? s_known[l - p.l_begin] + h * L.known_sh : nullptr;
+    const int W = (int)L.hi - p.start, k = (int)L.k;
+    int32_t* out = p.idx + l * p.idx_sl + h * p.idx_sh;
+    T my_sc[kBlk];
+    int32_t my_id[kBlk], my_tail[kPt];
+    const int32_t my_head = pf_head;
+#pragma unroll
+    for (int q = 0; q < kBlk; ++q) { my_sc[q] = pf_sc[q]; my_id[q] = pf_id[q]; }
+#pragma unroll
+    for (int q = 0; q < kPt; ++q) my_tail[q] = pf_tail[q];
+    LC_STAMP(l, 0);
+    if (l + 1 < p.l_end) prefetch(l + 1, true);
+    // ---- keys (registers)
+    unsigned key[kBlk];
+    bool in[kBlk];
+#pragma unroll
+    for (int q = 0; q < kBlk; ++q) {
+      in[q] = kBlk * tid + q < W;
+      bool member = true;
+      if (prev) {
+        const unsigned off = (unsigned)(my_id[q] - map_base);
+        if (off < (unsigned)R) {
+          member = s_map[off] == (uint8_t)l;
+        } else {
+          int lo = 0, hi = n_prev;
+          while (lo < hi) { const int mid = (lo + hi) >> 1; if (prev[mid] < my_id[q]) lo = mid + 1; else hi = mid; }
+          member = lo < n_prev && prev[lo] == my_id[q];
+        }
+      }
+      key[q] = ordered_key(member ? DT<T>::to_f32(my_sc[q]) : -INFINITY) & kKeyMask;
+    }
+    LC_STAMP(l, 1);
+    // ---- the key of the k-th largest: one histogram per pass (cleared one layer ago), one barrier per pass, every wave scans
+    unsigned prefix = 0, pmask = 0, k_rem = (unsigned)k;
+#pragma unroll
+    for (int pass = 0; pass < kPasses; ++pass) {
+      const int shift = 24 - 8 * pass;
+      unsigned* my_hist = s_hist[pass][wave % kBlkCopies];
+      // (r04 A/B: aggregating equal digits inside the wave first — ballot + one lane adds the count — is SLOWER on Gaussian scores,
+      //  10.8k against 9.2k cycles for the two passes: ~14 distinct exponent digits per wave cost more than the conflicts they save)
+#pragma unroll
+      for (int q = 0; q < kBlk; ++q)
+        if (in[q] && (key[q] & pmask) == prefix) atomicAdd(&my_hist[(key[q] >> shift) & 255u], 1u);
+      lds_sync();
+      unsigned c[4], tot = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        c[j] = 0;
+#pragma unroll
+        for (int q = 0; q < kBlkCopies; ++q) c[j] += s_hist[pass][q][255 - 4 * lane - j];
+        tot += c[j];
+      }
+      unsigned inc = tot;
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const unsigned t = __shfl_up(inc, off, kWave);
+        if (lane >= off) inc += t;
+      }
+      unsigned ex = inc - tot, digit = 0, before = 0;
+      const bool mine = ex < k_rem && k_rem <= inc;
+      if (mine) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (ex < k_rem && k_rem <= ex + c[j]) { digit = 255 - 4 * lane - j; before = ex; }
+          ex += c[j];
+        }
+      }
+      const unsigned long long hit = __ballot(mine);
+      const int src = hit ? (int)__builtin_ctzll(hit) : 0;
+      digit = __shfl(digit, src, kWave);
+      before = __shfl(before, src, kWave);
+      prefix |= digit << shift;
+      pmask |= 255u << shift;
+      k_rem -= before;
+    }
+    const unsigned thr = prefix, need_eq = k_rem;
+    LC_STAMP(l, 2);
+    // ---- order-preserving compaction: prefix over threads of (keys above the threshold, keys at it)
+    unsigned n_gt = 0, n_eq = 0;
+#pragma unroll
+    for (int q = 0; q < kBlk; ++q) { n_gt += (in[q] && key[q] > thr) ? 1u : 0u; n_eq += (in[q] && key[q] == thr) ? 1u : 0u; }
+    unsigned packed = n_gt | (n_eq << 16), inc = packed;          // both counts fit 16 bits (<= 4096 positions)
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const unsigned t = __shfl_up(inc, off, kWave);
+      if (lane >= off) inc += t;
+    }
+    if (lane == kWave - 1) { s_tot[wave][0] = inc & 0xFFFFu; s_tot[wave][1] = inc >> 16; }
+    lds_sync();
+    unsigned gt_before = (inc - packed) & 0xFFFFu, eq_before = (inc - packed) >> 16;
+#pragma unroll
+    for (int w = 0; w < kChainWaves; ++w)
+      if (w < wave) { gt_before += s_tot[w][0]; eq_before += s_tot[w][1]; }
+    // (the histograms of this layer are dead: every wave scanned them before the barrier above — clear them for the next layer)
+    for (int i = tid; i < kPasses * kBlkCopies * 256; i += kChainThreads) (&s_hist[0][0][0])[i] = 0u;
+    int32_t* nid = s_nid[l - p.l_begin] + h * L.new_ids_sh;
+    {
+      unsigned g = gt_before, e = eq_before;
+#pragma unroll
+      for (int q = 0; q < kBlk; ++q) {
+        const bool gt = in[q] && key[q] > thr, eq = in[q] && key[q] == thr;
+        const bool keep = gt || (eq && e < need_eq);
+        const unsigned pos = g + (e < need_eq ? e : need_eq);
+        if (keep) {
+          out[pos] = p.start + kBlk * tid + q;
+          nid[p.start + pos] = my_id[q];
+          stamp(my_id[q], l);
+        }
+        g += gt ? 1u : 0u;
+        e += eq ? 1u : 0u;
+      }
+    }
+    LC_STAMP(l, 3);
+    // ---- the ids of the head rows [0, start) and of the tail rows [hi, len) of the new cache
+    if (tid < p.start) { nid[tid] = my_head; stamp(my_head, l); }
+    for (int r = kChainThreads; r + tid < p.start; r += kChainThreads) {
+      const int32_t id = slot_id(L, known, r + tid);
+      nid[r + tid] = id; stamp(id, l);
+    }
+    {
+      const int tail = (int)(L.len - L.hi);
+      int qt = 0;
+      for (int t = tid; t < tail; t += kChainThreads, ++qt) {
+        int32_t id = 0;
+        if (qt < kPt) {
+#pragma unroll
+          for (int qq = 0; qq < kPt; ++qq) if (qq == qt) id = my_tail[qq];
+        } else {
+          id = slot_id(L, known, (int)L.hi + t);
+        }
+        const int r = p.start + k + t;
+        nid[r] = id;
+        stamp(id, l);
+      }
+    }
+    lds_sync();
+    prev = nid;
+    n_prev = (int)L.new_len;
+    LC_STAMP(l, 4);
+  }
+}
+
 struct RaggedParams {
   const LayerPrune* lay;
   const void* const* k_src_ptrs; const void* const* v_src_ptrs;
@@ -567,12 +785,32 @@ static int prune_layer_cascade_impl(int score_dtype, int kv_dtype, int layers, c
     }
     return SPATTEN_OK;
   };
+  // the blocked chain (keys in registers, 4 barriers per layer) where every window fits 4 positions per thread
+  static int env_blk = -1;
+  if (env_blk < 0) { const char* e = getenv("SPATTEN_LC_BLOCKED"); env_blk = e ? atoi(e) : 1; }
+  const bool blocked = env_blk != 0 && max_w <= kBlk * kChainThreads && c.map_ids > 0;
+  if (blocked) {
+    static bool attr_blk[4] = {};
+    const int di = score_dtype == SPATTEN_F32 ? 0 : (score_dtype == SPATTEN_BF16 ? 1 : 2);
+    if (!attr_blk[di]) {
+      hipError_t e = hipSuccess;
+      SPATTEN_BY_DTYPE(score_dtype, e = hipFuncSetAttribute((const void*)layer_cascade_select_blocked_kernel<T>,
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));   // = the map
+      if (e != hipSuccess) return SPATTEN_ERR_LAUNCH;
+      attr_blk[di] = true;
+    }
+  }
   bool forked = false;
   for (int g = 0; g < n_legs; ++g) {
     const int l0 = (int)((int64_t)layers * g / n_legs), l1 = (int)((int64_t)layers * (g + 1) / n_legs);
     c.l_begin = l0; c.l_end = l1;
-    SPATTEN_BY_DTYPE(score_dtype, hipLaunchKernelGGL((layer_cascade_select_kernel<T>), dim3((unsigned)heads), dim3(kChainThreads),
-                                                     lds, st, c));
+    if (blocked) {
+      SPATTEN_BY_DTYPE(score_dtype, hipLaunchKernelGGL((layer_cascade_select_blocked_kernel<T>), dim3((unsigned)heads),
+                                                       dim3(kChainThreads), (size_t)c.map_ids, st, c));
+    } else {
+      SPATTEN_BY_DTYPE(score_dtype, hipLaunchKernelGGL((layer_cascade_select_kernel<T>), dim3((unsigned)heads), dim3(kChainThreads),
+                                                       lds, st, c));
+    }
     if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
     if (g + 1 < n_legs) {       // this leg's gather goes to the side stream, behind the leg's chain
       if (hipEventRecord(side->ev[g % SideStream::kEvents], st) != hipSuccess) return SPATTEN_ERR_LAUNCH;
