@@ -417,7 +417,11 @@ int spatten_cascade_rank(int dtype, const void* score, int64_t score_sh, const i
  * last prune left (NULL when n_known = 0), slots j >= n_known hold token id_base + (j - n_known) (appended since);
  * new_ids_ptrs[l] -> int32 [H, new_len] out; idx int32 [layers, H, kmax] out (kept window positions, ascending);
  * key_scratch uint32 [H, key_scratch_sh >= max window]; K / V / shadow / accumulator pointer tables as in
- * spatten_prune_layers_scored (accumulators optional).  Same selection as spatten_cascade_rank + spatten_topk_select. */
+ * spatten_prune_layers_scored (accumulators optional).  Same selection as spatten_cascade_rank + spatten_topk_select.
+ * Round 4: the event is issued as a few legs of consecutive layers; each leg's gathers run on a LIBRARY-OWNED side stream
+ * (one per device, created on first use) behind an event, under the next leg's selection chain, and `stream` waits for that
+ * side stream before the call's work counts as done on it: for the caller everything is still ordered on `stream` (a
+ * stream capture follows the fork / join).  SPATTEN_LC_LEGS=1 keeps every launch on `stream`. */
 int spatten_prune_layer_cascade(int score_dtype, int kv_dtype, int layers, const void* lay_dev, const void* lay_host,
                                 const void* const* score_ptrs, const int32_t* const* known_ptrs, int32_t* const* new_ids_ptrs,
                                 const void* const* k_src_ptrs, const void* const* v_src_ptrs,
