@@ -33,6 +33,8 @@ for case in range(n):
     horizon = rng.choice([3, 8, 32, 200, True]) if os.environ.get("FUZZ_ANY_HORIZON") else rng.choice([3, 8, 16])
     imp, rec = rng.randint(30, 50), rng.randint(30, 50)
     turns = [(rng.randint(20, 150), rng.randint(3, 20)) for _ in range(rng.randint(2, 4))]
+    if turns[0][0] + turns[0][1] < 4 + imp + rec + 2:      # the first prune needs a window of at least `imp` candidates (the
+        turns[0] = (4 + imp + rec + 2, turns[0][1])        # reference's torch.topk raises on a shorter one, and so does the cache)
     tag = f"session {case}: {str(dt)[6:]} horizon={horizon} imp={imp} rec={rec} turns={turns} {kw}"
     try:
         torch.manual_seed(case)
