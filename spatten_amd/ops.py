@@ -845,37 +845,39 @@ def prune_layer_cascade(scores: Sequence[torch.Tensor], known_ids: Sequence[Opti
     kmax = max(keeps)
     if dst is not None:
         Kd, Vd, Krd = (list(x) for x in dst)
-        if any(Kd[l].shape[2] < new_lens[l] or Kd[l].stride() != Vd[l].stride() or Kd[l].stride() != Krd[l].stride()
-               or Kd[l].stride(3) != 1 or Kd[l].stride(2) != d for l in range(nl)):
-            raise ValueError("layer cascade: destination planes too small or not row-contiguous with equal strides")
+        for l in range(nl):
+            sd = Kd[l].stride()
+            if Kd[l].shape[2] < new_lens[l] or sd != Vd[l].stride() or sd != Krd[l].stride() or sd[3] != 1 or sd[2] != d:
+                raise ValueError("layer cascade: destination planes too small or not row-contiguous with equal strides")
     else:
         Kd = [torch.empty(B, H, max(capacities[l], new_lens[l]), d, dtype=dt, device=dev) for l in range(nl)]
         Vd = [torch.empty_like(x) for x in Kd]
         Krd = [torch.empty_like(x) for x in Kd]
     # one allocation per kind (32 layers x torch.empty / torch.zeros — 32 fill launches — were most of the event's host time)
     ids_all = torch.empty(nl, H, max(new_lens), dtype=torch.int32, device=dev)
-    new_ids = [ids_all[l, :, :new_lens[l]] for l in range(nl)]
+    new_ids = [ids_all[l].narrow(1, 0, new_lens[l]) for l in range(nl)]
     new_accs = None
     if accs is not None:
         widths = [max(Kd[l].shape[2], accs[l].shape[1]) for l in range(nl)]
         acc_all = torch.zeros(nl, H, max(widths), dtype=torch.float32, device=dev)
-        new_accs = [acc_all[l, :, :widths[l]] for l in range(nl)]
+        new_accs = [acc_all[l].narrow(1, 0, widths[l]) for l in range(nl)]
     idx = torch.empty(nl, H, kmax, dtype=torch.int32, device=dev)
     wmax = max(his[l] - start for l in range(nl))
     scratch = torch.empty(H, wmax, dtype=torch.int32, device=dev)
     sdt = scores[0].dtype
     rows = []
     for l in range(nl):
-        K, V, sc = Ks[l], Vs[l], scores[l]
-        if K.stride(3) != 1 or K.stride(2) != d or V.stride() != K.stride() or sc.stride(1) != 1 or sc.dtype != sdt:
+        sc = scores[l]
+        ks, ss, ds = Ks[l].stride(), sc.stride(), Kd[l].stride()
+        if ks[3] != 1 or ks[2] != d or Vs[l].stride() != ks or ss[1] != 1 or sc.dtype != sdt:
             raise ValueError("layer cascade: K / V need contiguous rows and equal strides, scores contiguous rows of one dtype")
         kn = known_ids[l]
         if kn is not None and (kn.dtype != torch.int32 or kn.stride(1) != 1 or kn.shape[0] != H):
             raise ValueError("known ids must be int32 [H, n] with contiguous rows")
         rows += [lens[l], his[l], keeps[l], new_lens[l],
-                 sc.stride(0), 0 if kn is None else kn.shape[1], 0 if kn is None else kn.stride(0), new_ids[l].stride(0),
-                 K.stride(0), K.stride(1), Kd[l].stride(0), Kd[l].stride(1),
-                 0 if accs is None else accs[l].stride(0), 0 if accs is None else new_accs[l].stride(0), int(id_base), 0]
+                 ss[0], 0 if kn is None else kn.shape[1], 0 if kn is None else kn.stride(0), ids_all.stride(1),
+                 ks[0], ks[1], ds[0], ds[1],
+                 0 if accs is None else accs[l].stride(0), 0 if accs is None else acc_all.stride(1), int(id_base), 0]
     groups = [scores, known_ids, new_ids, Ks, Vs, Kd, Vd, Krd] + ([list(accs), new_accs] if accs is not None else [])
     # the per-layer table (16 int64 per layer: LayerPrune of layer_cascade.hip) and the pointer rows behind it: ONE host tensor,
     # one copy to the device
@@ -889,8 +891,8 @@ def prune_layer_cascade(scores: Sequence[torch.Tensor], known_ids: Sequence[Opti
     _lib.check(rc, "spatten_prune_layer_cascade")
     keep_alive = (both, host, scratch)               # referenced until the launches were issued
     del keep_alive
-    return ([Kd[l][:, :, :new_lens[l]] for l in range(nl)], [Vd[l][:, :, :new_lens[l]] for l in range(nl)],
-            [Krd[l][:, :, :new_lens[l]] for l in range(nl)], [idx[l, :, :keeps[l]] for l in range(nl)], new_ids, new_accs)
+    return ([Kd[l].narrow(2, 0, new_lens[l]) for l in range(nl)], [Vd[l].narrow(2, 0, new_lens[l]) for l in range(nl)],
+            [Krd[l].narrow(2, 0, new_lens[l]) for l in range(nl)], [idx[l].narrow(1, 0, keeps[l]) for l in range(nl)], new_ids, new_accs)
 
 
 # ------------------------------------------------------------------------------------------------
