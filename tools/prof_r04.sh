@@ -18,3 +18,8 @@ for probe in "pq_profiles tools/mb/pqv_exp.py" "local_v tools/mb/localv_exp.py" 
   grep -v amdgpu.ids $O/r04_$1.txt | tail -6
   head -5 $O/r04_$1_kernel_stats.csv | cut -c1-160
 done
+# the paired-block prefill at q = N = 2048 (one shape per run: the file's average IS that shape's kernel time)
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_pf2048 -o p -- python $R/tools/probe_prefill_shape.py 2048 2048 > $O/r04_prefill_q2048_n2048.txt 2>&1
+python $R/tools/trim_stats.py $(find $O/prof_pf2048 -name "*kernel_stats.csv" | head -1) $O/r04_prefill_q2048_n2048_kernel_stats.csv
+grep -v amdgpu.ids $O/r04_prefill_q2048_n2048.txt | tail -1
+head -4 $O/r04_prefill_q2048_n2048_kernel_stats.csv | cut -c1-160
