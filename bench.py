@@ -899,8 +899,10 @@ def main():
             Vd_lc = [torch.empty_like(x) for x in Kd_lc]
             Krd_lc = [torch.empty_like(x) for x in Kd_lc]
             for tag_ in ("layer_cascade_prune_event_us",):
-                lc2 = lambda: ops.prune_layer_cascade(importance, [None] * L, 0, Kp, Vp, [CTX] * L, [hi] * L, keeps_lc, START,
-                                                      [cap] * L, (cos, sin), accs, dst=(Kd_lc, Vd_lc, Krd_lc))
+                # like the plain event above (PrunePlan): tables and pointer rows prebuilt, the timed call is the C call alone
+                lc_plan = ops.LayerCascadePlan(importance, [None] * L, 0, Kp, Vp, [CTX] * L, [hi] * L, keeps_lc, START,
+                                               [cap] * L, (cos, sin), accs, dst=(Kd_lc, Vd_lc, Krd_lc))
+                lc2 = lc_plan.run
                 lc2()
                 torch.cuda.synchronize()
                 e0.record()
@@ -910,7 +912,7 @@ def main():
                 torch.cuda.synchronize()
                 result["prune_event"][tag_] = round(e0.elapsed_time(e1) * 1e3 / 5, 1)
             result["prune_event"]["layer_cascade_vs_plain_event"] = round(result["prune_event"]["layer_cascade_prune_event_us"] / result["prune_event"]["us_all_layers"], 3)
-            del accs, acc_new, plan3, Kd_lc, Vd_lc, Krd_lc
+            del accs, acc_new, plan3, Kd_lc, Vd_lc, Krd_lc, lc_plan, lc2
             prune()   # restore the shadow planes for whatever runs next
 
         # ---- dense comparison legs ---------------------------------------------------------------------

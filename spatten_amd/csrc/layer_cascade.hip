@@ -9,6 +9,7 @@
 // (the layers keep different numbers of rows, so lengths and strides come from a per-layer table), and one moves the
 // cascade accumulators.
 #include <algorithm>
+#include <mutex>
 
 #include "common.h"
 
@@ -651,15 +652,14 @@ struct SideStream {
   hipEvent_t ev[kEvents] = {};
   hipEvent_t join = nullptr;
 };
-static SideStream* side_stream() {
+static std::mutex g_side_mutex;      // creation of the side streams, and the issue of one event's legs (its events are shared)
+static SideStream* side_stream() {   // (called with g_side_mutex held)
   static SideStream per_dev[16];
   static bool failed[16] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || failed[dev]) return nullptr;
   SideStream& S = per_dev[dev];
   if (S.s) return &S;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  (void)cs;
   if (hipStreamCreateWithFlags(&S.s, hipStreamNonBlocking) != hipSuccess) { S.s = nullptr; failed[dev] = true; return nullptr; }
   bool ok = hipEventCreateWithFlags(&S.join, hipEventDisableTiming) == hipSuccess;
   for (int i = 0; i < SideStream::kEvents && ok; ++i) ok = hipEventCreateWithFlags(&S.ev[i], hipEventDisableTiming) == hipSuccess;
@@ -768,6 +768,9 @@ static int prune_layer_cascade_impl(int score_dtype, int kv_dtype, int layers, c
   static int env_legs = -1;
   if (env_legs < 0) { const char* e = getenv("SPATTEN_LC_LEGS"); env_legs = e ? std::max(1, atoi(e)) : 4; }
   const int legs = std::min(std::max(env_legs, ceil_div(layers, kChainMaxLayers)), layers);
+  // two host threads issuing events on one device would re-record each other's fork events: one event's legs at a time
+  std::unique_lock<std::mutex> side_lock(g_side_mutex, std::defer_lock);
+  if (legs > 1) side_lock.lock();
   SideStream* side = legs > 1 ? side_stream() : nullptr;
   const int n_legs = side ? legs : ceil_div(layers, kChainMaxLayers);
   auto launch_gather = [&](int l0, int l1, hipStream_t s) -> int {
@@ -801,6 +804,13 @@ static int prune_layer_cascade_impl(int score_dtype, int kv_dtype, int layers, c
     }
   }
   bool forked = false;
+  // whatever happens after the fork, the caller's stream joins the side stream again (an unjoined fork would also invalidate a
+  // stream capture)
+  auto join = [&]() -> bool {
+    if (!forked) return true;
+    forked = false;
+    return hipEventRecord(side->join, side->s) == hipSuccess && hipStreamWaitEvent(st, side->join, 0) == hipSuccess;
+  };
   for (int g = 0; g < n_legs; ++g) {
     const int l0 = (int)((int64_t)layers * g / n_legs), l1 = (int)((int64_t)layers * (g + 1) / n_legs);
     c.l_begin = l0; c.l_end = l1;
@@ -811,21 +821,18 @@ static int prune_layer_cascade_impl(int score_dtype, int kv_dtype, int layers, c
       SPATTEN_BY_DTYPE(score_dtype, hipLaunchKernelGGL((layer_cascade_select_kernel<T>), dim3((unsigned)heads), dim3(kChainThreads),
                                                        lds, st, c));
     }
-    if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
+    if (hipGetLastError() != hipSuccess) { join(); return SPATTEN_ERR_LAUNCH; }
+    int rc;
     if (g + 1 < n_legs) {       // this leg's gather goes to the side stream, behind the leg's chain
-      if (hipEventRecord(side->ev[g % SideStream::kEvents], st) != hipSuccess) return SPATTEN_ERR_LAUNCH;
-      if (hipStreamWaitEvent(side->s, side->ev[g % SideStream::kEvents], 0) != hipSuccess) return SPATTEN_ERR_LAUNCH;
+      if (hipEventRecord(side->ev[g % SideStream::kEvents], st) != hipSuccess ||
+          hipStreamWaitEvent(side->s, side->ev[g % SideStream::kEvents], 0) != hipSuccess) { join(); return SPATTEN_ERR_LAUNCH; }
       forked = true;
-      const int rc = launch_gather(l0, l1, side->s);
-      if (rc != SPATTEN_OK) return rc;
+      rc = launch_gather(l0, l1, side->s);
     } else {
-      const int rc = launch_gather(l0, l1, st);
-      if (rc != SPATTEN_OK) return rc;
+      rc = launch_gather(l0, l1, st);
     }
+    if (rc != SPATTEN_OK) { join(); return rc; }
   }
-  if (forked) {                 // join: everything the side stream did is ordered before whatever follows on the caller's stream
-    if (hipEventRecord(side->join, side->s) != hipSuccess) return SPATTEN_ERR_LAUNCH;
-    if (hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return SPATTEN_ERR_LAUNCH;
-  }
+  if (!join()) return SPATTEN_ERR_LAUNCH;
   return SPATTEN_OK;
 }

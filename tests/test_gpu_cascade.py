@@ -342,6 +342,55 @@ def test_layer_cascade_event_in_three_launches_equals_the_per_layer_composition(
                                 [V[:, :, :L] for V, L in zip(Vs, lens)], lens, [start + 10] * nl, keeps, start, caps, (cos, sin))
 
 
+def test_layer_cascade_event_replays_from_a_captured_graph_and_from_its_plan():
+    """ops.LayerCascadePlan: the host preparation once, run() = the C call alone.  The event forks its gathers onto the library's
+    side stream and joins it again (include/spatten.h: spatten_prune_layer_cascade) — a stream capture follows both, so the whole
+    event replays from a HIP graph; results equal the one-shot op bit for bit, from the plan, from the graph, and with the legs
+    switched (4 legs over 6 layers vs the per-call default)."""
+    from spatten_amd import ops
+    tdt, B, H, d, start, recent = torch.bfloat16, 1, 8, 128, 4, 64
+    g = torch.Generator(device="cuda").manual_seed(9)
+    lens = [900, 900, 880, 880, 860, 860]
+    keeps = [400, 380, 360, 340, 320, 300]
+    nl = len(lens)
+    his = [L - recent for L in lens]
+    cos, sin = ops.rope_table(1024, d, tdt, "cuda")
+    Ks = [torch.randn(B, H, L, d, device="cuda", generator=g).to(tdt) for L in lens]
+    Vs = [torch.randn(B, H, L, d, device="cuda", generator=g).to(tdt) for L in lens]
+    scores = [torch.randn(H, L, device="cuda", generator=g).to(tdt) for L in lens]
+    known = [torch.arange(L - 50, device="cuda", dtype=torch.int32)[None].expand(H, L - 50).contiguous() for L in lens]
+    caps = [512] * nl
+    want = ops.prune_layer_cascade(scores, known, 5000, Ks, Vs, lens, his, keeps, start, caps, (cos, sin))
+    torch.cuda.synchronize()
+    dst = ([torch.zeros(B, H, 512, d, dtype=tdt, device="cuda") for _ in range(nl)],
+           [torch.zeros(B, H, 512, d, dtype=tdt, device="cuda") for _ in range(nl)],
+           [torch.zeros(B, H, 512, d, dtype=tdt, device="cuda") for _ in range(nl)])
+    plan = ops.LayerCascadePlan(scores, known, 5000, Ks, Vs, lens, his, keeps, start, caps, (cos, sin), dst=dst)
+
+    def check(got):
+        torch.cuda.synchronize()
+        for l in range(nl):
+            assert torch.equal(got[3][l], want[3][l]) and torch.equal(got[4][l], want[4][l]), l
+            assert torch.equal(got[0][l], want[0][l]) and torch.equal(got[1][l], want[1][l]) and torch.equal(got[2][l], want[2][l]), l
+    check(plan.run())                       # (also creates the side stream outside any capture)
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        plan.run()
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            plan.run()
+    for t in dst[0] + dst[1] + dst[2]:
+        t.zero_()
+    for t in plan.result[3] + plan.result[4]:
+        t.zero_()
+    torch.cuda.synchronize()
+    graph.replay()
+    check(plan.result)
+    graph.replay()                          # a second replay: the fork events are re-recorded inside the graph
+    check(plan.result)
+
+
 def test_cascade_prune_of_a_grouped_query_cache_vs_oracle(capsys):
     """importance_mode="cascade" on a grouped-query cache (Hkv < H): a key's importance is the sum of its group's
     accumulator rows (the reference-mode rule for GQA), the kept rows are the oracle's top-k of that sum per KV head, and
