@@ -46,13 +46,13 @@ template <int MODE> void run(const char* name, int threads, int n_instr) {
   float* out; unsigned long long* cyc; hipMalloc(&out, 256 * 1024 * 4); hipMalloc(&cyc, 8);
   const int iters = 4096;
   k<MODE><<<256, threads>>>(out, cyc, iters); hipDeviceSynchronize();
-  k<MODE><<<256, threads>>>(out, cyc, iters); hipDeviceSynchronize();
+  k<MODE><<<256, threads>>>(out, cyc, iters); hipDeviceSynchronize();   // (64 threads = one wave on one SIMD; 1024 = four per SIMD)
   unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
   printf("%-22s %4d threads/WG: %.2f s_memtime ticks per instruction per wave (%d instr per iteration)\n", name, threads, (double)c / iters / n_instr, n_instr);
   hipFree(out); hipFree(cyc);
 }
 int main() {
-  for (int th : {256, 512}) {
+  for (int th : {64, 256, 512, 1024}) {
     run<0>("v_mul_f32 x8", th, 8); run<1>("v_pk_mul_f32 x4", th, 4); run<2>("v_fma_f32 x8", th, 8); run<3>("v_pk_fma_f32 x4", th, 4);
     run<6>("v_pk_add_f32 x4", th, 4); run<4>("v_exp_f32 x8", th, 8); run<5>("v_cvt_pk_bf16_f32 x8", th, 8);
   }
