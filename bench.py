@@ -266,7 +266,7 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False, Fals
 
     from torch import nn
 
-    from spatten_amd import enable_spatten_llm
+    from spatten_amd import enable_spatten_llm, ops
 
     class LlamaAttention(nn.Module):
         def __init__(self):
@@ -327,6 +327,8 @@ def plugin_path_tokens_per_s(dev, dt, n_tokens=48, variants=((False, False, Fals
                 "plugin_path_assume_causal_fused_qkv_tokens_per_s" if fuse else (
                     "plugin_path_assume_causal_tokens_per_s" if flag else "plugin_path_eager_tokens_per_s"))
             out[key] = round(n_tokens / (time.perf_counter() - t0), 2)
+            if fused_step:      # (the option selected the 256-thread attention team process-wide: back to the default)
+                ops.set_decode_team(512)
             # ---- the same decode step as ONE captured HIP graph of the whole layer stack (spatten_amd/graph.py): the
             # device-resident step state (ABI 3) lets a single graph replay for every token of the turn
             if (flag and not fuse) or fused_step:
@@ -831,7 +833,7 @@ def main():
                     traffic = int(json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["traffic_bytes_per_launch"])
             except Exception:
                 traffic = None
-            result["roofline"] = {"kernel": "decode_lean_kernel<bf16,128> (decode_attn.hip)", "bound": "hbm", "achieved": round(gbs, 1),
+            result["roofline"] = {"kernel": "decode_lean_kernel<bf16,128,5,...,512> (decode_attn.hip; 512-thread team, two waves per SIMD)", "bound": "hbm", "achieved": round(gbs, 1),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                   "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4), "achievable_GBs": HBM_ACHIEVABLE_GBS,
                                   "traffic": traffic,

@@ -186,6 +186,13 @@ int spatten_attn_decode_args(const spatten_decode_args_t* args, void* stream);
 /* the fused q/k/v projection + attention launch (spatten_decode_args_t::qkv_*): scratch size, and whether a step of this
  * shape runs it (lean MHA step, bf16 / f16, head_dim 128, batch 1, <= 320 rows per split of the layout length) */
 size_t spatten_decode_qkv_exchange_bytes(int batch, int heads, int head_dim);
+/* Threads of the attention team of a single-row, single-shot decode step (ABI 4, round 4): 512 = two waves per SIMD (the
+ * default: 11.5 -> 11.0 us at the Llama-2-7B headline shape), 256 = the r03 form.  Process-wide; every route of such a step
+ * (lean / general, cascade accumulation, device length) follows it, so results stay bit-identical between routes; the two
+ * forms differ from each other in summation order (low bits).  The fused projection launch (qkv_*) contains the 256-thread
+ * body: a caller that wants its fused and separate steps bit-identical selects 256.  Returns the previous value (or
+ * SPATTEN_ERR_INVALID).  SPATTEN_DECODE_TEAM=256 in the environment sets the initial value. */
+int spatten_decode_set_team(int threads);
 int spatten_decode_qkv_supported(int dtype, int batch, int heads, int kv_heads, int head_dim, int kv_len_layout);
 
 /* ------------------------------------------------------------------------------------------------

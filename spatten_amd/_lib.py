@@ -208,6 +208,8 @@ def _declare(lib):
                                                 p, i64, p, i64, i, i, i, i, i, i, i, i, p]
 
 
+    lib.spatten_decode_set_team.restype = c_int
+    lib.spatten_decode_set_team.argtypes = [c_int]
     lib.spatten_prune_layer_cascade.restype = c_int
     lib.spatten_prune_layer_cascade.argtypes = [i, i, i, p, p, p, p, p, p, p, p, p, p, p, p, i, p, i, p, i64, p, p, i, i, i, i, p]
 def load():

@@ -37,6 +37,8 @@
 
 #include <algorithm>
 
+#include <atomic>
+
 #include "common.h"
 
 #ifdef SPATTEN_TRACE   // developer instrumentation: per-workgroup phase timestamps (tools/mb/decode_trace.cpp)
@@ -139,20 +141,21 @@ __device__ inline void store_granule(unsigned long long* g, float v, unsigned ta
 // projections of the whole head have been exchanged).  The rest — tile arithmetic, reduction, publication, merge — is the
 // plain step's, bit for bit.
 template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0, bool NT = LEAN, bool CASC = false,
-          bool PIPE = false, bool DYN = false, bool FUSED = false, bool OPROJ = false>
+          bool PIPE = false, bool DYN = false, bool FUSED = false, bool OPROJ = false, int THREADS = kDecodeThreads>
 __device__ __forceinline__ void decode_body(const DecodeParams<T>& p, const float* s_x = nullptr) {
   constexpr bool SCORES_ONLY = (MODE == 1);
   constexpr bool PQ = (KSRC != 0);
   constexpr int LPR = D / 16;                    // lanes per row
-  constexpr int RPI = kDecodeThreads / LPR;      // rows per row-group (one per thread group of LPR lanes)
+  constexpr int RPI = THREADS / LPR;             // rows per row-group (one per thread group of LPR lanes)
+  constexpr int NW = THREADS / kWave;            // waves of the attention team (4; 8 in the two-waves-per-SIMD form)
   constexpr int TILE = RPI * UNR;
   constexpr int HALF = D / 2;
-  constexpr int G = (kDecodeThreads / D) > 0 ? (kDecodeThreads / D) : 1;   // merge thread groups
+  constexpr int G = (THREADS / D) > 0 ? (THREADS / D) : 1;   // merge thread groups
   using V8 = Vec8<T>;
   using raw_t = typename V8::raw;
   using D8 = Dot8<T>;
 
-  __shared__ float s_o[4][D + 2];
+  __shared__ float s_o[NW][D + 2];
   __shared__ unsigned s_ticket;
 
   const int tid = threadIdx.x;
@@ -619,13 +622,27 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p, const floa
   __syncthreads();
   float o_tot = 0.f, l_tot = 0.f;
   {
-    const float m0 = s_o[0][D + 1], m1 = s_o[1][D + 1], m2 = s_o[2][D + 1], m3 = s_o[3][D + 1];
-    const float m_wg = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-    const float mu = (m_wg == -INFINITY) ? 0.f : m_wg;
-    const float w0 = __expf(m0 - mu), w1 = __expf(m1 - mu), w2 = __expf(m2 - mu), w3 = __expf(m3 - mu);   // exp(-inf) = 0
-    if (tid < D) o_tot = (s_o[0][tid] * w0 + s_o[1][tid] * w1) + (s_o[2][tid] * w2 + s_o[3][tid] * w3);
-    l_tot = (s_o[0][D] * w0 + s_o[1][D] * w1) + (s_o[2][D] * w2 + s_o[3][D] * w3);
-    m_run = m_wg;
+    if constexpr (NW == 4) {
+      const float m0 = s_o[0][D + 1], m1 = s_o[1][D + 1], m2 = s_o[2][D + 1], m3 = s_o[3][D + 1];
+      const float m_wg = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+      const float mu = (m_wg == -INFINITY) ? 0.f : m_wg;
+      const float w0 = __expf(m0 - mu), w1 = __expf(m1 - mu), w2 = __expf(m2 - mu), w3 = __expf(m3 - mu);   // exp(-inf) = 0
+      if (tid < D) o_tot = (s_o[0][tid] * w0 + s_o[1][tid] * w1) + (s_o[2][tid] * w2 + s_o[3][tid] * w3);
+      l_tot = (s_o[0][D] * w0 + s_o[1][D] * w1) + (s_o[2][D] * w2 + s_o[3][D] * w3);
+      m_run = m_wg;
+    } else {
+      float mw[NW], m_wg = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { mw[w] = s_o[w][D + 1]; m_wg = fmaxf(m_wg, mw[w]); }
+      const float mu = (m_wg == -INFINITY) ? 0.f : m_wg;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const float ww = __expf(mw[w] - mu);
+        if (tid < D) o_tot = fmaf(s_o[w][tid], ww, o_tot);
+        l_tot = fmaf(s_o[w][D], ww, l_tot);
+      }
+      m_run = m_wg;
+    }
   }
 #ifdef SPATTEN_EXP_NOMERGE    // A/B harness only: what do publish + ticket + merge cost?
   if (tid < D) p.out[b * p.out_sb + h * D + tid] = DT<T>::from_f32(o_tot / l_tot);
@@ -641,7 +658,12 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p, const floa
     __syncthreads();
     if (lane == 0) s_o[0][wave] = v;
     __syncthreads();
-    if (tid == 0 && commit) p.head_abs[unit] += (s_o[0][0] + s_o[0][1]) + (s_o[0][2] + s_o[0][3]);
+    if (tid == 0 && commit) {
+      float tot = (s_o[0][0] + s_o[0][1]) + (s_o[0][2] + s_o[0][3]);
+#pragma unroll
+      for (int w = 4; w < NW; ++w) tot += s_o[0][w];
+      p.head_abs[unit] += tot;
+    }
   };
   if (p.S == 1) {
     if (!SCORES_ONLY && tid < D) outp[tid] = DT<T>::from_f32(o_tot / l_tot);
@@ -675,12 +697,12 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p, const floa
   if (!p.poll_merge) {
     // the ticket is drawn by the LAST wave, which has no stores in flight: on CDNA4 vmcnt also counts stores, so a
     // wave that just issued granules would wait for their write-through acknowledgements before it sees its ticket
-    if (tid == kDecodeThreads - 1)
+    if (tid == THREADS - 1)
       s_ticket = __hip_atomic_fetch_add(p.ws_cnt + 2 * unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (tid < D && tid < kDecodeThreads - kWave) store_granule(part + tid, o_tot, tag);
-  if (D > kDecodeThreads - kWave && tid >= kDecodeThreads - kWave && tid < D) store_granule(part + tid, o_tot, tag);   // D = 256 only
-  if (tid == (D < kDecodeThreads - kWave ? D : 0)) { store_granule(part + D, m_run, tag); store_granule(part + D + 1, l_tot, tag); }
+  if (tid < D && tid < THREADS - kWave) store_granule(part + tid, o_tot, tag);
+  if (D > THREADS - kWave && tid >= THREADS - kWave && tid < D) store_granule(part + tid, o_tot, tag);   // D = 256 only
+  if (tid == (D < THREADS - kWave ? D : 0)) { store_granule(part + D, m_run, tag); store_granule(part + D + 1, l_tot, tag); }
   if (p.poll_merge) {
     if (split != p.S - 1) return;
   } else {
@@ -784,24 +806,24 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p, const floa
 }
 
 template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0, bool NT = LEAN, bool CASC = false,
-          bool PIPE = false, bool DYN = false>
-__global__ __launch_bounds__(kDecodeThreads) void decode_attn_kernel(const DecodeParams<T> p) {
-  decode_body<T, D, UNR, MODE, LEAN, KSRC, NT, CASC, PIPE, DYN>(p);
+          bool PIPE = false, bool DYN = false, int THREADS = kDecodeThreads>
+__global__ __launch_bounds__(THREADS) void decode_attn_kernel(const DecodeParams<T> p) {
+  decode_body<T, D, UNR, MODE, LEAN, KSRC, NT, CASC, PIPE, DYN, false, false, THREADS>(p);
 }
 
 // The plain decode step with its launch-critical arguments FIRST and 32-bit strides: built with
 // -amdgpu-kernarg-preload-count=16 (Makefile) the first 16 kernel-argument dwords — everything the query and the K/V
 // tile loads need (q is dense [B,H,D] here) — arrive in SGPRs with the wave, so those loads are issued without waiting
 // for a scalar load of the argument block (the other arguments are fetched while they are in flight).
-template <typename T, int D, int UNR, bool CASC, bool PIPE, bool DYN = false>
-__global__ __launch_bounds__(kDecodeThreads) void decode_lean_kernel(T* krc, T* vc, const T* q, const T* cos, const T* sin,
+template <typename T, int D, int UNR, bool CASC, bool PIPE, bool DYN = false, int THREADS = kDecodeThreads>
+__global__ __launch_bounds__(THREADS) void decode_lean_kernel(T* krc, T* vc, const T* q, const T* cos, const T* sin,
                                                                      int kv_sb, int kv_sh, int N, int chunk, int H, int pos_q,
                                                                      const DecodeParams<T> rest) {
   DecodeParams<T> p = rest;
   p.krc = krc; p.vc = vc; p.q = q; p.cos = cos; p.sin = sin;
   p.kv_sb = kv_sb; p.kv_sh = kv_sh; p.q_sb = (int64_t)H * D; p.q_sh = D;
   p.N = N; p.chunk = chunk; p.H = H; p.pos_q = pos_q;
-  decode_body<T, D, UNR, 0, true, 0, true, CASC, PIPE, DYN>(p);
+  decode_body<T, D, UNR, 0, true, 0, true, CASC, PIPE, DYN, false, false, THREADS>(p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1054,6 +1076,24 @@ template <typename T, int D> constexpr int decode_unr() { return sizeof(T) == 4 
 template <typename T, int D> constexpr int decode_unr_pipe() { return sizeof(T) == 4 ? 2 : SPATTEN_DECODE_UP; }
 static inline int decode_group_rows(int d) { return kDecodeThreads / (d / 16); }
 
+// threads of the attention team of a single-row, single-shot decode step: 512 (two waves per SIMD, round 4) or 256
+static std::atomic<int> g_decode_team{0};
+static int decode_team() {
+  int t = g_decode_team.load(std::memory_order_relaxed);
+  if (t == 0) {
+    const char* e = getenv("SPATTEN_DECODE_TEAM");
+    t = (e && atoi(e) == 256) ? 256 : 512;
+    g_decode_team.store(t, std::memory_order_relaxed);
+  }
+  return t;
+}
+extern "C" int spatten_decode_set_team(int threads) {
+  if (threads != 256 && threads != 512) return SPATTEN_ERR_INVALID;
+  const int prev = decode_team();
+  g_decode_team.store(threads, std::memory_order_relaxed);
+  return prev;
+}
+
 static int auto_splits(int units, int d, int kv_len) {
   // one workgroup per CU (256 CUs): measured best at Llama-2-7B decode sizes — more splits shorten each
   // workgroup's stream but lengthen the merge (a memory round trip per batch of partials)
@@ -1138,6 +1178,33 @@ static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_onl
         return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
       } else {
         return SPATTEN_ERR_UNSUPPORTED;
+      }
+    }
+    // TEAM 512 (round 4): the single-shot tile of a single-row step on TWO waves per SIMD — 512 threads, half as many row groups
+    // per thread (a wave issues a vector instruction every ~9 cycles however many waves share its SIMD,
+    // profiles/r04_prefill_anatomy.txt D; part of the step's ~2,900 vector instructions per wave is issue time): 11.5 -> 11.0 us at
+    // the headline shape.  Every route of such a step takes the same team (lean / general, cascade accumulation, device
+    // length) — a step must not change its bits with its route; pipelined (long) chunks, the quantised-key passes and the
+    // fused projection launch keep the 256-thread body.  spatten_decode_set_team(256) restores the r03 form process-wide.
+    if constexpr (sizeof(T) == 2 && D == 128) {
+      if (decode_team() == 512 && !pipe && p.n_q == 1) {
+        constexpr int U2 = (U + 1) / 2;
+        const dim3 blk512(2 * kDecodeThreads);
+#define SPATTEN_LEAN512(CC, DD)                                                                                                     \
+  hipLaunchKernelGGL((decode_lean_kernel<T, D, U2, CC, false, DD, 2 * kDecodeThreads>), grid, blk512, 0, stream, p.krc, p.vc, p.q, p.cos, \
+                     p.sin, (int)p.kv_sb, (int)p.kv_sh, p.N, p.chunk, p.H, p.pos_q, p)
+#define SPATTEN_GEN512(CC, DD) \
+  hipLaunchKernelGGL((decode_attn_kernel<T, D, U2, 0, false, 0, true, CC, false, DD, 2 * kDecodeThreads>), grid, blk512, 0, stream, p)
+        if (lean && small) {
+          if (dyn) { if (casc) SPATTEN_LEAN512(true, true); else SPATTEN_LEAN512(false, true); }
+          else { if (casc) SPATTEN_LEAN512(true, false); else SPATTEN_LEAN512(false, false); }
+        } else {
+          if (dyn) { if (casc) SPATTEN_GEN512(true, true); else SPATTEN_GEN512(false, true); }
+          else { if (casc) SPATTEN_GEN512(true, false); else SPATTEN_GEN512(false, false); }
+        }
+#undef SPATTEN_LEAN512
+#undef SPATTEN_GEN512
+        return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
       }
     }
     if (lean && small) {

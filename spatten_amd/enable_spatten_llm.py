@@ -47,10 +47,12 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     ``fused_step=True`` (needs ``fuse_qkv`` and ``native_gemv``): the q / k / v projections of a single-token step run INSIDE
     the attention launch (spatten_decode_args_t::qkv_*: every workgroup projects its share of its head's q / k / v while the
     step's K/V stream is already in flight; the values equal ``spatten_gemv``'s bit for bit) — one launch and one
-    host call per layer-step — for the EAGER per-call loop, which is host-bound (673 -> 841 tokens/s at Llama-2-7B geometry);
+    host call per layer-step — for the EAGER per-call loop, which is host-bound (684 -> 859 tokens/s at Llama-2-7B geometry);
     a step traced by ``DecodeGraph`` / ``auto_graph`` runs the separate launches (2 % faster there, bit-identical).  Applies
     to the plain step on MHA stacks at head_dim 128 in bf16 / f16, batch 1, up to 320 cache rows per split; other steps run
-    the separate launches.
+    the separate launches.  The fused launch contains the 256-thread attention team, so this option selects that team for
+    the process (``ops.set_decode_team(256)``: the separate steps then equal the fused ones bit for bit; the default
+    512-thread team is 4 % faster per attention launch and differs in summation order).
 
     ``auto_graph=True`` (or a token horizon; True = 64, the reference's max_gen_len — run_spatten_llama.py:61): ``model.forward`` is wrapped so that the reference's per-token loop
     (run_spatten_llama.py:27-35), unchanged, replays one captured HIP graph of the whole patched stack per token
@@ -87,6 +89,9 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
         raise ValueError("fused_step needs fuse_qkv=True and native_gemv=True (it reads the stacked weight the way spatten_gemv does)")
     if pq_profile is not None and pq_threshold is None:
         raise ValueError("pq_profile needs pq_threshold")
+    if fused_step:
+        from . import ops
+        ops.set_decode_team(256)        # the team the fused launch contains: fused and separate steps stay bit-identical
     extended = (importance_mode == "cascade" or head_keep is not None or pq_threshold is not None or local_v_keep is not None
                 or layer_keep is not None)
     for m in mods:

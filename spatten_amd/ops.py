@@ -482,6 +482,15 @@ class SlabDecodeCall:
         return out if proj is None else (out, y)
 
 
+def set_decode_team(threads: int) -> int:
+    """Threads of the attention team of a single-row decode step: 512 (two waves per SIMD, the default) or 256 (the form the
+    fused projection launch contains) — process-wide (include/spatten.h: spatten_decode_set_team).  Returns the previous value."""
+    prev = _lib.load().spatten_decode_set_team(int(threads))
+    if prev < 0:
+        raise ValueError("decode team: 256 or 512 threads")
+    return prev
+
+
 def gemv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``torch.nn.functional.linear(x, weight, bias)`` for single-token rows: x [..., K] with few rows (a decode step),

@@ -18,6 +18,16 @@ from tests.util import TORCH_DT, dev
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _team_256():
+    """The fused launch contains the 256-thread attention team: bit-identity with the separate step is stated against that
+    team (enable_spatten_llm(fused_step=True) selects it; the op-level tests do it here)."""
+    from spatten_amd import ops
+    prev = ops.set_decode_team(256)
+    yield
+    ops.set_decode_team(prev)
+
+
 def _planes(H, cap, d, P, tdt, g):
     k = torch.zeros(1, H, cap, d, dtype=tdt, device="cuda")
     v = torch.zeros_like(k)

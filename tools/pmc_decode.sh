@@ -11,7 +11,7 @@ done
 python3 - $R $N <<'PY'
 import csv, glob, json, sys
 R, N = sys.argv[1], int(sys.argv[2])
-out = {"kernel": "decode_lean_kernel<bf16,128,10> (= decode_body, plain decode step, single-shot tile)", "workload": f"B=1 H=32 d=128 kv_len={N} bf16, stash on (tools/mb/decode_bench)"}
+out = {"kernel": "decode_lean_kernel<bf16,128,5,...,512> (= decode_body, plain decode step, single-shot tile, 512-thread team)", "workload": f"B=1 H=32 d=128 kv_len={N} bf16, stash on (tools/mb/decode_bench)"}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"{R}/gpurun_out/pmc_{c}/**/*counter_collection.csv", recursive=True)[0]
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if ("decode_attn_kernel" in r["Kernel_Name"] or "decode_lean_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == c]
