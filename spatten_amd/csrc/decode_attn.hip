@@ -1187,6 +1187,27 @@ static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_onl
     // length) — a step must not change its bits with its route; pipelined (long) chunks, the quantised-key passes and the
     // fused projection launch keep the 256-thread body.  spatten_decode_set_team(256) restores the r03 form process-wide.
     if constexpr (sizeof(T) == 2 && D == 128) {
+      static int env_pipe512 = -1;      // (A/B) the pipelined form of long chunks on the 512-thread team as well
+      if (env_pipe512 < 0) { const char* e = getenv("SPATTEN_DECODE_TEAM_PIPE"); env_pipe512 = e ? atoi(e) : 0; }
+      if (decode_team() == 512 && pipe && env_pipe512 && p.n_q == 1) {
+        constexpr int UP2 = (UP + 1) / 2;
+        const dim3 blk512(2 * kDecodeThreads);
+#define SPATTEN_LEAN512P(CC, DD)                                                                                                    \
+  hipLaunchKernelGGL((decode_lean_kernel<T, D, UP2, CC, true, DD, 2 * kDecodeThreads>), grid, blk512, 0, stream, p.krc, p.vc, p.q, p.cos, \
+                     p.sin, (int)p.kv_sb, (int)p.kv_sh, p.N, p.chunk, p.H, p.pos_q, p)
+#define SPATTEN_GEN512P(CC, DD) \
+  hipLaunchKernelGGL((decode_attn_kernel<T, D, UP2, 0, false, 0, true, CC, true, DD, 2 * kDecodeThreads>), grid, blk512, 0, stream, p)
+        if (lean && small) {
+          if (dyn) { if (casc) SPATTEN_LEAN512P(true, true); else SPATTEN_LEAN512P(false, true); }
+          else { if (casc) SPATTEN_LEAN512P(true, false); else SPATTEN_LEAN512P(false, false); }
+        } else {
+          if (dyn) { if (casc) SPATTEN_GEN512P(true, true); else SPATTEN_GEN512P(false, true); }
+          else { if (casc) SPATTEN_GEN512P(true, false); else SPATTEN_GEN512P(false, false); }
+        }
+#undef SPATTEN_LEAN512P
+#undef SPATTEN_GEN512P
+        return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+      }
       if (decode_team() == 512 && !pipe && p.n_q == 1) {
         constexpr int U2 = (U + 1) / 2;
         const dim3 blk512(2 * kDecodeThreads);
