@@ -151,6 +151,9 @@ struct FlashParams {
 #ifndef SPATTEN_PF_VTR_MAXQ
 #define SPATTEN_PF_VTR_MAXQ 512  // transposing reads for query blocks up to this length
 #endif
+#ifndef SPATTEN_PF_LOCKSTEP      // A/B: both halves in the same phase (no ping-pong offset) — with DMA_MODE 1 both issue their pieces of
+#define SPATTEN_PF_LOCKSTEP 0    // stage t+1 at the top of the matrix phase and wait for them at the end of the vector phase
+#endif
 #ifndef SPATTEN_PF_P1            // the reference roundings of S(t+1) behind the wave's own P.V MFMAs (prefill_pp128_kernel)
 #define SPATTEN_PF_P1 0
 #endif
@@ -601,7 +604,9 @@ template <int ROWB> __device__ inline int swz_slot(int row, int p) {   // logica
 template <typename T, int D, bool MASK, int PQK = 0, bool FASTN = false, bool VTRP = false, bool PAIR = false>
 __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams<T> p) {
   constexpr bool FAST = FASTN || (SPATTEN_PF_EXPMODE & 1);
-  constexpr bool P1 = SPATTEN_PF_P1 && !FAST && PQK == 0 && !MASK;
+  // (P1 is neutral in the two-half ping-pong — 8192: 691 vs 679 us — and pays where a half runs ALONE, i.e. in the paired form's
+  //  solo steps: q = N = 2048 71.2 -> 67.7 us; lock-step halves instead of the ping-pong: 774 us at 8192, 728 with P1)
+  constexpr bool P1 = (SPATTEN_PF_P1 || PAIR) && !FAST && PQK == 0 && !MASK;
   constexpr int KT = 128, NKB = KT / 32;                      // keys per tile, 32-key blocks per tile
   constexpr int KK = D / 16, DB = D / 32, KROWB = D * 2;
   constexpr int KBYTES = KT * KROWB, VBYTES = D * 256, BUF = KBYTES + VBYTES;   // Vt row = 128 keys = 256 B
@@ -1010,7 +1015,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   if (wave_tiles > T0) softmax_tile(T0);
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
-  if (grp == 1) __syncthreads();                     // hold half 1 one phase behind
+  if (!SPATTEN_PF_LOCKSTEP && grp == 1) __syncthreads();                     // hold half 1 one phase behind
 
 #if SPATTEN_PF_PRIO == 1
   if (grp == 1) __builtin_amdgcn_s_setprio(1);   // static priority for the later-dispatched half (A/B knob)
@@ -1049,7 +1054,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     }
     PF_STAMP(1);
 
-    if (grp == 1) __builtin_amdgcn_s_waitcnt(0x0F70);    // half 1's pieces (issued one phase ago) have landed
+    if (!SPATTEN_PF_LOCKSTEP && grp == 1) __builtin_amdgcn_s_waitcnt(0x0F70);    // half 1's pieces (issued one phase ago) have landed
     __syncthreads();
     PF_STAMP(2);
     // ---- vector phase ----------------------------------------------------------------------------------------
@@ -1064,11 +1069,11 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     PF_STAMP(3);
     if (!(SPATTEN_PF_EXPMODE & 8) && t + 1 < wave_tiles) softmax_tile(t + 1, rounded);
     PF_STAMP(4);
-    if (grp == 0) __builtin_amdgcn_s_waitcnt(0x0F70);    // half 0's pieces (issued at the top of this iteration)
+    if (SPATTEN_PF_LOCKSTEP || grp == 0) __builtin_amdgcn_s_waitcnt(0x0F70);    // half 0's pieces (issued at the top of this iteration)
     __syncthreads();
     PF_STAMP(5);
   }
-  if (grp == 0) __syncthreads();
+  if (!SPATTEN_PF_LOCKSTEP && grp == 0) __syncthreads();
 
   // ---- epilogue: O = O^T / l, 4 consecutive dv per 8-byte store ---------------------------------
 #if SPATTEN_PF_ROWSUM_MFMA
