@@ -147,6 +147,32 @@ def test_decode_c2_full_size_vs_oracle():
         check_stash(st, stash, dt)
 
 
+@pytest.mark.parametrize("dt,P", [("bf16", 2080), ("f16", 600), ("bf16", 129), ("bf16", 2500)])
+def test_decode_teams_of_256_and_512_threads_vs_oracle(dt, P):
+    """spatten_decode_set_team (round 4): the single-row step on one or two waves per SIMD — both against the oracle at the stated
+    tolerance, the same stash bits (a logit is summed inside one 8-lane row group either way), outputs equal to rounding; the
+    setter validates its argument and returns the previous value."""
+    from spatten_amd import ops
+    B, H, d = 1, 8, 128
+    q, k, v, past = attn_inputs(B, H, H, d, P, 1, dt, seed=40 + P)
+    o, stash, _ = orc.attention_core(q, k, v, past[0], past[1], np.full((B, 1), P), None, dt)
+    prev = ops.set_decode_team(512)
+    try:
+        res = {}
+        for team in (512, 256):
+            assert ops.set_decode_team(team) in (256, 512)
+            out, st, _, _, _ = run_decode(q, k, v, past, dt)
+            np.testing.assert_allclose(out, o, err_msg=f"team {team}", **OUT_TOL[dt])
+            check_stash(st, stash, dt, f"team {team}")
+            res[team] = (out, st)
+        assert np.array_equal(res[256][1], res[512][1])
+        np.testing.assert_allclose(res[256][0], res[512][0], **OUT_TOL[dt])
+        with pytest.raises(ValueError):
+            ops.set_decode_team(384)
+    finally:
+        ops.set_decode_team(prev)
+
+
 def test_decode_workspace_rearms_across_launches():
     """Back-to-back launches on one stream reuse the ticket counters (re-armed by the last arriver)."""
     from spatten_amd import ops
