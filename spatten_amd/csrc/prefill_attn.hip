@@ -1358,7 +1358,8 @@ static inline bool use_vtr_for(int head_dim, int q_len, int kv_len) {
   // measured (tools/probe_vtr.py, H = 32, us per layer, Vt form | transposing reads): q = 64 on 2112: 36.2 | 28.7; 256 on
   // 2304: 44.3 | 37.5; 512 on 2560: 56.9 | 51.2; 1024 on 2048: 76.8 | 81.1; 1024 on 4096: 132.5 | 149.3; 2048 on 2048:
   // 79.9 | 83.5; 4096 on 4096: 246 | 265 — the pre-pass costs ~9 us per 2k keys, the two-read fragments ~7 % of the flash time
-  return q_len <= SPATTEN_PF_VTR_MAXQ;
+  // (r04, paired blocks: a first prompt of 1024 tokens — q = N = 1024 — 40.3 | 37.7; 2048 on 2048 68.4 | 68.6)
+  return q_len <= SPATTEN_PF_VTR_MAXQ || (q_len == kv_len && q_len <= 2 * SPATTEN_PF_VTR_MAXQ);
 }
 
 static int g_last_flash_kernel = 0;     // developer diagnostic: 1 = pp128, 2 = w4 (experiment builds only), 3 = the 64-key kernel
