@@ -51,7 +51,13 @@ struct PqvParams {
 #define SPATTEN_PQV_UP 4          // row-groups per pipelined tile.  r04 A/B at 8192 rows x 32 heads, profile (4, 8), MSB pass:
                                   // 12: 20.0 us, 8: 16.6, 6: 16.4, 4: 14.8 (tools/mb/pqv_ab.sh; rebuild with -DSPATTEN_PQV_UP=n)
 #endif
-constexpr int kPqvThreads = 256;
+#ifndef SPATTEN_PQV_THREADS     // A/B: 512 = two waves per SIMD (decode_attn.hip's 512-thread team).  r04 at 8192 rows x 32 heads, MSB pass of
+                                // the (4,8) / (8,8) / (6,6) profiles: 256 threads 14.9 / 17.3 / 16.0 us; 512 with UP = 4: 16.9 / 18.2 / 18.3; 512 with
+                                // UP = 2: 15.3 / 16.8 / 16.8 — the pipelined stream does not gain from the second wave.  256 stays.
+#define SPATTEN_PQV_THREADS 256
+#endif
+constexpr int kPqvThreads = SPATTEN_PQV_THREADS;
+constexpr int kPqvWaves = kPqvThreads / 64;
 
 __device__ inline void pqv_store_granule(unsigned long long* g, float v, unsigned tag) {
   __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams
   constexpr int VROW = D * VB / 8;
   using V8 = Vec8<T>;
 
-  __shared__ float s_o[4][D + 2];
+  __shared__ float s_o[kPqvWaves][D + 2];
   __shared__ unsigned s_ticket;
 
   const int tid = threadIdx.x;
@@ -325,13 +331,27 @@ __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams
   __syncthreads();
   float o_tot = 0.f, l_tot = 0.f;
   {
-    const float m0 = s_o[0][D + 1], m1 = s_o[1][D + 1], m2 = s_o[2][D + 1], m3 = s_o[3][D + 1];
-    const float m_wg = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-    const float mu = (m_wg == -INFINITY) ? 0.f : m_wg;
-    const float w0 = __expf(m0 - mu), w1 = __expf(m1 - mu), w2 = __expf(m2 - mu), w3 = __expf(m3 - mu);
-    if (tid < D) o_tot = (s_o[0][tid] * w0 + s_o[1][tid] * w1) + (s_o[2][tid] * w2 + s_o[3][tid] * w3);
-    l_tot = (s_o[0][D] * w0 + s_o[1][D] * w1) + (s_o[2][D] * w2 + s_o[3][D] * w3);
-    m_run = m_wg;
+    if constexpr (kPqvWaves == 4) {
+      const float m0 = s_o[0][D + 1], m1 = s_o[1][D + 1], m2 = s_o[2][D + 1], m3 = s_o[3][D + 1];
+      const float m_wg = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+      const float mu = (m_wg == -INFINITY) ? 0.f : m_wg;
+      const float w0 = __expf(m0 - mu), w1 = __expf(m1 - mu), w2 = __expf(m2 - mu), w3 = __expf(m3 - mu);
+      if (tid < D) o_tot = (s_o[0][tid] * w0 + s_o[1][tid] * w1) + (s_o[2][tid] * w2 + s_o[3][tid] * w3);
+      l_tot = (s_o[0][D] * w0 + s_o[1][D] * w1) + (s_o[2][D] * w2 + s_o[3][D] * w3);
+      m_run = m_wg;
+    } else {
+      float mw[kPqvWaves], m_wg = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < kPqvWaves; ++w) { mw[w] = s_o[w][D + 1]; m_wg = fmaxf(m_wg, mw[w]); }
+      const float mu = (m_wg == -INFINITY) ? 0.f : m_wg;
+#pragma unroll
+      for (int w = 0; w < kPqvWaves; ++w) {
+        const float ww = __expf(mw[w] - mu);
+        if (tid < D) o_tot = fmaf(s_o[w][tid], ww, o_tot);
+        l_tot = fmaf(s_o[w][D], ww, l_tot);
+      }
+      m_run = m_wg;
+    }
   }
   T* outp = p.out + b * p.out_sb + h * D;
   // head importance: the MSB pass adds only for confident heads, the refetch pass for the heads it recomputes
@@ -340,7 +360,12 @@ __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams
     __syncthreads();
     if (lane == 0) s_o[0][wave] = v;
     __syncthreads();
-    if (tid == 0 && commit) p.head_abs[unit] += (s_o[0][0] + s_o[0][1]) + (s_o[0][2] + s_o[0][3]);
+    if (tid == 0 && commit) {
+      float tot = (s_o[0][0] + s_o[0][1]) + (s_o[0][2] + s_o[0][3]);
+#pragma unroll
+      for (int w = 4; w < kPqvWaves; ++w) tot += s_o[0][w];
+      p.head_abs[unit] += tot;
+    }
   };
   if (p.S == 1) {
     if (tid < D) outp[tid] = DT<T>::from_f32(o_tot / l_tot);
