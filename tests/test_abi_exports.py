@@ -114,3 +114,18 @@ def test_prefill_workspace_covers_the_tail_slice_of_the_rows_leg():
     assert got >= 256 + need_tail, (got, need_tail)
     # and never below what one full slice needs
     assert got >= lib.spatten_prefill_workspace_bytes(0, B, H, H, d, 4096, 4096)
+
+
+def test_decode_team_option_is_a_validated_process_wide_setting():
+    """spatten_decode_set_team (no GPU needed): 256 / 512 accepted, the previous value returned, anything else refused."""
+    from spatten_amd import ops
+    prev = ops.set_decode_team(256)
+    try:
+        assert prev in (256, 512)
+        assert ops.set_decode_team(512) == 256
+        assert ops.set_decode_team(512) == 512
+        import pytest
+        with pytest.raises(ValueError):
+            ops.set_decode_team(128)
+    finally:
+        ops.set_decode_team(prev)
