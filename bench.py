@@ -42,6 +42,23 @@ sys.path.insert(0, ROOT)
 
 LAYERS, HEADS, HEAD_DIM, CTX = 32, 32, 128, 4096
 START, IMPORTANT, RECENT, TURN = 4, 1020, 1024, 64
+# BASELINE.json configs[1] / [2] / [4].  --config c2 is the headline (and the default: a bare
+# `python bench.py` measures BASELINE.json's metric on its config); c3 / c5 are the two configurations BASELINE.json names for
+# 8 GPUs, valid at --gpus 1..8 like c2 (`config.workload` names what ran).
+CONFIGS = {
+    "c2": dict(layers=32, heads=32, ctx=4096, start=4, important=1020, recent=1024, head_keep=None, pq=None,
+               workload="llama2-7b attention path: 4096-token KV cache -> per-head top-k prune to 2048 "
+                        "(start 4 / important 1020 / recent 1024) -> decode, 64-token turns"),
+    "c3": dict(layers=32, heads=32, ctx=4096, start=4, important=1020, recent=1024, head_keep=24, pq=None,
+               workload="llama2-7b attention path (BASELINE.json configs[2]): 4096-token KV cache -> per-head top-k prune to 2048 "
+                        "+ 25 % cascade head prune (24 of 32 heads survive, ranked by sum |O_h|; static ownership, pruned heads "
+                        "are not launched) -> decode, 64-token turns"),
+    "c5": dict(layers=40, heads=40, ctx=16384, start=4, important=4092, recent=4096, head_keep=30, pq=(8, 8), pq_threshold=0.05,
+               workload="llama2-13b attention path (BASELINE.json configs[4]): 16384-token KV cache -> per-head top-k prune to 8192 "
+                        "(start 4 / important 4092 / recent 4096) + 25 % cascade head prune (30 of 40) + progressive "
+                        "quantisation (8-bit key MSB plane + 4-bit LSB refetch below max-prob 0.05, 8-bit value plane) -> "
+                        "decode, 64-token turns"),
+}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0    # what a streaming copy reaches on this part (same guide; our gather / long decodes sit at 5.5-6.2)
 
@@ -55,6 +72,9 @@ def parse():
                     help="N > 1.  strong (default; BASELINE.json configs[2] / [4]): ONE sequence, H/N heads per rank — the "
                          "north star's head-parallel partition, 4 heads per GPU at N = 8.  weak: B = N sequences, every "
                          "rank holds H/N heads of each (the 1-GPU KV bytes per rank)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
+                    help="c2 (default) = BASELINE.json's headline; c3 = + 25 %% head prune (configs[2]); c5 = Llama-2-13B geometry, "
+                         "16384 -> 8192 rows, head prune 30 of 40, progressive quantisation k8v8 (configs[4]).  All valid at --gpus 1..8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the dense / eager comparison legs")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
@@ -524,6 +544,11 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_spawn(args))
+    global LAYERS, HEADS, CTX, START, IMPORTANT, RECENT
+    cfg = CONFIGS[args.config]
+    LAYERS, HEADS, CTX = cfg["layers"], cfg["heads"], cfg["ctx"]
+    START, IMPORTANT, RECENT = cfg["start"], cfg["important"], cfg["recent"]
+    headline = args.config == "c2"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -569,12 +594,43 @@ def main():
     ws = ops.DecodeWorkspace(B, Hl, d, dev)
     stash_full = [torch.empty(B, Hl, 1, CTX, dtype=dt, device=dev) for _ in range(L)]
     Krp = []
+    head_sc = []
     for l in range(L):
         kr = ops.rope_single(Kp[l], cos, sin)
-        ops.attn_decode(q[l], None, kr, Vp[l], CTX, cos, sin, CTX - 1, scores=stash_full[l].view(B, Hl, CTX), workspace=ws)
-        Krp.append(kr)
+        o_dense = ops.attn_decode(q[l], None, kr, Vp[l], CTX, cos, sin, CTX - 1, scores=stash_full[l].view(B, Hl, CTX), workspace=ws)
+        if cfg["head_keep"]:
+            head_sc.append(ops.head_scores(o_dense, Hl))                     # sum |O_h| of this rank's heads (README.md:21)
+        Krp.append(kr if headline else None)                                  # (the dense comparison legs of the headline run)
+        del kr
     importance = [ops.importance(s).contiguous() for s in stash_full]         # [Hl, CTX] (sum over batch, :51)
     torch.cuda.synchronize()
+
+    # ---- cascade head pruning (c3 / c5; parity unpinned, oracle: head_prune_cascade): cumulative sum |O_h| over the layers, the
+    # heads of ALL ranks ranked together (one all-gather of [L, H/N] scores), a head pruned in a layer stays pruned; ownership is
+    # static — a rank launches only its surviving heads (possibly none).  Decided ONCE here, from the dense step: in a session
+    # the fused `head_abs` accumulation of the decode launches feeds the same rule at every turn boundary.
+    hid = [None] * L
+    kept_heads = None
+    if cfg["head_keep"]:
+        sc = torch.stack(head_sc)                                             # [L, Hl] fp32
+        if dist_on:
+            allsc = torch.empty(world_eff, L, Hl, dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(allsc, sc.contiguous())
+            sc = allsc.permute(1, 0, 2).reshape(L, world_eff * Hl)
+        sc = sc.double().cpu()
+        cum = torch.zeros(sc.shape[1], dtype=torch.float64)
+        alive = torch.ones(sc.shape[1], dtype=torch.bool)
+        h_lo = hp.rank * Hl
+        kept_heads = []
+        for l in range(L):
+            cum += sc[l]
+            order = torch.sort(torch.where(alive, cum, torch.full_like(cum, -float("inf"))), descending=True, stable=True).indices
+            ids = order[: min(cfg["head_keep"], int(alive.sum()))].sort().values
+            alive = torch.zeros_like(alive)
+            alive[ids] = True
+            mine = ids[(ids >= h_lo) & (ids < h_lo + Hl)] - h_lo
+            hid[l] = mine.to(torch.int32).to(dev)
+            kept_heads.append(int(mine.numel()))
 
     # ---- pruned slabs (K, rotated shadow, V) with room for one turn ------------------------------------
     Kd = [torch.zeros(B, Hl, cap, d, dtype=dt, device=dev) for _ in range(L)]
@@ -585,20 +641,44 @@ def main():
     stash = [torch.empty(B, Hl, cap, dtype=dt, device=dev) for _ in range(L)]
     # attention outputs (and all-gather receive buffers) are double-buffered by the parity of the position in the
     # turn: the RCCL gather of token t then overlaps the attention graph of token t+1 without sharing a buffer
-    outs_flat = [torch.empty(L, B, Hl * d, dtype=dt, device=dev) for _ in range(2)]   # all layers' slices of one token
+    outs_flat = [torch.zeros(L, B, Hl * d, dtype=dt, device=dev) for _ in range(2)]   # all layers' slices of one token (a pruned head's stays 0)
     outs2 = [[outs_flat[par][l] for l in range(L)] for par in range(2)]
     outs = outs2[0]
     staging2 = [[hp.gather_staging(B, 1, d, dt, dev) for _ in range(L)] for _ in range(2)] if dist_on else None
     staging_flat = [torch.empty(world_eff * L * B * Hl * d, dtype=dt, device=dev) for _ in range(2)] if dist_on else None
 
+    # progressive quantisation (c5): profiled planes of the pruned rows — packed by the prune event, the step's row by the step
+    pq = cfg["pq"]
+    planes = need = None
+    if pq is not None:
+        planes = [ops.PQProfilePlanes(B, Hl, Hl, cap, d, dev, key_bits=pq[0], value_bits=pq[1]) for _ in range(L)]
+        need = [torch.zeros(B * Hl, dtype=torch.int32, device=dev) for _ in range(L)]
+        kn4 = [x[:, :, None] for x in kn]
+        vn4 = [x[:, :, None] for x in vn]
+
     def prune():
         ops.prune_layers(importance, Kp, Vp, CTX, lo, hi, IMPORTANT, dst=(Kd, Vd, Krd), plan=plan, idx=idx,
                          rope=(cos, sin))
+        if pq is not None:
+            for l in range(L):
+                ops.pq_pack_planes(Krd[l], Vd[l], planes[l], 0, new_len)
 
-    def decode_token(n, par=0):                # n = cache length AFTER the append
-        for l in range(L):
+    def layer_step(l, n, par):                 # one layer's attention step; n = cache length AFTER the append
+        ids = hid[l]
+        if ids is not None and ids.numel() == 0:
+            return                             # every head of this rank is pruned in this layer: its output slice stays zero
+        if pq is None:
             ops.attn_decode(q[l], Kd[l], Krd[l], Vd[l], n, cos, sin, n - 1, k_new=kn[l], v_new=vn[l],
-                            scores=stash[l], out=outs2[par][l], workspace=ws)
+                            scores=stash[l], out=outs2[par][l], workspace=ws, head_ids=ids)
+        else:
+            ops.kv_append(kn4[l], vn4[l], Kd[l], Krd[l], Vd[l], n - 1, cos, sin)
+            ops.pq_pack_planes(Krd[l], Vd[l], planes[l], n - 1, n)
+            ops.attn_decode_pqv(q[l], planes[l], n, cos, sin, n - 1, cfg["pq_threshold"], out=outs2[par][l], need_lsb=need[l],
+                                scores=stash[l], head_ids=ids, workspace=ws)
+
+    def decode_token(n, par=0):
+        for l in range(L):
+            layer_step(l, n, par)
 
     def gather_token(par):
         """The exchange step of the head-parallel path: every layer's [B, H/N*d] slice -> [B, H*d] on all ranks.
@@ -676,8 +756,7 @@ def main():
         if native and with_exchange and args.exchange == "per-layer":
             # dependency-faithful: layer l's gathered output exists before layer l + 1 is launched (same stream, same graph)
             for l in range(L):
-                ops.attn_decode(q[l], Kd[l], Krd[l], Vd[l], n, cos, sin, n - 1, k_new=kn[l], v_new=vn[l],
-                                scores=stash[l], out=outs2[par][l], workspace=ws)
+                layer_step(l, n, par)
                 exchange(outs2[par][l].view(-1), staging2[par][l].view(-1))
             return
         decode_token(n, par)
@@ -786,13 +865,16 @@ def main():
             comm = {"error": f"{type(e).__name__}: {e}"}
 
     result = {
-        "metric": "decode tokens/sec (attention path), Llama-2-7B N=4k, 50% token prune",
+        "metric": ("decode tokens/sec (attention path), Llama-2-7B N=4k, 50% token prune" if args.config in ("c2", "c3") else
+                   "decode tokens/sec (attention path), Llama-2-13B N=16k, 50% token prune"),
         "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "comm": comm,
-        "config": {"workload": "llama2-7b attention path: 4096-token KV cache -> per-head top-k prune to 2048 "
-                               "(start 4 / important 1020 / recent 1024) -> decode, 64-token turns",
+        "config": {"workload": cfg["workload"], "name": args.config,
+                   "heads_launched_per_layer_this_rank": kept_heads,
+                   "pq_profile": None if pq is None else {"key_msb_bits": pq[0], "value_bits": pq[1], "lsb_bits": 4,
+                                                          "threshold": cfg["pq_threshold"]},
                    "layers": L, "heads": HEADS, "head_dim": d, "batch": B, "kv_len_before_prune": CTX,
                    "kv_len_after_prune": new_len, "turn_tokens": TURN,
                    "prune_events_in_timed_region": -(-args.steps // TURN),
@@ -822,7 +904,15 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (reps * (TURN - 1) * L)
             n_avg = new_len + 1 + (TURN) / 2.0
-            algo_bytes = 2 * B * Hl * n_avg * d * 2 + 2 * B * Hl * d * 2 + B * Hl * n_avg * 2
+            h_act = Hl if kept_heads is None else sum(kept_heads) / float(L)   # heads launched per layer (head pruning)
+            if pq is None:
+                algo_bytes = 2 * B * h_act * n_avg * d * 2 + 2 * B * h_act * d * 2 + B * h_act * n_avg * 2
+            else:
+                # SURVEY 8d "progressive quant decode": the key MSB plane + the value plane of the kept rows (+ their fp32 row
+                # scales), Q / O, the stash; a refetch adds the 4-bit LSB plane of the flagged heads (counted from need_lsb)
+                n_ref = float(sum(int(x.sum().item()) for x in need)) / L
+                algo_bytes = (B * h_act * n_avg * d * (pq[0] + pq[1]) / 8 + 2 * B * h_act * n_avg * 4 + 2 * B * h_act * d * 2
+                              + B * h_act * n_avg * 2 + n_ref * n_avg * d / 2)
             gbs = algo_bytes / us / 1e3
             # HBM traffic per launch: PMC counters collected in separate rocprofv3 --pmc passes (tools/pmc_decode.sh,
             # FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md), committed under profiles/
@@ -833,7 +923,11 @@ def main():
                     traffic = int(json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["traffic_bytes_per_launch"])
             except Exception:
                 traffic = None
-            result["roofline"] = {"kernel": "decode_lean_kernel<bf16,128,5,...,512> (decode_attn.hip; 512-thread team, two waves per SIMD)", "bound": "hbm", "achieved": round(gbs, 1),
+            kname = ("decode_lean_kernel<bf16,128,5,...,512> (decode_attn.hip; 512-thread team, two waves per SIMD)" if headline else
+                     "decode_lean_hids_kernel<bf16,128,5,...,512> (decode_attn.hip; the lean step over a head list)" if pq is None else
+                     "pqv_decode_kernel (pq_decode.hip; the layer-step = row append + row pack + MSB pass (+ LSB refetch): "
+                     "avg_launch_us is the whole layer-step)")
+            result["roofline"] = {"kernel": kname, "bound": "hbm", "achieved": round(gbs, 1),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                   "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4), "achievable_GBs": HBM_ACHIEVABLE_GBS,
                                   "traffic": traffic,
@@ -867,58 +961,59 @@ def main():
                 "GBs_moved_incl_select": round(moved / pus / 1e3, 1), "frac_of_hbm_peak": round(moved / pus / 1e3 / HBM_PEAK_GBS, 4),
                 "gather_only_us": round(gus, 1), "gather_only_GBs_incl_select": round(gather_bytes / gus / 1e3, 1),
                 "gather_only_frac_of_hbm_peak": round(gather_bytes / gus / 1e3 / HBM_PEAK_GBS, 4)}
-            # the same event in cascade mode (importance = fp32 accumulators of softmax probabilities, README.md:11):
-            # select over fp32 scores + the fused gather + the accumulators' rows, three launches for all layers
-            accs = [torch.rand(Hl, CTX, device=dev, generator=gen) for _ in range(L)]
-            acc_new = torch.zeros(L, Hl, cap, dtype=torch.float32, device=dev)
-            plan3 = ops.PrunePlan(accs, Kp, Vp, Kd, Vd, Krd, accs, [acc_new[l] for l in range(L)])
-            casc = lambda: ops.prune_layers(accs, Kp, Vp, CTX, lo, hi, IMPORTANT, dst=(Kd, Vd, Krd), plan=plan3, idx=idx,
-                                            rope=(cos, sin), acc=(accs, [acc_new[l] for l in range(L)]))
-            casc()
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(5):
+            if headline:
+                # the same event in cascade mode (importance = fp32 accumulators of softmax probabilities, README.md:11):
+                # select over fp32 scores + the fused gather + the accumulators' rows, three launches for all layers
+                accs = [torch.rand(Hl, CTX, device=dev, generator=gen) for _ in range(L)]
+                acc_new = torch.zeros(L, Hl, cap, dtype=torch.float32, device=dev)
+                plan3 = ops.PrunePlan(accs, Kp, Vp, Kd, Vd, Krd, accs, [acc_new[l] for l in range(L)])
+                casc = lambda: ops.prune_layers(accs, Kp, Vp, CTX, lo, hi, IMPORTANT, dst=(Kd, Vd, Krd), plan=plan3, idx=idx,
+                                                rope=(cos, sin), acc=(accs, [acc_new[l] for l in range(L)]))
                 casc()
-            e1.record()
-            torch.cuda.synchronize()
-            result["prune_event"]["cascade_prune_event_us"] = round(e0.elapsed_time(e1) * 1e3 / 5, 1)
-            # layer-to-layer cascade (the traces' key_fetch_num shrinks layer by layer): layer l keeps k_l window tokens
-            # among those layer l-1 kept, k from 1020 down to 510; one chain kernel (a workgroup per head walks the
-            # layers) + ragged gathers; includes the allocation of the new planes (ops.prune_layer_cascade returns them)
-            keeps_lc = [IMPORTANT - (IMPORTANT // 2) * l // (L - 1) for l in range(L)]
-            lc = lambda: ops.prune_layer_cascade(importance, [None] * L, 0, Kp, Vp, [CTX] * L, [hi] * L, keeps_lc, START,
-                                                 [cap] * L, (cos, sin), accs)
-            lc()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                lc()
-            torch.cuda.synchronize()
-            result["prune_event"]["layer_cascade_prune_event_us_incl_allocation"] = round((time.perf_counter() - t0) / 3 * 1e6, 1)
-            # round 4: like the plain event above, into PRE-ALLOCATED destination planes, by device events
-            nl_ = [START + k_ + (CTX - hi) for k_ in keeps_lc]
-            Kd_lc = [torch.empty(B, Hl, cap, d, dtype=dt, device=dev) for _ in range(L)]
-            Vd_lc = [torch.empty_like(x) for x in Kd_lc]
-            Krd_lc = [torch.empty_like(x) for x in Kd_lc]
-            for tag_ in ("layer_cascade_prune_event_us",):
-                # like the plain event above (PrunePlan): tables and pointer rows prebuilt, the timed call is the C call alone
-                lc_plan = ops.LayerCascadePlan(importance, [None] * L, 0, Kp, Vp, [CTX] * L, [hi] * L, keeps_lc, START,
-                                               [cap] * L, (cos, sin), accs, dst=(Kd_lc, Vd_lc, Krd_lc))
-                lc2 = lc_plan.run
-                lc2()
                 torch.cuda.synchronize()
                 e0.record()
                 for _ in range(5):
-                    lc2()
+                    casc()
                 e1.record()
                 torch.cuda.synchronize()
-                result["prune_event"][tag_] = round(e0.elapsed_time(e1) * 1e3 / 5, 1)
-            result["prune_event"]["layer_cascade_vs_plain_event"] = round(result["prune_event"]["layer_cascade_prune_event_us"] / result["prune_event"]["us_all_layers"], 3)
-            del accs, acc_new, plan3, Kd_lc, Vd_lc, Krd_lc, lc_plan, lc2
+                result["prune_event"]["cascade_prune_event_us"] = round(e0.elapsed_time(e1) * 1e3 / 5, 1)
+                # layer-to-layer cascade (the traces' key_fetch_num shrinks layer by layer): layer l keeps k_l window tokens
+                # among those layer l-1 kept, k from 1020 down to 510; one chain kernel (a workgroup per head walks the
+                # layers) + ragged gathers; includes the allocation of the new planes (ops.prune_layer_cascade returns them)
+                keeps_lc = [IMPORTANT - (IMPORTANT // 2) * l // (L - 1) for l in range(L)]
+                lc = lambda: ops.prune_layer_cascade(importance, [None] * L, 0, Kp, Vp, [CTX] * L, [hi] * L, keeps_lc, START,
+                                                     [cap] * L, (cos, sin), accs)
+                lc()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    lc()
+                torch.cuda.synchronize()
+                result["prune_event"]["layer_cascade_prune_event_us_incl_allocation"] = round((time.perf_counter() - t0) / 3 * 1e6, 1)
+                # round 4: like the plain event above, into PRE-ALLOCATED destination planes, by device events
+                nl_ = [START + k_ + (CTX - hi) for k_ in keeps_lc]
+                Kd_lc = [torch.empty(B, Hl, cap, d, dtype=dt, device=dev) for _ in range(L)]
+                Vd_lc = [torch.empty_like(x) for x in Kd_lc]
+                Krd_lc = [torch.empty_like(x) for x in Kd_lc]
+                for tag_ in ("layer_cascade_prune_event_us",):
+                    # like the plain event above (PrunePlan): tables and pointer rows prebuilt, the timed call is the C call alone
+                    lc_plan = ops.LayerCascadePlan(importance, [None] * L, 0, Kp, Vp, [CTX] * L, [hi] * L, keeps_lc, START,
+                                                   [cap] * L, (cos, sin), accs, dst=(Kd_lc, Vd_lc, Krd_lc))
+                    lc2 = lc_plan.run
+                    lc2()
+                    torch.cuda.synchronize()
+                    e0.record()
+                    for _ in range(5):
+                        lc2()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    result["prune_event"][tag_] = round(e0.elapsed_time(e1) * 1e3 / 5, 1)
+                result["prune_event"]["layer_cascade_vs_plain_event"] = round(result["prune_event"]["layer_cascade_prune_event_us"] / result["prune_event"]["us_all_layers"], 3)
+                del accs, acc_new, plan3, Kd_lc, Vd_lc, Krd_lc, lc_plan, lc2
             prune()   # restore the shadow planes for whatever runs next
 
         # ---- dense comparison legs ---------------------------------------------------------------------
-        if not args.no_extras and not dist_on:
+        if not args.no_extras and not dist_on and headline:
             extras = {}
             gd = torch.cuda.CUDAGraph()
             so = torch.empty(B, Hl, CTX, dtype=dt, device=dev)
@@ -1087,6 +1182,16 @@ def main():
                     q[i % L], None, Krd[i % L], Vd[i % L], new_len, cos, sin, new_len - 1, out=outs[i % L], workspace=ws, head_ids=hid), n=L), 2)
                 extras["c2_decode_2048_32_heads_us"] = round(_time(lambda i: ops.attn_decode(
                     q[i % L], None, Krd[i % L], Vd[i % L], new_len, cos, sin, new_len - 1, out=outs[i % L], workspace=ws), n=L), 2)
+                # what ONE rank of a head-parallel run launches per layer (H/G heads of the same planes): the expected strong-scaling
+                # curve of --gpus 2 / 4 / 8 before any communication, on every headline line
+                prl = {}
+                for hg in (16, 8, 4):
+                    wsg = ops.DecodeWorkspace(1, hg, d, dev)
+                    og = torch.empty(1, hg * d, dtype=dt, device=dev)
+                    prl[f"c2_{hg}_heads"] = round(_time(lambda i: ops.attn_decode(
+                        q[i % L][:, :hg], None, Krd[i % L][:, :hg], Vd[i % L][:, :hg], new_len, cos, sin, new_len - 1, out=og, workspace=wsg), n=L), 2)
+                prl["c2_32_heads"] = extras["c2_decode_2048_32_heads_us"]
+                extras["per_rank_launch_us"] = prl
                 # batched decode (the C ABI takes a batch): B sequences on their own pruned 2048-row caches — the
                 # launch's fixed costs (boundary, ramp, split merge) amortise over B x the bytes
                 for Bb in (4, 8):
@@ -1141,6 +1246,20 @@ def main():
                 need5 = torch.zeros(H5, dtype=torch.int32, device=dev)
                 extras["c5_decode_13b_8192_kept_pq_k8v8_msb_only_us"] = round(_time(lambda i: ops.attn_decode_pqv(q5, pp5[i % 4], N5, c5, s5, N5 - 1, 0.0, out=o5, need_lsb=need5, workspace=ws5)), 2)
                 del pp5, pl5
+                # one rank's share of that launch at --gpus 2 / 4 / 8 (20 / 10 / 5 of the 40 heads, k8v8 MSB pass)
+                prl["c5_40_heads_pq_k8v8"] = extras["c5_decode_13b_8192_kept_pq_k8v8_msb_only_us"]
+                for hg in (20, 10, 5):
+                    ppg = []
+                    for kc_, vc_ in zip(K5, V5):
+                        pp_ = ops.PQProfilePlanes(1, hg, hg, N5, d, dev, key_bits=8, value_bits=8)
+                        ops.pq_pack_planes(kc_[:, :hg], vc_[:, :hg], pp_, 0, N5)
+                        ppg.append(pp_)
+                    wsg = ops.DecodeWorkspace(1, hg, d, dev)
+                    og = torch.empty(1, hg * d, dtype=dt, device=dev)
+                    needg = torch.zeros(hg, dtype=torch.int32, device=dev)
+                    qg = q5[:, :hg].contiguous()
+                    prl[f"c5_{hg}_heads_pq_k8v8"] = round(_time(lambda i: ops.attn_decode_pqv(qg, ppg[i % 4], N5, c5, s5, N5 - 1, 0.0, out=og, need_lsb=needg, workspace=wsg)), 2)
+                    del ppg
                 # round 4: local V pruning as ONE launch on the dense 16384-row cache, 30 % of the V rows fetched
                 # (SpAttenController.scala:546-558,591-612) beside the plain step over the same rows (above)
                 st5 = torch.empty(1, H5, 2 * N5, dtype=dt, device=dev)
@@ -1157,7 +1276,7 @@ def main():
         # reference's Python issues, timed within +-20 % of the imported reference in the build container —
         # profiles/r02_cpu_port_vs_reference.json) at all physical cores; beside it the same at one thread and the C
         # port (oracle/oracle.c, OpenMP over heads).
-        if not args.no_cpu_baseline and not dist_on:
+        if not args.no_cpu_baseline and not dist_on and headline:
             result["cpu_baseline"] = cpu_baseline(L, new_len, lo, hi)
     if dist_on:
         import torch.distributed as dist

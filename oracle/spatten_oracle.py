@@ -314,6 +314,32 @@ def head_prune_cascade(layer_scores: Sequence[np.ndarray], keep: Sequence[int],
     return out
 
 
+def global_token_scores(score: np.ndarray) -> np.ndarray:
+    """Global (cross-head) token importance — PARITY UNPINNED.  The SpAtten engine ranks TOKENS, not (head, token) pairs:
+    README.md:21 ("top-k engine to rank token and head importance"), and the traces carry ONE ``key_fetch_num`` and one
+    ``if_topk`` / ``topk`` / ``if_accumulate_importance`` row per layer for all heads (spatten_hardware/hardware/workloads/
+    small.csv:1).  Restated rule: a token's importance is the sum of its per-head importance rows; every head then keeps the
+    SAME set.  score [H, L] -> [H, L] with every row = float32(sum over heads taken in float64) — the wide accumulation makes
+    the ranking independent of the order in which heads (or head-parallel ranks) are added."""
+    g = score.astype(np.float64).sum(axis=0).astype(np.float32)
+    return np.broadcast_to(g, score.shape).copy()
+
+
+def global_token_prune(past, num_coming: int, scores: Sequence[np.ndarray], start: int, recent: int, important_size: int):
+    """The prune event of kv_cache_token_pruning.py:42-96 with ``global_token_scores`` as the ranking: same window, same
+    start / important / recent concat, one kept set per layer shared by all heads.  scores[l] [H, L] = the per-head
+    importance (reference mode: ``importance(stash)``; cascade mode: the accumulators).  Returns (new_past, idx_per_layer)."""
+    L = past[0][0].shape[2]
+    lo, hi = start, L - recent + num_coming
+    new_past, idxs = [], []
+    for (K, V), sc in zip(past, scores):
+        idx = topk_window(global_token_scores(sc[:, :L]), lo, hi, important_size)
+        Kn, Vn = kv_compact(K, V, idx, start, hi)
+        new_past.append([Kn, Vn])
+        idxs.append(idx)
+    return new_past, idxs
+
+
 def layer_cascade_prune(past, ids, scores, num_coming: int, start: int, recent: int, keeps: Sequence[int]):
     """Layer-to-layer cascade token pruning at one prune event (README.md:11 "cascade"; the traces' per-layer
     key_fetch_num shrinks layer by layer, workloads/*.csv columns if_topk / topk; TopK.scala:113-224 ranks, the

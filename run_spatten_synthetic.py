@@ -109,7 +109,10 @@ def chat(args):
         # per-layer schedule in the reference's workloads/*.csv format (spatten_amd/traces.py): the token keep ratios
         # become layer_keep (layer-to-layer cascade), the head ratios head_keep, the requant threshold pq_threshold
         from spatten_amd.traces import read_trace
-        fr = read_trace(args.schedule).fractions(0)
+        sched = read_trace(args.schedule)
+        fr = sched.fractions(0)
+        if sched.token_scope(0) == "global":      # one key_fetch_num per layer for all heads: ONE kept set per layer
+            ext["token_scope"] = "global"
         fr = [fr[min(i * len(fr) // args.layers, len(fr) - 1)] for i in range(args.layers)]      # stretch to our depth
         top = max(f["token_keep"] for f in fr)
         keeps, heads = [], []

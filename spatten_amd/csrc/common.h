@@ -44,18 +44,21 @@ template <> struct DT<bf16_t> {
   static constexpr bool k16 = true;
   __device__ static inline float to_f32(bf16_t x) { return (float)x; }
   __device__ static inline bf16_t from_f32(float x) { return (bf16_t)x; }  // v_cvt_pk_bf16_f32 (RNE)
-  __device__ static inline float round(float x) { return (float)(bf16_t)x; }
+  // ONE instruction: v_cvt_pk_bf16_f32 d, 0, x puts bf16(x) in the upper half of d over a zero lower half — which IS the
+  // fp32 encoding of the rounded value (r05; the cast pair (float)(bf16_t)x costs a convert and a shift, the packed
+  // convert of two values a convert, a shift and a mask)
+  __device__ static inline float round(float x) {
+#if defined(SPATTEN_ROUND_VIA_CAST) && SPATTEN_ROUND_VIA_CAST   // A/B only (tools/mb/pf_exp.sh): the two-instruction form of r01-r04
+    return (float)(bf16_t)x;
+#endif
+    typedef bf16_t bf2 __attribute__((ext_vector_type(2)));
+    bf2 b = __builtin_convertvector(f32x2{0.f, x}, bf2);
+    return __uint_as_float(*reinterpret_cast<uint32_t*>(&b));
+  }
 };
 
-// round(x) on a pair: bf16 has a packed convert (v_cvt_pk_bf16_f32), and both halves come back as fp32 with one
-// shift / one mask — 3 VALU ops per 2 values instead of 4; the other dtypes fall back to the scalar form.
+// round(x) on a pair (kept for its callers; one instruction per value for bf16 since r05, see DT<bf16_t>::round)
 template <typename T> __device__ inline f32x2 round2(f32x2 v) { return f32x2{DT<T>::round(v[0]), DT<T>::round(v[1])}; }
-template <> __device__ inline f32x2 round2<bf16_t>(f32x2 v) {
-  typedef bf16_t bf2 __attribute__((ext_vector_type(2)));
-  bf2 b = __builtin_convertvector(v, bf2);
-  const uint32_t u = *reinterpret_cast<uint32_t*>(&b);
-  return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u)};
-}
 // div_by_const (below) on a pair: packed fp32 multiply / fma (v_pk_mul_f32, v_pk_fma_f32)
 __device__ inline f32x2 div_by_const2(f32x2 x, float c, float rc) {
   const f32x2 c2 = {c, c}, rc2 = {rc, rc};
@@ -214,6 +217,20 @@ __device__ inline float wave_max(float v) {
   return xor32_max(xor16_max(v));
 }
 __device__ inline float wave_sum(float v) { return xor32_sum(xor16_sum(group_sum<16>(v))); }
+
+// acc + both halves of a packed model-dtype pair, on the packed-dot unit (v_dot2c_f32_bf16 / v_dot2_f32_f16 against (1, 1))
+template <typename T> __device__ inline float pair_sum(uint32_t packed, float acc);
+template <> __device__ inline float pair_sum<bf16_t>(uint32_t packed, float acc) {
+  typedef bf16_t bf2 __attribute__((ext_vector_type(2)));
+  const uint32_t ones = 0x3F803F80u;
+  return __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<bf2*>(&packed), *reinterpret_cast<const bf2*>(&ones), acc, false);
+}
+template <> __device__ inline float pair_sum<f16_t>(uint32_t packed, float acc) {
+  typedef f16_t h2 __attribute__((ext_vector_type(2)));
+  const uint32_t ones = 0x3C003C00u;
+  return __builtin_amdgcn_fdot2(*reinterpret_cast<h2*>(&packed), *reinterpret_cast<const h2*>(&ones), acc, false);
+}
+template <> __device__ inline float pair_sum<float>(uint32_t packed, float acc) { return acc + __uint_as_float(packed); }
 
 // dot product of 8 packed model-dtype pairs with fp32 accumulation (v_dot2c_f32_bf16 / v_dot2_f32_f16)
 template <typename T> struct Dot8;

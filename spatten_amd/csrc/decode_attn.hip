@@ -141,7 +141,8 @@ __device__ inline void store_granule(unsigned long long* g, float v, unsigned ta
 // projections of the whole head have been exchanged).  The rest — tile arithmetic, reduction, publication, merge — is the
 // plain step's, bit for bit.
 template <typename T, int D, int UNR, int MODE = 0, bool LEAN = false, int KSRC = 0, bool NT = LEAN, bool CASC = false,
-          bool PIPE = false, bool DYN = false, bool FUSED = false, bool OPROJ = false, int THREADS = kDecodeThreads>
+          bool PIPE = false, bool DYN = false, bool FUSED = false, bool OPROJ = false, int THREADS = kDecodeThreads,
+          bool HIDS = false>
 __device__ __forceinline__ void decode_body(const DecodeParams<T>& p, const float* s_x = nullptr) {
   constexpr bool SCORES_ONLY = (MODE == 1);
   constexpr bool PQ = (KSRC != 0);
@@ -167,7 +168,9 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p, const floa
 
   // grid = (S, H, B * n_q): no integer divisions on the way to the first load
   const int split = blockIdx.x;
-  const int h = (!LEAN && p.head_ids) ? p.head_ids[blockIdx.y] : (int)blockIdx.y;
+  // HIDS: the lean step over a LIST of heads (head pruning / a head-parallel rank's survivors): one scalar load on the way to
+  // the first tile load instead of the general kernel's whole argument block
+  const int h = HIDS ? p.head_ids[blockIdx.y] : ((!LEAN && p.head_ids) ? p.head_ids[blockIdx.y] : (int)blockIdx.y);
   const int b = (LEAN || p.n_q == 1) ? (int)blockIdx.z : (int)blockIdx.z / p.n_q;
   const int qi = (LEAN || p.n_q == 1) ? 0 : (int)blockIdx.z - b * p.n_q;
   const int hkv = (LEAN || p.Hkv == p.H) ? h : h / (p.H / p.Hkv);
@@ -826,6 +829,19 @@ __global__ __launch_bounds__(THREADS) void decode_lean_kernel(T* krc, T* vc, con
   decode_body<T, D, UNR, 0, true, 0, true, CASC, PIPE, DYN, false, false, THREADS>(p);
 }
 
+// The same with a head list (round 5): blockIdx.y -> head_ids[blockIdx.y].  The pointer rides among the preloaded arguments
+// (H and pos_q arrive with the rest of the block), so the id is requested by the wave's first instruction.
+template <typename T, int D, int UNR, bool DYN = false, int THREADS = kDecodeThreads>
+__global__ __launch_bounds__(THREADS) void decode_lean_hids_kernel(T* krc, T* vc, const T* q, const int32_t* head_ids, const T* cos,
+                                                                          const T* sin, int kv_sb, int kv_sh, int N, int chunk, int H,
+                                                                          int pos_q, const DecodeParams<T> rest) {
+  DecodeParams<T> p = rest;
+  p.krc = krc; p.vc = vc; p.q = q; p.cos = cos; p.sin = sin; p.head_ids = head_ids;
+  p.kv_sb = kv_sb; p.kv_sh = kv_sh; p.q_sb = (int64_t)H * D; p.q_sh = D;
+  p.N = N; p.chunk = chunk; p.H = H; p.pos_q = pos_q;
+  decode_body<T, D, UNR, 0, true, 0, true, false, false, DYN, false, false, THREADS, true>(p);
+}
+
 // ------------------------------------------------------------------------------------------------
 // decode_qkv_kernel — the layer-step's q / k / v projections AND its attention in ONE launch (round 4).
 //
@@ -1211,6 +1227,18 @@ static int launch_decode(const DecodeParams<T>& p, int n_active, bool scores_onl
       if (decode_team() == 512 && !pipe && p.n_q == 1) {
         constexpr int U2 = (U + 1) / 2;
         const dim3 blk512(2 * kDecodeThreads);
+        // a head list (head pruning; a head-parallel rank's surviving heads) on the lean step (r05): the general kernel cost
+        // the 24-of-32-heads launch more than the heads it skipped saved
+        const bool lean_h = p.Hkv == p.H && !p.mask && !p.pos_ids && p.head_ids && !p.causal && !p.x && !casc &&
+                            p.q_sh == D && p.q_sb == (int64_t)p.H * D;
+        if (lean_h && small) {
+#define SPATTEN_LEANH512(DD)                                                                                                         \
+  hipLaunchKernelGGL((decode_lean_hids_kernel<T, D, U2, DD, 2 * kDecodeThreads>), grid, blk512, 0, stream, p.krc, p.vc, p.q, p.head_ids, \
+                     p.cos, p.sin, (int)p.kv_sb, (int)p.kv_sh, p.N, p.chunk, p.H, p.pos_q, p)
+          if (dyn) SPATTEN_LEANH512(true); else SPATTEN_LEANH512(false);
+#undef SPATTEN_LEANH512
+          return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+        }
 #define SPATTEN_LEAN512(CC, DD)                                                                                                     \
   hipLaunchKernelGGL((decode_lean_kernel<T, D, U2, CC, false, DD, 2 * kDecodeThreads>), grid, blk512, 0, stream, p.krc, p.vc, p.q, p.cos, \
                      p.sin, (int)p.kv_sb, (int)p.kv_sh, p.N, p.chunk, p.H, p.pos_q, p)

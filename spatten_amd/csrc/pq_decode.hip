@@ -84,6 +84,17 @@ template <int W> __device__ inline void bload(__amdgpu_buffer_rsrc_t r, int voff
 __device__ inline float bload_f32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+template <int W> __device__ inline void bstore(__amdgpu_buffer_rsrc_t r, int voff, int soff, const uint32_t (&w)[W]) {
+  if constexpr (W == 4) {
+    const u32x4 x = {w[0], w[1], w[2], w[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(x, r, voff, soff, 0);
+  } else if constexpr (W == 2) {
+    const u32x2 x = {w[0], w[1]};
+    __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b32(w[0], r, voff, soff, 0);
+  }
+}
 __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int64_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes < 0x7FFFFFFF ? (bytes > 0 ? bytes : 0) : 0x7FFFFFFF),
                                            0x00020000);
@@ -153,28 +164,27 @@ __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams
   const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(p.pl.vq + b * p.pl.vq_sb + hkv * p.pl.vq_sh, (int64_t)rl * VROW);
   const __amdgpu_buffer_rsrc_t rs_vs = make_rsrc(p.pl.vs + b * p.pl.sc_sb + hkv * p.pl.sc_sh, (int64_t)rl * 4);
   const __amdgpu_buffer_rsrc_t rs_lg = make_rsrc(lgb, (int64_t)rl * 4);
-  const int vo_k = r * KROW + c * (2 * KBITS), vo_v = r * VROW + c * (2 * VB), vo_s = r * 4;
+  // Rows of a tile (round 5): thread-row r owns the UP CONSECUTIVE rows t0 + r UP + u (r04: t0 + u RPI + r) — a wave's rows of a
+  // tile are then one contiguous run, the UP row scales of a lane are ONE 16-byte load per plane (r04: a 4-byte load per
+  // row-group and plane — half of the kernel's memory instructions carried 32 bytes per wave), and a lane's UP stash entries /
+  // MSB logits leave as one store.  The plane rows of one wave instruction are UP rows apart: still whole 64- / 96- / 128-byte rows.
+  static_assert(UP == 4 || UP == 2, "row scales travel as one 8- or 16-byte load");
+  const int vo_k = r * (UP * KROW) + c * (2 * KBITS), vo_v = r * (UP * VROW) + c * (2 * VB), vo_s = r * (UP * 4);
 
   struct Tile {
-    uint32_t kw[UP][KW]; float ks[UP];           // this lane's piece of the key row + the row's scale
-    uint32_t vw[UP][VW]; float vs[UP];
-    float lg[UP];                                // PASS 2: the MSB logit pass 1 left
+    uint32_t kw[UP][KW]; uint32_t ks[UP];        // this lane's piece of the key row + the rows' scales (fp32 bits)
+    uint32_t vw[UP][VW]; uint32_t vs[UP];
+    uint32_t lg[UP];                             // PASS 2: the MSB logits pass 1 left
   };
   Tile tile_a, tile_b;
   auto issue = [&](Tile& tl, int t0) {
+    bload<UP>(rs_ks, vo_s, t0 * 4, tl.ks);
+    if (PASS == 2) bload<UP>(rs_lg, vo_s, t0 * 4, tl.lg);
 #pragma unroll
-    for (int u = 0; u < UP; ++u) {
-      const int row0 = t0 + u * RPI;             // wave-uniform: goes into the scalar offset
-      bload<KW>(rs_k, vo_k, row0 * KROW, tl.kw[u]);
-      tl.ks[u] = bload_f32(rs_ks, vo_s, row0 * 4);
-      if (PASS == 2) tl.lg[u] = bload_f32(rs_lg, vo_s, row0 * 4);
-    }
+    for (int u = 0; u < UP; ++u) bload<KW>(rs_k, vo_k, (t0 + u) * KROW, tl.kw[u]);   // (wave-uniform part in the scalar offset)
+    bload<UP>(rs_vs, vo_s, t0 * 4, tl.vs);
 #pragma unroll
-    for (int u = 0; u < UP; ++u) {
-      const int row0 = t0 + u * RPI;
-      bload<VW>(rs_v, vo_v, row0 * VROW, tl.vw[u]);
-      tl.vs[u] = bload_f32(rs_vs, vo_s, row0 * 4);
-    }
+    for (int u = 0; u < UP; ++u) bload<VW>(rs_v, vo_v, (t0 + u) * VROW, tl.vw[u]);
   };
 
   typename V8::raw q_raw[4];
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams
   T* stashp = p.scores ? p.scores + b * p.sc_sb + h * p.sc_sh : nullptr;
   const __amdgpu_buffer_rsrc_t rs_st = make_rsrc(stashp, stashp ? (int64_t)hi * (int64_t)sizeof(T) : 0);
   const __amdgpu_buffer_rsrc_t rs_lgw = make_rsrc(lgb, PASS == 1 ? (int64_t)hi * 4 : 0);
-  const int vo_st = (c == 0) ? r * (int)sizeof(T) : 0x40000000, vo_lw = (c == 0) ? r * 4 : 0x40000000;
+  const int vo_st = (c == 0) ? r * (UP * (int)sizeof(T)) : 0x40000000, vo_lw = (c == 0) ? r * (UP * 4) : 0x40000000;
 
   float m_run = -INFINITY, l_run = 0.f, off_run = 0.f;
   float o16[16];
@@ -240,26 +250,46 @@ __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams
         a = dot_piece<KBITS, KW>(tl.kw[u], qv) - (float)(1 << (KB - 1)) * qsum;
       }
       a = group_sum<LPR>(a);
-      const float s = a * (tl.ks[u] * (PASS == 1 ? 16.f * rsqrt_d : rsqrt_d));
-      sc[u] = (PASS == 2) ? s + tl.lg[u] : s;
+      const float s = a * (__uint_as_float(tl.ks[u]) * (PASS == 1 ? 16.f * rsqrt_d : rsqrt_d));
+      sc[u] = (PASS == 2) ? s + __uint_as_float(tl.lg[u]) : s;
+    }
+    // stash (:116-119) and the MSB logits: a lane's UP rows are consecutive — one store each when the whole tile lies inside the
+    // split (wave-uniform test), else row by row against the descriptor's end
+    if (t0 + TILE <= hi) {
+      uint32_t lw[UP];
+#pragma unroll
+      for (int u = 0; u < UP; ++u) lw[u] = __float_as_uint(sc[u]);
+      if constexpr (sizeof(T) == 4) {
+        if (stashp) bstore<UP>(rs_st, vo_st, t0 * 4, lw);
+      } else {
+        uint32_t sw[UP / 2];
+#pragma unroll
+        for (int u = 0; u < UP; u += 2) {
+          const T a0 = DT<T>::from_f32(sc[u]), a1 = DT<T>::from_f32(sc[u + 1]);
+          sw[u / 2] = (uint32_t)*reinterpret_cast<const unsigned short*>(&a0) | ((uint32_t)*reinterpret_cast<const unsigned short*>(&a1) << 16);
+        }
+        bstore<UP / 2>(rs_st, vo_st, t0 * 2, sw);
+      }
+      if (PASS == 1) bstore<UP>(rs_lgw, vo_lw, t0 * 4, lw);
+    } else {
+#pragma unroll
+      for (int u = 0; u < UP; ++u) {
+        const float s = sc[u];
+        if constexpr (sizeof(T) == 4) {
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s), rs_st, vo_st, (t0 + u) * 4, 0);
+        } else {
+          const T sv = DT<T>::from_f32(s);
+          __builtin_amdgcn_raw_buffer_store_b16(*reinterpret_cast<const unsigned short*>(&sv), rs_st, vo_st, (t0 + u) * 2, 0);
+        }
+        if (PASS == 1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s), rs_lgw, vo_lw, (t0 + u) * 4, 0);
+      }
     }
     float m_new = m_run;
 #pragma unroll
     for (int u = 0; u < UP; ++u) {
-      const int j = t0 + u * RPI + r;
+      const int j = t0 + r * UP + u;
       const bool valid = j < hi;
-      float s = sc[u];
-      {
-        const int row0 = t0 + u * RPI;
-        if constexpr (sizeof(T) == 4) {
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s), rs_st, vo_st, row0 * 4, 0);
-        } else {
-          const T sv = DT<T>::from_f32(s);
-          __builtin_amdgcn_raw_buffer_store_b16(*reinterpret_cast<const unsigned short*>(&sv), rs_st, vo_st, row0 * 2, 0);
-        }
-        if (PASS == 1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s), rs_lgw, vo_lw, row0 * 4, 0);
-      }
-      s = valid ? s : -INFINITY;
+      const float s = valid ? sc[u] : -INFINITY;
       sc[u] = s;
       m_new = fmaxf(m_new, s);
     }
@@ -276,7 +306,7 @@ __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams
       const float pj = __expf(sc[u] - m_run);      // exp(-inf) = 0; m_run is finite once a valid row has been seen
       const float pz = (sc[u] == -INFINITY) ? 0.f : pj;
       l_run += pz;
-      const float wgt = pz * tl.vs[u];
+      const float wgt = pz * __uint_as_float(tl.vs[u]);
       fma_piece<VB, VW>(o16, tl.vw[u], wgt);
       off_run += wgt;
 #ifdef SPATTEN_PQV_PVBAR     // A/B: keep the row-groups' products apart (16 independent accumulators per row-group)

@@ -160,8 +160,13 @@ struct FlashParams {
 #ifndef SPATTEN_PF_ROWSUM_MFMA  // row sums of P on the matrix pipe instead of 64 VALU adds per lane and tile: MEASURED SLOWER
 #define SPATTEN_PF_ROWSUM_MFMA 0   // (713 vs 768): the 8 extra MFMAs per tile cost more than the adds they replace.  Off.
 #endif
+#ifndef SPATTEN_PF_DIET         // r05 instruction diet of prefill_pp128_kernel's softmax (bits, A/B: tools/mb/pf_exp.sh SPATTEN_PF_DIET 0 2 ...):
+#define SPATTEN_PF_DIET 2       //   2 = no per-tile maximum on fully visible tiles (exponentials against the running maximum, the lane's
+#endif                          //       sum bounds every one of them; the rare tile that outgrows it is redone), 4 = row sums of the
+                                //       ROUNDED P on the packed-dot unit (measured slower: v_dot2 is ~2.4 plain issues)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kDeferMax = 8.0f;   // natural-log units of the scaled logits
+constexpr float kSumBound = 2980.0f;   // < e^kDeferMax: a lane whose 64 exponentials sum to no more holds none above e^kDeferMax
 
 template <int ROWB> __device__ inline int lds_off(int row, int slot) {
   // 16-byte slots, XOR-swizzled so the 16 lanes of a ds_read_b128 group land on distinct bank quads
@@ -607,6 +612,8 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   // (P1 is neutral in the two-half ping-pong — 8192: 691 vs 679 us — and pays where a half runs ALONE, i.e. in the paired form's
   //  solo steps: q = N = 2048 71.2 -> 67.7 us; lock-step halves instead of the ping-pong: 774 us at 8192, 728 with P1)
   constexpr bool P1 = (SPATTEN_PF_P1 || PAIR) && !FAST && PQK == 0 && !MASK;
+  constexpr bool NOMAX = (SPATTEN_PF_DIET & 2) && PQK == 0;      // (pass 1 of the quantised keys tracks the row's TRUE maximum)
+  constexpr bool DOTSUM = (SPATTEN_PF_DIET & 4) && DT<T>::k16;
   constexpr int KT = 128, NKB = KT / 32;                      // keys per tile, 32-key blocks per tile
   constexpr int KK = D / 16, DB = D / 32, KROWB = D * 2;
   constexpr int KBYTES = KT * KROWB, VBYTES = D * 256, BUF = KBYTES + VBYTES;   // Vt row = 128 keys = 256 B
@@ -934,13 +941,38 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
       }
     }
     }
-    float m_new, m_base;                            // new running max; the max the exponentials are taken against
-    if (!MASK && !edge) {
-      // fully visible tile.  Deferred rescale: the running maximum only moves (and O is only rescaled: 64 multiplies
-      // per lane) when some row of the wave outgrew it by more than kDeferMax; until then P = exp(s - m_run) <=
-      // e^kDeferMax, which bf16 P (constant relative precision) and the fp32 sums carry without loss.  O / l is
-      // mathematically unchanged.  All of the previous tile's P·V is already in O (matrix phase, program order), so
-      // the decision covers it.
+    const float sc2 = (FAST && !PQK && !MASK && !edge) ? kLog2e * rsqrt_d : kLog2e;
+    // P = exp(s - m_base) as one fma + v_exp_f32 (a base-2 exponential) per logit, packed into the P.V operand; returns this
+    // lane's sum of them (its 64 of the row's 128 keys)
+    auto exp_pass = [&](float m_base) -> float {
+      const float m2 = m_base * kLog2e;
+      float ls[4] = {0.f, 0.f, 0.f, 0.f};             // independent partial sums
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+#if SPATTEN_PF_EXPMODE & 16      // anatomy: what do the 64 transcendentals per wave-tile cost?  (WRONG results)
+            const float pvv = fmaf(s[kb][t * 8 + e], sc2, -m2);
+#else
+            const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], sc2, -m2));
+#endif
+#if !SPATTEN_PF_ROWSUM_MFMA
+            if (!DOTSUM) ls[e & 3] += pvv;
+#endif
+            pf[kb][t][e] = DT<T>::from_f32(pvv);
+          }
+#if !SPATTEN_PF_ROWSUM_MFMA
+          if constexpr (DOTSUM) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ls[j] = pair_sum<T>(reinterpret_cast<const uint32_t*>(&pf[kb][t])[j], ls[j]);
+          }
+#endif
+        }
+      return (ls[0] + ls[1]) + (ls[2] + ls[3]);
+    };
+    auto tile_max = [&]() -> float {
       float mt[NKB];
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
@@ -948,11 +980,34 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 #pragma unroll
         for (int r = 0; r < 16; r += 2) mt[kb] = max3_raw(mt[kb], s[kb][r], s[kb][r + 1]);
       }
-      const float m_tile = xor32_max(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3]))) * (FAST && !PQK ? rsqrt_d : 1.0f);
-      const bool move = __builtin_amdgcn_ballot_w64(m_tile - m_run > kDeferMax) != 0;   // -inf start: inf > thr
-      m_new = move ? fmaxf(m_run, m_tile) : m_run;
-      if (PQK == 1) m_true = fmaxf(m_true, m_tile);
-      m_base = m_new;
+      return xor32_max(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3]))) * (FAST && !PQK ? rsqrt_d : 1.0f);
+    };
+    float m_new, lsum;                              // new running max (= the max the exponentials are taken against)
+    if (!MASK && !edge) {
+      // fully visible tile.  Deferred rescale: the running maximum only moves (and O is only rescaled: 64 multiplies
+      // per lane) when some row of the wave outgrew it by more than kDeferMax; until then P = exp(s - m_run) <=
+      // e^kDeferMax, which bf16 P (constant relative precision) and the fp32 sums carry without loss.  O / l is
+      // mathematically unchanged.  All of the previous tile's P·V is already in O (matrix phase, program order), so
+      // the decision covers it.
+      if constexpr (NOMAX) {
+        // r05: no maximum at all on the common path (32 v_max3 + the exchange per tile).  The exponentials are taken against
+        // the running maximum as it stands; the lane's sum of its 64 bounds every one of them, so "sum <= kSumBound" proves
+        // that none outgrew e^kDeferMax — the deferred rule's own condition.  Otherwise (first tile: m_run = -inf gives
+        // inf; an outlier key; NaN) the tile is redone against its true maximum: P and the sum are overwritten, nothing of
+        // the first pass survives.
+        m_new = m_run;
+        lsum = exp_pass(m_run);
+        if (__builtin_amdgcn_ballot_w64(!(lsum <= kSumBound)) != 0) {
+          m_new = fmaxf(m_run, tile_max());
+          lsum = exp_pass(m_new);
+        }
+      } else {
+        const float m_tile = tile_max();
+        const bool move = __builtin_amdgcn_ballot_w64(m_tile - m_run > kDeferMax) != 0;   // -inf start: inf > thr
+        m_new = move ? fmaxf(m_run, m_tile) : m_run;
+        if (PQK == 1) m_true = fmaxf(m_true, m_tile);
+        lsum = exp_pass(m_new);
+      }
     } else {
       // explicit mask and / or a tile that straddles the causal diagonal: per-element visibility
       float m_tile = -INFINITY;
@@ -970,29 +1025,10 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
       m_tile = xor32_max(m_tile);
       if (PQK == 1) m_true = fmaxf(m_true, m_tile);
       m_new = fmaxf(m_run, m_tile);
-      m_base = (m_new == -INFINITY) ? 0.f : m_new;  // a fully masked row: exp2(-inf) = 0 for every key
+      lsum = exp_pass((m_new == -INFINITY) ? 0.f : m_new);   // a fully masked row: exp2(-inf) = 0 for every key
     }
-    const float m2 = m_base * kLog2e;
-    const float sc2 = (FAST && !PQK && !MASK && !edge) ? kLog2e * rsqrt_d : kLog2e;
-    float ls[4] = {0.f, 0.f, 0.f, 0.f};             // independent partial sums
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-#if SPATTEN_PF_EXPMODE & 16      // anatomy: what do the 64 transcendentals per wave-tile cost?  (WRONG results)
-          const float pvv = fmaf(s[kb][t * 8 + e], sc2, -m2);
-#else
-          const float pvv = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], sc2, -m2));
-#endif
-#if !SPATTEN_PF_ROWSUM_MFMA
-          ls[e & 3] += pvv;
-#endif
-          pf[kb][t][e] = DT<T>::from_f32(pvv);
-        }
     if (m_new != m_run) {
-      const float alpha = __expf(m_run - m_base);
+      const float alpha = __expf(m_run - ((m_new == -INFINITY) ? 0.f : m_new));
       l_run *= alpha;
       osum[0] *= alpha;
 #pragma unroll
@@ -1001,7 +1037,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
         for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
       m_run = m_new;
     }
-    l_run += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+    l_run += lsum;
   };
 
   // ---- prologue (all 8 waves together): K(0) parked in stage 1's K area, stage 0 = { K(1), Vt(0) } --------------

@@ -26,7 +26,7 @@ _FAMILIES: Dict[str, Callable] = {"llama": _patch_llama}
 def enable_spatten_llm(model, start_size, important_size, recent_size, importance_mode="reference",
                        prefill_stash=True, assume_causal=False, head_keep=None, pq_threshold=None, local_v_keep=None,
                        layer_keep=None, fuse_qkv=False, native_gemv=False, head_parallel=None, numerics="reference",
-                       auto_graph=False, pq_profile=None, fused_step=False):
+                       auto_graph=False, pq_profile=None, fused_step=False, token_scope="head"):
     """The reference's four positional arguments (enable_spatten_llm.py:5) plus opt-in extensions:
 
     ``prefill_stash=False``: forwards with ``q_len > 1`` do not materialise ``self.attn_scores`` ([B,H,q,N]: 4 GiB per
@@ -74,14 +74,18 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     bits, value bits) of the planes: (4, 8), (8, 8) or (6, 6) — the quantised VALUE plane and the LSB-only refetch;
     MatrixFetcher.scala:48-51, TestSpAtten.scala:64,83-97,173-176; None = 4-bit MSB plane, V in the model dtype), ``local_v_keep``
     (local V pruning at decode: fraction of the keys whose V row is fetched), ``layer_keep`` (layer-to-layer cascade token
-    pruning: one important-token count per layer, non-increasing — the surviving set shrinks through the layers)."""
+    pruning: one important-token count per layer, non-increasing — the surviving set shrinks through the layers),
+    ``token_scope="global"`` (ONE kept token set per layer shared by all heads, ranked by the importance summed over the
+    heads — README.md:21, workloads/small.csv:1; head-parallel ranks all-reduce the [layers, L] sums once per prune event;
+    default "head" = the reference's per-head top-k)."""
     model_type = model.config.model_type
     patch = next((fn for key, fn in _FAMILIES.items() if key in model_type), None)
     if patch is None:
         raise ValueError(f"got {model_type}")
     k_dim, v_dim = patch(model)
     cache = SpAttenKVCache(start_size=start_size, recent_size=recent_size, important_size=important_size,
-                           k_seq_dim=k_dim, v_seq_dim=v_dim, importance_mode=importance_mode)
+                           k_seq_dim=k_dim, v_seq_dim=v_dim, importance_mode=importance_mode, token_scope=token_scope)
+    cache.head_parallel = head_parallel
     from .pos_shift.modify_llama import attention_modules
 
     mods = attention_modules(model)                                # model.modules() order = layer order (:74-77)

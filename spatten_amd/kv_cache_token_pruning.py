@@ -13,6 +13,12 @@ Documented divergences (reference quirks):
   * ties exactly at the k-th score keep the LOWEST positions (torch's order there is unspecified);
   * the returned tensors are views of slabs with spare capacity for ``num_coming`` tokens so the
     attention forward can append in place instead of re-``cat``-ing the whole cache every token.
+
+Extension (PARITY UNPINNED): ``token_scope="global"`` — ONE kept token set per layer, shared by every head, ranked by the
+importance summed over the heads (the SpAtten paper / RTL semantic: README.md:21 "top-k engine to rank token and head
+importance"; the traces carry one ``key_fetch_num`` and one ``if_topk`` / ``topk`` row per layer for all heads,
+spatten_hardware/hardware/workloads/small.csv:1).  The reference's Python prunes per head (kv_cache_token_pruning.py:59-69),
+which stays the default (``token_scope="head"``).
 """
 from __future__ import annotations
 
@@ -40,7 +46,7 @@ DIM_TO_SLICE = {1: slice1d, 2: slice2d, 3: slice3d}
 
 class SpAttenKVCache:
     def __init__(self, start_size=4, recent_size=128, important_size=128, k_seq_dim=2, v_seq_dim=2,
-                 importance_mode="reference"):
+                 importance_mode="reference", token_scope="head"):
         # the reference prints this banner from its constructor (kv_cache_token_pruning.py:32)
         print(f"SpAttenKVCache: keep start: {start_size}, keep recent: {recent_size}, keep important: {important_size}")
         self.start_size = start_size
@@ -57,6 +63,14 @@ class SpAttenKVCache:
         # "cascade"  : importance = running sum of softmax probabilities over every forward since the key entered
         #              the cache (SpAtten paper / README.md:11; PARITY UNPINNED), accumulated by the patched forward.
         self.importance_mode = importance_mode
+        if token_scope not in ("head", "global"):
+            raise ValueError("token_scope must be 'head' or 'global'")
+        # "head"  : every head keeps its own top-k (kv_cache_token_pruning.py:59-69).
+        # "global": one kept set per layer for all heads, ranked by the importance summed over the heads (README.md:21,
+        #           workloads/small.csv:1; PARITY UNPINNED; oracle: global_token_scores).  Head-parallel ranks all-reduce the
+        #           [layers, L] sums once per prune event (``head_parallel``, set by enable_spatten_llm).
+        self.token_scope = token_scope
+        self.head_parallel = None
         self.ext = None                     # spatten_amd.extensions.SpattenExtensions (enable_spatten_llm's opt-in modes)
         self.importance_score: Optional[List[torch.Tensor]] = None
         self.keep_indices: Optional[torch.Tensor] = None      # int32 [layers, H, important] of the last prune
@@ -114,6 +128,8 @@ class SpAttenKVCache:
             # (a pruned query head is not launched any more: its stash row is stale — it does not vote)
             self.importance_score = [_group_rows(self._live_rows(layer, s), kv_heads) for layer, s in enumerate(self.importance_score)]
         scores = _common_rows(self.importance_score)
+        if self.token_scope == "global":
+            scores = self._global_scores([s[:, :seq_len] for s in scores])
         Ks = [_rows(kv[0]) for kv in past_key_values]
         Vs = [_rows(kv[1]) for kv in past_key_values]
         Ks, Vs = _common_strides(Ks, Vs)
@@ -134,6 +150,20 @@ class SpAttenKVCache:
                 self.ext.layers[layer].pending_len = 0
             out.append([k, v])
         return out                                                            # list of lists (:72-96)
+
+    def _global_scores(self, scores: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        """``token_scope="global"``: per layer, the importance summed over the heads — over the heads of EVERY rank when the
+        cache is head-parallel (one all-reduce of the [layers, L] sums per prune event) — handed to the select as H rows of
+        stride 0, so every head keeps the same set and the gather / accumulator rows downstream are unchanged.  The sum is
+        taken in fp64 and rounded once to fp32: the ranking then does not depend on the order in which heads or ranks are
+        added (oracle: global_token_scores)."""
+        H = scores[0].shape[0]
+        g = torch.stack([s.sum(0, dtype=torch.float64) for s in scores])           # [layers, L]
+        hp = self.head_parallel
+        if hp is not None and hp.world > 1:
+            g = hp.all_reduce_sum(g)
+        g = g.to(torch.float32)
+        return [g[layer].unsqueeze(0).expand(H, -1) for layer in range(len(scores))]
 
     def _live_rows(self, layer: int, score: torch.Tensor) -> torch.Tensor:
         """Grouped-query caches under head pruning: the rows of pruned query heads zeroed before the group sum."""
@@ -172,7 +202,8 @@ class SpAttenKVCache:
         cap = kv_slab.round_capacity(new_len + max(int(num_coming), 0))
         rope = kv_slab.rope_tables(cap, d, Ks[0].dtype, Ks[0].device, base, scaling)
         new_acc = torch.zeros(n_layers, H, max(cap, accs[0].shape[1]), dtype=torch.float32, device=Ks[0].device)
-        Kn, Vn, Krn, idx = ops.prune_layers(accs, Ks, Vs, seq_len, lo, hi, self.important_size, capacity=cap, rope=rope,
+        ranked = self._global_scores([a[:, :seq_len] for a in accs]) if self.token_scope == "global" else accs
+        Kn, Vn, Krn, idx = ops.prune_layers(ranked, Ks, Vs, seq_len, lo, hi, self.important_size, capacity=cap, rope=rope,
                                             acc=(accs, [new_acc[layer] for layer in range(n_layers)]))
         out = []
         for layer, (k, v, kr) in enumerate(zip(Kn, Vn, Krn)):
@@ -193,6 +224,8 @@ class SpAttenKVCache:
         group = accs[0].shape[0] // Hkv
         scores = _common_rows([_group_rows(self._live_rows(layer, a[:, :seq_len]), Hkv) for layer, a in enumerate(accs)])
         self.importance_score = scores
+        if self.token_scope == "global":
+            scores = self._global_scores(scores)
         cap = kv_slab.round_capacity(new_len + max(int(num_coming), 0))
         rope = kv_slab.rope_tables(cap, d, Ks[0].dtype, Ks[0].device, base, scaling)
         Kn, Vn, Krn, idx = ops.prune_layers(scores, Ks, Vs, seq_len, lo, hi, self.important_size, capacity=cap, rope=rope)
@@ -237,6 +270,9 @@ class SpAttenKVCache:
                     raise NotImplementedError("layer_keep with cascade importance on a grouped-query cache: the accumulators "
                                               "have one row per query head")
                 score = _group_rows(score, K.shape[1])        # grouped-query cache: a key's importance = its group's sum
+            if self.token_scope == "global":
+                # (every layer has its own length here: one reduction per layer; the kernel wants real rows)
+                score = self._global_scores([score])[0].contiguous()
             if score.stride(1) != 1:
                 score = score.contiguous()
             Ks.append(K); Vs.append(V); lens.append(L); his.append(hi); keeps.append(k_l); scores.append(score)

@@ -6,7 +6,8 @@ heads [r*H/G, (r+1)*H/G) and the KV planes of those heads; KV never moves.  The 
 is the all-gather of the per-rank attention outputs [B, q, H/G*d] -> [B, q, H*d] in front of o_proj (RCCL
 ``all_gather_into_tensor`` over xGMI; backend "nccl" on ROCm IS RCCL), plus — for head pruning — an
 all-gather of H/G fp32 head scores followed by an identical, deterministic top-k on every rank.
-Token pruning needs no communication at all.
+Per-head token pruning needs no communication at all; the GLOBAL token scope (one kept set per layer for all heads) needs one
+all-reduce of the [layers, L] head-summed importance per prune event (``all_reduce_sum``).
 """
 from __future__ import annotations
 
@@ -37,12 +38,13 @@ class _Pending:
 
 class HeadParallel:
     def __init__(self, num_heads: int, num_kv_heads: Optional[int] = None, group=None, rank: Optional[int] = None,
-                 world: Optional[int] = None, gather_fn=None):
+                 world: Optional[int] = None, gather_fn=None, reduce_fn=None):
         """Default: rank / world of the torch.distributed process group.  ``rank`` / ``world`` / ``gather_fn`` given
         explicitly: a partition WITHOUT a process group — ``gather_fn(local [B,q,H/G*d], rank) -> full [B,q,H*d]`` stands
         in for the all-gather (tests run every rank's shard in one process, one after the other)."""
         self.group = group
         self.gather_fn = gather_fn
+        self.reduce_fn = reduce_fn          # explicit partitions: reduce_fn(t, rank) -> the sum over ranks (global token scope)
         if rank is not None or world is not None:
             if rank is None or world is None or not (0 <= rank < world) or gather_fn is None:
                 raise ValueError("an explicit partition needs rank, world and gather_fn")
@@ -220,6 +222,19 @@ class HeadParallel:
         if getattr(self, "_peer", None) is not None:
             _lib.load().spatten_peer_destroy(self._peer)
             self._peer = None
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        """Sum over the ranks, on every rank (global token pruning: the [layers, L] importance summed over the heads of all
+        ranks, once per prune event — kv_cache_token_pruning.SpAttenKVCache._global_scores)."""
+        if self.reduce_fn is not None:
+            return self.reduce_fn(t, self.rank)
+        if self.world == 1:
+            return t
+        if self.gather_fn is not None:
+            raise ValueError("an explicit partition needs reduce_fn for the global token scope")
+        t = t.contiguous()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
 
     def gather_head_scores(self, local_scores: torch.Tensor) -> torch.Tensor:
         """[H/G] fp32 -> [H] on every rank (head pruning: every rank then runs the same top-k)."""

@@ -49,6 +49,7 @@ class LayerStep:
     requant_threshold: float = -1.0
     accumulate_importance: bool = False
     next_keys: int = -1        # `topk` of the row flagged if_topk: the token set the NEXT layer starts from
+    keys_uniform: bool = True  # every head row of the layer carries the same key_fetch_num (ONE token set for all heads)
 
 
 @dataclass
@@ -58,15 +59,23 @@ class CascadeSchedule:
     def layers(self, iteration: int = 0) -> List[LayerStep]:
         return self.iterations[iteration]
 
+    def token_scope(self, iteration: int = 0) -> str:
+        """"global" when every layer of the iteration carries ONE ``key_fetch_num`` for all of its heads — the accelerator
+        model's token pruning, one kept set per layer (workloads/small.csv:1) — else "head".  What
+        ``enable_spatten_llm(..., token_scope=...)`` should be given for this trace."""
+        return "global" if all(s.keys_uniform for s in self.layers(iteration)) else "head"
+
     def pq_profile(self, iteration: int = 0):
         """(key MSB bits, value bits) the accelerator model fetches this trace at — TestSpAtten.scala:64-97: a key width of
-        -1 / 10 / 12 runs as 8 bits with the requant on, a value width of -1 / 10 / 12 as 8 — or None when no layer of the
-        iteration carries quantisation columns at all.  The widest profile over the layers (they agree in the reference's
+        -1 / 10 / 12 runs as 8 bits with the requant on, a value width of -1 / 10 / 12 as 8 (a layer written -1 / -1 inside a
+        quantised trace therefore counts as (8, 8)) — or None when NO layer of the iteration carries a quantisation width at
+        all (the software model's unquantised traces).  The widest profile over the layers (they agree in the reference's
         traces)."""
         best = None
-        for s in self.layers(iteration):
-            if s.key_bits == -1 and s.value_bits == -1:
-                continue
+        steps = self.layers(iteration)
+        if all(s.key_bits == -1 and s.value_bits == -1 for s in steps):
+            return None
+        for s in steps:
             kb = 8 if s.key_bits in (-1, 10, 12) else s.key_bits
             vb = 8 if s.value_bits in (-1, 10, 12) else s.value_bits
             best = (kb, vb) if best is None else (max(best[0], kb), max(best[1], vb))
@@ -101,6 +110,8 @@ def read_trace(path: str) -> CascadeSchedule:
             st.heads.append(head)
             st.head_dim = int(float(r["embedding_length_D"]))
             st.length = int(r["sentence_length_L"])
+            if len(st.heads) > 1 and st.keys != int(r["key_fetch_num"]):
+                st.keys_uniform = False
             st.keys = int(r["key_fetch_num"])
             st.values = int(r["value_fetch_num"])
             st.key_bits, st.value_bits = int(r["quant_key_bit"]), int(r["quant_value_bit"])

@@ -29,3 +29,21 @@ def test_bench_emits_one_json_line_with_the_contract_keys():
     assert 0.05 < r["frac"] < 1.0 and (r["traffic"] is None or r["traffic"] > 0.9 * r["algorithmic_bytes_per_launch"])
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+
+
+@pytest.mark.parametrize("config", ["c3", "c5"])
+def test_bench_runs_the_8_gpu_configs_of_baseline_json_on_one_rank_through_rccl(config):
+    """BASELINE.json configs[2] (C3) and configs[4] (C5) are head-parallel configurations: `bench.py --config c3|c5` must be
+    valid at any --gpus; here one rank with --force-dist (the RCCL communicator, the per-layer exchange inside the graph)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--gpus", "1", "--steps", "66",
+                          "--warmup", "2", "--force-dist"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    c = d["config"]
+    assert c["name"] == config and "configs[" in c["workload"]
+    assert c["rccl_ranks"] == 1 and c["exchange"] == "per-layer" and d["comm"]["comm_us_per_token"] is not None
+    kept = c["heads_launched_per_layer_this_rank"]
+    assert len(kept) == c["layers"] and all(k == (24 if config == "c3" else 30) for k in kept)
+    if config == "c5":
+        assert c["pq_profile"]["key_msb_bits"] == 8 and c["heads"] == 40 and c["kv_len_before_prune"] == 16384
+    assert d["value"] > 0 and c["prune_events_in_timed_region"] == 2

@@ -196,6 +196,48 @@ def test_multi_turn_protocol_cascade_importance_mode():
     assert kv_cache.n_pruned_total > 0
 
 
+@pytest.mark.parametrize("importance_mode", ["reference", "cascade"])
+def test_multi_turn_protocol_global_token_scope(importance_mode):
+    """Extension (parity unpinned; README.md:21, workloads/small.csv:1): token_scope="global" — ONE kept token set per layer
+    for all heads, ranked by the importance summed over the heads (the last decode step's logits in reference mode, the
+    accumulated probabilities in cascade mode).  GPU plugin vs the oracle's restatement over three turns."""
+    from spatten_amd import enable_spatten_llm
+    torch.manual_seed(3)
+    model = TinyLlama().cuda().float()
+    for p in model.parameters():
+        p.data.mul_(0.6)
+    casc = importance_mode == "cascade"
+    ref = NumpyReplica(model, cascade=casc)
+    kv_cache = enable_spatten_llm(model, START, IMPORTANT, RECENT, importance_mode=importance_mode, token_scope="global")
+    attn_modules = [m for m in model.modules() if type(m).__name__ == "LlamaAttention"]
+    rng = np.random.default_rng(4)
+    prompts = [rng.integers(0, VOCAB, size=n)[None] for n in (38, 28, 24)]
+    past_g = past_r = None
+    for turn, prompt in enumerate(prompts):
+        if turn > 0:
+            space_needed = prompt.shape[1] + MAX_GEN
+            Lc = past_r[0][0].shape[2]
+            scores_r = [ref.acc[i][:, :Lc] for i in range(L)] if casc else [orc.importance(s, "f32") for s in ref.stash]
+            past_g = kv_cache.apply_token_pruning(past_g, space_needed, None if casc else [m.attn_scores for m in attn_modules])
+            assert Lc + space_needed > START + IMPORTANT + RECENT
+            new_r, idxs = orc.global_token_prune(past_r, space_needed, scores_r, START, RECENT, IMPORTANT)
+            hi = min(Lc - RECENT + space_needed, Lc)
+            for i in range(L):
+                got = kv_cache.keep_indices[i].cpu().numpy()
+                assert np.array_equal(got, idxs[i]), f"turn {turn} layer {i}"
+                assert all(np.array_equal(got[0], got[h]) for h in range(H))
+                if casc:      # the per-head accumulators follow the shared row map
+                    a = ref.acc[i][:, :Lc]
+                    ref.acc[i] = np.concatenate([a[:, :START], np.take_along_axis(a, idxs[i], 1), a[:, hi:]], 1)
+            past_r = new_r
+        tg, past_g, _ = greedy(lambda i, p: model(i, p), torch.from_numpy(prompt).cuda(), past_g,
+                               lambda a: torch.tensor(a, device="cuda"))
+        tr, past_r, _ = greedy(ref.forward, prompt, past_r, lambda a: np.asarray(a))
+        assert tg == tr, f"turn {turn}"
+        assert past_g[0][0].shape[2] == past_r[0][0].shape[2]
+    assert kv_cache.n_pruned_total > 0
+
+
 class ExtReplica(NumpyReplica):
     """NumpyReplica + the oracle's restatements of head pruning / progressive quantisation / local V pruning at
     single-token steps (the modes enable_spatten_llm wires into the patched forward)."""

@@ -244,3 +244,49 @@ def test_grouped_query_cache_is_pruned_by_the_sum_of_its_group():
     assert np.array_equal(cache.keep_indices[0].cpu().numpy(), idx)
     assert np.array_equal(host(out[0][0]), wk) and np.array_equal(host(out[0][1]), wv)
     assert cache.importance_score[0].shape == (Hkv, L)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_global_token_scope_keeps_one_set_per_layer_vs_oracle(dt):
+    """token_scope="global" (README.md:21, workloads/small.csv:1; parity unpinned): the kept set is ranked by the importance
+    summed over the heads and shared by all of them — K', V' and the indices equal the oracle's, bit for bit; also when the
+    heads are split over two head-parallel ranks (the [layers, L] sums all-reduced once per event)."""
+    from spatten_amd import SpAttenKVCache
+    from spatten_amd.parallel import HeadParallel
+    H, L, d, layers, start, recent, important, c = 8, 600, 64, 3, 4, 100, 200, 16
+    past_np, stash_np = [], []
+    for l in range(layers):
+        stash, K, V = prune_inputs(H, L, d, 1, dt, 41 + l, 0)
+        past_np.append((K, V)); stash_np.append(stash)
+    scores = [orc.importance(s, dt) for s in stash_np]
+    want, want_idx = orc.global_token_prune(past_np, c, scores, start, recent, important)
+    cache = SpAttenKVCache(start_size=start, recent_size=recent, important_size=important, token_scope="global")
+    out = cache.apply_token_pruning([(dev(K, dt), dev(V, dt)) for K, V in past_np], c, [dev(s, dt) for s in stash_np])
+    torch.cuda.synchronize()
+    for l in range(layers):
+        idx = cache.keep_indices[l].cpu().numpy()
+        assert np.array_equal(idx, want_idx[l])
+        assert all(np.array_equal(idx[0], idx[h]) for h in range(H))          # one set for every head
+        assert np.array_equal(host(out[l][0]), want[l][0]) and np.array_equal(host(out[l][1]), want[l][1])
+    # two head-parallel ranks, run one after the other: each sums its own heads, the "all-reduce" adds the other's
+    halves = []
+    for rank in range(2):
+        hs = slice(rank * H // 2, (rank + 1) * H // 2)
+        other = slice((1 - rank) * H // 2, (2 - rank) * H // 2)
+        far = torch.stack([dev(sc[other], dt).sum(0, dtype=torch.float64) for sc in scores])
+        hp = HeadParallel(H, rank=rank, world=2, gather_fn=lambda t, r: t, reduce_fn=lambda t, r, far=far: t + far)
+        cr = SpAttenKVCache(start_size=start, recent_size=recent, important_size=important, token_scope="global")
+        cr.head_parallel = hp
+        o = cr.apply_token_pruning([(dev(K[:, hs], dt), dev(V[:, hs], dt)) for K, V in past_np], c,
+                                   [dev(s[:, hs], dt) for s in stash_np])
+        halves.append(o)
+    torch.cuda.synchronize()
+    for l in range(layers):
+        got_k = np.concatenate([host(halves[0][l][0]), host(halves[1][l][0])], axis=1)
+        assert np.array_equal(got_k, want[l][0])
+
+
+def test_token_scope_is_validated():
+    from spatten_amd import SpAttenKVCache
+    with pytest.raises(ValueError):
+        SpAttenKVCache(token_scope="layer")

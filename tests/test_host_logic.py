@@ -77,3 +77,24 @@ def test_bf16_logit_scale_by_reciprocal_is_exact():
         for sgn in (1.0, -1.0):
             xs = (x * np.float32(sgn)).astype(np.float32)
             assert np.array_equal(orc.round_dt((xs / c).astype(np.float32), "bf16"), orc.round_dt((xs * rc).astype(np.float32), "bf16")), e
+
+
+def test_global_token_scope_rows_and_validation():
+    """token_scope="global" (README.md:21; workloads/small.csv:1): the select is handed H stride-0 rows of the head-summed
+    importance (fp64 sum, one rounding to fp32) — pure host logic, equal to the oracle's restatement."""
+    import numpy as np
+    from oracle import spatten_oracle as orc
+    with pytest.raises(ValueError):
+        SpAttenKVCache(token_scope="layer")
+    cache = SpAttenKVCache(start_size=4, recent_size=8, important_size=8, token_scope="global")
+    assert cache.token_scope == "global" and cache.head_parallel is None
+    sc = [orc.synth_normal(3 + l, 1, (6, 50), "f32") for l in range(2)]
+    rows = cache._global_scores([torch.from_numpy(s) for s in sc])
+    for l in range(2):
+        assert rows[l].shape == (6, 50) and rows[l].stride() == (0, 1) and rows[l].dtype == torch.float32
+        np.testing.assert_array_equal(rows[l].numpy(), orc.global_token_scores(sc[l]))
+    # an explicit two-rank partition sums through reduce_fn
+    other = torch.from_numpy(np.stack([s[3:].astype(np.float64).sum(0) for s in sc]))
+    cache.head_parallel = HeadParallel(6, rank=0, world=2, gather_fn=lambda t, r: t, reduce_fn=lambda t, r: t + other)
+    rows = cache._global_scores([torch.from_numpy(s[:3]) for s in sc])
+    np.testing.assert_array_equal(rows[1].numpy(), orc.global_token_scores(sc[1])[:3])

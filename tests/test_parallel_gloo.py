@@ -56,6 +56,19 @@ def _worker(rank, world, port, ret):
         np.testing.assert_allclose(hs.numpy(), hs_full, rtol=1e-6)
         keep = orc.head_prune_select(hs.numpy(), 6)
         assert np.array_equal(keep, orc.head_prune_select(hs_full, 6))
+        # global token scope: ONE kept set per layer, ranked by the importance summed over the heads of ALL ranks — the
+        # all-reduce of the [layers, L] sums (SpAttenKVCache._global_scores) gives every rank the oracle's ranking
+        from spatten_amd.kv_cache_token_pruning import SpAttenKVCache
+        cache = SpAttenKVCache(start_size=4, recent_size=20, important_size=30, token_scope="global")
+        cache.head_parallel = hp
+        imp_full = orc.importance(full_stash, dt)
+        rows = cache._global_scores([torch.from_numpy(imp), torch.from_numpy(imp * 0.5)])
+        want = orc.global_token_scores(imp_full)
+        assert rows[0].shape == (hi - lo, P + 1) and rows[0].stride(0) == 0
+        np.testing.assert_array_equal(rows[0].numpy(), want[: hi - lo])
+        np.testing.assert_array_equal(rows[1].numpy(), orc.global_token_scores(imp_full * 0.5)[: hi - lo])
+        idx_g = orc.topk_window(rows[0].numpy(), 4, P - 20, 30)
+        assert np.array_equal(idx_g, orc.topk_window(want, 4, P - 20, 30)[lo:hi])
         ret[rank] = 1
     finally:
         dist.destroy_process_group()

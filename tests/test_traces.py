@@ -22,6 +22,8 @@ def test_read_synthetic_trace():
     # the bit columns: 6-bit keys + 4 LSBs on refetch, 6-bit values — the (6, 2) fused profile of the per8 trace
     assert (steps[0].key_bits, steps[0].lsb_bits, steps[0].value_bits) == (6, 4, 6) and s.pq_profile(0) == (6, 6)
     assert not steps[0].rescale_previous_importance
+    # one key_fetch_num per layer for all heads: the accelerator model's GLOBAL token pruning (one kept set per layer)
+    assert all(st.keys_uniform for st in steps) and s.token_scope(0) == "global"
 
 
 def test_pq_profile_follows_the_harness_mapping(tmp_path):
@@ -35,6 +37,18 @@ def test_pq_profile_follows_the_harness_mapping(tmp_path):
     s = read_trace(str(p))
     assert s.pq_profile(0) == (8, 8)
     assert s.layers(0)[0].rescale_previous_importance and not s.layers(0)[1].rescale_previous_importance
+    # a layer written -1 / -1 inside a quantised trace counts as (8, 8) — here layer 0 is (6, 6), layer 1 is -1 / -1
+    rows2 = [rows[0], "0,0,0,64.0,100,100,6,16,-1,False,-1,100,6,True,True,False,-1",
+             "0,0,1,64.0,100,90,6,16,-1,False,-1,100,6,True,True,False,-1", rows[2]]
+    p2 = tmp_path / "t2.csv"
+    p2.write_text("\n".join(rows2) + "\n")
+    s2 = read_trace(str(p2))
+    assert s2.pq_profile(0) == (8, 8)
+    assert not s2.layers(0)[0].keys_uniform and s2.token_scope(0) == "head"      # heads of layer 0 fetch 100 and 90 keys
+    # a trace without any quantisation width: no profile
+    p3 = tmp_path / "t3.csv"
+    p3.write_text("\n".join([rows[0], rows[2]]) + "\n")
+    assert read_trace(str(p3)).pq_profile(0) is None
 
 
 def test_rejects_other_csv(tmp_path):

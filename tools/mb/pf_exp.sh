@@ -5,7 +5,7 @@ M=$1; shift
 cp spatten_amd/lib/libspatten_hip.so /tmp/lib_orig.so
 for var in "$@"; do
   mkdir -p /tmp/pfl; rm -f /tmp/pfl/*.o
-  for f in decode_attn prefill_attn prune cascade pq comm step gemv layer_cascade; do
+  for f in $(ls spatten_amd/csrc/*.hip | xargs -n1 basename | sed 's/.hip//'); do
     if [ $f = prefill_attn ]; then
       /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -fno-slp-vectorize -D$M=$var -c spatten_amd/csrc/$f.hip -o /tmp/pfl/$f.o &
     else cp build/$f.o /tmp/pfl/$f.o 2>/dev/null || /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -c spatten_amd/csrc/$f.hip -o /tmp/pfl/$f.o &
