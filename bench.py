@@ -612,25 +612,8 @@ def main():
     hid = [None] * L
     kept_heads = None
     if cfg["head_keep"]:
-        sc = torch.stack(head_sc)                                             # [L, Hl] fp32
-        if dist_on:
-            allsc = torch.empty(world_eff, L, Hl, dtype=torch.float32, device=dev)
-            dist.all_gather_into_tensor(allsc, sc.contiguous())
-            sc = allsc.permute(1, 0, 2).reshape(L, world_eff * Hl)
-        sc = sc.double().cpu()
-        cum = torch.zeros(sc.shape[1], dtype=torch.float64)
-        alive = torch.ones(sc.shape[1], dtype=torch.bool)
-        h_lo = hp.rank * Hl
-        kept_heads = []
-        for l in range(L):
-            cum += sc[l]
-            order = torch.sort(torch.where(alive, cum, torch.full_like(cum, -float("inf"))), descending=True, stable=True).indices
-            ids = order[: min(cfg["head_keep"], int(alive.sum()))].sort().values
-            alive = torch.zeros_like(alive)
-            alive[ids] = True
-            mine = ids[(ids >= h_lo) & (ids < h_lo + Hl)] - h_lo
-            hid[l] = mine.to(torch.int32).to(dev)
-            kept_heads.append(int(mine.numel()))
+        hid = hp.surviving_local_heads(torch.stack(head_sc), cfg["head_keep"])   # [L] int32 local ids (spatten_amd/parallel.py)
+        kept_heads = [int(x.numel()) for x in hid]
 
     # ---- pruned slabs (K, rotated shadow, V) with room for one turn ------------------------------------
     Kd = [torch.zeros(B, Hl, cap, d, dtype=dt, device=dev) for _ in range(L)]

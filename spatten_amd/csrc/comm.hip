@@ -203,8 +203,15 @@ extern "C" int spatten_peer_create(void** peer_out, int rank, int nranks, size_t
   ps->slot = (max_bytes_per_rank + 255) / 256 * 256;
   const size_t bytes = kPeerFlagBytes + 2 * (size_t)nranks * ps->slot;
   void* w = nullptr;
+  // The exchange's relaxed system-scope stores + flag are only a protocol on FINE-GRAINED memory (a peer's xGMI writes reach a
+  // kernel that is already polling); a coarse-grained window would need release / acquire fences around every slice.  Several
+  // ranks without fine-grained memory: unsupported — the caller keeps RCCL.  One rank (loopback) has no peer.
   if (hipExtMallocWithFlags(&w, bytes, hipDeviceMallocFinegrained) == hipSuccess && w) ps->finegrained = true;
-  else { (void)hipGetLastError(); if (hipMalloc(&w, bytes) != hipSuccess || !w) { delete ps; return SPATTEN_ERR_LAUNCH; } }
+  else {
+    (void)hipGetLastError();
+    if (nranks > 1) { delete ps; return SPATTEN_ERR_UNSUPPORTED; }
+    if (hipMalloc(&w, bytes) != hipSuccess || !w) { delete ps; return SPATTEN_ERR_LAUNCH; }
+  }
   ps->window = (char*)w;
   void* st = nullptr;
   if (hipMemset(w, 0, bytes) != hipSuccess || hipMalloc(&st, 256) != hipSuccess || hipMemset(st, 0, 256) != hipSuccess) {

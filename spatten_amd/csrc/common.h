@@ -413,6 +413,29 @@ __device__ inline void rope_pair(const float (&xlo)[8], const float (&xhi)[8], c
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Per-device facts the host side sizes co-resident grids by: asked once per device, not assumed.  (Dynamic LDS
+// requests are checked through hipFuncSetAttribute's own answer, per device: local_v.hip, layer_cascade.hip.)
+struct DeviceFacts { int cus = 0; int lds_per_block = 0; };
+inline const DeviceFacts& device_facts() {
+  static DeviceFacts facts[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  DeviceFacts& f = facts[dev];
+  if (f.cus == 0) {
+    int c = 0, l = 0;
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+    if (hipDeviceGetAttribute(&l, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || l <= 0) l = 64 * 1024;
+    f.lds_per_block = l;
+    f.cus = c;
+  }
+  return f;
+}
+// Workgroups of a launch that the device starts without waiting for another to finish: one per CU — what a merge that POLLS
+// for its sibling splits needs (every workgroup of the grid resident).  A larger grid takes the ticket protocol.  The bound
+// assumes the launch has the device to itself: work on other streams (RCCL, a second model) can delay residency — the spins
+// are bounded and a timeout is reported through the workspace status (spatten_decode_workspace_status).
+inline int coresident_workgroups() { return device_facts().cus; }
+
 // progressive-quant key planes handed to decode_rows (decode_attn.hip); see pq.hip for the storage format
 struct PQKeys {
   const uint8_t* msb; const uint8_t* lsb; const float* scale;

@@ -105,7 +105,7 @@ struct DecodeParams {
 #endif
 constexpr int kDecodeThreads = 256;
 constexpr int kGemvChunksFused = 8;      // = gemv.hip's kGemvChunks: the fused projection keeps its summation order
-constexpr int kDecodeCoResident = 256;   // workgroups the chip starts without waiting for another to finish: one per CU
+// (co-residency bound of the polling merge: common.h coresident_workgroups() — the device's CU count, asked per device)
 
 // one 8-byte {value, tag} granule of a published partial (tag != 0 <=> the value has landed)
 __device__ inline void store_granule(unsigned long long* g, float v, unsigned tag) {
@@ -1334,7 +1334,7 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   // the conservative protocol there); SPATTEN_DECODE_POLL=0 forces the ticket protocol (A/B measurements).
   static int env_poll = -1;
   if (env_poll < 0) { const char* e = getenv("SPATTEN_DECODE_POLL"); env_poll = e ? atoi(e) : 1; }
-  const int poll_merge = (env_poll != 0 && S > 1 && c.n_q == 1 && (long long)S * n_active * c.batch <= kDecodeCoResident) ? 1 : 0;
+  const int poll_merge = (env_poll != 0 && S > 1 && c.n_q == 1 && (long long)S * n_active * c.batch <= coresident_workgroups()) ? 1 : 0;
 
   // ---- the output projection of the step (modify_llama.py:163) as a second launch of the same call: one C call per
   // layer-step for the host.  (r03: fusing it INTO the launch — projection waves in the decode workgroups that stream the
@@ -1438,7 +1438,7 @@ extern "C" int spatten_decode_qkv_supported(int dtype, int batch, int heads, int
   S = ceil_div(kv_len_layout, chunk);
   static int env_poll = -1;
   if (env_poll < 0) { const char* e = getenv("SPATTEN_DECODE_POLL"); env_poll = e ? atoi(e) : 1; }
-  const int poll = (env_poll != 0 && S > 1 && (long long)S * heads * batch <= kDecodeCoResident) ? 1 : 0;
+  const int poll = (env_poll != 0 && S > 1 && (long long)S * heads * batch <= coresident_workgroups()) ? 1 : 0;
   if (!decode_qkv_shape_ok(head_dim, S, poll)) return 0;
   return chunk <= 10 * decode_group_rows(head_dim) ? 1 : 0;      // a single-shot tile per split
 }

@@ -736,14 +736,16 @@ static int prune_layer_cascade_impl(int score_dtype, int kv_dtype, int layers, c
   c.map_ids = layers <= 254 ? (int)std::min<int64_t>(96 * 1024, 140 * 1024 - (int64_t)c.lds_keys * 4) & ~3 : 0;
   const size_t lds = (size_t)c.lds_keys * sizeof(uint32_t) + (size_t)c.map_ids;
   {
-    static bool attr_set[4] = {};
+    static bool attr_set[64][4] = {};     // per DEVICE and score dtype (the attribute is a per-device property: ADVICE r04)
     const int di = score_dtype == SPATTEN_F32 ? 0 : (score_dtype == SPATTEN_BF16 ? 1 : 2);
-    if (!attr_set[di]) {
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 0;
+    if (!attr_set[dev_][di]) {
       hipError_t e = hipSuccess;
       SPATTEN_BY_DTYPE(score_dtype, e = hipFuncSetAttribute((const void*)layer_cascade_select_kernel<T>,
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-      if (e != hipSuccess) return SPATTEN_ERR_LAUNCH;
-      attr_set[di] = true;
+      if (e != hipSuccess) { (void)hipGetLastError(); return SPATTEN_ERR_UNSUPPORTED; }
+      attr_set[dev_][di] = true;
     }
   }
   const int es = kv_dtype == SPATTEN_F32 ? 4 : 2;

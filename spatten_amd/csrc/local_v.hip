@@ -489,7 +489,9 @@ extern "C" int spatten_attn_decode_local_v(int dtype, const void* q, int64_t q_s
   if (!step_state && (pos_q < 0 || pos_q >= table_rows)) return SPATTEN_ERR_INVALID;
   const int lay = (!step_state && kv_len_layout > kv_len) ? kv_len_layout : kv_len;
   const long long units = (long long)batch * heads;
-  int S = (int)std::max(1LL, 256 / units);
+  const int resident = coresident_workgroups();      // the splits of a head poll each other: the whole grid must be resident
+  if (units > resident) return SPATTEN_ERR_UNSUPPORTED;   // (cascade.local_v_decode falls back to the three-launch path)
+  int S = (int)std::max(1LL, resident / units);
   if (S > kLvMaxSplits) S = kLvMaxSplits;
   const int min_rows = 256;                          // a split shorter than this is all latency
   if (S > std::max(1, lay / min_rows)) S = std::max(1, lay / min_rows);
@@ -517,10 +519,15 @@ extern "C" int spatten_attn_decode_local_v(int dtype, const void* q, int64_t q_s
     p.keep_frac = keep_fraction; p.keep = keep;                                                                        \
     p.B = batch; p.H = heads; p.Hkv = kv_heads; p.N = kv_len; p.S = S; p.chunk = chunk;                                 \
     p.sqrt_d = sqrtf((float)head_dim);                                                                                 \
-    static bool attr_set = false;                                                                                      \
-    if (!attr_set) {                                                                                                   \
-      (void)hipFuncSetAttribute((const void*)local_v_kernel<T, DD, DYN_>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); \
-      attr_set = true;                                                                                                 \
+    static bool attr_set[64] = {};       /* the attribute is per DEVICE */                                \
+    int dev_ = 0;                                                                                                      \
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 0;                                         \
+    if (!attr_set[dev_]) {                                                                                             \
+      if (hipFuncSetAttribute((const void*)local_v_kernel<T, DD, DYN_>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) != hipSuccess) { \
+        (void)hipGetLastError();                                                                                       \
+        return SPATTEN_ERR_UNSUPPORTED;                                                                                \
+      }                                                                                                                \
+      attr_set[dev_] = true;                                                                                           \
     }                                                                                                                  \
     hipLaunchKernelGGL((local_v_kernel<T, DD, DYN_>), grid, dim3(kLvThreads), lds, st, p);                              \
   }

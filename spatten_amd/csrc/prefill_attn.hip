@@ -1189,11 +1189,8 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 }
 
 
-// The one-wave-per-SIMD flash kernel of round 3 (a measured-slower experiment) lives under
-// tools/experiments/ and is compiled only into an experiment build of the library (tools/experiments/build_w4.sh).
-#ifdef SPATTEN_WITH_W4_EXPERIMENT
-#include "../../tools/experiments/prefill_w4.h"
-#endif
+// (The one-wave-per-SIMD flash kernel of round 3 — measured slower, 616-642 against 740-766 TFLOP/s — was removed in round 5:
+//  HISTORY.md, `git show 8a7875c:tools/experiments/prefill_w4.h`.)
 
 // Fold the key-split partials of prefill_pp128_kernel: one wave per query row (D/64 output elements per lane).
 // out = sum_s O_s e^(m_s - m) / sum_s l_s e^(m_s - m),  m = max_s m_s   (a split without keys has m = -inf, l = 0)
@@ -1398,16 +1395,6 @@ static inline bool use_vtr_for(int head_dim, int q_len, int kv_len) {
   return q_len <= SPATTEN_PF_VTR_MAXQ || (q_len == kv_len && q_len <= 2 * SPATTEN_PF_VTR_MAXQ);
 }
 
-static int g_last_flash_kernel = 0;     // developer diagnostic: 1 = pp128, 2 = w4 (experiment builds only), 3 = the 64-key kernel
-#ifdef SPATTEN_WITH_W4_EXPERIMENT
-// experiment builds only (tools/experiments/): correct (tools/experiments/check_prefill_w4.py) but 616-642 TFLOP/s against
-// 740-766 for prefill_pp128_kernel at q = N = 8192; selected by SPATTEN_PREFILL_W4=1
-static inline bool use_w4_for(int q_len) {
-  static int env = -1;
-  if (env < 0) { const char* e = getenv("SPATTEN_PREFILL_W4"); env = e ? atoi(e) : 0; }
-  return env == 1;
-}
-#endif
 
 // Key split of the plain flash kernel: only when the launch would leave most of the chip idle (few query blocks x heads)
 // and every range still has >= 2 key tiles.  The same rule sizes the workspace.
@@ -1451,17 +1438,6 @@ static void launch_flash_m(const FlashParams<T>& p, hipStream_t st) {
       return;
     }
     if (prefill_variant() == 0) {
-#ifdef SPATTEN_WITH_W4_EXPERIMENT
-      if constexpr (D == 128) {
-        if (use_w4_for(p.q_len) && !p.mask && !p.vtr && p.ksplit <= 1) {
-          if (p.fast) hipLaunchKernelGGL((prefill_w4_kernel<T, true>), grid, dim3(256), 0, st, p);
-          else hipLaunchKernelGGL((prefill_w4_kernel<T, false>), grid, dim3(256), 0, st, p);
-          g_last_flash_kernel = 2;
-          return;
-        }
-      }
-#endif
-      g_last_flash_kernel = 1;
       const dim3 gridk((unsigned)(p.nqb * p.H * p.B * (p.ksplit > 1 ? p.ksplit : 1)));
       if (p.mask) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, true>), gridk, dim3(512), 0, st, p);
       else if (p.fast) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, 0, true>), gridk, dim3(512), 0, st, p);
@@ -1476,7 +1452,6 @@ static void launch_flash_m(const FlashParams<T>& p, hipStream_t st) {
       return;
     }
   }
-  g_last_flash_kernel = 3;
   if (p.mask) hipLaunchKernelGGL((prefill_pp_kernel<T, D, ST, CI, true>), grid, dim3(512), 0, st, p);
   else hipLaunchKernelGGL((prefill_pp_kernel<T, D, ST, CI, false>), grid, dim3(512), 0, st, p);
 }
@@ -1730,7 +1705,6 @@ extern "C" int spatten_attn_prefill_pq(int dtype, const void* q, int64_t q_sb, i
 }
 
 // developer diagnostic (not part of the boundary, not in include/spatten.h): which flash kernel the last prefill call launched
-extern "C" int spatten_debug_last_prefill_kernel(void) { return g_last_flash_kernel; }
 
 #ifdef SPATTEN_PF_TRACE
 extern "C" int spatten_debug_set_pf_trace(unsigned long long* buf) {

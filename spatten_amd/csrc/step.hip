@@ -63,3 +63,4 @@ extern "C" int spatten_step_advance(void* state, int dtype, int head_dim, const 
                                     int delta, void* stream) {
   return step_update(state, dtype, head_dim, cos, sin, table_rows, 0, 0, 0, delta, (hipStream_t)stream);
 }
+

@@ -106,6 +106,8 @@ class SpAttenKVCache:
                 f"(seq_len={seq_len}, num_coming={num_coming})")
         n_layers = len(past_key_values)
         ops.check_workspaces()              # a natural sync point: surface a device-side merge timeout, if any
+        if self.head_parallel is not None:
+            self.head_parallel.peer_status()    # ... and a peer slice that never arrived (peer-store all-gather), if any
         if self.ext is not None:
             self.ext.before_prune()         # fold the pending decode step, pick the heads that survive
         if self.ext is not None and self.ext.layer_keep is not None:

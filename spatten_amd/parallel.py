@@ -236,6 +236,40 @@ class HeadParallel:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def surviving_local_heads(self, layer_scores: torch.Tensor, keep) -> list:
+        """Cascade head pruning over the heads of ALL ranks with static ownership ("keep static ownership, pruned
+        heads simply skip"; oracle: head_prune_cascade).  ``layer_scores`` fp32 [layers, H/G] = sum |O_h| of this rank's heads
+        per layer; ``keep`` = heads that survive (int, or one per layer, non-increasing).  One all-gather of the [layers, H/G]
+        block; every rank then runs the same deterministic rule — cumulative score over the layers, a head pruned in a
+        layer stays pruned, ties keep the lowest head id — and returns, per layer, the int32 LOCAL ids (ascending) of its
+        own surviving heads: what its attention launch is given as ``head_ids``.  The lists are uneven across ranks and may
+        be empty (that rank then launches nothing for the layer; its output slice stays zero)."""
+        L, Hl = layer_scores.shape
+        sc = layer_scores.to(torch.float32).contiguous()
+        if self.gather_fn is not None:
+            sc = self.gather_fn(sc.reshape(1, L, Hl).transpose(0, 1).contiguous(), self.rank).reshape(L, -1)
+        elif self.world > 1:
+            allsc = torch.empty(self.world * L, Hl, dtype=torch.float32, device=sc.device)   # concatenation form (RCCL and gloo)
+            dist.all_gather_into_tensor(allsc, sc, group=self.group)
+            sc = allsc.view(self.world, L, Hl).permute(1, 0, 2).reshape(L, self.world * Hl)
+        sc = sc.double().cpu()
+        H = sc.shape[1]
+        keeps = [int(keep)] * L if isinstance(keep, int) else [int(k) for k in keep]
+        cum = torch.zeros(H, dtype=torch.float64)
+        alive = torch.ones(H, dtype=torch.bool)
+        lo = self.rank * Hl
+        out = []
+        for l in range(L):
+            cum += sc[l]
+            ranked = torch.where(alive, cum, torch.full_like(cum, -float("inf")))
+            order = torch.sort(ranked, descending=True, stable=True).indices
+            ids = order[: min(keeps[l], int(alive.sum()))].sort().values
+            alive = torch.zeros_like(alive)
+            alive[ids] = True
+            mine = ids[(ids >= lo) & (ids < lo + Hl)] - lo
+            out.append(mine.to(torch.int32).to(layer_scores.device))
+        return out
+
     def gather_head_scores(self, local_scores: torch.Tensor) -> torch.Tensor:
         """[H/G] fp32 -> [H] on every rank (head pruning: every rank then runs the same top-k)."""
         if self.gather_fn is not None:

@@ -56,6 +56,16 @@ def _worker(rank, world, port, ret):
         np.testing.assert_allclose(hs.numpy(), hs_full, rtol=1e-6)
         keep = orc.head_prune_select(hs.numpy(), 6)
         assert np.array_equal(keep, orc.head_prune_select(hs_full, 6))
+        # cascade head pruning with STATIC ownership (BASELINE.json configs[2] / [4]; bench.py --config c3 / c5): the heads of
+        # all ranks are ranked together, every rank keeps the local ids of its own survivors — uneven, here even none
+        sc_full = np.array([[9, 8, 7, 6, 1, 2, 3, 5], [1, 1, 1, 1, 9, 0, 0, 0], [0, 0, 0, 0, 0, 0, 0, 0]], np.float32)
+        keep = [5, 3, 2]
+        want = orc.head_prune_cascade(list(sc_full), keep)
+        got = hp.surviving_local_heads(torch.from_numpy(sc_full[:, lo:hi].copy()), keep)
+        for l in range(3):
+            mine = [int(h) - lo for h in want[l] if lo <= h < hi]
+            assert got[l].dtype == torch.int32 and got[l].tolist() == mine, (rank, l, got[l].tolist(), mine)
+        assert [len(g) for g in got] == ([4, 3, 2] if rank == 0 else [1, 0, 0])
         # global token scope: ONE kept set per layer, ranked by the importance summed over the heads of ALL ranks — the
         # all-reduce of the [layers, L] sums (SpAttenKVCache._global_scores) gives every rank the oracle's ranking
         from spatten_amd.kv_cache_token_pruning import SpAttenKVCache

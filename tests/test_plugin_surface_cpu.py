@@ -112,7 +112,7 @@ def test_mt_bench_loader_flattens_turns():
     rows = load_jsonl(path)
     assert [r["question_id"] for r in rows] == [81, 82, 83]
     prompts = load_mt_bench_prompts(path)
-    assert len(prompts) == 5 and prompts[1].startswith("Rewrite") and prompts[-1] == "What is 7 times 6?"
+    assert len(prompts) == 5 and prompts[1].startswith("Now shorten") and prompts[-1] == "What is 7 times 6?"
 
 
 def test_bounded_caches():
