@@ -160,10 +160,11 @@ struct FlashParams {
 #ifndef SPATTEN_PF_ROWSUM_MFMA  // row sums of P on the matrix pipe instead of 64 VALU adds per lane and tile: MEASURED SLOWER
 #define SPATTEN_PF_ROWSUM_MFMA 0   // (713 vs 768): the 8 extra MFMAs per tile cost more than the adds they replace.  Off.
 #endif
-#ifndef SPATTEN_PF_DIET         // r05 instruction diet of prefill_pp128_kernel's softmax (bits, A/B: tools/mb/pf_exp.sh SPATTEN_PF_DIET 0 2 ...):
-#define SPATTEN_PF_DIET 2       //   2 = no per-tile maximum on fully visible tiles (exponentials against the running maximum, the lane's
-#endif                          //       sum bounds every one of them; the rare tile that outgrows it is redone), 4 = row sums of the
-                                //       ROUNDED P on the packed-dot unit (measured slower: v_dot2 is ~2.4 plain issues)
+#ifndef SPATTEN_PF_DIET         // r05 A/B switches of prefill_pp128_kernel's softmax (bits; prebuilt variants: tools/mb/build_variant.sh):
+#define SPATTEN_PF_DIET 0       //   2 = no per-tile maximum on fully visible tiles (exponentials against the running maximum, the lane's
+#endif                          //       sum bounds every one of them; the rare tile that outgrows it is redone): parity-green, MEASURED
+                                //       NEUTRAL-TO-SLOWER (824-831 vs 841-850 TFLOP/s at q = N = 8192, alternating in one call) — off;
+                                //   4 = row sums of the ROUNDED P on the packed-dot unit: slower (785; v_dot2 costs ~2.4 plain issues)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kDeferMax = 8.0f;   // natural-log units of the scaled logits
 constexpr float kSumBound = 2980.0f;   // < e^kDeferMax: a lane whose 64 exponentials sum to no more holds none above e^kDeferMax

@@ -13,7 +13,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
-enum { NONE = 0, FMA, EXP, CVT, AND, DOT2, PKMUL, MAX3, DSRD, SAME, MIX, CVT0 };
+enum { NONE = 0, FMA, EXP, CVT, AND, DOT2, PKMUL, MAX3, DSRD, SAME, MIX, CVT0, RINGRD };
 
 template <int T>
 __device__ inline void filler(float (&x)[8], int j, unsigned lds_addr) {
@@ -31,15 +31,19 @@ __device__ inline void filler(float (&x)[8], int j, unsigned lds_addr) {
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     u4 t;
     asm volatile("ds_read_b128 %0, %1" : "=v"(t) : "v"(lds_addr));
-  } else if (T == MIX) {   // the flash kernel's softmax mix per logit: cvt, mul, cvt, fma, exp, add, half a cvt
+  } else if (T == MIX) {   // the flash kernel's softmax per logit (cvt, mul, cvt, fma, exp, add, half a packed cvt) as a chain on ONE
+    // register, eight registers interleaved, constants chosen so that the values stay O(1) (the first version of this mix
+    // drifted into inf / NaN / denormals and ran ~200 cycles per instruction: not an issue-port effect)
+    float& rr = x[(j / 7) & 7];
+    const float c0 = 0.99f, c1 = 0.3f, c2 = 0.2f, c3 = -0.9f;
     switch (j % 7) {
-      case 0: asm volatile("v_cvt_pk_bf16_f32 %0, 0, %0" : "+v"(r)); break;
-      case 1: asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r) : "v"(q)); break;
-      case 2: asm volatile("v_cvt_pk_bf16_f32 %0, 0, %0" : "+v"(r)); break;
-      case 3: asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(r) : "v"(q)); break;
-      case 4: asm volatile("v_exp_f32 %0, %0" : "+v"(r)); break;
-      case 5: asm volatile("v_add_f32 %0, %0, %1" : "+v"(r) : "v"(q)); break;
-      default: asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(r) : "v"(q)); break;
+      case 0: asm volatile("v_cvt_pk_bf16_f32 %0, 0, %0" : "+v"(rr)); break;
+      case 1: asm volatile("v_mul_f32 %0, %0, %1" : "+v"(rr) : "v"(c0)); break;
+      case 2: asm volatile("v_cvt_pk_bf16_f32 %0, 0, %0" : "+v"(rr)); break;
+      case 3: asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(rr) : "v"(c1), "v"(c2)); break;
+      case 4: asm volatile("v_exp_f32 %0, %0" : "+v"(rr)); break;
+      case 5: asm volatile("v_add_f32 %0, %0, %1" : "+v"(rr) : "v"(c3)); break;
+      default: asm volatile("v_cvt_pk_bf16_f32 %0, 0, %0" : "+v"(rr)); break;
     }
   }
 }
@@ -51,8 +55,28 @@ template <int GAP> __device__ inline void gap() {
   if (GAP == 8) asm volatile("s_nop 7");
 }
 
+// the shipped matrix phase: every MFMA takes its A operand from a KA-deep register ring fed by ds_read_b128 (one read behind
+// every MFMA, s_waitcnt lgkmcnt(KA - 1) in front of it) — swizzled, lane-distinct addresses over 32 KB of LDS
+template <int KA>
+__device__ inline void a_ring_iter(f32x16 (&acc)[4], bf8 b, unsigned lds_addr) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  u4 ring[KA];
+#pragma unroll
+  for (int i = 0; i < KA; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[i]) : "v"(lds_addr), "i"((i * 1024) & 0x7FFF));
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    if (KA == 2) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+    if (KA == 4) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+    if (KA == 8) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i & 3]) : "v"(ring[i % KA]), "v"(b));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[i % KA]) : "v"(lds_addr), "i"((((i + KA) * 1024) ^ ((i & 3) * 4096)) & 0x7FF0));
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 template <int KA, int TA>
 __device__ inline void a_iter(f32x16 (&acc)[4], bf8 a, bf8 b, float (&x)[8], unsigned lds_addr) {
+  if constexpr (TA == RINGRD) { a_ring_iter<KA>(acc, b, lds_addr); return; }
 #pragma unroll
   for (int i = 0; i < 64; ++i) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i & 3]) : "v"(a), "v"(b));
@@ -62,7 +86,7 @@ __device__ inline void a_iter(f32x16 (&acc)[4], bf8 a, bf8 b, float (&x)[8], uns
   if (TA == DSRD) asm volatile("s_waitcnt lgkmcnt(0)");
 }
 
-template <int KA, int TA, int TB, int GAP, int PRIO>
+template <int KA, int TA, int TB, int GAP, int PRIO, int SWAP = 0>
 __global__ __launch_bounds__(512, 1) void k(int iters, unsigned long long* cyc, unsigned long long* bcount, float* sink) {
   __shared__ __attribute__((aligned(16))) char lds[65536];
   __shared__ int done;
@@ -73,7 +97,7 @@ __global__ __launch_bounds__(512, 1) void k(int iters, unsigned long long* cyc, 
   float x[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) x[j] = 1.0f + 0.001f * (lane + j);
-  const unsigned lds_addr = (unsigned)(lane * 16 + wave * 1024);
+  const unsigned lds_addr = (unsigned)((((lane & 31) * 256) + (((lane >> 5) ^ (lane & 15)) << 4)) & 0x7FF0);
   f32x16 acc[4];
   bf8 a, b;
 #pragma unroll
@@ -82,14 +106,14 @@ __global__ __launch_bounds__(512, 1) void k(int iters, unsigned long long* cyc, 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  const bool role_a = wave < 4;
+  const bool role_a = SWAP ? wave >= 4 : wave < 4;
   if (PRIO == 1 && role_a) __builtin_amdgcn_s_setprio(1);
   if (PRIO == 2 && !role_a) __builtin_amdgcn_s_setprio(1);
   if (role_a || TB == SAME) {
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) a_iter<KA, TA>(acc, a, b, x, lds_addr);
     const unsigned long long t1 = __builtin_readcyclecounter();
-    if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+    if (lane == 0) cyc[blockIdx.x * 8 + (SWAP ? (wave ^ 4) : wave)] = t1 - t0;
     if (role_a && lane == 0) atomicAdd(&done, 1);
   } else if (TB != NONE) {
     unsigned long long n = 0;
@@ -100,7 +124,7 @@ __global__ __launch_bounds__(512, 1) void k(int iters, unsigned long long* cyc, 
       n += 256;
       if (__hip_atomic_load(&done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= 4) break;
     }
-    if (lane == 0) bcount[blockIdx.x * 8 + wave] = n;
+    if (lane == 0) bcount[blockIdx.x * 8 + (SWAP ? (wave ^ 4) : wave)] = n;
   }
   asm volatile("s_nop 15\n\ts_nop 15");
   float s = 0.f;
@@ -111,7 +135,7 @@ __global__ __launch_bounds__(512, 1) void k(int iters, unsigned long long* cyc, 
   if (s == 12345.678f) sink[threadIdx.x] = s;
 }
 
-template <int KA, int TA, int TB, int GAP, int PRIO>
+template <int KA, int TA, int TB, int GAP, int PRIO, int SWAP = 0>
 void run(const char* name) {
   const int iters = 200, G = 256;
   unsigned long long *cyc, *bc;
@@ -124,10 +148,10 @@ void run(const char* name) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  k<KA, TA, TB, GAP, PRIO><<<G, 512>>>(20, cyc, bc, sink);
+  k<KA, TA, TB, GAP, PRIO, SWAP><<<G, 512>>>(20, cyc, bc, sink);
   hipMemset(bc, 0, G * 8 * 8);
   hipEventRecord(e0);
-  k<KA, TA, TB, GAP, PRIO><<<G, 512>>>(iters, cyc, bc, sink);
+  k<KA, TA, TB, GAP, PRIO, SWAP><<<G, 512>>>(iters, cyc, bc, sink);
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms;
@@ -196,5 +220,20 @@ int main() {
   run<7, MIX, DSRD, 0, 0>("A + 7 mix, B ds_read dense");
   run<7, MIX, DSRD, 4, 0>("A + 7 mix, B ds_read + s_nop 3");
   run<10, MIX, DSRD, 4, 0>("A + 10 mix, B ds_read + s_nop 3");
+  printf("== r05b: the shipped matrix phase (operand ring from LDS) beside the partner's softmax; which half is older\n");
+  run<4, RINGRD, NONE, 0, 0>("A ring-4 from LDS, B none");
+  run<8, RINGRD, NONE, 0, 0>("A ring-8 from LDS, B none");
+  run<4, RINGRD, FMA, 0, 0>("A ring-4 (older half), B fma dense");
+  run<4, RINGRD, MIX, 0, 0>("A ring-4 (older half), B softmax mix");
+  run<4, RINGRD, MIX, 0, 0, 1>("A ring-4 (YOUNGER half), B softmax mix (older)");
+  run<4, RINGRD, MIX, 0, 1, 1>("A ring-4 (younger, prio 1), B softmax mix (older)");
+  run<8, RINGRD, MIX, 0, 0, 1>("A ring-8 (younger half), B softmax mix (older)");
+  run<2, RINGRD, MIX, 0, 0, 1>("A ring-2 (younger half), B softmax mix (older)");
+  run<0, NONE, MIX, 0, 0, 1>("A bare (younger half), B softmax mix (older)");
+  run<0, NONE, MIX, 0, 0>("A bare (older half), B softmax mix");
+  run<4, RINGRD, SAME, 0, 0>("both ring-4 MFMA (lock-step matrix phases)");
+  run<7, MIX, SAME, 0, 0>("both MFMA + 7 stable softmax mix");
+  run<8, MIX, SAME, 0, 0>("both MFMA + 8 stable softmax mix");
+  run<7, MIX, NONE, 0, 0>("A + 7 stable softmax mix alone");
   return 0;
 }
