@@ -175,9 +175,7 @@ def _socket0_physical_cpus():
             if sock == 0 and core not in seen:
                 seen.add(core)
                 cpus.append(cpu)
-        allowed = os.sched_getaffinity(0)
-        cpus = [c_ for c_ in cpus if c_ in allowed]
-        return cpus or None
+        return cpus or None      # (not intersected with this process's affinity: a runtime may have pinned the calling thread)
     except Exception:
         return None
 
@@ -276,11 +274,10 @@ def cpu_baseline(L, new_len, lo, hi):
     cpus = _socket0_physical_cpus()
     env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores")
     env.pop("OMP_NUM_THREADS", None)
-    kw = {}
     if cpus:
-        kw["preexec_fn"] = lambda: os.sched_setaffinity(0, cpus)
+        env["SPATTEN_BENCH_PIN_CPUS"] = ",".join(str(c_) for c_ in cpus)      # the child pins itself before its first parallel region
     pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child"], capture_output=True, text=True, env=env,
-                        timeout=900, **kw)
+                        timeout=900)
     line = [ln for ln in pr.stdout.splitlines() if ln.startswith("CPU_BASELINE_JSON ")]
     if pr.returncode != 0 or not line:
         raise RuntimeError(f"cpu baseline child failed: {pr.stderr[-800:]}")
@@ -595,6 +592,12 @@ def main():
     global LAYERS, HEADS, CTX, START, IMPORTANT, RECENT
     args = parse()
     if args.cpu_baseline_child:         # (spawned by cpu_baseline(): pinned, no GPU work)
+        pin = os.environ.get("SPATTEN_BENCH_PIN_CPUS")
+        if pin:
+            try:
+                os.sched_setaffinity(0, [int(x) for x in pin.split(",")])
+            except OSError:
+                pass                    # CPUs outside this container's set: run unpinned (pinned_cpus in the output says which)
         cpu_baseline_child(LAYERS, START + IMPORTANT + RECENT, START, CTX - RECENT)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void pv_gather_kernel(const T* __restrict__ st
 // equal work whatever the distribution of the kept rows over the cache — first (index, probability) pairs into LDS
 // (one dependent round trip for the whole slice), then the V rows 8 row-groups in flight per lane.  Partials go to the
 // workspace; the LAST workgroup of a (b, h) to arrive (ticket) adds them in split order, so the result does not depend
-// on arrival order.  r02: 193 -> see DESIGN §3.6 us at 40 heads x 4915 kept rows.
+// on arrival order.  r02: 193 -> see HISTORY.md (DESIGN r04 §3.6) us at 40 heads x 4915 kept rows.
 constexpr int kPvMaxPer = 1024;
 constexpr int kPvMaxSplits = 64;
 

@@ -1341,7 +1341,7 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   // weight rows while the attention runs and wait only for the merged output — was built and measured: 21.2 us against
   // 18.4 for the two launches; the weight stream does hide under the decode step (15.3 us with the wait removed), but the
   // hand-off "all heads merged -> every CU" costs a poll round trip plus an activation read under load, more than the
-  // kernel boundary it replaces.  DESIGN 3.9.)
+  // kernel boundary it replaces.  HISTORY.md, r04 §3.9.)
   const bool want_proj = c.proj_w != nullptr;
   if (want_proj && (!c.proj_out || c.proj_n <= 0 || c.n_q != 1 || scores_only || c.proj_w_sn < (int64_t)c.heads * c.head_dim))
     return SPATTEN_ERR_INVALID;

@@ -129,7 +129,7 @@ struct FlashParams {
   float* part_ml;     // [B*H*nqb][ksplit][256][2]
 };
 
-// A/B switches (tools/mb/pf_exp.sh rebuilds with -D<macro>=<v>; findings in DESIGN §3.4).
+// A/B switches (tools/mb/pf_exp.sh rebuilds with -D<macro>=<v>; findings in DESIGN §3.4 and HISTORY.md).
 #ifndef SPATTEN_PF_PRIO         // static s_setprio for one half: MEASURED SLOWER (775-789 vs 812 TFLOP/s).  Off.
 #define SPATTEN_PF_PRIO 0
 #endif

@@ -202,7 +202,7 @@ def test_plugin_with_fused_step_equals_the_unfused_plugin_bitwise_eager_and_unde
     x0 = torch.randn(1, P, HID, device="cuda", generator=g).to(dt)
     _, pa = a(x0, None)
     _, pb = b(x0, None)
-    pa = kv_slab.reserve(pa, P + 3 * T + 8)          # equal slab capacities: equal split layouts
+    pa = kv_slab.reserve(pa, P + 3 * T + 8)          # equal slab capacities: equal split layouts (HISTORY.md, r04 §3.8)
     pb = kv_slab.reserve(pb, P + 3 * T + 8)
     launches = []
     from spatten_amd import ops
