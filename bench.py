@@ -15,11 +15,13 @@ The timed region always STARTS AT A TURN BOUNDARY (slot 0 = the prune event): K 
 prune events, whatever K the caller picks — never fewer than the workload's one-per-64-tokens.
 
 N > 1: head-parallel (spatten_amd/parallel.py); `python bench.py --gpus N` spawns its own N ranks (torch.distributed.run
-on a free local port) when it is not already running under a launcher.  --scaling strong (default): ONE sequence
-(B = 1) split over the ranks, H/N heads each (BASELINE.json configs[2] / [4]: 4 resp. 5 heads per GPU at N = 8) — total
-work fixed.  --scaling weak: the batch grows with N (B = N sequences), every rank owns H/N heads of every sequence — the
-same KV bytes per rank as the single-GPU run.  Either way each token all-gathers the layers' [B, H/N*d] output slices
-over RCCL (`config.rccl_ranks` = what the library's communicator reports).
+on a free local port) when it is not already running under a launcher.  --scaling weak (default since round 5): the batch
+grows with N (B = N sequences), every rank owns H/N heads of every sequence — the same KV bytes per rank as the single-GPU
+run, i.e. per-GPU work is fixed.  --scaling strong: ONE sequence (B = 1) split over the ranks, H/N heads each
+(BASELINE.json configs[2] / [4]: 4 resp. 5 heads per GPU at N = 8) — total work fixed; at the c2 shape that launch is at its
+latency floor (extras.per_rank_launch_us: 8.9 us for 4 heads against 11.0 for 32), so sharding ONE 2048-row sequence cannot
+pay before any communication — kept measurable, no longer the default.  Either way each token all-gathers
+the layers' [B, H/N*d] output slices over RCCL (`config.rccl_ranks` = what the library's communicator reports).
 
 Defaults: --steps 512 --warmup 64 (8 turns timed; ~0.2 s of GPU time + ~25 s of CPU-baseline sampling and side
 measurements); the driver may pass any K / W — the timed region always starts at a turn boundary.
@@ -68,13 +70,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
-                    help="N > 1.  strong (default; BASELINE.json configs[2] / [4]): ONE sequence, H/N heads per rank — the "
-                         "north star's head-parallel partition, 4 heads per GPU at N = 8.  weak: B = N sequences, every "
-                         "rank holds H/N heads of each (the 1-GPU KV bytes per rank)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1.  weak (default): B = N sequences, every rank holds H/N heads of each (the 1-GPU KV bytes per "
+                         "rank: per-GPU work fixed).  strong (BASELINE.json configs[2] / [4]): ONE sequence, H/N heads per "
+                         "rank, 4 resp. 5 heads per GPU at N = 8 — latency-floor-bound at the c2 shape")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="c2 (default) = BASELINE.json's headline; c3 = + 25 %% head prune (configs[2]); c5 = Llama-2-13B geometry, "
                          "16384 -> 8192 rows, head prune 30 of 40, progressive quantisation k8v8 (configs[4]).  All valid at --gpus 1..8")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="sequences per step (default: 1, or N under --scaling weak); lets ONE rank run the per-rank shape of a weak-"
+                         "scaling run (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-extras", action="store_true", help="skip the dense / eager comparison legs")
@@ -633,7 +638,7 @@ def main():
 
     dt = torch.bfloat16
     hp = HeadParallel(HEADS)
-    B, Hl, d, L = (1 if args.scaling == "strong" else world), hp.local_heads, HEAD_DIM, LAYERS
+    B, Hl, d, L = (args.batch if args.batch > 0 else (1 if args.scaling == "strong" else world)), hp.local_heads, HEAD_DIM, LAYERS
     world_eff = hp.world
     new_len = START + IMPORTANT + RECENT                     # 2048
     cap = kv_slab.round_capacity(new_len + TURN)             # 2176

@@ -35,8 +35,10 @@ def test_bench_emits_one_json_line_with_the_contract_keys():
 def test_bench_runs_the_8_gpu_configs_of_baseline_json_on_one_rank_through_rccl(config):
     """BASELINE.json configs[2] (C3) and configs[4] (C5) are head-parallel configurations: `bench.py --config c3|c5` must be
     valid at any --gpus; here one rank with --force-dist (the RCCL communicator, the per-layer exchange inside the graph)."""
+    # (c3 with a batch of 2: the per-rank shape of a weak-scaling run at 2 GPUs — B sequences x the rank's heads)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--gpus", "1", "--steps", "66",
-                          "--warmup", "2", "--force-dist"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                          "--warmup", "2", "--force-dist"] + (["--batch", "2"] if config == "c3" else []),
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
     c = d["config"]
@@ -46,4 +48,4 @@ def test_bench_runs_the_8_gpu_configs_of_baseline_json_on_one_rank_through_rccl(
     assert len(kept) == c["layers"] and all(k == (24 if config == "c3" else 30) for k in kept)
     if config == "c5":
         assert c["pq_profile"]["key_msb_bits"] == 8 and c["heads"] == 40 and c["kv_len_before_prune"] == 16384
-    assert d["value"] > 0 and c["prune_events_in_timed_region"] == 2
+    assert d["value"] > 0 and c["prune_events_in_timed_region"] == 2 and c["batch"] == (2 if config == "c3" else 1)
