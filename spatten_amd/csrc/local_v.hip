@@ -84,6 +84,16 @@ __device__ inline unsigned long long lv_load(const unsigned long long* g) {
   return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifdef SPATTEN_LV_TRACE     // developer instrumentation (tools/mb/lv_trace.py): phase timestamps of the workgroups of head 0
+__device__ unsigned long long* g_lv_trace = nullptr;
+#define LV_STAMP(slot)                                                                                      \
+  do {                                                                                                      \
+    if (g_lv_trace && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)                               \
+      g_lv_trace[blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter();                                  \
+  } while (0)
+#else
+#define LV_STAMP(slot)
+#endif
 #ifndef SPATTEN_LV_UK
 #define SPATTEN_LV_UK 6          // key row-groups per pipelined tile of phase 1
 #endif
@@ -114,7 +124,9 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
   const int unit = b * p.H + h;
 
   int n_dyn = 0;
+  LV_STAMP(0);
   if (DYN) n_dyn = p.step[opaque_lane(0)];
+  s_hist[tid] = 0u;               // the first radix pass's histogram is counted WHILE the keys stream (round 5)
   const int lo = split * p.chunk;
   const int rl = min(lo + p.chunk, p.N);                 // static limit of the load addresses (DYN: p.N is the bound)
   key_t* skey = reinterpret_cast<key_t*>(smem);          // [chunk] ordered keys of this split's logits
@@ -147,6 +159,7 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
   issue_k(ka, lo);
   const unsigned gen = p.ws_gen[unit + opaque_lane(0)];
   __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();                 // (the zeroed histogram, before any wave's first count; the tile loads are in flight)
   const int N = DYN ? __builtin_amdgcn_readfirstlane(n_dyn) : p.N;
   const int hi = min(lo + p.chunk, N);
   const int n_loc = max(hi - lo, 0);
@@ -182,7 +195,9 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
       const bool valid = j < hi;
       if (c == 0 && valid) {
         stashp[j] = DT<T>::from_f32(sc[u]);                                          // :116-119
-        skey[j - lo] = (key_t)OKey<T>::from(sc[u]);
+        const uint32_t ok = OKey<T>::from(sc[u]);
+        skey[j - lo] = (key_t)ok;
+        atomicAdd(&s_hist[(ok >> (8 * (NP - 1))) & 255u], 1u);                       // most significant digit (phase 2, pass 0)
       }
       sc[u] = valid ? sc[u] : -INFINITY;
       m_new = fmaxf(m_new, sc[u]);
@@ -200,6 +215,7 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
     __builtin_amdgcn_sched_barrier(0);
     if (t0 + KT < hi) score_tile(kb, t0 + KT);
   }
+  LV_STAMP(1);      // end of the key stream
   // (max, sum) of the chunk: every row's LPR lanes agree, so only the row's first lane contributes its sum
   float m_s, l_s;
   {
@@ -222,42 +238,41 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
   int need = keep;                // rank of the threshold among the keys that match the prefix (1 = the largest)
   unsigned ties_before = 0, ties_mine = 0;
   float m_g = m_s, l_g = l_s;
+  // bin `tid` of one histogram of every split: 8 loads per round trip; adds up all splits (tot) and the splits before this one
+  // (with_aux: threads 0 .. S-1 fetch their split's (max, sum) pair in the SAME batch — a separate poll was a second ~2 us
+  //  round trip through the memory side in front of the second pass, phase stamps r05)
+  auto gather_bins = [&](auto region_of, unsigned want_tag, unsigned& tot, unsigned& before, bool with_aux) {
+    tot = 0; before = 0;
+    for (int s0 = 0; s0 < p.S; s0 += 8) {
+      unsigned long long g[8], a0 = 0, a1 = 0;
+      const bool aux_here = with_aux && s0 == 0 && tid < p.S;
+      const unsigned long long* ax = wsu + (int64_t)min(tid, p.S - 1) * kLvSlot + kLvMaxPasses * 256;
+      int spins = 0;
+      bool landed;
+      do {
+        unsigned diff = 0u;
 #pragma unroll
-  for (int pass = 0; pass < NP; ++pass) {
-    const int shift = 8 * (NP - 1 - pass);
-    s_hist[tid] = 0u;
-    __syncthreads();
-    for (int i = tid; i < n_loc; i += kLvThreads) {
-      const uint32_t k = skey[i];
-      if (pass == 0 || (k >> (shift + 8)) == prefix) atomicAdd(&s_hist[(k >> shift) & 255u], 1u);
+        for (int k = 0; k < 8; ++k) {
+          const int s = min(s0 + k, p.S - 1);
+          g[k] = lv_load(wsu + (int64_t)s * kLvSlot + region_of(s) * 256 + tid);
+          diff |= (unsigned)(g[k] >> 32) ^ want_tag;
+        }
+        if (aux_here) {
+          a0 = lv_load(ax); a1 = lv_load(ax + 1);
+          diff |= ((unsigned)(a0 >> 32) ^ want_tag) | ((unsigned)(a1 >> 32) ^ want_tag);
+        }
+        landed = diff == 0u;
+      } while (!landed && ++spins < (1 << 16));
+      expired |= !landed;
+      if (aux_here) { s_aux[0][tid] = __uint_as_float((unsigned)a0); s_aux[1][tid] = __uint_as_float((unsigned)a1); }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (s0 + k < p.S) { tot += (unsigned)g[k]; if (s0 + k < split) before += (unsigned)g[k]; }
     }
-    __syncthreads();
-    unsigned tot = s_hist[tid], before = 0, mine = s_hist[tid];
-    if (p.S > 1) {
-      lv_store(slot + pass * 256 + tid, s_hist[tid], tag);
-      if (pass == 0 && tid < 2) lv_store(slot + kLvMaxPasses * 256 + tid, __float_as_uint(tid == 0 ? m_s : l_s), tag);
-      tot = 0;
-      for (int s0 = 0; s0 < p.S; s0 += 8) {             // bin `tid` of every split's histogram: 8 loads per round trip
-        unsigned long long g[8];
-        int spins = 0;
-        bool landed;
-        do {
-          unsigned diff = 0u;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const int s = min(s0 + k, p.S - 1);
-            g[k] = lv_load(wsu + (int64_t)s * kLvSlot + pass * 256 + tid);
-            diff |= (unsigned)(g[k] >> 32) ^ tag;
-          }
-          landed = diff == 0u;
-        } while (!landed && ++spins < (1 << 16));
-        expired |= !landed;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (s0 + k < p.S) { tot += (unsigned)g[k]; if (s0 + k < split) before += (unsigned)g[k]; }
-      }
-    }
-    // suffix sums over the bins (keys are ranked largest first): above[t] = keys in bins > t
+  };
+  // the bin that holds the `need`-th largest key: suffix sums over the 256 bins (keys are ranked largest first), exactly one bin
+  // brackets the rank; leaves {bin, keys above it, `before`, `mine` of that bin} in s_misc[0..3]
+  auto pick_bin = [&](unsigned tot, unsigned before, unsigned mine, int rank) {
     s_scan[tid] = tot;
     __syncthreads();
     if (wave == 0) {
@@ -276,94 +291,140 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
     }
     __syncthreads();
     const unsigned above = s_scan[tid];
-    if (above < (unsigned)need && (unsigned)need <= above + tot) {           // exactly one bin
+    if (above < (unsigned)rank && (unsigned)rank <= above + tot) {           // exactly one bin
       s_misc[0] = (unsigned)tid; s_misc[1] = above; s_misc[2] = before; s_misc[3] = mine;
     }
     __syncthreads();
-    prefix = (prefix << 8) | s_misc[0];
+  };
+  // keys of this split whose digits above `shift + 8` equal `pfx`, counted by their digit at `shift` into hist[256]
+  // (16-byte LDS reads: 8 / 4 keys per lane and read; r04 read them one by one: 3.2 us of a pass at 2731 keys per split)
+  auto count_digit = [&](unsigned* hist, uint32_t pfx, int shift) {
+    constexpr int KPV = 16 / (int)sizeof(key_t);
+    for (int i0 = tid * KPV; i0 < n_loc; i0 += kLvThreads * KPV) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(skey + i0);
+      const key_t* kv = reinterpret_cast<const key_t*>(&v);
+#pragma unroll
+      for (int j = 0; j < KPV; ++j) {
+        const uint32_t k = kv[j];
+        if (i0 + j < n_loc && (k >> (shift + 8)) == pfx) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+      }
+    }
+  };
+  // (r05, measured and dropped: for 16-bit logits ONE publish round — the low-byte histograms of three candidate high bytes
+  //  published beside the first histogram, then all four regions + the auxiliary words fetched in one batch of loads: a round trip
+  //  through the memory side is ~2 us under this load and grows with what it carries; phase 2 stayed at 9-10 us.  HISTORY.md)
+  // the head's (max, sum): every split's pair (published with its first histogram), folded in split order by every thread
+  auto fold_max_sum = [&]() {       // (s_aux was filled by the first gather; pick_bin's barriers stand between)
+    float mm = -INFINITY;
+    for (int s = 0; s < p.S; ++s) mm = fmaxf(mm, s_aux[0][s]);
+    const float mu = (mm == -INFINITY) ? 0.f : mm;
+    float ll = 0.f;
+    for (int s = 0; s < p.S; ++s) ll += s_aux[1][s] * __expf(s_aux[0][s] - mu);
+    m_g = mm; l_g = ll;
+  };
+  auto take_pick = [&](int bits_done) {
+    prefix = (bits_done == 0) ? s_misc[0] : ((prefix << 8) | s_misc[0]);
     need -= (int)s_misc[1];
     ties_before = s_misc[2];
     ties_mine = s_misc[3];
-    if (pass == 0 && p.S > 1) {   // the head's (max, sum): every split's pair, folded in split order by every thread
-      if (tid < p.S) {
-        const unsigned long long* ax = wsu + (int64_t)tid * kLvSlot + kLvMaxPasses * 256;
-        unsigned long long g0, g1;
-        int spins = 0;
-        do { g0 = lv_load(ax); g1 = lv_load(ax + 1); }
-        while (((unsigned)(g0 >> 32) != tag || (unsigned)(g1 >> 32) != tag) && ++spins < (1 << 16));
-        expired |= ((unsigned)(g0 >> 32) != tag || (unsigned)(g1 >> 32) != tag);
-        s_aux[0][tid] = __uint_as_float((unsigned)g0);
-        s_aux[1][tid] = __uint_as_float((unsigned)g1);
+  };
+  __syncthreads();                                  // the stream's counts of the most significant digit are complete
+  LV_STAMP(2);
+  if (p.S == 1) {
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+      if (pass > 0) {
+        s_hist[tid] = 0u;
+        __syncthreads();
+        count_digit(s_hist, prefix, 8 * (NP - 1 - pass));
+        __syncthreads();
       }
-      __syncthreads();
-      float mm = -INFINITY;
-      for (int s = 0; s < p.S; ++s) mm = fmaxf(mm, s_aux[0][s]);
-      const float mu = (mm == -INFINITY) ? 0.f : mm;
-      float ll = 0.f;
-      for (int s = 0; s < p.S; ++s) ll += s_aux[1][s] * __expf(s_aux[0][s] - mu);
-      m_g = mm; l_g = ll;
+      pick_bin(s_hist[tid], 0u, s_hist[tid], need);
+      take_pick(pass);
+    }
+  } else {
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+      if (pass > 0) {
+        __syncthreads();
+        s_hist[tid] = 0u;
+        __syncthreads();
+        count_digit(s_hist, prefix, 8 * (NP - 1 - pass));
+        __syncthreads();
+      }
+      lv_store(slot + pass * 256 + tid, s_hist[tid], tag);
+      if (pass == 0 && tid < 2) lv_store(slot + kLvMaxPasses * 256 + tid, __float_as_uint(tid == 0 ? m_s : l_s), tag);
+      unsigned tot, before;
+      gather_bins([&](int) { return pass; }, tag, tot, before, pass == 0);
+      pick_bin(tot, before, s_hist[tid], need);
+      take_pick(pass);
+      if (pass == 0) fold_max_sum();
     }
   }
   // threshold key = prefix; `need` of the keys EQUAL to it are kept, lowest index first: this split takes what the
   // splits before it leave
+  LV_STAMP(8);        // threshold known
   const uint32_t thr = prefix;
   const int t_mine = max(0, min((int)ties_mine, need - (int)ties_before));
 
   // ================================ phase 3: compact the kept rows, gather their V rows ============================
-  // order-preserving compaction: per 64-row segment (one wave instruction) the (greater, equal) counts, a scan over the
-  // segments, then positions from ballots
-  const int n_seg = (n_loc + kWave - 1) / kWave;
-  unsigned* seg = s_scan;                                // [<= 256] packed (gt << 16 | eq) — chunks up to 16384 rows
-  for (int sg = wave; sg < n_seg; sg += 4) {
-    const int i = sg * kWave + lane;
-    const uint32_t k = i < n_loc ? (uint32_t)skey[i] : 0u;
-    const unsigned long long mg = __ballot(i < n_loc && k > thr), me = __ballot(i < n_loc && k == thr);
-    if (lane == 0) seg[sg] = ((unsigned)__popcll(mg) << 16) | (unsigned)__popcll(me);
-  }
-  __syncthreads();
-  if (wave == 0) {       // exclusive scan of the segments' (gt, eq) counts; 4 segments per lane (n_seg <= 256)
-    unsigned v4[4], s4 = 0;
+  // order-preserving compaction (round 5): a thread owns a CONTIGUOUS run of keys (16-byte LDS reads), counts its (greater, equal)
+  // keys, one exclusive scan over the 256 threads' packed counts, then every thread writes its kept rows at its offset — one pass
+  // over the keys each way (r04: two passes of 64-key segments with ballots per segment: 4.4 us at 2731 keys, phase stamps)
+  constexpr int KPV = 16 / (int)sizeof(key_t);
+  const int run = ((n_loc + kLvThreads - 1) / kLvThreads + KPV - 1) / KPV * KPV;      // keys per thread, whole 16-byte reads
+  const int r0 = tid * run;
+  unsigned cnt_gt = 0, cnt_eq = 0;
+  for (int i0 = r0; i0 < r0 + run && i0 < n_loc; i0 += KPV) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(skey + i0);
+    const key_t* kv = reinterpret_cast<const key_t*>(&v);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { v4[i] = (4 * lane + i) < n_seg ? seg[4 * lane + i] : 0u; s4 += v4[i]; }
-    unsigned incl = s4;
+    for (int j = 0; j < KPV; ++j) {
+      const uint32_t k = kv[j];
+      const bool in = i0 + j < n_loc;
+      cnt_gt += (in && k > thr) ? 1u : 0u;
+      cnt_eq += (in && k == thr) ? 1u : 0u;
+    }
+  }
+  unsigned* seg = s_scan;                                // [256] exclusive prefix of the packed (gt << 16 | eq) counts; [256] the total
+  {
+    const unsigned mine = (cnt_gt << 16) | cnt_eq;       // (chunk <= 16384 rows: either count fits 15 bits)
+    unsigned incl = mine;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
       const unsigned o = __shfl_up(incl, off, kWave);
       if (lane >= off) incl += o;
     }
-    unsigned run = incl - s4;
+    if (lane == kWave - 1) s_misc[4 + wave] = incl;
+    __syncthreads();
+    unsigned base = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { if ((4 * lane + i) < n_seg) seg[4 * lane + i] = run; run += v4[i]; }
+    for (int w = 0; w < 4; ++w) base += (w < wave) ? s_misc[4 + w] : 0u;
+    seg[tid] = base + incl - mine;
+    if (tid == kLvThreads - 1) seg[256] = base + incl;
   }
   __syncthreads();
-  for (int sg = wave; sg < n_seg; sg += 4) {
-    const int i = sg * kWave + lane;
-    const uint32_t k = i < n_loc ? (uint32_t)skey[i] : 0u;
-    const bool gt = i < n_loc && k > thr, eq = i < n_loc && k == thr;
-    const unsigned long long mg = __ballot(gt), me = __ballot(eq);
-    const unsigned lt_mask_lo = __builtin_amdgcn_mbcnt_lo((unsigned)me, 0u);
-    const unsigned eq_rank = (seg[sg] & 0xFFFFu) + __builtin_amdgcn_mbcnt_hi((unsigned)(me >> 32), lt_mask_lo);   // equal keys before this one
-    const bool kept = gt || (eq && (int)eq_rank < t_mine);
-    // kept rows before this one = greater rows before + min(equal rows before, t_mine)
-    const unsigned gt_rank = (seg[sg] >> 16) + __builtin_amdgcn_mbcnt_hi((unsigned)(mg >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mg, 0u));
-    if (kept) klist[gt_rank + min(eq_rank, (unsigned)t_mine)] = (uint16_t)i;
-  }
-  __syncthreads();
-  int n_kept;
   {
-    // total kept of this split: greater rows + its share of the ties
-    unsigned total_gt = 0;
-    if (n_seg > 0) {
-      const int last = n_seg - 1;
-      const int i0 = last * kWave;
-      // greater rows of the last segment, recounted by wave 0's lanes (cheap; avoids another LDS word)
-      const int i = i0 + lane;
-      const uint32_t k = (i < n_loc) ? (uint32_t)skey[i] : 0u;
-      const unsigned long long mg = __ballot(i < n_loc && k > thr);
-      total_gt = (seg[last] >> 16) + (unsigned)__popcll(mg);
+    const unsigned ex = seg[tid];
+    unsigned g_run = ex >> 16, e_run = ex & 0xFFFFu;
+    for (int i0 = r0; i0 < r0 + run && i0 < n_loc; i0 += KPV) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(skey + i0);
+      const key_t* kv = reinterpret_cast<const key_t*>(&v);
+#pragma unroll
+      for (int j = 0; j < KPV; ++j) {
+        const uint32_t k = kv[j];
+        const bool in = i0 + j < n_loc;
+        const bool gt = in && k > thr, eq = in && k == thr;
+        // kept rows before this one = greater rows before + min(equal rows before, t_mine)
+        if (gt || (eq && (int)e_run < t_mine)) klist[g_run + min(e_run, (unsigned)t_mine)] = (uint16_t)(i0 + j);
+        g_run += gt ? 1u : 0u;
+        e_run += eq ? 1u : 0u;
+      }
     }
-    n_kept = (int)total_gt + t_mine;
   }
+  __syncthreads();
+  const int n_kept = (int)(seg[256] >> 16) + t_mine;     // greater rows of the split + its share of the ties
+  LV_STAMP(9);        // kept rows compacted
   const float mu_g = (m_g == -INFINITY) ? 0.f : m_g;
   const float rl_g = 1.0f / l_g;
   struct VTile { raw_t v_lo[UV], v_hi[UV]; float pj[UV]; };
@@ -404,6 +465,7 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
       if (g0 + UV < n_grp) pv_tile(vb);
     }
   }
+  LV_STAMP(10);       // V rows gathered
   // lanes with equal c across the wave's row groups, then the 4 waves (decode_attn.hip's reduction)
   if (LPR == 4) {
 #pragma unroll
@@ -433,6 +495,7 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
     return;
   }
   if (tid < D) lv_store(slot + kLvMaxPasses * 256 + 4 + tid, __float_as_uint(o_tot), tag);
+  LV_STAMP(11);       // partial published
   if (split != p.S - 1) return;
   float og = 0.f;
   if (tid < D) {
@@ -457,6 +520,7 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
     }
   }
   if (expired) { atomicOr(p.ws_err, 1u); og = __builtin_nanf(""); }
+  LV_STAMP(12);       // merged
   if (tid < D) outp[tid] = DT<T>::from_f32(og);
   if (tid == 0) {
     if (p.lse != nullptr) { p.lse[unit * 2] = m_g; p.lse[unit * 2 + 1] = l_g; }
@@ -464,6 +528,13 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
   }
 }
 
+#ifdef SPATTEN_LV_TRACE
+}  // namespace spatten
+extern "C" int spatten_debug_set_lv_trace(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(spatten::g_lv_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+namespace spatten {
+#endif
 static inline size_t lv_gen_bytes(size_t units) { return (units * sizeof(unsigned) + 255) / 256 * 256; }
 
 }  // namespace spatten
