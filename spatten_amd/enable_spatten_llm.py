@@ -93,9 +93,19 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
         raise ValueError("fused_step needs fuse_qkv=True and native_gemv=True (it reads the stacked weight the way spatten_gemv does)")
     if pq_profile is not None and pq_threshold is None:
         raise ValueError("pq_profile needs pq_threshold")
+    prev_team = None
     if fused_step:
+        import warnings
+
         from . import ops
-        ops.set_decode_team(256)        # the team the fused launch contains: fused and separate steps stay bit-identical
+        prev_team = ops.set_decode_team(256)   # the team the fused launch contains: fused and separate steps stay bit-identical
+        if prev_team != 256:
+            # PROCESS-WIDE: every other model / DecodeGraph of this process changes its summation order with it —
+            # graphs captured earlier with the 512-thread team must be re-captured to stay bit-identical with eager steps
+            warnings.warn("spatten_amd: fused_step=True selected the 256-thread decode team for the whole process "
+                          f"(was {prev_team}); re-capture DecodeGraphs made before this call, or restore it with "
+                          "cache.restore_process_options()", RuntimeWarning, stacklevel=2)
+    cache._prev_decode_team = prev_team
     extended = (importance_mode == "cascade" or head_keep is not None or pq_threshold is not None or local_v_keep is not None
                 or layer_keep is not None)
     for m in mods:

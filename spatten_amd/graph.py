@@ -76,7 +76,7 @@ class DecodeGraph:
         self.states: dict = {}                  # cache-length offset (vs layer 0) -> ops.StepState
         self.touched: List[tuple] = []          # (module, slab) pairs of the last traced step, in call order
         self.workspaces: List = []              # every scratch buffer a traced launch used: the captured graph holds raw
-                                                # pointers into them (ops._ws_pins), so it keeps them alive
+                                                # pointers into them (ops.set_ws_pins), so it keeps them alive
         self.static_in: Optional[List[torch.Tensor]] = None
         self.static_out = None
         self.n_replays = 0
@@ -123,15 +123,14 @@ class DecodeGraph:
     def _trace(self, inputs):
         """Run step_fn once in device-length mode on the current stream (eagerly, or under capture)."""
         self.touched = []
-        prev, prev_pins = kv_slab.set_graph_ctx(self), ops._ws_pins
-        ops._ws_pins = self.workspaces
+        prev, prev_pins = kv_slab.set_graph_ctx(self), ops.set_ws_pins(self.workspaces)
         try:
             for st in self.states.values():
                 st.advance(1)
             new_past, out = self.step_fn(self._past, *inputs)
         finally:
             kv_slab.set_graph_ctx(prev)
-            ops._ws_pins = prev_pins
+            ops.set_ws_pins(prev_pins)
         if not self.touched:
             raise RuntimeError("DecodeGraph: step_fn did not run a single-token step through the patched forward")
         self._past = new_past

@@ -77,6 +77,13 @@ class SpAttenKVCache:
         self.n_pruned_last = 0
         self.n_pruned_total = 0
 
+    def restore_process_options(self):
+        """Undo what ``enable_spatten_llm(fused_step=True)`` changed process-wide (the decode team, spatten_decode_set_team)."""
+        prev = getattr(self, "_prev_decode_team", None)
+        if prev is not None:
+            ops.set_decode_team(prev)
+            self._prev_decode_team = None
+
     # -- pure host logic (unit-tested without a GPU) --------------------------------------------
     def window(self, seq_len: int, num_coming: int):
         """(lo, hi, tail_lo, new_len) of a prune at this length, Python-slice semantics of

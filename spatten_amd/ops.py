@@ -6,6 +6,7 @@ PyTorch is plumbing here: it owns device memory and the stream; every op below p
 from __future__ import annotations
 
 import ctypes
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -119,12 +120,22 @@ _ws_cache = _LRU(16)
 # While a DecodeGraph traces a step (spatten_amd/graph.py) every workspace a launch uses is also appended here: a captured
 # graph bakes the workspace's raw pointers in, so the graph — not only this LRU — has to keep the buffers alive (an entry
 # evicted by other streams / shapes would otherwise be replayed into freed memory).
-_ws_pins: Optional[list] = None
+# The list is per THREAD, like the tracing context it belongs to (kv_slab.set_graph_ctx): two threads tracing at once — or one
+# tracing while another finishes — must not restore each other's list mid-trace.
+_pins_tls = threading.local()
+
+
+def set_ws_pins(pins: Optional[list]) -> Optional[list]:
+    """Install this thread's pin list (None = not tracing); returns the previous one."""
+    prev = getattr(_pins_tls, "pins", None)
+    _pins_tls.pins = pins
+    return prev
 
 
 def _pin(ws):
-    if _ws_pins is not None and not any(w is ws for w in _ws_pins):
-        _ws_pins.append(ws)
+    pins = getattr(_pins_tls, "pins", None)
+    if pins is not None and not any(w is ws for w in pins):
+        pins.append(ws)
     return ws
 
 

@@ -243,3 +243,20 @@ def test_plugin_with_fused_step_equals_the_unfused_plugin_bitwise_eager_and_unde
     nb = cb.apply_token_pruning(pb, 40, [m.attn_scores for m in b.layers])
     for (ka, va), (kb, vb) in zip(na, nb):
         assert torch.equal(ka, kb) and torch.equal(va, vb)
+
+
+def test_fused_step_warns_about_the_process_wide_team_and_can_restore_it():
+    """fused_step=True selects the 256-thread decode team for the WHOLE process — it says so, and the cache object
+    can put the previous team back."""
+    import warnings
+
+    from spatten_amd import enable_spatten_llm, ops
+    ops.set_decode_team(512)
+    m = Stack(torch.bfloat16)
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        cache = enable_spatten_llm(m, 4, 60, 64, fuse_qkv=True, native_gemv=True, assume_causal=True, fused_step=True)
+    assert any("256-thread decode team" in str(x.message) for x in w)
+    assert ops.set_decode_team(256) == 256          # selected
+    cache.restore_process_options()
+    assert ops.set_decode_team(512) == 512          # restored
