@@ -12,8 +12,9 @@ for N in (2048, 8192):
     cos, sin = ops.rope_table(N, d, dt, "cuda")
     kr = ops.rope_single(k, cos, sin)
     out = torch.empty(B, N, H * d, device="cuda", dtype=dt)
-    for name, kw in (("causal", dict(causal=True)), ("causal+colimp", dict(causal=True, col_importance=torch.zeros(B, H, N, device="cuda")))):
-        reps = 20 if name == "causal" else 5
+    for name, kw in (("causal", dict(causal=True)), ("causal fast", dict(causal=True, numerics="fast")),
+                     ("causal+colimp", dict(causal=True, col_importance=torch.zeros(B, H, N, device="cuda")))):
+        reps = 20 if name.startswith("causal") and "colimp" not in name else 5
         for _ in range(3):
             ops.attn_prefill(q, kr, v, N, cos, sin, 0, out=out, **kw)
         torch.cuda.synchronize()
