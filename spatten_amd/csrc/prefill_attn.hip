@@ -115,6 +115,10 @@ struct FlashParams {
   const float* kscale; int64_t ks_sb, ks_sh;   // [B,Hkv,N] fp32
   int32_t* need;      // [B,H,q_len]: pass 1 writes max prob < thr, pass 2 recomputes the flagged rows
   float pq_thr;
+  // pass 2 (round 5): the flagged rows of a (b, h), compacted — ascending query indices [B,H,q_len] and their count [B,H]
+  // (pq_rows_compact_kernel).  A workgroup of pass 2 serves 256 LIST entries, not 256 consecutive rows: at a realistic refetch
+  // rate (5 % of the rows: nearly every 256-row block and 4 of 5 waves hold a flagged row) the pass costs what it recomputes
+  const int32_t* rows; const int32_t* row_cnt;
   int B, H, Hkv, q_len, N, Npad, causal, nqb;
   int pair;           // prefill_pp128_kernel<..., PAIR>: a workgroup's halves take the 128-row blocks i and n - 1 - i (see the kernel)
   int vtr;     // this launch reads V through the transposing LDS reads (no Vt copy was made)
@@ -630,22 +634,37 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   const int grp = wave_u >> 2;
   const int nqb = p.nqb;
   int h, qblk, b;
-  const int ksplit = PQK ? 1 : p.ksplit;
-  const int ks = ksplit > 1 ? (int)blockIdx.x % ksplit : 0;          // which range of key tiles
-  const int item = ksplit > 1 ? (int)blockIdx.x / ksplit : (int)blockIdx.x;
+  const int ksplit = PQK == 1 ? 1 : p.ksplit;                       // (pass 2 of the quantised keys may split its key tiles too)
+  // which range of key tiles.  Pass 2 of the quantised keys (PQK == 2) lays its grid out range-major: first the B H nqb
+  // workgroups of range 0 — all that stay when the pass decides NOT to split (many flagged rows): spread over the XCDs, where
+  // item-major the survivors of an 8-way split all landed on ONE XCD (workgroup i runs on XCD i % 8: 4.0 ms instead of 0.5) —
+  // then, for every further range, only the list blocks a split pass can have (a split needs <= q_len / 4 flagged rows).
+  const int nq4 = (nqb + 3) / 4;
+  int ks = 0, item = (int)blockIdx.x, nq_dec = nqb;
+  if (ksplit > 1) {
+    if (PQK == 2) {
+      const int n_full = p.B * p.H * nqb, n_q = p.B * p.H * nq4;
+      if ((int)blockIdx.x >= n_full) { const int r_ = (int)blockIdx.x - n_full; ks = 1 + r_ / n_q; item = r_ % n_q; nq_dec = nq4; }
+    } else {
+      ks = (int)blockIdx.x % ksplit;
+      item = (int)blockIdx.x / ksplit;
+    }
+  }
   {
     const int i = item;
-    const int per_b = p.H * nqb;
+    const int per_b = p.H * nq_dec;
     b = i / per_b;
     const int j = i - b * per_b;
     if ((p.H & 7) == 0) {
       const int xx = j & 7, ss = j >> 3;
-      h = xx + 8 * (ss / nqb);
-      qblk = nqb - 1 - (ss % nqb);
+      h = xx + 8 * (ss / nq_dec);
+      qblk = nq_dec - 1 - (ss % nq_dec);
     } else {
-      h = j / nqb;
-      qblk = nqb - 1 - (j % nqb);
+      h = j / nq_dec;
+      qblk = nq_dec - 1 - (j % nq_dec);
     }
+    // the slot of this (b, h, block) in the partial buffers: the full-grid item (what prefill_merge_kernel computes)
+    if (nq_dec != nqb) item = b * p.H * nqb + (((p.H & 7) == 0) ? (h & 7) + 8 * ((h >> 3) * nqb + (nqb - 1 - qblk)) : h * nqb + (nqb - 1 - qblk));
   }
   const int hkv = p.Hkv == p.H ? h : h / (p.H / p.Hkv);
   // PAIR (round 4; causal, no more workgroups than CUs): a 256-row block of a causal prefill needs 2, 4, ... 2 nqb key tiles, and
@@ -660,28 +679,34 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   // (75.6 us): a step is bound by the 64-KB tile fill of its CU, not by the halves' arithmetic.  Removed.)
   constexpr bool paired = PAIR;        // (its own instantiation: the plain kernel keeps its register allocation)
   const int blk128 = paired ? (grp == 0 ? 2 * nqb - 1 - qblk : qblk) : 0;
-  const int q0 = paired ? blk128 * 128 + (wave & 3) * 32 : qblk * 256 + wave * 32;
-  const int myq = q0 + qi;
+  // PQK == 2 (the LSB-refetch pass, RequantDecision.scala:44-72 / SpAttenController.scala:402): only the rows pass 1
+  // flagged are recomputed, ONCE, from the 8-bit keys.  Round 5: the flagged rows of the head arrive as a compacted ascending
+  // list; workgroup `qblk` serves list entries [256 qblk, +256) — lane (wave, qi) owns entry 256 qblk + 32 wave + qi, whatever
+  // query row that is — and leaves at once when the list is shorter; a wave whose entries lie past the list's end keeps
+  // serving the tile DMA and the barriers but computes nothing.  Rows of a wave ascend: its first row bounds the tiles every
+  // lane sees in full, its last row the tiles it needs at all.
+  int list_cnt = 0, q0_l = 0, qlast_l = -1, blkend_l = 0, myq_l = 0;
+  bool wave_live = true;
+  if (PQK == 2) {
+    list_cnt = p.row_cnt[b * p.H + h];
+    if (qblk * 256 >= list_cnt) return;
+    const int32_t* rowl = p.rows + (int64_t)(b * p.H + h) * p.q_len;
+    const int wpos = qblk * 256 + wave_u * 32;
+    wave_live = wpos < list_cnt;
+    q0_l = wave_live ? rowl[wpos] : p.q_len;
+    qlast_l = wave_live ? rowl[min(wpos + 31, list_cnt - 1)] : -1;
+    blkend_l = rowl[min(qblk * 256 + 255, list_cnt - 1)] + 1;
+    myq_l = (wpos + qi) < list_cnt ? rowl[wpos + qi] : p.q_len;
+  }
+  const int q0 = PQK == 2 ? q0_l : (paired ? blk128 * 128 + (wave & 3) * 32 : qblk * 256 + wave * 32);
+  const int myq = PQK == 2 ? myq_l : q0 + qi;
   const bool qvalid = myq < p.q_len;
   const int P = p.N - p.q_len;
   const float rsqrt_d = 1.0f / p.sqrt_d;
-  // PQK == 2 (the LSB-refetch pass, RequantDecision.scala:44-72 / SpAttenController.scala:402): only the rows pass 1
-  // flagged are recomputed, ONCE, from the 8-bit keys.  A block without a flagged row leaves at once (every wave reads
-  // the block's 256 flags itself, so the decision is uniform without a barrier); a wave without one keeps serving the
-  // tile DMA and the barriers but computes nothing.
-  int my_flag = 1;
-  if (PQK == 2) {
-    const int32_t* nf = p.need + (int64_t)(b * p.H + h) * p.q_len;
-    int any = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = qblk * 256 + lane + 64 * i;
-      any |= idx < p.q_len ? nf[idx] : 0;
-    }
-    if (__builtin_amdgcn_ballot_w64(any != 0) == 0) return;
-    my_flag = qvalid ? nf[myq] : 0;
-  }
-  const bool wave_live = PQK != 2 || __builtin_amdgcn_ballot_w64(my_flag != 0) != 0;
+  const int my_flag = qvalid ? 1 : 0;        // (every listed row is a flagged row)
+  // pass 2 splits its key tiles only when few rows were flagged (the rule is the merge kernel's too): a long list fills the chip
+  const int ks_eff = (PQK == 2 && ksplit > 1 && (long long)list_cnt * 4 > p.q_len) ? 1 : ksplit;
+  if (PQK == 2 && ks >= ks_eff) return;
 
   // Q fragments, rotated here (modify_llama.py:92, the reference's three rounded ops): fragment kk holds elements
   // [16kk + 8hi, +8) of the row, so kk and kk + KK/2 are exactly the (x[i], x[i + d/2]) pairs RoPE combines
@@ -723,17 +748,18 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   for (int e = 0; e < 8; ++e) ones[e] = DT<T>::from_f32(qi == 0 ? 1.f : 0.f);
   float m_true = -INFINITY;   // PQK == 1: the row's TRUE running maximum (m_run may lag it: deferred rescale)
 
-  const int wg_q_end = min(p.q_len, paired ? (2 * nqb - qblk) * 128 : qblk * 256 + 256);   // (paired: the end of the LATER block)
+  const int wg_q_end = PQK == 2 ? blkend_l : min(p.q_len, paired ? (2 * nqb - qblk) * 128 : qblk * 256 + 256);   // (paired: the end of the LATER block)
   const int att_keys = p.causal ? min(p.N, P + wg_q_end) : p.N;
   const int all_tiles = (att_keys + KT - 1) / KT;
   // this workgroup's tiles [T0, T1) (all of them without a key split); an empty range leaves an empty partial
-  const int per_split = (all_tiles + ksplit - 1) / ksplit;
+  const int per_split = (all_tiles + ks_eff - 1) / ks_eff;
   const int T0 = min(ks * per_split, all_tiles), T1 = min(T0 + per_split, all_tiles);
   const int n_att_tiles = T1;
   const int n_tiles = T1;
   const int my_vis = p.causal ? min(p.N, P + myq + 1) : p.N;
   const int wave_full_keys = p.causal ? min(p.N, P + q0 + 1) : p.N;
-  const int wave_att_tiles = !wave_live ? 0 : (p.causal ? min(n_att_tiles, (max(min(p.N, P + min(q0 + 32, p.q_len)), 0) + KT - 1) / KT) : n_att_tiles);
+  const int q_past_wave = PQK == 2 ? qlast_l + 1 : min(q0 + 32, p.q_len);      // one past the wave's last query row
+  const int wave_att_tiles = !wave_live ? 0 : (p.causal ? min(n_att_tiles, (max(min(p.N, P + q_past_wave), 0) + KT - 1) / KT) : n_att_tiles);
   const int wave_tiles = wave_att_tiles;
 
   const T* krb = p.kr + b * p.kv_sb + hkv * p.kv_sh;
@@ -1118,7 +1144,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 #else
   const float l_tot = xor32_sum(l_run);
 #endif
-  if (ksplit > 1) {       // partial result of this key range: un-normalised O^T, (m, l) — folded by prefill_merge_kernel
+  if (ks_eff > 1) {       // partial result of this key range: un-normalised O^T, (m, l) — folded by prefill_merge_kernel
     const int64_t slot = ((int64_t)item * ksplit + ks) * 256 + wave * 32 + qi;
     float* po = p.part_o + slot * D;
     if (qvalid) {           // rows past q_len are never read back
@@ -1195,15 +1221,33 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 
 // Fold the key-split partials of prefill_pp128_kernel: one wave per query row (D/64 output elements per lane).
 // out = sum_s O_s e^(m_s - m) / sum_s l_s e^(m_s - m),  m = max_s m_s   (a split without keys has m = -inf, l = 0)
+constexpr int kMergeListWgs = 32;
+template <typename T, int D>
+__device__ __forceinline__ void prefill_merge_row(const FlashParams<T>& p, int bh, int lpos, int qi, int lane);
 template <typename T, int D>
 __global__ __launch_bounds__(256) void prefill_merge_kernel(const FlashParams<T> p) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (p.rows != nullptr) {
+    // the refetch pass of the quantised keys: rows are LIST entries of a (b, h); kMergeListWgs workgroups per (b, h) walk the
+    // list (the count lives on the device: a grid over every possible row was 65,536 workgroups that mostly left at once);
+    // nothing to fold when the pass did not split (its own rule)
+    const int bh = (int)blockIdx.x / kMergeListWgs, w0 = ((int)blockIdx.x % kMergeListWgs) * 4 + wave;
+    const int cnt = p.row_cnt[bh];
+    if ((long long)cnt * 4 > p.q_len) return;
+    for (int lpos = w0; lpos < cnt; lpos += kMergeListWgs * 4) prefill_merge_row<T, D>(p, bh, lpos, p.rows[(int64_t)bh * p.q_len + lpos], lane);
+    return;
+  }
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;                 // over B * H * q_len
   if (row >= (int64_t)p.B * p.H * p.q_len) return;
-  const int qi = (int)(row % p.q_len);
-  const int bh = (int)(row / p.q_len), h = bh % p.H, b = bh / p.H;
+  prefill_merge_row<T, D>(p, (int)(row / p.q_len), (int)(row % p.q_len), (int)(row % p.q_len), lane);
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void prefill_merge_row(const FlashParams<T>& p, int bh, int lpos, int qi, int lane) {
+  const int h = bh % p.H, b = bh / p.H;
+  // lpos = position inside the (b, h)'s blocks: the row itself, or its list entry; qi = the query row written
   // the flash kernel's work order: item = b * H * nqb + j with j as decoded there
-  const int qblk = qi / 256, qin = qi % 256, nqb = p.nqb;
+  const int qblk = lpos / 256, qin = lpos % 256, nqb = p.nqb;
   int j;
   if ((p.H & 7) == 0) j = (h & 7) + 8 * ((h >> 3) * nqb + (nqb - 1 - qblk));
   else j = h * nqb + (nqb - 1 - qblk);
@@ -1226,7 +1270,31 @@ __global__ __launch_bounds__(256) void prefill_merge_kernel(const FlashParams<T>
   T* orow = p.out + b * p.out_sb + (int64_t)qi * p.out_sq + h * D;
 #pragma unroll
   for (int e = 0; e < D / 64; ++e) orow[lane + 64 * e] = DT<T>::from_f32(acc[e] * inv);
-  if (p.lse != nullptr && lane == 0) { float* ls = p.lse + row * 2; ls[0] = m; ls[1] = l; }
+  if (p.lse != nullptr && lane == 0) { float* ls = p.lse + ((int64_t)bh * p.q_len + qi) * 2; ls[0] = m; ls[1] = l; }
+}
+
+// The flagged query rows of every (b, h) after pass 1 of the quantised-key prefill, compacted in ascending order (the list pass 2
+// walks): one workgroup per (b, h), 256 flags per step, positions from ballots + a running count.
+__global__ __launch_bounds__(256) void pq_rows_compact_kernel(const int32_t* __restrict__ need, int32_t* __restrict__ rows,
+                                                              int32_t* __restrict__ cnt, int q_len) {
+  __shared__ int s_w[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t base = (int64_t)blockIdx.x * q_len;
+  int run = 0;
+  for (int i0 = 0; i0 < q_len; i0 += 256) {
+    const int i = i0 + tid;
+    const bool f = i < q_len && need[base + i] != 0;
+    const unsigned long long m = __ballot(f);
+    if (lane == 0) s_w[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int c = s_w[w]; if (w < wave) before += c; total += c; }
+    if (f) rows[base + run + before + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = i;
+    run += total;
+    __syncthreads();
+  }
+  if (tid == 0) cnt[blockIdx.x] = run;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1424,6 +1492,19 @@ static inline size_t flash_partial_bytes(int batch, int heads, int head_dim, int
   return (size_t)batch * heads * ceil_div(q_len, 256) * ks * 256 * (head_dim + 2) * sizeof(float);
 }
 
+// key ranges of the refetch pass of the quantised-key prefill: >= 8 tiles of 128 keys each, at most 8 ranges (the kernel falls
+// back to ONE range by itself when more than a quarter of the rows were flagged: a long list fills the chip without splitting)
+static inline int pq_pass2_ksplit(int kv_len) {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("SPATTEN_PQ_PASS2_KSPLIT"); env = e ? atoi(e) : 0; }     // 1 = off (A/B)
+  const int tiles = ceil_div(kv_len, 128);
+  int ks = env > 0 ? env : tiles / 8;
+  if (ks > 8) ks = 8;
+  if (ks < 1) ks = 1;
+  const int per = ceil_div(tiles, ks);
+  return ceil_div(tiles, per);
+}
+
 template <typename T, int D, bool ST, bool CI>
 static void launch_flash_m(const FlashParams<T>& p, hipStream_t st) {
   const dim3 grid((unsigned)(p.nqb * p.H * p.B));
@@ -1433,8 +1514,11 @@ static void launch_flash_m(const FlashParams<T>& p, hipStream_t st) {
         if (p.mask) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, true, 1>), grid, dim3(512), 0, st, p);
         else hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, 1>), grid, dim3(512), 0, st, p);
       } else {
-        if (p.mask) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, true, 2>), grid, dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, 2>), grid, dim3(512), 0, st, p);
+        const dim3 grid2((unsigned)(p.H * p.B * (p.nqb + (p.ksplit > 1 ? (p.ksplit - 1) * ((p.nqb + 3) / 4) : 0))));   // (see the kernel)
+        if (p.mask) hipLaunchKernelGGL((prefill_pp128_kernel<T, D, true, 2>), grid2, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((prefill_pp128_kernel<T, D, false, 2>), grid2, dim3(512), 0, st, p);
+        if (p.ksplit > 1)
+          hipLaunchKernelGGL((prefill_merge_kernel<T, D>), dim3((unsigned)(p.B * p.H * kMergeListWgs)), dim3(256), 0, st, p);
       }
       return;
     }
@@ -1565,6 +1649,7 @@ extern "C" int spatten_attn_prefill(int dtype, const void* q, int64_t q_sb, int6
 #define SPATTEN_FLASH(T, DD)                                                                           \
   {                                                                                                    \
     FlashParams<T> p;                                                                                  \
+    p.rows = nullptr; p.row_cnt = nullptr;                                                             \
     p.q = (const T*)q; p.q_sb = q_sb; p.q_sh = q_sh; p.q_sq = q_sq;                                    \
     p.cos = (const T*)cos; p.sin = (const T*)sin; p.table_rows = table_rows;                           \
     p.pos_ids = position_ids; p.pos_sb = pos_sb; p.pos_q0 = pos_q0;                                    \
@@ -1634,7 +1719,9 @@ extern "C" size_t spatten_prefill_pq_workspace_bytes(int dtype, int batch, int h
                                                      int q_len, int kv_len) {
   if (batch <= 0 || heads <= 0 || kv_heads <= 0 || head_dim <= 0 || q_len <= 0 || kv_len <= 0) return 0;
   const size_t npad = (size_t)ceil_div(kv_len, 128) * 128, rows = (size_t)batch * kv_heads * kv_len;
-  return 256 + align256((size_t)batch * kv_heads * head_dim * npad * 2) + 2 * align256(rows * head_dim * 2) + align256(rows * 4);
+  return 256 + align256((size_t)batch * kv_heads * head_dim * npad * 2) + 2 * align256(rows * head_dim * 2) + align256(rows * 4)
+         + align256((size_t)batch * heads * q_len * 4) + align256((size_t)batch * heads * 4)               // pass 2: row lists + counts
+         + align256(flash_partial_bytes(batch, heads, head_dim, q_len, pq_pass2_ksplit(kv_len)));          // ... and its key-split partials
 }
 
 // Prefill over progressively quantised keys (BASELINE.json configs[3]): MSB-first fetch, max-probability decision PER
@@ -1667,6 +1754,10 @@ extern "C" int spatten_attn_prefill_pq(int dtype, const void* q, int64_t q_sb, i
   char* k_msb = ws + align256((size_t)batch * kv_heads * head_dim * npad * 2);
   char* k_full = k_msb + align256(rows * head_dim * 2);
   float* kscale = (float*)(k_full + align256(rows * head_dim * 2));
+  int32_t* row_list = (int32_t*)((char*)kscale + align256(rows * 4));
+  int32_t* row_cnt = (int32_t*)((char*)row_list + align256((size_t)batch * heads * q_len * 4));
+  const int ks2 = pq_pass2_ksplit(kv_len);
+  float* part2 = (float*)((char*)row_cnt + align256((size_t)batch * heads * 4));
   {
     const dim3 grid((unsigned)(npad / 64), (unsigned)kv_heads, (unsigned)batch);
     if (head_dim == 128)
@@ -1680,6 +1771,7 @@ extern "C" int spatten_attn_prefill_pq(int dtype, const void* q, int64_t q_sb, i
 #define SPATTEN_FLASH_PQ(T, DD, KPTR, THR)                                                              \
   {                                                                                                    \
     FlashParams<T> p;                                                                                  \
+    p.rows = (THR) < 0.f ? row_list : nullptr; p.row_cnt = row_cnt;                                    \
     p.q = (const T*)q; p.q_sb = q_sb; p.q_sh = q_sh; p.q_sq = q_sq;                                    \
     p.cos = (const T*)cos; p.sin = (const T*)sin; p.table_rows = table_rows;                           \
     p.pos_ids = position_ids; p.pos_sb = pos_sb; p.pos_q0 = pos_q0;                                    \
@@ -1692,6 +1784,10 @@ extern "C" int spatten_attn_prefill_pq(int dtype, const void* q, int64_t q_sb, i
     p.B = batch; p.H = heads; p.Hkv = kv_heads; p.q_len = q_len; p.N = kv_len; p.Npad = npad;          \
     p.causal = causal & 1; p.fast = 0; p.sqrt_d = sqrtf((float)head_dim); p.nqb = ceil_div(q_len, 256); p.pair = 0;   \
     p.ksplit = 1; p.part_o = nullptr; p.part_ml = nullptr;                                             \
+    if ((THR) < 0.f && ks2 > 1) {                                                                      \
+      p.ksplit = ks2; p.part_o = part2;                                                                \
+      p.part_ml = part2 + (size_t)batch * heads * p.nqb * ks2 * 256 * head_dim;                        \
+    }                                                                                                  \
     rc = launch_flash<T, DD>(p, st);                                                                   \
   }
 #define SPATTEN_FLASH_PQ_ANY(KPTR, THR)                                                                                  \
@@ -1699,6 +1795,8 @@ extern "C" int spatten_attn_prefill_pq(int dtype, const void* q, int64_t q_sb, i
   else { if (head_dim == 128) SPATTEN_FLASH_PQ(f16_t, 128, KPTR, THR) else SPATTEN_FLASH_PQ(f16_t, 64, KPTR, THR) }
   SPATTEN_FLASH_PQ_ANY(k_msb, threshold)          // pass 1 (pq_thr >= 0 selects it)
   if (rc != SPATTEN_OK) return rc;
+  hipLaunchKernelGGL(pq_rows_compact_kernel, dim3((unsigned)(batch * heads)), dim3(256), 0, st, need_lsb, row_list, row_cnt, q_len);
+  if (hipGetLastError() != hipSuccess) return SPATTEN_ERR_LAUNCH;
   SPATTEN_FLASH_PQ_ANY(k_full, -1.0f)              // pass 2: flagged rows from the 8-bit keys
 #undef SPATTEN_FLASH_PQ_ANY
 #undef SPATTEN_FLASH_PQ

@@ -182,6 +182,48 @@ def test_c4_prefill_8192_pq_keyed_full_size():
     assert torch.equal(out.view(B, N, H, d)[keep], o_msb.view(B, N, H, d)[keep])
 
 
+def test_c4_prefill_8192_pq_few_flagged_rows_take_the_compacted_key_split_pass():
+    """configs[3] at a realistic refetch rate (round 5): when at most a quarter of the query rows is flagged, pass 2 walks the
+    COMPACTED list of flagged rows (256 list entries per workgroup) with its key tiles split over workgroups and a merge launch.
+    Most rows here are confident (they point at their own key), every 19th is random: ~5 % flagged, scattered over all blocks."""
+    from spatten_amd import ops
+    dt, B, H, d, N = "bf16", 1, 32, 128, 8192
+    K, V, Kr, planes, cos, sin, gen = _pq_setup(B, H, d, N, dt, 45)
+    Q = (K.float() * 6.0).to(TORCH_DT[dt])
+    loose = torch.arange(7, N, 19, device="cuda")
+    Q[:, :, loose] = torch.randn(B, H, loose.numel(), d, device="cuda", generator=gen).to(TORCH_DT[dt])
+    thr = 0.05
+    out, need = ops.attn_prefill_pq(Q, planes, V, N, cos, sin, 0, thr, causal=True)
+    torch.cuda.synchronize()
+    need_h = need.cpu().numpy().astype(bool)
+    frac = need_h.mean(axis=-1)
+    assert 0.01 < frac.min() and frac.max() < 0.25, (frac.min(), frac.max())      # every head takes the split pass
+    rows = [7, 26, 8 + 19 * 100, 7 + 19 * 215, 7 + 19 * 400, 7 + 19 * 430, 4100, 8000]
+    msb, lsb, scale = planes.unpack(N)
+    c, s = host(cos), host(sin)
+    cs, sn = np.concatenate([c, c], -1), np.concatenate([s, s], -1)
+    qr = orc.apply_rotary_pos_emb_single(host(Q[:, :, rows]), cs, sn, np.asarray(rows)[None], dt)
+    checked = 0
+    for n, i in enumerate(rows):
+        w, nd, pm = orc.pq_prefill_attention(qr[:, :, n:n + 1], msb[:, :, :i + 1], lsb[:, :, :i + 1], scale[:, :, :i + 1],
+                                             host(V[:, :, :i + 1]), thr, i)
+        clear = np.abs(pm[:, :, 0] - thr) > 1e-4
+        assert np.array_equal(need_h[:, :, i][clear], nd[:, :, 0][clear]), i
+        if clear.all():
+            np.testing.assert_allclose(host(out[:, i]), orc.round_dt(w[:, 0], dt), err_msg=f"row {i}", **OUT_TOL[dt])
+            checked += int(nd.any())
+    assert checked >= 3                                                            # flagged rows were among the compared ones
+    # un-flagged rows carry exactly the MSB-pass result; a flagged row equals the PQ decode step over its prefix
+    o_msb, _ = ops.attn_prefill_pq(Q, planes, V, N, cos, sin, 0, 0.0, causal=True)
+    keep = (need == 0).permute(0, 2, 1)
+    assert torch.equal(out.view(B, N, H, d)[keep], o_msb.view(B, N, H, d)[keep])
+    for i in (7 + 19 * 215, 7 + 19 * 430):
+        nd = torch.empty(B * H, dtype=torch.int32, device="cuda")
+        o1 = ops.attn_decode_pq(Q[:, :, i].contiguous(), planes, V, i + 1, cos, sin, i, thr, need_lsb=nd)
+        assert torch.equal(nd.view(B, H) != 0, need[:, :, i] != 0)
+        np.testing.assert_allclose(host(out[:, i]), host(o1), atol=1e-2, rtol=2e-2)
+
+
 def test_c3_head_pruned_decode_full_size():
     """configs[2] at full size: Llama-2-7B geometry, 4096 -> 2048 token prune, head importance -> keep 24 of 32 heads ->
     decode launched on the kept heads only; everything against the oracle."""
