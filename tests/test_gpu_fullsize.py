@@ -182,6 +182,36 @@ def test_c4_prefill_8192_pq_keyed_full_size():
     assert torch.equal(out.view(B, N, H, d)[keep], o_msb.view(B, N, H, d)[keep])
 
 
+@pytest.mark.parametrize("B,H,P,ql", [(2, 5, 300, 2000), (1, 8, 0, 2176)])
+def test_prefill_pq_split_refetch_pass_ragged_every_row(B, H, P, ql):
+    """The compacted, key-split refetch pass on ragged shapes (round 5), EVERY row against the oracle: head count not a multiple of
+    8, a query block on a longer cache, key tiles that do not divide by the ranges; head 0 is flagged almost everywhere (it keeps
+    the unsplit list pass: more than a quarter of its rows), the other heads have every 13th row flagged (split pass + merge)."""
+    from spatten_amd import ops
+    dt, d, N = "bf16", 128, P + ql
+    K, V, Kr, planes, cos, sin, gen = _pq_setup(B, H, d, N, dt, 91)
+    Q = (K[:, :, P:].float() * 6.0).to(TORCH_DT[dt])
+    Q[:, :, 5::13] = torch.randn(B, H, len(range(5, ql, 13)), d, device="cuda", generator=gen).to(TORCH_DT[dt])
+    Q[:, 0] = torch.randn(B, ql, d, device="cuda", generator=gen).to(TORCH_DT[dt])
+    thr = 0.05
+    msb, lsb, scale = planes.unpack(N)
+    c, s = host(cos), host(sin)
+    cs, sn = np.concatenate([c, c], -1), np.concatenate([s, s], -1)
+    qr = orc.apply_rotary_pos_emb_single(host(Q), cs, sn, np.arange(P, N)[None], dt)
+    want, need, pmax = orc.pq_prefill_attention(qr, msb, lsb, scale, host(V), thr, P)
+    out, need_g = ops.attn_prefill_pq(Q, planes, V, N, cos, sin, P, thr, causal=True)
+    torch.cuda.synchronize()
+    ng = need_g.cpu().numpy().astype(bool)
+    frac = ng.mean(axis=-1)                                          # [B, H]
+    assert (frac[:, 0] > 0.25).all() and (frac[:, 1:] < 0.25).all() and (frac[:, 1:] > 0.02).all(), frac
+    clear = np.abs(pmax - thr) > 1e-4
+    assert np.array_equal(ng[clear], need[clear])
+    ok_rows = clear.all(axis=1)
+    assert ok_rows.mean() > 0.9
+    got = host(out).reshape(B, ql, H, d)
+    np.testing.assert_allclose(got[ok_rows], orc.round_dt(want, dt).reshape(B, ql, H, d)[ok_rows], **OUT_TOL[dt])
+
+
 def test_c4_prefill_8192_pq_few_flagged_rows_take_the_compacted_key_split_pass():
     """configs[3] at a realistic refetch rate (round 5): when at most a quarter of the query rows is flagged, pass 2 walks the
     COMPACTED list of flagged rows (256 list entries per workgroup) with its key tiles split over workgroups and a merge launch.
