@@ -19,6 +19,9 @@ namespace spatten {
 #ifndef SPATTEN_GEMV_ROWS
 #define SPATTEN_GEMV_ROWS 4
 #endif
+#ifndef SPATTEN_GEMV_NT
+#define SPATTEN_GEMV_NT 1         // weights with the non-temporal policy (A/B switch)
+#endif
 constexpr int kGemvRows = SPATTEN_GEMV_ROWS;      // weight rows per wave
 constexpr int kGemvChunks = 8;    // 512-column chunks per pass
 
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ x, cons
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int c = 0; c < C; ++c) wr[r][c] = V8::ldg_stream(wrow[r] + min(k0 + c * 512 + lane * 8, K - 8));
+      for (int c = 0; c < C; ++c) wr[r][c] = SPATTEN_GEMV_NT ? V8::ldg_stream(wrow[r] + min(k0 + c * 512 + lane * 8, K - 8)) : V8::ldg(wrow[r] + min(k0 + c * 512 + lane * 8, K - 8));
     __builtin_amdgcn_sched_barrier(0);     // every load of the pass is issued before the first product
 #pragma unroll
     for (int c = 0; c < C; ++c) {
