@@ -344,6 +344,13 @@ template <> struct NibbleDot<float> {
     return acc;
   }
 };
+// (x & mask) | magic as ONE v_and_or_b32 (round 5): left to the compiler, two literals become v_and_b32 + v_or_b32 — a VOP3 cannot
+// carry a literal on gfx950, so the mask rides in an SGPR and the magic in a VGPR, both loop invariant
+__device__ inline uint32_t and_or_b32(uint32_t x, uint32_t mask, uint32_t magic) {
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(mask), "v"(magic));
+  return r;
+}
 template <typename T, uint32_t MAGIC, int BASE>
 struct NibbleDot16 {
   struct packed { uint32_t q[4]; float qsum; };   // q[k] = {element k, element k + 4}
@@ -361,7 +368,7 @@ struct NibbleDot16 {
   __device__ static inline float dot(const packed& a, uint32_t w, float bias) {
     u32x4 x, y;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { x[k] = a.q[k]; y[k] = ((w >> (4 * k)) & 0x000F000Fu) | MAGIC; }
+    for (int k = 0; k < 4; ++k) { x[k] = a.q[k]; y[k] = and_or_b32(w >> (4 * k), 0x000F000Fu, MAGIC); }
     return Dot8<T>::dot(x, y, -((float)BASE + bias) * a.qsum);
   }
 };

@@ -108,8 +108,37 @@ template <int BITS, int W> __device__ inline float field_f32(const uint32_t (&w)
   else f = __builtin_amdgcn_alignbit(w[wi + 1 < W ? wi + 1 : wi], w[wi], off) & mask;
   return (float)f;
 }
+#ifndef SPATTEN_PQV_MAGIC6      // A/B: 6-bit fields through the mantissa (below) instead of extract + convert.  1 = on
+#define SPATTEN_PQV_MAGIC6 1
+#endif
+// 6-bit fields without a conversion (round 5): the 32-bit window that starts at bit `s` of the piece (one shift / v_alignbit) puts
+// a field into mantissa bits [P, P + 6) of an fp32 whose exponent makes the mantissa's bit P worth 1 — `(win & mask) | magic`
+// (one v_and_or_b32) IS the float 2^(23-P) + field, exactly; the constant leaves through the weight sum like the offset-binary
+// bias.  P = 17 (64 + f) and P = 11 (4096 + f) hold two NEIGHBOURING fields of one window: 1.5 instructions per field (values:
+// the 4096 costs 6 bits of the accumulator — 2^-12 of a field step per addition, the output tolerance is 2^-7 of full scale);
+// P = 17 only: 2 per field (keys: the fp32 logits keep their precision).  r04: shift + and + v_cvt_f32_u32, 3 for a field that
+// straddles two dwords = 2.5 per field.
+constexpr float kMagic6Hi = 64.0f, kMagic6Lo = 4096.0f;
+template <int W> __device__ inline uint32_t piece_window(const uint32_t (&w)[W], int s) {   // bits [s, s + 32) of the piece (s compile-time)
+  if (s < 0) return w[0] << (-s);
+  const int wi = s / 32, sh = s % 32;
+  if (sh == 0) return w[wi];
+  if (wi + 1 < W) return __builtin_amdgcn_alignbit(w[wi + 1], w[wi], sh);
+  return w[wi] >> sh;
+}
+__device__ inline float magic6_hi(uint32_t win) { return __uint_as_float(and_or_b32(win, 0x007E0000u, 0x42800000u)); }   // 64 + field at [17, 23)
+__device__ inline float magic6_lo(uint32_t win) { return __uint_as_float(and_or_b32(win, 0x0001F800u, 0x45800000u)); }   // 4096 + field at [11, 17)
+
 template <int BITS, int W> __device__ inline float dot_piece(const uint32_t (&w)[W], const float (&qv)[16]) {
   float a0 = 0.f, a1 = 0.f;
+  if constexpr (BITS == 6 && SPATTEN_PQV_MAGIC6) {       // every field at [17, 23): sum_t q_t (64 + f_t); the caller takes 64 qsum out
+#pragma unroll
+    for (int t = 0; t < 16; t += 2) {
+      a0 = fmaf(qv[t], magic6_hi(piece_window<W>(w, 6 * t - 17)), a0);
+      a1 = fmaf(qv[t + 1], magic6_hi(piece_window<W>(w, 6 * (t + 1) - 17)), a1);
+    }
+    return a0 + a1;
+  }
 #pragma unroll
   for (int t = 0; t < 16; t += 2) {
     a0 = fmaf(qv[t], field_f32<BITS, W>(w, t), a0);
@@ -117,7 +146,18 @@ template <int BITS, int W> __device__ inline float dot_piece(const uint32_t (&w)
   }
   return a0 + a1;
 }
+// (magic form: o[t] gains wgt * (4096 + f) for even t, wgt * (64 + f) for odd t: piece_bias6(t) * the weight sum is taken out at the end)
+__device__ inline float piece_bias6(int t) { return (t & 1) ? kMagic6Hi : kMagic6Lo; }
 template <int BITS, int W> __device__ inline void fma_piece(float (&o)[16], const uint32_t (&w)[W], float wgt) {
+  if constexpr (BITS == 6 && SPATTEN_PQV_MAGIC6) {
+#pragma unroll
+    for (int t = 0; t < 16; t += 2) {
+      const uint32_t win = piece_window<W>(w, 6 * t - 11);     // field t at [11, 17), field t + 1 at [17, 23)
+      o[t] = fmaf(wgt, magic6_lo(win), o[t]);
+      o[t + 1] = fmaf(wgt, magic6_hi(win), o[t + 1]);
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < 16; ++t) o[t] = fmaf(wgt, field_f32<BITS, W>(w, t), o[t]);
 }
@@ -247,7 +287,7 @@ __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams
       if (KBITS == 4) {      // fields hold msb + 8 (pass 1) / the LSB nibble (pass 2)
         a = NibbleDot<T>::dot(qn[0], tl.kw[u][0], PASS == 1 ? 8.f : 0.f) + NibbleDot<T>::dot(qn[1], tl.kw[u][KW - 1], PASS == 1 ? 8.f : 0.f);
       } else {               // fields hold msb + 2^(KB-1)
-        a = dot_piece<KBITS, KW>(tl.kw[u], qv) - (float)(1 << (KB - 1)) * qsum;
+        a = dot_piece<KBITS, KW>(tl.kw[u], qv) - ((float)(1 << (KB - 1)) + ((KBITS == 6 && SPATTEN_PQV_MAGIC6) ? kMagic6Hi : 0.f)) * qsum;
       }
       a = group_sum<LPR>(a);
       const float s = a * (__uint_as_float(tl.ks[u]) * (PASS == 1 ? 16.f * rsqrt_d : rsqrt_d));
@@ -325,7 +365,7 @@ __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams
   {   // the fields hold qv + 2^(VB-1): take the constant out through the weight sum
     const float k = (float)(1 << (VB - 1)) * off_run;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o16[i] -= k;
+    for (int i = 0; i < 16; ++i) o16[i] -= (VB == 6 && SPATTEN_PQV_MAGIC6) ? fmaf(piece_bias6(i), off_run, k) : k;
   }
 
   // ---- reconcile the row groups (decode_attn.hip): per-wave max and sums in registers, one LDS hop across the waves ----

@@ -1460,8 +1460,10 @@ static inline bool use_vtr_for(int head_dim, int q_len, int kv_len) {
   // measured (tools/probe_vtr.py, H = 32, us per layer, Vt form | transposing reads): q = 64 on 2112: 36.2 | 28.7; 256 on
   // 2304: 44.3 | 37.5; 512 on 2560: 56.9 | 51.2; 1024 on 2048: 76.8 | 81.1; 1024 on 4096: 132.5 | 149.3; 2048 on 2048:
   // 79.9 | 83.5; 4096 on 4096: 246 | 265 — the pre-pass costs ~9 us per 2k keys, the two-read fragments ~7 % of the flash time
-  // (r04, paired blocks: a first prompt of 1024 tokens — q = N = 1024 — 40.3 | 37.7; 2048 on 2048 68.4 | 68.6)
-  return q_len <= SPATTEN_PF_VTR_MAXQ || (q_len == kv_len && q_len <= 2 * SPATTEN_PF_VTR_MAXQ);
+  // (r04, paired blocks: a first prompt of 1024 tokens — q = N = 1024 — 40.3 | 37.7; 2048 on 2048 68.4 | 68.6;
+  //  r05, after the softmax diet: q = N = 1024 39.4 | 35.7, 1536 52.7 | 49.4, 2048 66.3 | 64.1, 2560 104.1 | 101.7, 3072 144.0 |
+  //  155.0; 1024 on 2048 68.2 | 69.4, 2048 on 4096 148.4 | 148.4 — a whole prompt up to 2560 tokens takes the transposing reads)
+  return q_len <= SPATTEN_PF_VTR_MAXQ || (q_len == kv_len && q_len <= 5 * SPATTEN_PF_VTR_MAXQ);
 }
 
 

@@ -502,11 +502,13 @@ def test_prefill_fast_numerics_stays_within_the_stated_tolerance(dt, d, P, ql):
         run_prefill(q, k, v, past, dt, causal=True, stash=False, numerics="sloppy")
 
 
-@pytest.mark.parametrize("case", [("bf16", 1, 8, 8, 2000, 64), ("f16", 2, 4, 2, 700, 300), ("bf16", 1, 4, 4, 0, 512), ("bf16", 1, 4, 1, 3000, 17)])
+@pytest.mark.parametrize("case", [("bf16", 1, 8, 8, 2000, 64), ("f16", 2, 4, 2, 700, 300), ("bf16", 1, 4, 4, 0, 512), ("bf16", 1, 4, 1, 3000, 17),
+                                  ("bf16", 1, 4, 4, 0, 2304), ("f16", 1, 2, 2, 0, 1300)])
 def test_prefill_transposing_read_form_vs_oracle(case):
-    """Query blocks of up to 512 rows at d = 128 run the flash kernel that reads V through gfx950's transposing LDS reads
-    (ds_read_b64_tr_b16) from the value rows themselves — no key-contiguous copy of V is made; longer blocks keep the Vt
-    pre-pass.  Both forms against the oracle (GQA, key split, ragged lengths, a past longer than the block)."""
+    """Query blocks of up to 512 rows — and, since round 5, whole prompts (q = N) of up to 2560 tokens — at d = 128 run the flash
+    kernel that reads V through gfx950's transposing LDS reads (ds_read_b64_tr_b16) from the value rows themselves — no
+    key-contiguous copy of V is made; longer blocks keep the Vt pre-pass.  Both forms against the oracle (GQA, key split,
+    ragged lengths, a past longer than the block)."""
     dt, B, H, Hkv, P, ql = case
     d = 128
     q, k, v, past = attn_inputs(B, H, Hkv, d, P, ql, dt, seed=1200 + P + ql)
