@@ -698,8 +698,6 @@ def main():
     if pq is not None:
         planes = [ops.PQProfilePlanes(B, Hl, Hl, cap, d, dev, key_bits=pq[0], value_bits=pq[1]) for _ in range(L)]
         need = [torch.zeros(B * Hl, dtype=torch.int32, device=dev) for _ in range(L)]
-        kn4 = [x[:, :, None] for x in kn]
-        vn4 = [x[:, :, None] for x in vn]
 
     def prune():
         ops.prune_layers(importance, Kp, Vp, CTX, lo, hi, IMPORTANT, dst=(Kd, Vd, Krd), plan=plan, idx=idx,
@@ -716,8 +714,7 @@ def main():
             ops.attn_decode(q[l], Kd[l], Krd[l], Vd[l], n, cos, sin, n - 1, k_new=kn[l], v_new=vn[l],
                             scores=stash[l], out=outs2[par][l], workspace=ws, head_ids=ids)
         else:
-            ops.kv_append(kn4[l], vn4[l], Kd[l], Krd[l], Vd[l], n - 1, cos, sin)
-            ops.pq_pack_planes(Krd[l], Vd[l], planes[l], n - 1, n)
+            ops.kv_append_planes(kn[l], vn[l], Kd[l], Krd[l], Vd[l], planes[l], n - 1, cos, sin)     # (r05: one launch)
             ops.attn_decode_pqv(q[l], planes[l], n, cos, sin, n - 1, cfg["pq_threshold"], out=outs2[par][l], need_lsb=need[l],
                                 scores=stash[l], head_ids=ids, workspace=ws)
 
@@ -970,7 +967,7 @@ def main():
                 traffic = None
             kname = ("decode_lean_kernel<bf16,128,5,...,512> (decode_attn.hip; 512-thread team, two waves per SIMD)" if headline else
                      "decode_lean_hids_kernel<bf16,128,5,...,512> (decode_attn.hip; the lean step over a head list)" if pq is None else
-                     "pqv_decode_kernel (pq_decode.hip; the layer-step = row append + row pack + MSB pass (+ LSB refetch): "
+                     "pqv_decode_kernel (pq_decode.hip; the layer-step = row append + pack (one launch) + MSB pass (+ LSB refetch): "
                      "avg_launch_us is the whole layer-step)")
             result["roofline"] = {"kernel": kname, "bound": "hbm", "achieved": round(gbs, 1),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),

@@ -532,6 +532,16 @@ size_t spatten_pq_plane_row_bytes(int head_dim, int bits);
 int spatten_pq_pack_planes(int dtype, const void* kr_cache, const void* v_cache, int64_t kv_sb, int64_t kv_sh,
                            const spatten_pq_planes_t* planes, int batch, int kv_heads, int head_dim, int row_lo, int row_hi,
                            const void* step_state, void* stream);
+/* ONE decode step's append and its plane rows in ONE launch (round 5; replaces spatten_kv_append[_step] followed by
+ * spatten_pq_pack_planes for the step's row — bit for bit the same planes and cache rows; modify_llama.py:95-104 + the packing
+ * above): row `row` of k_cache (optional) / v_cache <- k_new / v_new [B,Hkv,d] (strides new_sb, new_sh), of kr_cache <- k_new
+ * rotated at slot position `row` (cos / sin [table_rows, d/2]), and that row of every plane.  With `step_state` the row is
+ * (state word 0) - 1 and the rotary row is the state's staged one (cos / sin / row ignored): capturable.  A row >= capacity is
+ * not written (step form) / refused (host form).  head_dim 64 / 128, the three bit profiles. */
+int spatten_kv_append_planes(int dtype, const void* k_new, const void* v_new, int64_t new_sb, int64_t new_sh, void* k_cache,
+                             void* kr_cache, void* v_cache, int64_t kv_sb, int64_t kv_sh, const spatten_pq_planes_t* planes,
+                             const void* cos, const void* sin, int table_rows, int batch, int kv_heads, int head_dim, int row,
+                             int capacity, const void* step_state, void* stream);
 /* The decode step over the planes: pass 1 (MSB logits -> stash + msb_logit, softmax, P.V over the quantised V,
  * need_lsb[b*H+h] = max_j prob_j < threshold; RequantDecision.scala:44-72) and the refetch pass for the flagged heads (LSB plane +
  * msb_logit; V again, because the probabilities change).  Arguments as in spatten_decode_args_t; the launch appends nothing.

@@ -150,6 +150,8 @@ def _declare(lib):
     lib.spatten_pq_plane_row_bytes.argtypes = [i, i]
     lib.spatten_pq_pack_planes.restype = c_int
     lib.spatten_pq_pack_planes.argtypes = [i, p, p, i64, i64, POINTER(PQPlanesDesc), i, i, i, i, i, p, p]
+    lib.spatten_kv_append_planes.restype = c_int
+    lib.spatten_kv_append_planes.argtypes = [i, p, p, i64, i64, p, p, p, i64, i64, POINTER(PQPlanesDesc), p, p, i, i, i, i, i, i, p, p]
     lib.spatten_attn_decode_pq.restype = c_int
     lib.spatten_attn_decode_pq.argtypes = [POINTER(PQDecodeArgs), p]
     lib.spatten_prefill_workspace_bytes.restype = c_size_t

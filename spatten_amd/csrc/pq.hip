@@ -183,6 +183,58 @@ template <int W> __device__ inline void store_words(uint8_t* p, const uint32_t (
   for (int i = 0; i < W; ++i) q[i] = w[i];
 }
 
+// symmetric per-row quantisation of a lane's 16 elements to `bits` bits: the row maximum over the LPR lanes of the row, scale =
+// max / (2^(bits-1) - 1), round to nearest even, clamp (oracle: pq_quantize / pq_quantize_values)
+template <int LPR>
+__device__ inline void quantise_piece(const float (&x)[16], int bits, float& sc_out, int (&q)[16]) {
+  float amax = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(x[e]));
+  amax = fmaxf(amax, dpp_mov<kDppXor1>(amax));
+  amax = fmaxf(amax, dpp_mov<kDppXor2>(amax));
+  if (LPR == 8) amax = fmaxf(amax, dpp_mov<kDppHalfMirror>(amax));
+  const float qmax = (float)((1 << (bits - 1)) - 1);
+  const float sc = amax > 0.f ? amax / qmax : 1.0f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    int qv = (int)rintf(x[e] / sc);
+    q[e] = max(-(int)qmax - 1, min((int)qmax, qv));
+  }
+  sc_out = sc;
+}
+// one row's pieces of the profiled planes from the lane's 16 rotated-key and 16 value elements (piece order)
+template <int D, int KB, int VB>
+__device__ inline void store_plane_pieces(const PlanesDev& pl, int b, int hkv, int row, int c, const float (&kx)[16], const float (&vx)[16]) {
+  constexpr int LPR = D / 16;
+  const int64_t so = b * pl.sc_sb + hkv * pl.sc_sh + row;
+  {   // keys: T = KB + 4 bits, MSB plane = q >> 4, LSB plane = q & 15
+    int q[16];
+    float sc;
+    quantise_piece<LPR>(kx, KB + 4, sc, q);
+    uint32_t fm[16], fl[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { fm[e] = (uint32_t)((q[e] >> 4) + (1 << (KB - 1))); fl[e] = (uint32_t)(q[e] & 15); }
+    uint32_t wm[KB / 2], wl[2];
+    pack_fields<KB>(fm, wm);
+    pack_fields<4>(fl, wl);
+    store_words<KB / 2>(pl.km + b * pl.km_sb + hkv * pl.km_sh + (int64_t)row * (D * KB / 8) + 2 * KB * c, wm);
+    store_words<2>(pl.kl + b * pl.kl_sb + hkv * pl.kl_sh + (int64_t)row * (D / 2) + 8 * c, wl);
+    if (c == 0) pl.ks[so] = sc;
+  }
+  {   // values: one plane of VB bits
+    int q[16];
+    float sc;
+    quantise_piece<LPR>(vx, VB, sc, q);
+    uint32_t f[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) f[e] = (uint32_t)(q[e] + (1 << (VB - 1)));
+    uint32_t w[VB / 2];
+    pack_fields<VB>(f, w);
+    store_words<VB / 2>(pl.vq + b * pl.vq_sb + hkv * pl.vq_sh + (int64_t)row * (D * VB / 8) + 2 * VB * c, w);
+    if (c == 0) pl.vs[so] = sc;
+  }
+}
+
 // LPR = D/16 lanes per row (the decode kernels' value mapping): lane c owns elements [8c, 8c+8) and [D/2+8c, D/2+8c+8)
 template <typename T, int D, int KB, int VB>
 __global__ __launch_bounds__(256) void pq_pack_planes_kernel(const T* __restrict__ kr, const T* __restrict__ v,
@@ -198,60 +250,71 @@ __global__ __launch_bounds__(256) void pq_pack_planes_kernel(const T* __restrict
   if (row < 0 || row >= hi) return;       // (whole LPR-groups leave together)
   const int hkv = blockIdx.y, b = blockIdx.z;
   using V8 = Vec8<T>;
-  auto quantise = [&](const T* src, int bits, float& sc_out, int (&q)[16]) {
-    float x[16];
-    {
-      float a[8], bq[8];
-      V8::unpack(V8::ldg(src + 8 * c), a);
-      V8::unpack(V8::ldg(src + HALF + 8 * c), bq);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { x[e] = a[e]; x[8 + e] = bq[e]; }
-    }
-    float amax = 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(x[e]));
-    amax = fmaxf(amax, dpp_mov<kDppXor1>(amax));
-    amax = fmaxf(amax, dpp_mov<kDppXor2>(amax));
-    if (LPR == 8) amax = fmaxf(amax, dpp_mov<kDppHalfMirror>(amax));
-    const float qmax = (float)((1 << (bits - 1)) - 1);
-    const float sc = amax > 0.f ? amax / qmax : 1.0f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      int qv = (int)rintf(x[e] / sc);
-      q[e] = max(-(int)qmax - 1, min((int)qmax, qv));
-    }
-    sc_out = sc;
-  };
   const int64_t src = b * kv_sb + hkv * kv_sh + (int64_t)row * D;
-  const int64_t so = b * pl.sc_sb + hkv * pl.sc_sh + row;
-  {   // keys: T = KB + 4 bits, MSB plane = q >> 4, LSB plane = q & 15
-    int q[16];
-    float sc;
-    quantise(kr + src, KB + 4, sc, q);
-    {
-      uint32_t fm[16], fl[16];
+  float kx[16], vx[16];
+  {
+    float a[8], bq[8];
+    V8::unpack(V8::ldg(kr + src + 8 * c), a);
+    V8::unpack(V8::ldg(kr + src + HALF + 8 * c), bq);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { fm[e] = (uint32_t)((q[e] >> 4) + (1 << (KB - 1))); fl[e] = (uint32_t)(q[e] & 15); }
-      uint32_t wm[KB / 2], wl[2];
-      pack_fields<KB>(fm, wm);
-      pack_fields<4>(fl, wl);
-      store_words<KB / 2>(pl.km + b * pl.km_sb + hkv * pl.km_sh + (int64_t)row * (D * KB / 8) + 2 * KB * c, wm);
-      store_words<2>(pl.kl + b * pl.kl_sb + hkv * pl.kl_sh + (int64_t)row * (D / 2) + 8 * c, wl);
-    }
-    if (c == 0) pl.ks[so] = sc;
-  }
-  {   // values: one plane of VB bits
-    int q[16];
-    float sc;
-    quantise(v + src, VB, sc, q);
-    uint32_t f[16];
+    for (int e = 0; e < 8; ++e) { kx[e] = a[e]; kx[8 + e] = bq[e]; }
+    V8::unpack(V8::ldg(v + src + 8 * c), a);
+    V8::unpack(V8::ldg(v + src + HALF + 8 * c), bq);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) f[e] = (uint32_t)(q[e] + (1 << (VB - 1)));
-    uint32_t w[VB / 2];
-    pack_fields<VB>(f, w);
-    store_words<VB / 2>(pl.vq + b * pl.vq_sb + hkv * pl.vq_sh + (int64_t)row * (D * VB / 8) + 2 * VB * c, w);
-    if (c == 0) pl.vs[so] = sc;
+    for (int e = 0; e < 8; ++e) { vx[e] = a[e]; vx[8 + e] = bq[e]; }
   }
+  store_plane_pieces<D, KB, VB>(pl, b, hkv, row, c, kx, vx);
+}
+
+// ---- one decode step's append AND its plane rows in ONE launch (round 5): row `row` (device-length form: state word 0 - 1) of
+// k / v, its rotation into the shadow (modify_llama.py:95-104) and that row of the profiled planes — bit for bit what
+// kv_append_kernel followed by pq_pack_planes_kernel leave there (the rotated values ARE model-dtype values: rope_pair rounds).
+// The two one-row launches cost 4.8 + 3.5 us per layer-step of BASELINE configs[4] under the graph; this one launch replaces them.
+template <typename T, int D, int KB, int VB>
+__global__ __launch_bounds__(64) void kv_append_planes_kernel(const T* __restrict__ k_new, const T* __restrict__ v_new,
+                                                              int64_t new_sb, int64_t new_sh, T* __restrict__ kc,
+                                                              T* __restrict__ krc, T* __restrict__ vc, int64_t kv_sb,
+                                                              int64_t kv_sh, const PlanesDev pl, const T* __restrict__ cos,
+                                                              const T* __restrict__ sin, int table_rows, int B, int H,
+                                                              int row_host, int cap, const int32_t* __restrict__ step) {
+  constexpr int HALF = D / 2, LPR = D / 16, RPB = 64 / LPR;
+  const int lane = threadIdx.x, c = lane % LPR;
+  const int unit = blockIdx.x * RPB + lane / LPR;
+  const int row = step ? step[0] - 1 : row_host;
+  if (unit >= B * H || row < 0 || row >= cap) return;      // (whole LPR-groups leave together)
+  const int b = unit / H, h = unit % H;
+  using V8 = Vec8<T>;
+  const T* cr;
+  const T* sr;
+  if (step) {                                             // the state's staged rotary row 1 = the appended key's slot
+    const T* rows = reinterpret_cast<const T*>(reinterpret_cast<const char*>(step) + kStepHeader);   // cos[2][HALF] | sin[2][HALF]
+    cr = rows + HALF; sr = rows + 3 * HALF;
+  } else {
+    const int ps = min(row, table_rows - 1);
+    cr = cos + (int64_t)ps * HALF; sr = sin + (int64_t)ps * HALF;
+  }
+  const T* kp = k_new + b * new_sb + h * new_sh;
+  const T* vp = v_new + b * new_sb + h * new_sh;
+  const typename V8::raw k0 = V8::ldg(kp + 8 * c), k1 = V8::ldg(kp + HALF + 8 * c);
+  const typename V8::raw v0 = V8::ldg(vp + 8 * c), v1 = V8::ldg(vp + HALF + 8 * c);
+  float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8];
+  V8::unpack(k0, xlo);
+  V8::unpack(k1, xhi);
+  V8::unpack(V8::ldg(cr + 8 * c), cc);
+  V8::unpack(V8::ldg(sr + 8 * c), ss);
+  rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
+  const int64_t dst = b * kv_sb + h * kv_sh + (int64_t)row * D;
+  if (kc) { V8::stg(kc + dst + 8 * c, k0); V8::stg(kc + dst + HALF + 8 * c, k1); }
+  V8::stg(krc + dst + 8 * c, V8::pack(ylo));
+  V8::stg(krc + dst + HALF + 8 * c, V8::pack(yhi));
+  V8::stg(vc + dst + 8 * c, v0);
+  V8::stg(vc + dst + HALF + 8 * c, v1);
+  float kx[16], vx[16], va[8], vb[8];
+  V8::unpack(v0, va);
+  V8::unpack(v1, vb);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { kx[e] = ylo[e]; kx[8 + e] = yhi[e]; vx[e] = va[e]; vx[8 + e] = vb[e]; }
+  store_plane_pieces<D, KB, VB>(pl, b, h, row, c, kx, vx);
 }
 
 bool planes_to_dev(const spatten_pq_planes_t* p, PlanesDev& d) {
@@ -343,5 +406,36 @@ extern "C" int spatten_pq_pack_planes(int dtype, const void* kr_cache, const voi
 #undef SPATTEN_PACKP_T
 #undef SPATTEN_PACKP_D
 #undef SPATTEN_PACKP
+  return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+}
+
+extern "C" int spatten_kv_append_planes(int dtype, const void* k_new, const void* v_new, int64_t new_sb, int64_t new_sh,
+                                        void* k_cache, void* kr_cache, void* v_cache, int64_t kv_sb, int64_t kv_sh,
+                                        const spatten_pq_planes_t* planes, const void* cos, const void* sin, int table_rows,
+                                        int batch, int kv_heads, int head_dim, int row, int capacity, const void* step_state,
+                                        void* stream) {
+  PlanesDev pd;
+  if (!k_new || !v_new || !kr_cache || !v_cache || !planes_to_dev(planes, pd) || batch <= 0 || kv_heads <= 0 || capacity <= 0)
+    return SPATTEN_ERR_INVALID;
+  if (!step_state && (!cos || !sin || table_rows <= 0 || row < 0 || row >= capacity)) return SPATTEN_ERR_INVALID;
+  if (!ok_dtype(dtype)) return SPATTEN_ERR_INVALID;
+  if (head_dim != 64 && head_dim != 128) return SPATTEN_ERR_UNSUPPORTED;
+  const int kb = planes->key_msb_bits, vb = planes->value_bits;
+  if (!pq_profile_supported(kb, vb)) return SPATTEN_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int rpb = 64 / (head_dim / 16);
+  const dim3 grid((unsigned)ceil_div(batch * kv_heads, rpb));
+#define SPATTEN_APL(T, DD, KB, VB)                                                                                            \
+  hipLaunchKernelGGL((kv_append_planes_kernel<T, DD, KB, VB>), grid, dim3(64), 0, st, (const T*)k_new, (const T*)v_new, new_sb, \
+                     new_sh, (T*)k_cache, (T*)kr_cache, (T*)v_cache, kv_sb, kv_sh, pd, (const T*)cos, (const T*)sin, table_rows, \
+                     batch, kv_heads, row, capacity, (const int32_t*)step_state)
+#define SPATTEN_APL_D(T, KB, VB) do { if (head_dim == 128) SPATTEN_APL(T, 128, KB, VB); else SPATTEN_APL(T, 64, KB, VB); } while (0)
+#define SPATTEN_APL_T(KB, VB) do { if (dtype == SPATTEN_BF16) SPATTEN_APL_D(bf16_t, KB, VB); else if (dtype == SPATTEN_F16) SPATTEN_APL_D(f16_t, KB, VB); else SPATTEN_APL_D(float, KB, VB); } while (0)
+  if (kb == 4) SPATTEN_APL_T(4, 8);
+  else if (kb == 8) SPATTEN_APL_T(8, 8);
+  else SPATTEN_APL_T(6, 6);
+#undef SPATTEN_APL_T
+#undef SPATTEN_APL_D
+#undef SPATTEN_APL
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }

@@ -56,6 +56,8 @@ struct PqvParams {
                                 // UP = 2: 15.3 / 16.8 / 16.8 — the pipelined stream does not gain from the second wave.  256 stays.
 #define SPATTEN_PQV_THREADS 256
 #endif
+// (r05, measured and dropped: THREE tiles in flight instead of two — (4,8) 14.5 -> 15.3-15.5 us, (8,8) 16.9 -> 18.0-18.2, with tiles of
+//  64 rows 14.7 / 17.7-18.1: the pass is not waiting for bytes in flight)
 constexpr int kPqvThreads = SPATTEN_PQV_THREADS;
 constexpr int kPqvWaves = kPqvThreads / 64;
 

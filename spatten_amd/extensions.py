@@ -173,12 +173,11 @@ class SpattenExtensions:
             return st.out, st.stash[0][:, :, None, :kv_len]
         if self.pq_threshold is not None and self.pq_profile is not None:
             # profiled planes: rows [0, kv_len - 1) packed with host lengths before the capture, the step's row by the
-            # device-length append (k / kr / v) + the device-length pack of that row, then the two passes over the planes
+            # device-length append + pack of that row (one launch: spatten_kv_append_planes), then the two passes over the planes
             slab.ensure_pq(kv_len - 1, self.pq_profile, H)
             if slab.pq.capacity < cap:
                 raise RuntimeError("progressive-quant planes smaller than the slab capacity")
-            ops.kv_append_step(k_new, v_new, slab.k, slab.kr, slab.v, step, None)
-            ops.pq_pack_planes(slab.kr, slab.v, slab.pq, 0, cap, step=step)
+            ops.kv_append_planes(k_new, v_new, slab.k, slab.kr, slab.v, slab.pq, 0, cos, sin, step=step)   # (r05: one launch)
             slab.pq_len = kv_len
             ops.attn_decode_pqv(q, slab.pq, cap, cos, sin, 0, self.pq_threshold, out=st.out, need_lsb=st.need_lsb,
                                 scores=st.stash[0], lse=st.lse[0], head_ids=st.head_ids,
@@ -233,8 +232,9 @@ class SpattenExtensions:
             casc = (st.acc, st.stash[cur ^ 1], st.lse[cur ^ 1], min(st.pending_len, kv_len))
         head_abs = st.head_abs if self.head_keep is not None else None
         if self.pq_threshold is not None and self.pq_profile is not None:
-            ops.kv_append(k_new[:, :, None], v_new[:, :, None], slab.k, slab.kr, slab.v, past_len, cos, sin)
-            slab.ensure_pq(kv_len, self.pq_profile, H)
+            slab.ensure_pq(past_len, self.pq_profile, H)                  # (rows a prefill left unpacked, if any)
+            ops.kv_append_planes(k_new, v_new, slab.k, slab.kr, slab.v, slab.pq, past_len, cos, sin)     # (r05: one launch)
+            slab.pq_len = kv_len
             ops.attn_decode_pqv(q, slab.pq, kv_len, cos, sin, past_len, self.pq_threshold, out=st.out, need_lsb=st.need_lsb,
                                 scores=stash, lse=lse, head_ids=st.head_ids, head_abs=head_abs, layout=slab.capacity)
         elif self.pq_threshold is not None:

@@ -1224,6 +1224,30 @@ def pq_pack_planes(kr_cache: torch.Tensor, v_cache: torch.Tensor, planes: PQProf
     _lib.check(rc, "spatten_pq_pack_planes")
 
 
+def kv_append_planes(k_new: torch.Tensor, v_new: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: torch.Tensor,
+                     v_cache: torch.Tensor, planes: PQProfilePlanes, row: int, cos: torch.Tensor, sin: torch.Tensor,
+                     step: Optional["StepState"] = None):
+    """One decode step's append AND its rows of the profiled planes in one launch (spatten_kv_append_planes): row ``row`` of the
+    slab planes from k_new / v_new [B,Hkv,d] — what ``kv_append`` + ``pq_pack_planes(row, row + 1)`` leave, bit for bit; with
+    ``step`` the row (state length) - 1, rotated with the state's staged row (capturable; ``row`` / ``cos`` / ``sin`` unused)."""
+    _dev(k_new, v_new, k_cache, kr_cache, v_cache, planes.msb)
+    B, Hkv, d = k_new.shape
+    if k_new.stride(2) != 1 or v_new.stride() != k_new.stride():
+        raise ValueError("k_new / v_new need contiguous d and identical strides")
+    if kr_cache.stride(3) != 1 or kr_cache.stride(2) != d or v_cache.stride() != kr_cache.stride() \
+            or (k_cache is not None and k_cache.stride() != kr_cache.stride()):
+        raise ValueError("cache planes need contiguous rows (pitch d) and identical strides")
+    cap = min(kr_cache.shape[2], planes.capacity)
+    if step is None and not (0 <= row < cap and row < cos.shape[0]):
+        raise ValueError("append exceeds cache capacity, the planes or the rotary table")
+    rc = _lib.load().spatten_kv_append_planes(_dt(k_new), k_new.data_ptr(), v_new.data_ptr(), k_new.stride(0), k_new.stride(1),
+                                              _ptr(k_cache), kr_cache.data_ptr(), v_cache.data_ptr(), kr_cache.stride(0),
+                                              kr_cache.stride(1), ctypes.byref(planes.desc), cos.data_ptr(), sin.data_ptr(),
+                                              cos.shape[0], B, Hkv, d, int(row), int(cap),
+                                              None if step is None else step.data_ptr(), _stream())
+    _lib.check(rc, "spatten_kv_append_planes")
+
+
 def attn_decode_pqv(q: torch.Tensor, planes: PQProfilePlanes, kv_len: int, cos: torch.Tensor, sin: torch.Tensor, pos_q: int,
                     threshold: float, out: Optional[torch.Tensor] = None, need_lsb: Optional[torch.Tensor] = None,
                     scores: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,

@@ -135,6 +135,51 @@ def test_profile_pack_of_the_step_row_in_device_length_form(kb, vb):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("kb,vb", PROFILES)
+@pytest.mark.parametrize("dt,d,Hkv", [("bf16", 128, 8), ("f16", 64, 4), ("f32", 128, 2)])
+def test_fused_append_and_plane_rows_equal_the_two_launches(kb, vb, dt, d, Hkv):
+    """spatten_kv_append_planes (round 5): the step's append and its plane rows in ONE launch — cache rows and every plane bit for
+    bit what spatten_kv_append followed by spatten_pq_pack_planes leave, in the host-length and in the device-length form."""
+    from spatten_amd import ops
+    B, H, P = 2, 8, 300
+    q, kc, vc, stash, (qd, krd, vd, cos, sin, N) = setup_decode(B, H, Hkv, d, P, dt, 46)
+    cap = N + 8
+    tdt = TORCH_DT[dt]
+    k_new = torch.randn(B, Hkv, d, device="cuda", dtype=torch.float32).to(tdt)
+    v_new = torch.randn(B, Hkv, d, device="cuda", dtype=torch.float32).to(tdt)
+    c_p, s_p = orc.rope_table(cap, d, dt)
+    cos_p, sin_p = dev(c_p[:, : d // 2], dt), dev(s_p[:, : d // 2], dt)
+
+    def fresh():
+        k0 = torch.zeros(B, Hkv, cap, d, device="cuda", dtype=tdt)
+        kr0 = torch.zeros_like(k0)
+        v0 = torch.zeros_like(k0)
+        kr0[:, :, :N] = krd
+        v0[:, :, :N] = vd
+        pl = ops.PQProfilePlanes(B, Hkv, H, cap, d, "cuda", key_bits=kb, value_bits=vb)
+        ops.pq_pack_planes(kr0, v0, pl, 0, N)
+        return k0, kr0, v0, pl
+
+    ka, kra, va, pa = fresh()
+    ops.kv_append(k_new[:, :, None], v_new[:, :, None], ka, kra, va, N, cos_p, sin_p)
+    ops.pq_pack_planes(kra, va, pa, N, N + 1)
+    kb_, krb, vb_, pb = fresh()
+    ops.kv_append_planes(k_new, v_new, kb_, krb, vb_, pb, N, cos_p, sin_p)
+    kc_, krc, vc_, pc = fresh()
+    st = ops.StepState(cos_p, sin_p)
+    st.set(N, N - 1)
+    st.advance()                               # length N + 1: the step's row is N
+    ops.kv_append_planes(k_new, v_new, kc_, krc, vc_, pc, 0, cos_p, sin_p, step=st)
+    torch.cuda.synchronize()
+    for other_k, other_kr, other_v, other_p in ((kb_, krb, vb_, pb), (kc_, krc, vc_, pc)):
+        assert torch.equal(ka, other_k) and torch.equal(kra, other_kr) and torch.equal(va, other_v)
+        for x, y in ((pa.msb, other_p.msb), (pa.lsb, other_p.lsb), (pa.scale, other_p.scale), (pa.vq, other_p.vq),
+                     (pa.vscale, other_p.vscale)):
+            assert torch.equal(x, y)
+    with pytest.raises(ValueError):
+        ops.kv_append_planes(k_new, v_new, kb_, krb, vb_, pb, cap, cos_p, sin_p)
+
+
 def test_profile_c4_c5_scale_decode_vs_oracle():
     """BASELINE.json configs[3] / configs[4] geometry through the profiled planes: Llama-2-7B heads at 8192 rows (4, 8) and
     Llama-2-13B heads (H = 40) at 16384 rows (8, 8) — outputs and refetch flags vs the oracle."""
