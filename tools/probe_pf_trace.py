@@ -20,8 +20,10 @@ q, k, v = (torch.randn(B, H, N, d, device="cuda", dtype=dt) for _ in range(3))
 cos, sin = ops.rope_table(N, d, dt, "cuda")
 kr = ops.rope_single(k, cos, sin)
 out = torch.empty(B, N, H * d, device="cuda", dtype=dt)
+numerics = "fast" if len(sys.argv) > 1 and sys.argv[1] == "fast" else "reference"      # probe_pf_trace.py [fast]
+print(f"numerics = {numerics}")
 for _ in range(2):
-    ops.attn_prefill(q, kr, v, N, cos, sin, 0, out=out, causal=True)
+    ops.attn_prefill(q, kr, v, N, cos, sin, 0, out=out, causal=True, numerics=numerics)
 torch.cuda.synchronize()
 t = buf.cpu().numpy().reshape(8, 16, 8).astype("float64")
 names = ["matrix", "bar1 wait", "staging", "softmax", "bar2 wait"]
