@@ -164,9 +164,6 @@ struct FlashParams {
 #ifndef SPATTEN_PF_ROWSUM_MFMA  // row sums of P on the matrix pipe instead of 64 VALU adds per lane and tile: MEASURED SLOWER
 #define SPATTEN_PF_ROWSUM_MFMA 0   // (713 vs 768): the 8 extra MFMAs per tile cost more than the adds they replace.  Off.
 #endif
-#ifndef SPATTEN_PF_DMAI         // r05 A/B: the 8 LDS-DMA instructions of a stage BETWEEN the P.V MFMAs (one behind every fourth) instead of in
-#define SPATTEN_PF_DMAI 0       // front of them (an LDS-DMA instruction holds the wave's issue ~125 cycles: in front, the matrix pipe idles)
-#endif
 #ifndef SPATTEN_PF_DIET         // r05 A/B switches of prefill_pp128_kernel's softmax (bits; prebuilt variants: tools/mb/build_variant.sh):
 #define SPATTEN_PF_DIET 0       //   2 = no per-tile maximum on fully visible tiles (exponentials against the running maximum, the lane's
 #endif                          //       sum bounds every one of them; the rare tile that outgrows it is redone): parity-green, MEASURED
@@ -620,7 +617,6 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
   // (P1 is neutral in the two-half ping-pong — 8192: 691 vs 679 us — and pays where a half runs ALONE, i.e. in the paired form's
   //  solo steps: q = N = 2048 71.2 -> 67.7 us; lock-step halves instead of the ping-pong: 774 us at 8192, 728 with P1)
   constexpr bool P1 = (SPATTEN_PF_P1 || PAIR) && !FAST && PQK == 0 && !MASK;
-  constexpr bool DMAI = SPATTEN_PF_DMAI && SPATTEN_PF_DMA_MODE == 1 && !P1 && PQK == 0 && !(VTRP && D == 128);
   constexpr bool NOMAX = (SPATTEN_PF_DIET & 2) && PQK == 0;      // (pass 1 of the quantised keys tracks the row's TRUE maximum)
   constexpr bool DOTSUM = (SPATTEN_PF_DIET & 4) && DT<T>::k16;
   constexpr int KT = 128, NKB = KT / 32;                      // keys per tile, 32-key blocks per tile
@@ -876,21 +872,8 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     s[kb][r] = v[0];
     s[kb][r + 1] = v[1];
   };
-  auto pv = [&](const char* vbuf, auto with_p1, auto with_dma, int dj, bool dok) {
+  auto pv = [&](const char* vbuf, auto with_p1) {
     constexpr bool WP1 = decltype(with_p1)::value;
-    constexpr bool WD = decltype(with_dma)::value;     // DMAI: stage dj's pieces of this wave ride between the MFMAs below
-    int kb_lane = 0, vb_lane = 0;
-    int64_t kbytes_e = 0, vbytes_e = 0;                // (an invalid stage: zero-size descriptors — no traffic, no branch)
-    if constexpr (WD) {
-      constexpr int LPRW = KROWB / 16;
-      const int ln = opaque_lane(lane);
-      const int lr = ln / LPRW, ps = ln % LPRW;
-      kb_lane = lr * KROWB + ((ps ^ (KROWB == 256 ? lr : (lr >> 1))) << 4);
-      const int l4 = ln >> 4, ps4 = ln & 15;
-      vb_lane = l4 * p.Npad * 2 + ((ps4 ^ l4) << 4);
-      kbytes_e = (dok && dj + 1 < n_tiles) ? k_bytes : 0;
-      vbytes_e = (dok && dj < n_att_tiles) ? v_bytes : 0;
-    }
     frag a[RING];
     const unsigned vu = (unsigned)(vbuf - lds) + qi * 256 + ((qi & 15) << 4);
     // VTR: lane (qi, hi) needs, for d = 32 db + qi, the 8 keys its P fragment holds — elements 0..3: keys k16 + 4 hi + 0..3,
@@ -924,19 +907,6 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
 #if SPATTEN_PF_ROWSUM_MFMA
       if (db == DB - 1) osum = Mfma<T>::mma(ones, pf[kt >> 1][kt & 1], osum);
 #endif
-      if constexpr (WD) {
-        if (i % 4 == 1 && i / 4 < KINST + VINST) {
-          const int pc = i / 4;
-          if (pc < KINST) {
-            const int piece = wave_u * KINST + pc;
-            const int fp = KROWB == 256 ? ((piece * 4) & 15) : ((piece * 4) & 7);
-            dma16(krb, kbytes_e, k_area(dj) + piece * 1024, kb_lane ^ (fp << 4), (dj + 1) * (KT * D * 2) + piece * 1024);
-          } else {
-            const int piece = wave_u * VINST + (pc - KINST);
-            dma16(vtb, vbytes_e, v_area(dj) + piece * 1024, vb_lane ^ (((piece * 4) & 15) << 4), dj * (KT * 2) + piece * 4 * p.Npad * 2);
-          }
-        }
-      }
       if constexpr (WP1) {      // 2 * NKB * DB MFMAs, NKB * 8 logit pairs: pairs_per logit pairs behind each MFMA
         constexpr int pairs_per = (NKB * 8) / (2 * NKB * DB) > 0 ? (NKB * 8) / (2 * NKB * DB) : 1;
 #pragma unroll
@@ -952,7 +922,6 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       if constexpr (WP1) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-      if constexpr (WD) { if (i % 4 == 1 && i / 4 < KINST + VINST) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); }
     }
     if constexpr (WP1) {
 #pragma unroll
@@ -1126,7 +1095,8 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     // tile).  Half 0 issues in global phase 2t and has the whole following vector phase for them to land; half 1 issues
     // in phase 2t+1 and waits for them at the end of that same phase (stage t+1 is first read in phase 2t+2).  The
     // slot's previous tenant, stage t-1, was last read in phase 2t-1.
-    if (!DMAI && !(SPATTEN_PF_EXPMODE & 2) && t >= T0 + 1 && t + 1 < n_tiles) dma_stage(t + 1);
+    if (!(SPATTEN_PF_EXPMODE & 2) && t >= T0 + 1 && t + 1 < n_tiles) dma_stage(t + 1);
+    PF_STAMP(6);           // (the stage's LDS-DMA pieces issued)
 #elif SPATTEN_PF_DMA_MODE == 0
     if (grp == 0 && t >= T0 + 1 && t + 1 < n_tiles) dma_stage(t + 1);
 #endif
@@ -1138,18 +1108,13 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
       if (nxt) qk(k_area(t));
       __builtin_amdgcn_sched_barrier(0);
       if (t < wave_att_tiles) {
-        if (nxt) { pv(v_area(t), std::true_type{}, std::false_type{}, 0, false); rounded = true; }
-        else pv(v_area(t), std::false_type{}, std::false_type{}, 0, false);
+        if (nxt) { pv(v_area(t), std::true_type{}); rounded = true; }
+        else pv(v_area(t), std::false_type{});
       }
     } else {
-      if constexpr (DMAI) {
-        const bool dok = !(SPATTEN_PF_EXPMODE & 2) && t >= T0 + 1 && t + 1 < n_tiles;
-        if (t < wave_att_tiles) pv(v_area(t), std::false_type{}, std::true_type{}, t + 1, dok);
-        else if (dok) dma_stage(t + 1);                    // (a wave past its last tile still serves its pieces)
-      } else {
-        if (t < wave_att_tiles) pv(v_area(t), std::false_type{}, std::false_type{}, 0, false);
-      }
+      if (t < wave_att_tiles) pv(v_area(t), std::false_type{});
       __builtin_amdgcn_sched_barrier(0);                   // P is dead from here on: keep S(t+1) out of its live range
+      PF_STAMP(7);         // (the P.V MFMAs issued)
       if (t + 1 < wave_tiles) qk(k_area(t));
     }
     PF_STAMP(1);

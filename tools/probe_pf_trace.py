@@ -31,4 +31,7 @@ print("wave " + " ".join(f"{n:>10s}" for n in names) + "      tile")
 for w in range(8):
     d_ = [(t[w, :, i + 1] - t[w, :, i]).mean() for i in range(5)]
     tile = (t[w, 1:, 0] - t[w, :-1, 0]).mean()
-    print(f"{w:4d} " + " ".join(f"{x:10.0f}" for x in d_) + f" {tile:9.0f}")
+    dma = (t[w, :, 6] - t[w, :, 0]).mean()          # stamp 6: the stage's LDS-DMA pieces issued; 7: the P.V MFMAs issued
+    pv_ = (t[w, :, 7] - t[w, :, 6]).mean()
+    qk_ = (t[w, :, 1] - t[w, :, 7]).mean()
+    print(f"{w:4d} " + " ".join(f"{x:10.0f}" for x in d_) + f" {tile:9.0f}   matrix = dma {dma:5.0f} + pv {pv_:5.0f} + qk {qk_:5.0f}")
