@@ -256,11 +256,32 @@ def cpu_baseline_child(L, new_len, lo, hi):
         cport = {}
         for threads in (min(ncpu, H), 1):
             co.set_threads(threads)
-            td, _ = med(lambda: co.attn_decode_raw("bf16", qh, kc, vc, cs, sn, None, oh, sh, 1, H, H, d, n, n - 1), 2.0)
-            tp, _ = med(c_prune, 0.5, warm=1, min_reps=3)
-            cport[str(threads)] = {"value": round(tps(td, tp), 4), "ms_per_layer_decode": round(td * 1e3, 3),
-                                   "ms_per_layer_prune": round(tp * 1e3, 3)}
+            reps = []
+            for _ in range(3):
+                td, nd = med(lambda: co.attn_decode_raw("bf16", qh, kc, vc, cs, sn, None, oh, sh, 1, H, H, d, n, n - 1), 0.8)
+                tp, npr = med(c_prune, 0.3, warm=1, min_reps=3)
+                reps.append((tps(td, tp), td, tp, nd, npr))
+            reps.sort()
+            mid = reps[1]
+            cport[str(threads)] = {"value": round(mid[0], 4), "ms_per_layer_decode": round(mid[1] * 1e3, 3),
+                                   "ms_per_layer_prune": round(mid[2] * 1e3, 3), "repetitions": [round(r[0], 4) for r in reps],
+                                   "spread": round((reps[-1][0] - reps[0][0]) / mid[0], 4),
+                                   "n_decode": sum(r[3] for r in reps), "n_prune": sum(r[4] for r in reps)}
         out["c_port_by_threads"] = cport
+        # The REPORTED baseline (round 5): the C port on ONE pinned thread.  On the driver's shared hosts the
+        # multi-threaded legs swing with the other tenants (torch mirror, best thread count: 12 / 2.6 / 41 / 5.1 / 25 tokens/s over five
+        # hosts; C port on 32 threads 17.6 / 20.7) while this one repeats to < 1 % (0.983 / 0.987) — a baseline has to be the same
+        # number twice.  The faster legs stay on the line beside it.
+        one = cport["1"]
+        out.update({"torch_mirror_best": {"value": out["value"], "cores": out["cores"], "spread": out["spread"], "sample": out["sample"]},
+                    "value": one["value"], "cores": 1, "spread": one["spread"],
+                    "ms_per_layer_decode": one["ms_per_layer_decode"], "ms_per_layer_prune": one["ms_per_layer_prune"],
+                    "sample": f"{one['n_decode']} decode-attention layer steps at kv_len {n} + {one['n_prune']} one-layer prune events ({CTX} -> "
+                              f"{new_len}: window top-k + K and V compaction) in 3 repetitions (median of the repetitions' medians), the C "
+                              f"restatement of the reference's op sequence (oracle/oracle.c, -march=native, pinned to one physical core), "
+                              f"extrapolated to {L} layers per token and one prune per {TURN} tokens; the multi-threaded legs "
+                              f"(c_port_by_threads, by_threads = the torch-CPU mirror) depend on the host's other tenants and are "
+                              f"reported beside it"})
     except Exception as e:
         out["c_port_error"] = f"{type(e).__name__}: {e}"
     print("CPU_BASELINE_JSON " + json.dumps(out), flush=True)
