@@ -1360,6 +1360,17 @@ def main():
                 extras["c5_decode_13b_16384_local_v_30pct_us"] = round(_time(lambda i: ops.attn_decode_local_v(
                     q5, K6[i % 2], V6[i % 2], 2 * N5, c5, s5, 2 * N5 - 1, keep5, st5, out=o5)), 2)
                 extras["c5_local_v_30pct_vs_plain_decode"] = round(extras["c5_decode_13b_16384_local_v_30pct_us"] / extras["c5_decode_13b_16384_dense_bf16_keys_us"], 3)
+                # ... and as the plugin runs the step: WITH the append of the token's row (inside the launch since round 5), beside the
+                # plain decode step with ITS append (always inside the launch)
+                kn5 = torch.randn(1, H5, d, device=dev, dtype=torch.float32).to(dt)
+                vn5 = torch.randn(1, H5, d, device=dev, dtype=torch.float32).to(dt)
+                ku6 = torch.zeros_like(K6[0])             # the un-rotated plane both steps append to
+                extras["c5_decode_13b_16384_dense_with_append_us"] = round(_time(lambda i: ops.attn_decode(
+                    q5, ku6, K6[i % 2], V6[i % 2], 2 * N5, c5, s5, 2 * N5 - 1, k_new=kn5, v_new=vn5, out=o5, workspace=ws5)), 2)
+                extras["c5_decode_13b_16384_local_v_30pct_with_append_us"] = round(_time(lambda i: ops.attn_decode_local_v(
+                    q5, K6[i % 2], V6[i % 2], 2 * N5, c5, s5, 2 * N5 - 1, keep5, st5, out=o5, k_new=kn5, v_new=vn5, k_cache=ku6)), 2)
+                extras["c5_local_v_30pct_vs_plain_decode_with_append"] = round(
+                    extras["c5_decode_13b_16384_local_v_30pct_with_append_us"] / extras["c5_decode_13b_16384_dense_with_append_us"], 3)
             except Exception as e:  # the headline number must not depend on the side measurements
                 extras["side_measurements_error"] = f"{type(e).__name__}: {e}"
             result["extras"] = extras

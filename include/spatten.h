@@ -475,6 +475,18 @@ int spatten_attn_decode_local_v(int dtype, const void* q, int64_t q_sb, int64_t 
                                 int64_t sc_sh, float* lse, void* workspace, int batch, int heads, int kv_heads,
                                 int head_dim, int kv_len, int keep, double keep_fraction, int kv_len_layout,
                                 const void* step_state, void* stream);
+/* The same step WITH the append inside the launch (round 5; modify_llama.py:95-104): row kv_len - 1 (step_state: state word 0 - 1)
+ * of k_cache (optional) / kr_cache / v_cache <- k_new / v_new [B,Hkv,d] (strides new_sb, new_sh), the key rotated at that slot; the
+ * split that owns the row scores it from registers as one extra key, the kept-row gather may read its V row back.  kv_len counts
+ * the appended row.  Replaces spatten_kv_append[_step] + spatten_attn_decode_local_v: same stash, same kept set, same cache rows
+ * (the head's (max, sum) and the output agree to rounding: the extra key is folded first instead of last). */
+int spatten_attn_decode_local_v_append(int dtype, const void* q, int64_t q_sb, int64_t q_sh, const void* k_new,
+                                       const void* v_new, int64_t new_sb, int64_t new_sh, void* k_cache, void* kr_cache,
+                                       void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* cos, const void* sin,
+                                       int table_rows, int pos_q, void* out, int64_t out_sb, void* scores, int64_t sc_sb,
+                                       int64_t sc_sh, float* lse, void* workspace, int batch, int heads, int kv_heads,
+                                       int head_dim, int kv_len, int keep, double keep_fraction, int kv_len_layout,
+                                       const void* step_state, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Progressive quantisation of the (rotated) key cache — MSB-first fetch with LSB refetch on low confidence

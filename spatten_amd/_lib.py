@@ -146,6 +146,9 @@ def _declare(lib):
     lib.spatten_attn_decode_local_v.restype = c_int
     lib.spatten_attn_decode_local_v.argtypes = [i, p, i64, i64, p, p, i64, i64, p, p, i, i, p, i64, p, i64, i64, p, p,
                                                 i, i, i, i, i, i, ctypes.c_double, i, p, p]
+    lib.spatten_attn_decode_local_v_append.restype = c_int
+    lib.spatten_attn_decode_local_v_append.argtypes = [i, p, i64, i64, p, p, i64, i64, p, p, p, i64, i64, p, p, i, i, p, i64, p, i64,
+                                                       i64, p, p, i, i, i, i, i, i, ctypes.c_double, i, p, p]
     lib.spatten_pq_plane_row_bytes.restype = c_size_t
     lib.spatten_pq_plane_row_bytes.argtypes = [i, i]
     lib.spatten_pq_pack_planes.restype = c_int

@@ -41,11 +41,13 @@ class CascadeImportance:
 
 
 def local_v_decode(q, kr_cache, v_cache, kv_len, cos, sin, pos_q, keep, mask=None, workspace=None, out=None, stash=None,
-                   lse=None, three_launches: bool = False, layout: int = 0):
+                   lse=None, three_launches: bool = False, layout: int = 0, k_new=None, v_new=None, k_cache=None):
     """Decode step with local V pruning: scores + (max, sum) without touching V, per-(b,h) top-``keep`` of the logits
     (same order as the probabilities), P·V over the kept rows only — ONE launch (ops.attn_decode_local_v, round 4); with an
     additive ``mask``, splits beyond 16384 rows or ``three_launches=True`` the r02 form: three dependent launches.
-    Returns (out [B,H*d], stash); ``stash`` [B,H,>=kv_len] / ``lse`` [B,H,2] may be caller buffers."""
+    Returns (out [B,H*d], stash); ``stash`` [B,H,>=kv_len] / ``lse`` [B,H,2] may be caller buffers.  ``k_new`` / ``v_new``
+    [B,Hkv,d]: the step's append (row kv_len - 1 of k_cache / kr_cache / v_cache) — inside the one launch (round 5), by
+    ``ops.kv_append`` in front of the three-launch form."""
     B, H, d = q.shape
     if stash is None:
         stash = torch.empty(B, H, kv_len, dtype=q.dtype, device=q.device)
@@ -54,10 +56,12 @@ def local_v_decode(q, kr_cache, v_cache, kv_len, cos, sin, pos_q, keep, mask=Non
     if mask is None and not three_launches and d in (64, 128):
         try:
             out = ops.attn_decode_local_v(q, kr_cache, v_cache, kv_len, cos, sin, pos_q, min(keep, kv_len), stash, out=out,
-                                          lse=lse, layout=layout)
+                                          lse=lse, layout=layout, k_new=k_new, v_new=v_new, k_cache=k_cache)
             return out, stash
         except NotImplementedError:
             pass
+    if k_new is not None:
+        ops.kv_append(k_new[:, :, None], v_new[:, :, None], k_cache, kr_cache, v_cache, kv_len - 1, cos, sin)
     ops.attn_decode(q, None, kr_cache, v_cache, kv_len, cos, sin, pos_q, mask=mask, scores=stash, lse=lse,
                     scores_only=True, workspace=workspace)
     keep = min(keep, kv_len)

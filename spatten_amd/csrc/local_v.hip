@@ -52,6 +52,9 @@ struct LvParams {
   double keep_frac; int keep;
   int B, H, Hkv, N, S, chunk;
   float sqrt_d;
+  // the step's APPEND inside the launch (round 5; optional): row N - 1 of kc (optional) / krc / vc <- k_new / v_new [B,Hkv,d]
+  // (modify_llama.py:95-104), rotated with rotary row `nr_row` of cos / sin (device-length form: the state's staged row 1)
+  const T* k_new; const T* v_new; int64_t new_sb, new_sh; T* kc; T* krc_w; T* vc_w; int nr_row;
 };
 
 // order-preserving integer key of a logit that IS a model-dtype value (NaN largest, -0 == +0: the order torch.topk ranks by)
@@ -157,11 +160,45 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
     q_raw[3] = V8::ldg(p.sin + (int64_t)pq * HALF + 8 * c);
   }
   issue_k(ka, lo);
+  // APPEND (round 5): every split's first thread-row requests the new token's K / V pieces and the rotary row of its slot (static
+  // addresses: nothing waits for the length); the split that owns row N - 1 rotates, stores the three rows in front of the barrier
+  // below (whose fence completes the stores: the value gather of phase 3 may read the V row back) and scores the row from
+  // registers as one extra key — the key tiles never read it
+  const bool app = p.k_new != nullptr;
+  raw_t nk_raw[2], nv_raw[2], nr_raw[2];
+  if (app && tid < LPR) {
+    const T* kp = p.k_new + b * p.new_sb + hkv * p.new_sh;
+    const T* vp = p.v_new + b * p.new_sb + hkv * p.new_sh;
+    nk_raw[0] = V8::ldg(kp + 8 * c); nk_raw[1] = V8::ldg(kp + HALF + 8 * c);
+    nv_raw[0] = V8::ldg(vp + 8 * c); nv_raw[1] = V8::ldg(vp + HALF + 8 * c);
+    nr_raw[0] = V8::ldg(p.cos + (int64_t)p.nr_row * HALF + 8 * c);
+    nr_raw[1] = V8::ldg(p.sin + (int64_t)p.nr_row * HALF + 8 * c);
+  }
   const unsigned gen = p.ws_gen[unit + opaque_lane(0)];
   __builtin_amdgcn_sched_barrier(0);
-  __syncthreads();                 // (the zeroed histogram, before any wave's first count; the tile loads are in flight)
   const int N = DYN ? __builtin_amdgcn_readfirstlane(n_dyn) : p.N;
   const int hi = min(lo + p.chunk, N);
+  const bool owns_new = app && lo <= N - 1 && N - 1 < hi;       // (wave-uniform)
+  const int hi_t = owns_new ? hi - 1 : hi;                       // rows the key tiles score
+  typename D8::packed nk_lo, nk_hi;                              // the appended key, rotated (owner's first thread-row)
+  if (owns_new && tid < LPR) {
+    float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8];
+    V8::unpack(nk_raw[0], xlo);
+    V8::unpack(nk_raw[1], xhi);
+    V8::unpack(nr_raw[0], cc);
+    V8::unpack(nr_raw[1], ss);
+    rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
+    nk_lo = D8::pack(ylo);
+    nk_hi = D8::pack(yhi);
+    const int64_t dst = b * p.kv_sb + hkv * p.kv_sh + (int64_t)(N - 1) * D;
+    if (p.kc) { V8::stg(p.kc + dst + 8 * c, nk_raw[0]); V8::stg(p.kc + dst + HALF + 8 * c, nk_raw[1]); }
+    V8::stg(p.krc_w + dst + 8 * c, V8::pack(ylo));
+    V8::stg(p.krc_w + dst + HALF + 8 * c, V8::pack(yhi));
+    V8::stg(p.vc_w + dst + 8 * c, nv_raw[0]);
+    V8::stg(p.vc_w + dst + HALF + 8 * c, nv_raw[1]);
+  }
+  __syncthreads();                 // (the zeroed histogram, before any wave's first count; the tile loads are in flight;
+                                   //  the appended rows are in memory)
   const int n_loc = max(hi - lo, 0);
   int keep = p.keep;
   if (DYN) keep = (int)ceil(p.keep_frac * (double)N);
@@ -192,7 +229,7 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
 #pragma unroll
     for (int u = 0; u < UK; ++u) {
       const int j = t0 + u * RPI + r;
-      const bool valid = j < hi;
+      const bool valid = j < hi_t;
       if (c == 0 && valid) {
         stashp[j] = DT<T>::from_f32(sc[u]);                                          // :116-119
         const uint32_t ok = OKey<T>::from(sc[u]);
@@ -206,14 +243,25 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
 #pragma unroll
     for (int u = 0; u < UK; ++u) l_run += (sc[u] == -INFINITY) ? 0.f : __expf(sc[u] - m_run);
   };
+  if (owns_new && tid < LPR) {      // the appended key: one extra row of the first thread-row's softmax (same arithmetic as a tile row)
+    const float a = group_sum<LPR>(D8::dot(q_hi, nk_hi, D8::dot(q_lo, nk_lo, 0.f)));
+    const float sn = DT<T>::round(div_by_const(DT<T>::round(a), p.sqrt_d, rsqrt_d));
+    if (c == 0) {
+      stashp[N - 1] = DT<T>::from_f32(sn);
+      const uint32_t ok = OKey<T>::from(sn);
+      skey[N - 1 - lo] = (key_t)ok;
+      atomicAdd(&s_hist[(ok >> (8 * (NP - 1))) & 255u], 1u);
+    }
+    m_run = sn; l_run = 1.f;
+  }
   constexpr int KT = RPI * UK;
-  for (int t0 = lo; t0 < hi; t0 += 2 * KT) {
+  for (int t0 = lo; t0 < hi_t; t0 += 2 * KT) {
     issue_k(kb, t0 + KT);
     __builtin_amdgcn_sched_barrier(0);
     score_tile(ka, t0);
     issue_k(ka, t0 + 2 * KT);
     __builtin_amdgcn_sched_barrier(0);
-    if (t0 + KT < hi) score_tile(kb, t0 + KT);
+    if (t0 + KT < hi_t) score_tile(kb, t0 + KT);
   }
   LV_STAMP(1);      // end of the key stream
   // (max, sum) of the chunk: every row's LPR lanes agree, so only the row's first lane contributes its sum
@@ -547,12 +595,14 @@ extern "C" size_t spatten_local_v_workspace_bytes(int batch, int heads) {
   return kLvHeader + lv_gen_bytes(units) + units * kLvMaxSplits * kLvSlot * sizeof(unsigned long long);
 }
 
-extern "C" int spatten_attn_decode_local_v(int dtype, const void* q, int64_t q_sb, int64_t q_sh, const void* kr_cache,
-                                           const void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* cos, const void* sin,
-                                           int table_rows, int pos_q, void* out, int64_t out_sb, void* scores, int64_t sc_sb,
-                                           int64_t sc_sh, float* lse, void* workspace, int batch, int heads, int kv_heads,
-                                           int head_dim, int kv_len, int keep, double keep_fraction, int kv_len_layout,
-                                           const void* step_state, void* stream) {
+static int local_v_launch(int dtype, const void* q, int64_t q_sb, int64_t q_sh, const void* kr_cache,
+                          const void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* cos, const void* sin,
+                          int table_rows, int pos_q, void* out, int64_t out_sb, void* scores, int64_t sc_sb,
+                          int64_t sc_sh, float* lse, void* workspace, int batch, int heads, int kv_heads,
+                          int head_dim, int kv_len, int keep, double keep_fraction, int kv_len_layout,
+                          const void* step_state, void* stream, const void* k_new, const void* v_new, int64_t new_sb,
+                          int64_t new_sh, void* k_cache) {
+  if ((k_new == nullptr) != (v_new == nullptr)) return SPATTEN_ERR_INVALID;
   if (!q || !kr_cache || !v_cache || !cos || !sin || !out || !scores || !workspace) return SPATTEN_ERR_INVALID;
   if (!ok_dtype(dtype) || batch <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads != 0 || kv_len <= 0) return SPATTEN_ERR_INVALID;
   if (head_dim != 64 && head_dim != 128) return SPATTEN_ERR_UNSUPPORTED;
@@ -590,6 +640,9 @@ extern "C" int spatten_attn_decode_local_v(int dtype, const void* q, int64_t q_s
     p.keep_frac = keep_fraction; p.keep = keep;                                                                        \
     p.B = batch; p.H = heads; p.Hkv = kv_heads; p.N = kv_len; p.S = S; p.chunk = chunk;                                 \
     p.sqrt_d = sqrtf((float)head_dim);                                                                                 \
+    p.k_new = (const T*)k_new; p.v_new = (const T*)v_new; p.new_sb = new_sb; p.new_sh = new_sh; p.kc = (T*)k_cache;     \
+    p.krc_w = (T*)const_cast<void*>(kr_cache); p.vc_w = (T*)const_cast<void*>(v_cache);                                 \
+    p.nr_row = step_state ? 1 : std::min(kv_len - 1, table_rows - 1);                                                  \
     static bool attr_set[64] = {};       /* the attribute is per DEVICE */                                \
     int dev_ = 0;                                                                                                      \
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 0;                                         \
@@ -610,4 +663,28 @@ extern "C" int spatten_attn_decode_local_v(int dtype, const void* q, int64_t q_s
 #undef SPATTEN_LV_D
 #undef SPATTEN_LV
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
+}
+
+extern "C" int spatten_attn_decode_local_v(int dtype, const void* q, int64_t q_sb, int64_t q_sh, const void* kr_cache,
+                                           const void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* cos, const void* sin,
+                                           int table_rows, int pos_q, void* out, int64_t out_sb, void* scores, int64_t sc_sb,
+                                           int64_t sc_sh, float* lse, void* workspace, int batch, int heads, int kv_heads,
+                                           int head_dim, int kv_len, int keep, double keep_fraction, int kv_len_layout,
+                                           const void* step_state, void* stream) {
+  return local_v_launch(dtype, q, q_sb, q_sh, kr_cache, v_cache, kv_sb, kv_sh, cos, sin, table_rows, pos_q, out, out_sb, scores, sc_sb,
+                        sc_sh, lse, workspace, batch, heads, kv_heads, head_dim, kv_len, keep, keep_fraction, kv_len_layout, step_state,
+                        stream, nullptr, nullptr, 0, 0, nullptr);
+}
+
+extern "C" int spatten_attn_decode_local_v_append(int dtype, const void* q, int64_t q_sb, int64_t q_sh, const void* k_new,
+                                                  const void* v_new, int64_t new_sb, int64_t new_sh, void* k_cache, void* kr_cache,
+                                                  void* v_cache, int64_t kv_sb, int64_t kv_sh, const void* cos, const void* sin,
+                                                  int table_rows, int pos_q, void* out, int64_t out_sb, void* scores,
+                                                  int64_t sc_sb, int64_t sc_sh, float* lse, void* workspace, int batch, int heads,
+                                                  int kv_heads, int head_dim, int kv_len, int keep, double keep_fraction,
+                                                  int kv_len_layout, const void* step_state, void* stream) {
+  if (!k_new || !v_new) return SPATTEN_ERR_INVALID;
+  return local_v_launch(dtype, q, q_sb, q_sh, kr_cache, v_cache, kv_sb, kv_sh, cos, sin, table_rows, pos_q, out, out_sb, scores, sc_sb,
+                        sc_sh, lse, workspace, batch, heads, kv_heads, head_dim, kv_len, keep, keep_fraction, kv_len_layout, step_state,
+                        stream, k_new, v_new, new_sb, new_sh, k_cache);
 }

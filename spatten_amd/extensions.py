@@ -163,9 +163,8 @@ class SpattenExtensions:
         if self.local_v_keep is not None:
             # local V pruning: the step's append in device-length form, then the one-launch step (the kept count follows the
             # device length); head pruning's zero-fill and head scores are stream operations on fixed buffers
-            ops.kv_append_step(k_new, v_new, slab.k, slab.kr, slab.v, step, None)
             ops.attn_decode_local_v(q, slab.kr, slab.v, cap, cos, sin, 0, 1, st.stash[0], out=st.out, lse=st.lse[0],
-                                    keep_fraction=self.local_v_keep, step=step)
+                                    keep_fraction=self.local_v_keep, step=step, k_new=k_new, v_new=v_new, k_cache=slab.k)   # (r05: appends inside)
             if st.pruned_ids is not None:
                 st.out.view(B, H, d).index_fill_(1, st.pruned_ids, 0)
             if self.head_keep is not None:
@@ -246,10 +245,9 @@ class SpattenExtensions:
                             head_abs=head_abs, layout=slab.capacity)
         elif self.local_v_keep is not None:
             from .cascade import local_v_decode
-            ops.kv_append(k_new[:, :, None], v_new[:, :, None], slab.k, slab.kr, slab.v, past_len, cos, sin)
             keep = max(1, min(kv_len, math.ceil(self.local_v_keep * kv_len)))
             local_v_decode(q, slab.kr, slab.v, kv_len, cos, sin, past_len, keep, out=st.out, stash=stash, lse=lse,
-                           layout=slab.capacity)
+                           layout=slab.capacity, k_new=k_new, v_new=v_new, k_cache=slab.k)      # (r05: the launch appends)
             if casc is not None:        # the scores-only launch does not carry the fused accumulation
                 ops.importance_accumulate(st.acc, casc[1][:, :, None, :casc[3]], casc[2][:, :, None, :])
             if st.pruned_ids is not None:

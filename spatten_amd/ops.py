@@ -1101,11 +1101,14 @@ def _local_v_workspace(batch, heads, device) -> torch.Tensor:
 def attn_decode_local_v(q: torch.Tensor, kr_cache: torch.Tensor, v_cache: torch.Tensor, kv_len: int, cos: torch.Tensor,
                         sin: torch.Tensor, pos_q: int, keep: int, scores: torch.Tensor, out: Optional[torch.Tensor] = None,
                         lse: Optional[torch.Tensor] = None, keep_fraction: float = 0.0, step: Optional["StepState"] = None,
-                        layout: int = 0, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+                        layout: int = 0, workspace: Optional[torch.Tensor] = None, k_new: Optional[torch.Tensor] = None,
+                        v_new: Optional[torch.Tensor] = None, k_cache: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The decode step with local V pruning as ONE launch (spatten_attn_decode_local_v): stash + (max, sum), exact per-head
     top-``keep`` of the logits, P.V over the kept V rows with the full denominator.  q [B,H,d]; kr_cache / v_cache
-    [B,Hkv,cap,d]; scores [B,H,>=kv_len] (written).  With ``step`` the kept count is ceil(keep_fraction * device length)."""
-    _dev(q, kr_cache, v_cache, cos, sin, scores, out, lse)
+    [B,Hkv,cap,d]; scores [B,H,>=kv_len] (written).  With ``step`` the kept count is ceil(keep_fraction * device length).
+    With ``k_new`` / ``v_new`` [B,Hkv,d] the launch also APPENDS the step's row kv_len - 1 (round 5,
+    spatten_attn_decode_local_v_append; ``k_cache`` = the optional un-rotated plane): kv_len counts that row."""
+    _dev(q, kr_cache, v_cache, cos, sin, scores, out, lse, k_new, v_new, k_cache)
     B, H, d = q.shape
     Hkv, cap = v_cache.shape[1], v_cache.shape[2]
     if q.stride(2) != 1 or v_cache.stride(3) != 1 or v_cache.stride(2) != d or kr_cache.stride() != v_cache.stride() \
@@ -1116,6 +1119,22 @@ def attn_decode_local_v(q: torch.Tensor, kr_cache: torch.Tensor, v_cache: torch.
     if out is None:
         out = torch.empty(B, H * d, dtype=q.dtype, device=q.device)
     ws = workspace if workspace is not None else _local_v_workspace(B, H, q.device)
+    if (k_new is None) != (v_new is None):
+        raise ValueError("k_new and v_new go together")
+    if k_new is not None:
+        if k_new.shape != (B, Hkv, d) or k_new.stride(2) != 1 or v_new.stride() != k_new.stride() \
+                or (k_cache is not None and k_cache.stride() != v_cache.stride()):
+            raise ValueError("k_new / v_new [B,Hkv,d] with contiguous d and identical strides; k_cache like v_cache")
+        rc = _lib.load().spatten_attn_decode_local_v_append(
+            _dt(q), q.data_ptr(), (H * d if B == 1 else q.stride(0)), q.stride(1), k_new.data_ptr(), v_new.data_ptr(),
+            k_new.stride(0), k_new.stride(1), _ptr(k_cache), kr_cache.data_ptr(), v_cache.data_ptr(), v_cache.stride(0),
+            v_cache.stride(1), cos.data_ptr(), sin.data_ptr(), cos.shape[0], int(pos_q), out.data_ptr(), out.stride(0),
+            scores.data_ptr(), scores.stride(0), scores.stride(1), _ptr(lse), ws.data_ptr(), B, H, Hkv, d, int(kv_len), int(keep),
+            float(keep_fraction), int(layout), None if step is None else step.data_ptr(), _stream())
+        if rc == -2:
+            raise NotImplementedError("spatten_attn_decode_local_v_append: split longer than 16384 rows")
+        _lib.check(rc, "spatten_attn_decode_local_v_append")
+        return out
     rc = _lib.load().spatten_attn_decode_local_v(
         _dt(q), q.data_ptr(), (H * d if B == 1 else q.stride(0)), q.stride(1), kr_cache.data_ptr(), v_cache.data_ptr(),
         v_cache.stride(0), v_cache.stride(1), cos.data_ptr(), sin.data_ptr(), cos.shape[0], int(pos_q), out.data_ptr(),

@@ -110,3 +110,50 @@ def test_device_length_form_equals_the_static_launch_bitwise(dt):
     torch.cuda.synchronize()
     assert torch.equal(oa, ob) and torch.equal(sa, sb) and torch.equal(la, lb)
     assert float(sb[:, :, N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt,d,B,H,Hkv,P,frac", [("bf16", 128, 1, 8, 8, 2500, 0.35), ("f16", 64, 2, 8, 4, 700, 0.5),
+                                                  ("f32", 128, 1, 4, 4, 300, 0.2), ("bf16", 128, 1, 40, 40, 16383, 0.3),
+                                                  ("bf16", 128, 2, 4, 2, 100, 0.9)])
+def test_append_inside_the_launch_equals_append_then_launch(dt, d, B, H, Hkv, P, frac):
+    """spatten_attn_decode_local_v_append (round 5): the step's append inside the one launch — cache rows and the stash bit for bit
+    what spatten_kv_append followed by spatten_attn_decode_local_v leave, the same kept set; (max, sum) and the output agree to
+    rounding (the appended key is folded first instead of last).  Host- and device-length forms (bitwise equal to each other)."""
+    from spatten_amd import ops
+    q, kc, vc, stash, (qd, krd, vd, cos, sin, N0) = setup_decode(B, H, Hkv, d, P, dt, 58)
+    N = N0 + 1                                   # the step appends row N0
+    cap = N + 100
+    tdt = TORCH_DT[dt]
+    c_p, s_p = orc.rope_table(cap, d, dt)
+    cos_p, sin_p = dev(c_p[:, : d // 2], dt), dev(s_p[:, : d // 2], dt)
+    k_new = torch.randn(B, Hkv, d, device="cuda", dtype=torch.float32).to(tdt)
+    v_new = torch.randn(B, Hkv, d, device="cuda", dtype=torch.float32).to(tdt)
+    keep = max(1, int(np.ceil(frac * N)))
+
+    def fresh():
+        k0 = torch.zeros(B, Hkv, cap, d, dtype=tdt, device="cuda")
+        kr0, v0 = torch.zeros_like(k0), torch.zeros_like(k0)
+        kr0[:, :, :N0], v0[:, :, :N0] = krd, vd
+        return k0, kr0, v0, torch.zeros(B, H, cap, dtype=tdt, device="cuda"), torch.zeros(B, H, 2, dtype=torch.float32, device="cuda")
+
+    ka, kra, va, sa, la = fresh()
+    ops.kv_append(k_new[:, :, None], v_new[:, :, None], ka, kra, va, N0, cos_p, sin_p)
+    oa = ops.attn_decode_local_v(qd, kra, va, N, cos_p, sin_p, N - 1, keep, sa, lse=la, layout=cap)
+    kb_, krb, vb, sb, lb = fresh()
+    ob = ops.attn_decode_local_v(qd, krb, vb, N, cos_p, sin_p, N - 1, keep, sb, lse=lb, layout=cap, k_new=k_new, v_new=v_new, k_cache=kb_)
+    kc_, krc, vc_, sc, lc = fresh()
+    st = ops.StepState(cos_p, sin_p)
+    st.set(N0, N0 - 1)
+    st.advance()                                 # length N, query position N - 1
+    oc = ops.attn_decode_local_v(qd, krc, vc_, cap, cos_p, sin_p, 0, 1, sc, lse=lc, keep_fraction=keep / N if False else frac, step=st,
+                                 k_new=k_new, v_new=v_new, k_cache=kc_)
+    torch.cuda.synchronize()
+    assert torch.equal(ka, kb_) and torch.equal(kra, krb) and torch.equal(va, vb)
+    assert torch.equal(sa, sb)
+    np.testing.assert_allclose(la.cpu().numpy(), lb.cpu().numpy(), atol=1e-5, rtol=1e-5)
+    tol = dict(atol=2e-5, rtol=1e-4) if dt == "f32" else OUT_TOL[dt]
+    np.testing.assert_allclose(host(oa), host(ob), **tol)
+    # the device-length form: same rows, same stash; the kept count is ceil(frac * N) there
+    assert torch.equal(ka, kc_) and torch.equal(kra, krc) and torch.equal(va, vc_) and torch.equal(sa, sc)
+    if int(np.ceil(frac * N)) == keep:
+        assert torch.equal(ob, oc) and torch.equal(lb, lc)
