@@ -735,9 +735,9 @@ def main():
             ops.attn_decode(q[l], Kd[l], Krd[l], Vd[l], n, cos, sin, n - 1, k_new=kn[l], v_new=vn[l],
                             scores=stash[l], out=outs2[par][l], workspace=ws, head_ids=ids)
         else:
-            ops.kv_append_planes(kn[l], vn[l], Kd[l], Krd[l], Vd[l], planes[l], n - 1, cos, sin)     # (r05: one launch)
+            # (r05: the step's append + plane rows inside the MSB pass; r05 earlier: spatten_kv_append_planes, one launch; r04: two)
             ops.attn_decode_pqv(q[l], planes[l], n, cos, sin, n - 1, cfg["pq_threshold"], out=outs2[par][l], need_lsb=need[l],
-                                scores=stash[l], head_ids=ids, workspace=ws)
+                                scores=stash[l], head_ids=ids, workspace=ws, append=(kn[l], vn[l], Kd[l], Krd[l], Vd[l]))
 
     def decode_token(n, par=0):
         for l in range(L):
@@ -988,7 +988,7 @@ def main():
                 traffic = None
             kname = ("decode_lean_kernel<bf16,128,5,...,512> (decode_attn.hip; 512-thread team, two waves per SIMD)" if headline else
                      "decode_lean_hids_kernel<bf16,128,5,...,512> (decode_attn.hip; the lean step over a head list)" if pq is None else
-                     "pqv_decode_kernel (pq_decode.hip; the layer-step = row append + pack (one launch) + MSB pass (+ LSB refetch): "
+                     "pqv_decode_kernel (pq_decode.hip; the layer-step = MSB pass with the row's append + pack inside (+ LSB refetch): "
                      "avg_launch_us is the whole layer-step)")
             result["roofline"] = {"kernel": kname, "bound": "hbm", "achieved": round(gbs, 1),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),

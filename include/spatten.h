@@ -573,6 +573,13 @@ typedef struct spatten_pq_decode_args {
   const int32_t* head_ids; int32_t n_active_heads; int32_t pad0_;
   float* head_abs_acc;
   const void* step_state;
+  /* round 5 — the step's APPEND inside the MSB pass (all NULL / 0: the launch appends nothing, as before): row kv_len - 1
+     (step_state: state word 0 - 1) of k_cache (optional) / kr_cache / v_cache [B,Hkv,cap,d] (strides kv_sb, kv_sh) <- k_new / v_new
+     [B,Hkv,d] (strides new_sb, new_sh), the key rotated at that slot (modify_llama.py:95-104), and that row of every plane — what
+     spatten_kv_append_planes leaves, bit for bit; the owning split scores the row from its registers.  kv_len counts the row.
+     Only the LAUNCHED heads append (a head list skips pruned heads, as spatten_attn_decode_args does). */
+  const void* k_new; const void* v_new; int64_t new_sb, new_sh;
+  void* k_cache; void* kr_cache; void* v_cache; int64_t kv_sb, kv_sh;
 } spatten_pq_decode_args_t;
 int spatten_attn_decode_pq(const spatten_pq_decode_args_t* args, void* stream);
 

@@ -74,6 +74,8 @@ class PQDecodeArgs(ctypes.Structure):
         ("head_ids", c_void_p), ("n_active_heads", c_int32), ("pad0_", c_int32),
         ("head_abs_acc", c_void_p),
         ("step_state", c_void_p),
+        ("k_new", c_void_p), ("v_new", c_void_p), ("new_sb", c_int64), ("new_sh", c_int64),
+        ("k_cache", c_void_p), ("kr_cache", c_void_p), ("v_cache", c_void_p), ("kv_sb", c_int64), ("kv_sh", c_int64),
     ]
 
 

@@ -29,6 +29,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "pq_pack.h"
 
 namespace spatten {
 
@@ -45,6 +46,9 @@ struct PqvParams {
   unsigned long long* ws_part; unsigned* ws_cnt; unsigned* ws_err; int64_t ws_unit;
   int B, H, Hkv, N, pos_q, S, chunk, poll_merge;
   float sqrt_d;
+  // the step's APPEND inside the MSB pass (round 5, optional): row N - 1 of kc (optional) / krc / vc <- k_new / v_new [B,Hkv,d]
+  // (modify_llama.py:95-104; the key rotated with rotary row nr_row of cos / sin) and that row of every plane
+  const T* k_new; const T* v_new; int64_t new_sb, new_sh; T* kc; T* krc; T* vc; int64_t kv_sb, kv_sh; int nr_row;
 };
 
 #ifndef SPATTEN_PQV_UP
@@ -239,11 +243,26 @@ __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams
     q_raw[3] = V8::ldg(p.sin + (int64_t)pq * HALF + 8 * c);
   }
   issue(tile_a, lo);
+  // APPEND (round 5, MSB pass): every split's first thread-row requests the new token's K / V pieces and the rotary row of its slot
+  // behind the first tile (static addresses); the split that owns row N - 1 rotates, stores the cache rows, packs and stores the row
+  // of every plane and scores it FROM ITS REGISTERS as one extra key (the tiles never read it; the refetch pass is another launch)
+  const bool app = PASS == 1 && p.k_new != nullptr;
+  typename V8::raw nk_raw[2], nv_raw[2], nr_raw[2];
+  if (app && tid < LPR) {
+    const T* kp = p.k_new + b * p.new_sb + hkv * p.new_sh;
+    const T* vp = p.v_new + b * p.new_sb + hkv * p.new_sh;
+    nk_raw[0] = V8::ldg(kp + 8 * c); nk_raw[1] = V8::ldg(kp + HALF + 8 * c);
+    nv_raw[0] = V8::ldg(vp + 8 * c); nv_raw[1] = V8::ldg(vp + HALF + 8 * c);
+    nr_raw[0] = V8::ldg(p.cos + (int64_t)p.nr_row * HALF + 8 * c);
+    nr_raw[1] = V8::ldg(p.sin + (int64_t)p.nr_row * HALF + 8 * c);
+  }
   const unsigned gen = p.ws_cnt[(p.S > 1 ? 2 * unit + 1 : 0) + opaque_lane(0)];
   __builtin_amdgcn_sched_barrier(0);
 
   const int N = DYN ? __builtin_amdgcn_readfirstlane(n_dyn) : p.N;
-  const int hi = min(lo + p.chunk, N);
+  const int hi_all = min(lo + p.chunk, N);
+  const bool owns_new = app && lo <= N - 1 && N - 1 < hi_all;      // (wave-uniform)
+  const int hi = owns_new ? hi_all - 1 : hi_all;                   // rows the tiles score
 
   // ---- the rotated query: fp32 values (they ARE model-dtype values: rope_pair rounds) in piece order; for the nibble planes
   // also packed for the pair-dot trick (common.h NibbleDot: nibble k of a dword pairs with nibble k + 4)
@@ -280,6 +299,44 @@ __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams
 #pragma unroll
   for (int i = 0; i < 16; ++i) o16[i] = 0.f;
 
+  if constexpr (PASS == 1) {
+    if (owns_new && tid < LPR) {
+      float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8], va[8], vb[8];
+      V8::unpack(nk_raw[0], xlo);
+      V8::unpack(nk_raw[1], xhi);
+      V8::unpack(nr_raw[0], cc);
+      V8::unpack(nr_raw[1], ss);
+      rope_pair<T>(xlo, xhi, cc, ss, ylo, yhi);
+      const int64_t dst = b * p.kv_sb + hkv * p.kv_sh + (int64_t)(N - 1) * D;
+      if (p.kc) { V8::stg(p.kc + dst + 8 * c, nk_raw[0]); V8::stg(p.kc + dst + HALF + 8 * c, nk_raw[1]); }
+      V8::stg(p.krc + dst + 8 * c, V8::pack(ylo));
+      V8::stg(p.krc + dst + HALF + 8 * c, V8::pack(yhi));
+      V8::stg(p.vc + dst + 8 * c, nv_raw[0]);
+      V8::stg(p.vc + dst + HALF + 8 * c, nv_raw[1]);
+      V8::unpack(nv_raw[0], va);
+      V8::unpack(nv_raw[1], vb);
+      float kx[16], vx[16];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { kx[e] = ylo[e]; kx[8 + e] = yhi[e]; vx[e] = va[e]; vx[8 + e] = vb[e]; }
+      PlanePieces<D, KB, VB> pp;
+      pack_plane_pieces<D, KB, VB>(kx, vx, pp);
+      store_plane_words<D, KB, VB>(p.pl, b, hkv, N - 1, c, pp);
+      // its MSB logit, exactly as a tile row's
+      float a;
+      if (KBITS == 4) a = NibbleDot<T>::dot(qn[0], pp.wm[0], 8.f) + NibbleDot<T>::dot(qn[1], pp.wm[KW - 1], 8.f);
+      else a = fmaf(-((float)(1 << (KB - 1)) + ((KBITS == 6 && SPATTEN_PQV_MAGIC6) ? kMagic6Hi : 0.f)), qsum, dot_piece<KBITS, KW>(pp.wm, qv));
+      a = group_sum<LPR>(a);
+      const float sn = a * (pp.ks * (16.f * rsqrt_d));
+      if (c == 0) {
+        if (stashp) stashp[N - 1] = DT<T>::from_f32(sn);
+        lgb[N - 1] = sn;
+      }
+      m_run = sn; l_run = 1.f;                           // the first key of this thread-row's softmax
+      const float wgt = pp.vs;
+      fma_piece<VB, VW>(o16, pp.wv, wgt);
+      off_run = wgt;
+    }
+  }
   // every row-group of a tile is computed unconditionally (rows past the split read as zeros); `valid` gates the results
   auto process_tile = [&](Tile& tl, int t0) {
     float sc[UP];
@@ -289,7 +346,8 @@ __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams
       if (KBITS == 4) {      // fields hold msb + 8 (pass 1) / the LSB nibble (pass 2)
         a = NibbleDot<T>::dot(qn[0], tl.kw[u][0], PASS == 1 ? 8.f : 0.f) + NibbleDot<T>::dot(qn[1], tl.kw[u][KW - 1], PASS == 1 ? 8.f : 0.f);
       } else {               // fields hold msb + 2^(KB-1)
-        a = dot_piece<KBITS, KW>(tl.kw[u], qv) - ((float)(1 << (KB - 1)) + ((KBITS == 6 && SPATTEN_PQV_MAGIC6) ? kMagic6Hi : 0.f)) * qsum;
+        // (an explicit fma: the appended row's logit is computed by the same expression elsewhere and must round the same way)
+        a = fmaf(-((float)(1 << (KB - 1)) + ((KBITS == 6 && SPATTEN_PQV_MAGIC6) ? kMagic6Hi : 0.f)), qsum, dot_piece<KBITS, KW>(tl.kw[u], qv));
       }
       a = group_sum<LPR>(a);
       const float s = a * (__uint_as_float(tl.ks[u]) * (PASS == 1 ? 16.f * rsqrt_d : rsqrt_d));
@@ -618,6 +676,9 @@ static int run_pqv(const spatten_pq_decode_args_t* a, const PlanesDev& pd, hipSt
   p.B = a->batch; p.H = a->heads; p.Hkv = a->kv_heads; p.N = a->kv_len; p.S = S; p.chunk = chunk;
   p.poll_merge = 0;      // decided per instantiation in launch_pqv (co-residency of the whole grid)
   p.sqrt_d = sqrtf((float)d);
+  p.k_new = (const T*)a->k_new; p.v_new = (const T*)a->v_new; p.new_sb = a->new_sb; p.new_sh = a->new_sh;
+  p.kc = (T*)a->k_cache; p.krc = (T*)a->kr_cache; p.vc = (T*)a->v_cache; p.kv_sb = a->kv_sb; p.kv_sh = a->kv_sh;
+  p.nr_row = a->step_state ? 1 : std::min(a->kv_len - 1, a->table_rows - 1);
   const bool dyn = a->step_state != nullptr, msb_only = (a->flags & SPATTEN_PQ_MSB_PASS_ONLY) != 0;
 #define SPATTEN_PQV(DD, KB, VB) return launch_pqv<T, DD, KB, VB>(p, n_active, dyn, msb_only, env_poll, st)
   if (d == 128) {
@@ -642,6 +703,8 @@ extern "C" int spatten_attn_decode_pq(const spatten_pq_decode_args_t* a, void* s
   if (a->batch <= 0 || a->heads <= 0 || a->kv_heads <= 0 || a->heads % a->kv_heads != 0 || a->kv_len <= 0) return SPATTEN_ERR_INVALID;
   if (!a->step_state && (a->pos_q < 0 || a->pos_q >= a->table_rows)) return SPATTEN_ERR_INVALID;
   if (a->kv_len_layout < 0) return SPATTEN_ERR_INVALID;
+  if ((a->k_new == nullptr) != (a->v_new == nullptr)) return SPATTEN_ERR_INVALID;
+  if (a->k_new && (!a->kr_cache || !a->v_cache)) return SPATTEN_ERR_INVALID;
   const int n_active = a->head_ids ? a->n_active_heads : a->heads;
   if (n_active <= 0 || n_active > a->heads) return SPATTEN_ERR_INVALID;
   if (!ok_dtype(a->dtype)) return SPATTEN_ERR_INVALID;

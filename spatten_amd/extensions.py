@@ -176,11 +176,15 @@ class SpattenExtensions:
             slab.ensure_pq(kv_len - 1, self.pq_profile, H)
             if slab.pq.capacity < cap:
                 raise RuntimeError("progressive-quant planes smaller than the slab capacity")
-            ops.kv_append_planes(k_new, v_new, slab.k, slab.kr, slab.v, slab.pq, 0, cos, sin, step=step)   # (r05: one launch)
+            if st.head_ids is None:      # (r05) every head is launched: the append + plane rows ride inside the MSB pass
+                app = (k_new, v_new, slab.k, slab.kr, slab.v)
+            else:                        # a head list: the pruned heads' rows are still appended (a later turn may re-rank the heads)
+                ops.kv_append_planes(k_new, v_new, slab.k, slab.kr, slab.v, slab.pq, 0, cos, sin, step=step)
+                app = None
             slab.pq_len = kv_len
             ops.attn_decode_pqv(q, slab.pq, cap, cos, sin, 0, self.pq_threshold, out=st.out, need_lsb=st.need_lsb,
                                 scores=st.stash[0], lse=st.lse[0], head_ids=st.head_ids,
-                                head_abs=st.head_abs if self.head_keep is not None else None, step=step)
+                                head_abs=st.head_abs if self.head_keep is not None else None, step=step, append=app)
             return st.out, st.stash[0][:, :, None, :kv_len]
         if self.pq_threshold is not None:
             # rows [0, kv_len - 1) packed with host lengths BEFORE the capture (the eager first step of the binding does it:
@@ -232,10 +236,14 @@ class SpattenExtensions:
         head_abs = st.head_abs if self.head_keep is not None else None
         if self.pq_threshold is not None and self.pq_profile is not None:
             slab.ensure_pq(past_len, self.pq_profile, H)                  # (rows a prefill left unpacked, if any)
-            ops.kv_append_planes(k_new, v_new, slab.k, slab.kr, slab.v, slab.pq, past_len, cos, sin)     # (r05: one launch)
+            if st.head_ids is None:
+                app = (k_new, v_new, slab.k, slab.kr, slab.v)
+            else:
+                ops.kv_append_planes(k_new, v_new, slab.k, slab.kr, slab.v, slab.pq, past_len, cos, sin)
+                app = None
             slab.pq_len = kv_len
             ops.attn_decode_pqv(q, slab.pq, kv_len, cos, sin, past_len, self.pq_threshold, out=st.out, need_lsb=st.need_lsb,
-                                scores=stash, lse=lse, head_ids=st.head_ids, head_abs=head_abs, layout=slab.capacity)
+                                scores=stash, lse=lse, head_ids=st.head_ids, head_abs=head_abs, layout=slab.capacity, append=app)
         elif self.pq_threshold is not None:
             ops.kv_append(k_new[:, :, None], v_new[:, :, None], slab.k, slab.kr, slab.v, past_len, cos, sin)
             slab.ensure_pq(kv_len)

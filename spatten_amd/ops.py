@@ -1272,9 +1272,11 @@ def attn_decode_pqv(q: torch.Tensor, planes: PQProfilePlanes, kv_len: int, cos: 
                     scores: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,
                     head_ids: Optional[torch.Tensor] = None, head_abs: Optional[torch.Tensor] = None,
                     step: Optional["StepState"] = None, layout: int = 0, n_splits: int = 0, msb_only: bool = False,
-                    workspace: Optional[DecodeWorkspace] = None) -> torch.Tensor:
+                    workspace: Optional[DecodeWorkspace] = None, append=None) -> torch.Tensor:
     """Decode over the profiled planes (spatten_attn_decode_pq): MSB pass + LSB-only refetch for the flagged heads, P.V over
-    the quantised values.  q [B,H,d]; returns out [B, H*d]; ``need_lsb`` int32 [B*H] is written."""
+    the quantised values.  q [B,H,d]; returns out [B, H*d]; ``need_lsb`` int32 [B*H] is written.
+    ``append`` = (k_new, v_new, k_cache | None, kr_cache, v_cache): the step's append INSIDE the MSB pass (round 5) — row kv_len - 1
+    of the cache planes and of every quantised plane, for the launched heads (what ``kv_append_planes`` leaves)."""
     _dev(q, planes.msb, cos, sin, out, need_lsb, scores, lse, head_ids, head_abs)
     B, H, d = q.shape
     Hkv = planes.msb.shape[1]
@@ -1312,6 +1314,17 @@ def attn_decode_pqv(q: torch.Tensor, planes: PQProfilePlanes, kv_len: int, cos: 
         a.head_ids, a.n_active_heads = head_ids.data_ptr(), head_ids.numel()
     a.head_abs_acc = _ptr(head_abs)
     a.step_state = None if step is None else step.data_ptr()
+    if append is not None:
+        k_new, v_new, k_cache, kr_cache, v_cache = append
+        _dev(k_new, v_new, k_cache, kr_cache, v_cache)
+        if k_new.shape != (B, Hkv, d) or k_new.stride(2) != 1 or v_new.stride() != k_new.stride():
+            raise ValueError("append: k_new / v_new [B,Hkv,d] with contiguous d and identical strides")
+        if kr_cache.stride(3) != 1 or kr_cache.stride(2) != d or v_cache.stride() != kr_cache.stride() \
+                or (k_cache is not None and k_cache.stride() != kr_cache.stride()) or kr_cache.shape[2] < kv_len:
+            raise ValueError("append: cache planes need contiguous rows (pitch d), identical strides and >= kv_len rows")
+        a.k_new, a.v_new, a.new_sb, a.new_sh = k_new.data_ptr(), v_new.data_ptr(), k_new.stride(0), k_new.stride(1)
+        a.k_cache, a.kr_cache, a.v_cache = _ptr(k_cache), kr_cache.data_ptr(), v_cache.data_ptr()
+        a.kv_sb, a.kv_sh = kr_cache.stride(0), kr_cache.stride(1)
     _lib.check(_lib.load().spatten_attn_decode_pq(ctypes.byref(a), stream), "spatten_attn_decode_pq")
     return out
 

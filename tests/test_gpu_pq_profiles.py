@@ -180,6 +180,72 @@ def test_fused_append_and_plane_rows_equal_the_two_launches(kb, vb, dt, d, Hkv):
         ops.kv_append_planes(k_new, v_new, kb_, krb, vb_, pb, cap, cos_p, sin_p)
 
 
+@pytest.mark.parametrize("kb,vb", PROFILES)
+@pytest.mark.parametrize("dt,d,H,Hkv,P", [("bf16", 128, 8, 8, 5000), ("f16", 64, 8, 4, 300), ("f32", 128, 4, 2, 130)])
+def test_append_inside_the_msb_pass_equals_append_then_decode(kb, vb, dt, d, H, Hkv, P):
+    """spatten_pq_decode_args_t.k_new / v_new (round 5): the step's append and its plane rows inside the MSB pass — cache rows, every
+    plane, the stash and the refetch flags bit for bit what spatten_kv_append_planes followed by the decode leave; (max, sum) and the
+    output agree to rounding (the appended key is folded first instead of last).  Host- and device-length forms; a head list appends
+    only for the heads it launches."""
+    from spatten_amd import ops
+    B = 2
+    q, kc, vc, stash, (qd, krd, vd, cos, sin, N0) = setup_decode(B, H, Hkv, d, P, dt, 47)
+    N, cap = N0 + 1, N0 + 1 + 40
+    tdt = TORCH_DT[dt]
+    k_new = torch.randn(B, Hkv, d, device="cuda", dtype=torch.float32).to(tdt)
+    v_new = torch.randn(B, Hkv, d, device="cuda", dtype=torch.float32).to(tdt)
+    c_p, s_p = orc.rope_table(cap, d, dt)
+    cos_p, sin_p = dev(c_p[:, : d // 2], dt), dev(s_p[:, : d // 2], dt)
+    thr = 0.02
+
+    def fresh():
+        k0 = torch.zeros(B, Hkv, cap, d, device="cuda", dtype=tdt)
+        kr0, v0 = torch.zeros_like(k0), torch.zeros_like(k0)
+        kr0[:, :, :N0], v0[:, :, :N0] = krd, vd
+        pl = ops.PQProfilePlanes(B, Hkv, H, cap, d, "cuda", key_bits=kb, value_bits=vb)
+        ops.pq_pack_planes(kr0, v0, pl, 0, N0)
+        return (k0, kr0, v0, pl, torch.zeros(B, H, cap, dtype=tdt, device="cuda"), torch.zeros(B, H, 2, dtype=torch.float32, device="cuda"),
+                torch.full((B * H,), -1, dtype=torch.int32, device="cuda"))
+
+    def same_state(x, y, heads_kv=None):
+        sel = slice(None) if heads_kv is None else heads_kv
+        for a_, b_ in ((x[0], y[0]), (x[1], y[1]), (x[2], y[2]), (x[3].msb, y[3].msb), (x[3].lsb, y[3].lsb), (x[3].scale, y[3].scale),
+                       (x[3].vq, y[3].vq), (x[3].vscale, y[3].vscale)):
+            assert torch.equal(a_[:, sel], b_[:, sel])
+
+    A = fresh()
+    ops.kv_append_planes(k_new, v_new, A[0], A[1], A[2], A[3], N0, cos_p, sin_p)
+    oa = ops.attn_decode_pqv(qd, A[3], N, cos_p, sin_p, N - 1, thr, scores=A[4], lse=A[5], need_lsb=A[6], layout=cap)
+    Bf = fresh()
+    ob = ops.attn_decode_pqv(qd, Bf[3], N, cos_p, sin_p, N - 1, thr, scores=Bf[4], lse=Bf[5], need_lsb=Bf[6], layout=cap,
+                             append=(k_new, v_new, Bf[0], Bf[1], Bf[2]))
+    C = fresh()
+    st = ops.StepState(cos_p, sin_p)
+    st.set(N0, N0 - 1)
+    st.advance()
+    oc = ops.attn_decode_pqv(qd, C[3], cap, cos_p, sin_p, 0, thr, scores=C[4], lse=C[5], need_lsb=C[6], step=st,
+                             append=(k_new, v_new, C[0], C[1], C[2]))
+    torch.cuda.synchronize()
+    same_state(A, Bf)
+    same_state(A, C)
+    assert torch.equal(A[4], Bf[4]) and torch.equal(A[6], Bf[6])
+    assert torch.equal(Bf[4], C[4]) and torch.equal(Bf[6], C[6]) and torch.equal(ob, oc) and torch.equal(Bf[5], C[5])
+    np.testing.assert_allclose(A[5].cpu().numpy(), Bf[5].cpu().numpy(), atol=1e-5, rtol=1e-5)
+    tol = dict(atol=2e-5, rtol=1e-4) if dt == "f32" else OUT_TOL[dt]
+    np.testing.assert_allclose(host(oa), host(ob), **tol)
+    # a head list: only the launched heads' kv heads get the row
+    if H == Hkv:
+        keep = torch.tensor([1, 2], dtype=torch.int32, device="cuda")
+        Dd = fresh()
+        o_d = torch.zeros(B, H * d, dtype=tdt, device="cuda")
+        ops.attn_decode_pqv(qd, Dd[3], N, cos_p, sin_p, N - 1, thr, out=o_d, scores=Dd[4], need_lsb=Dd[6], layout=cap, head_ids=keep,
+                            append=(k_new, v_new, Dd[0], Dd[1], Dd[2]))
+        torch.cuda.synchronize()
+        same_state(A, Dd, heads_kv=[1, 2])
+        assert float(Dd[1][:, [0, 3], N0].abs().max()) == 0.0
+        np.testing.assert_allclose(host(o_d.view(B, H, d)[:, [1, 2]]), host(ob.view(B, H, d)[:, [1, 2]]), **tol)   # (other split count)
+
+
 def test_profile_c4_c5_scale_decode_vs_oracle():
     """BASELINE.json configs[3] / configs[4] geometry through the profiled planes: Llama-2-7B heads at 8192 rows (4, 8) and
     Llama-2-13B heads (H = 40) at 16384 rows (8, 8) — outputs and refetch flags vs the oracle."""
