@@ -114,7 +114,8 @@ def test_device_length_form_equals_the_static_launch_bitwise(dt):
 
 @pytest.mark.parametrize("dt,d,B,H,Hkv,P,frac", [("bf16", 128, 1, 8, 8, 2500, 0.35), ("f16", 64, 2, 8, 4, 700, 0.5),
                                                   ("f32", 128, 1, 4, 4, 300, 0.2), ("bf16", 128, 1, 40, 40, 16383, 0.3),
-                                                  ("bf16", 128, 2, 4, 2, 100, 0.9)])
+                                                  ("bf16", 128, 2, 4, 2, 100, 0.9), ("bf16", 128, 1, 2, 2, 1, 1.0),
+                                                  ("f16", 128, 1, 32, 32, 4100, 0.25)])
 def test_append_inside_the_launch_equals_append_then_launch(dt, d, B, H, Hkv, P, frac):
     """spatten_attn_decode_local_v_append (round 5): the step's append inside the one launch — cache rows and the stash bit for bit
     what spatten_kv_append followed by spatten_attn_decode_local_v leave, the same kept set; (max, sum) and the output agree to
