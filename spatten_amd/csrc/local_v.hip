@@ -119,6 +119,7 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
   __shared__ unsigned s_scan[260];
   __shared__ float s_red[4][D + 2];
   __shared__ unsigned s_misc[8];
+  __shared__ unsigned s_bef[256], s_mine[256];
   __shared__ float s_aux[2][kLvMaxSplits];
 
   const int tid = threadIdx.x, c = tid % LPR, r = tid / LPR, wave = tid / kWave, lane = tid % kWave;
@@ -319,30 +320,40 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
     }
   };
   // the bin that holds the `need`-th largest key: suffix sums over the 256 bins (keys are ranked largest first), exactly one bin
-  // brackets the rank; leaves {bin, keys above it, `before`, `mine` of that bin} in s_misc[0..3]
-  auto pick_bin = [&](unsigned tot, unsigned before, unsigned mine, int rank) {
+  // brackets the rank.  Round 5: ONE barrier — every wave scans all 256 totals itself (4 descending bins per lane, one wave scan,
+  // a ballot finds the bracketing bin) and reads `before` / `mine` of that bin from LDS (r04: wave 0 scanned, the pick travelled
+  // through s_misc: three barriers, ~1.9k cycles per pick by the phase stamps).  Returns {bin, keys above it, before, mine}.
+  struct Pick { unsigned bin, above, before, mine; };
+  auto pick_bin = [&](unsigned tot, unsigned before, unsigned mine, int rank) -> Pick {
     s_scan[tid] = tot;
+    s_bef[tid] = before;
+    s_mine[tid] = mine;
     __syncthreads();
-    if (wave == 0) {
-      unsigned v4[4], run = 0;
+    unsigned v4[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v4[i] = s_scan[255 - (4 * lane + i)];       // descending bins
-      unsigned mysum = v4[0] + v4[1] + v4[2] + v4[3], incl = mysum;
+    for (int i = 0; i < 4; ++i) v4[i] = s_scan[255 - (4 * lane + i)];       // descending bins
+    const unsigned mysum = v4[0] + v4[1] + v4[2] + v4[3];
+    unsigned incl = mysum;
 #pragma unroll
-      for (int off = 1; off < kWave; off <<= 1) {
-        const unsigned o = __shfl_up(incl, off, kWave);
-        if (lane >= off) incl += o;
-      }
-      run = incl - mysum;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { s_scan[255 - (4 * lane + i)] = run; run += v4[i]; }   // now: keys in bins above
+    for (int off = 1; off < kWave; off <<= 1) {
+      const unsigned o = __shfl_up(incl, off, kWave);
+      if (lane >= off) incl += o;
     }
-    __syncthreads();
-    const unsigned above = s_scan[tid];
-    if (above < (unsigned)rank && (unsigned)rank <= above + tot) {           // exactly one bin
-      s_misc[0] = (unsigned)tid; s_misc[1] = above; s_misc[2] = before; s_misc[3] = mine;
+    unsigned run = incl - mysum, hb = 0, ha = 0;
+    bool hit = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (run < (unsigned)rank && (unsigned)rank <= run + v4[i]) { hit = true; hb = 255u - (unsigned)(4 * lane + i); ha = run; }
+      run += v4[i];
     }
-    __syncthreads();
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+    const int L = m ? (int)__builtin_ctzll(m) : 0;
+    Pick pk;
+    pk.bin = (unsigned)__shfl((int)hb, L, kWave);
+    pk.above = (unsigned)__shfl((int)ha, L, kWave);
+    pk.before = s_bef[pk.bin];
+    pk.mine = s_mine[pk.bin];
+    return pk;
   };
   // keys of this split whose digits above `shift + 8` equal `pfx`, counted by their digit at `shift` into hist[256]
   // (16-byte LDS reads: 8 / 4 keys per lane and read; r04 read them one by one: 3.2 us of a pass at 2731 keys per split)
@@ -370,11 +381,11 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
     for (int s = 0; s < p.S; ++s) ll += s_aux[1][s] * __expf(s_aux[0][s] - mu);
     m_g = mm; l_g = ll;
   };
-  auto take_pick = [&](int bits_done) {
-    prefix = (bits_done == 0) ? s_misc[0] : ((prefix << 8) | s_misc[0]);
-    need -= (int)s_misc[1];
-    ties_before = s_misc[2];
-    ties_mine = s_misc[3];
+  auto take_pick = [&](int bits_done, const Pick& pk) {
+    prefix = (bits_done == 0) ? pk.bin : ((prefix << 8) | pk.bin);
+    need -= (int)pk.above;
+    ties_before = pk.before;
+    ties_mine = pk.mine;
   };
   __syncthreads();                                  // the stream's counts of the most significant digit are complete
   LV_STAMP(2);
@@ -387,8 +398,8 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
         count_digit(s_hist, prefix, 8 * (NP - 1 - pass));
         __syncthreads();
       }
-      pick_bin(s_hist[tid], 0u, s_hist[tid], need);
-      take_pick(pass);
+      const Pick pk = pick_bin(s_hist[tid], 0u, s_hist[tid], need);
+      take_pick(pass, pk);
     }
   } else {
 #pragma unroll
@@ -399,13 +410,16 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
         __syncthreads();
         count_digit(s_hist, prefix, 8 * (NP - 1 - pass));
         __syncthreads();
+        if (pass == 1) LV_STAMP(5);     // second histogram built
       }
       lv_store(slot + pass * 256 + tid, s_hist[tid], tag);
       if (pass == 0 && tid < 2) lv_store(slot + kLvMaxPasses * 256 + tid, __float_as_uint(tid == 0 ? m_s : l_s), tag);
       unsigned tot, before;
       gather_bins([&](int) { return pass; }, tag, tot, before, pass == 0);
-      pick_bin(tot, before, s_hist[tid], need);
-      take_pick(pass);
+      if (pass == 0) LV_STAMP(3);       // first histograms of every split read
+      if (pass == 1) LV_STAMP(6);       // second histograms read
+      const Pick pk = pick_bin(tot, before, s_hist[tid], need);
+      take_pick(pass, pk);
       if (pass == 0) fold_max_sum();
     }
   }

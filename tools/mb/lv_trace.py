@@ -29,4 +29,5 @@ for it in range(4):
     print(f"run {it}: {S} splits of head 0; cycles since the first split's start")
     for s_ in range(S):
         row = t[s_]
-        print("  split %d: " % s_ + "  ".join(f"{names[i]} {int(row[i]) - t0}" for i in range(13) if names[i] != "-" and int(row[i]) > 0))
+        base = int(row[0])           # (every XCD has its own counter: a split's stamps are relative to ITS start)
+        print("  split %d: " % s_ + "  ".join(f"{names[i]} {int(row[i]) - base}" for i in range(1, 13) if names[i] != "-" and int(row[i]) > 0))
