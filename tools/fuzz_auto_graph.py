@@ -26,6 +26,11 @@ for case in range(n):
         kw["head_keep"] = 6
     if rng.random() < 0.3:
         kw["pq_threshold"] = 0.05
+        if rng.random() < 0.6 and "importance_mode" not in kw:      # (round 5: the profiled planes — append inside the MSB pass)
+            kw["pq_profile"] = rng.choice([(4, 8), (8, 8), (6, 6)])
+    elif rng.random() < 0.25 and "importance_mode" not in kw:        # (round 5: local V pruning — append inside the launch; with the
+                                                                     #  cascade accumulation its step is not graph-capable by design)
+        kw["local_v_keep"] = rng.choice([0.3, 0.6])
     if rng.random() < 0.4:
         kw.update(fuse_qkv=True, native_gemv=True)
     # (horizons that keep the slab capacity of the eager run — capacities are rounded to 128 rows: the split-N layout follows the
