@@ -1110,7 +1110,7 @@ extern "C" int spatten_decode_set_team(int threads) {
   return prev;
 }
 
-static int auto_splits(int units, int d, int kv_len) {
+static int auto_splits(int units, int d, int kv_len, int elt = 2) {
   // one workgroup per CU (256 CUs): measured best at Llama-2-7B decode sizes — more splits shorten each
   // workgroup's stream but lengthen the merge (a memory round trip per batch of partials)
   int s = 256 / (units > 0 ? units : 1);
@@ -1124,6 +1124,11 @@ static int auto_splits(int units, int d, int kv_len) {
   // splits 12.4 us, 32 splits 10.9 (tools/probe_few_heads.py).  One round unless the rows are long enough to pay for more.
   const int cap_by_merge = std::max(16, ceil_div(kv_len, 256));
   if (env_s <= 0 && s > cap_by_merge) s = cap_by_merge;
+  // r05 (tools/mb/split_sweep.py, 2081 rows): whenever EIGHT splits still hold their chunk in one single-shot tile, eight beat every
+  // larger count — the merge folds up to 8 partials in one thread group (no LDS fold, no barrier) and a fuller tile costs nothing
+  // while every load is issued up front: 4 / 8 / 16 / 24 / 28 heads 9.30 / 9.56 / 10.09 / 11.29 / 12.11 -> 8.84 / 9.04 / 9.58 /
+  // 10.09 / 10.58 us (32 heads were at 8 already).  Longer rows (pipelined tiles) keep one workgroup per CU.
+  if (env_s <= 0 && elt == 2 && d != 256 && s > 8 && ceil_div(kv_len, 8) <= 10 * decode_group_rows(d)) s = 8;
   if (s < 1) s = 1;
   if (s > kDecodeMaxSplits) s = kDecodeMaxSplits;
   return s;
@@ -1321,7 +1326,7 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   // the length the splits are laid out for: the step's own, or a common layout length of a whole turn (the device-length
   // form is laid out for its bound, kv_len)
   const int lay = (!c.step && c.layout_len > c.kv_len && c.n_q == 1) ? c.layout_len : c.kv_len;
-  int S = c.n_splits > 0 ? c.n_splits : auto_splits(c.batch * n_active * c.n_q, c.head_dim, lay);
+  int S = c.n_splits > 0 ? c.n_splits : auto_splits(c.batch * n_active * c.n_q, c.head_dim, lay, c.dtype == SPATTEN_F32 ? 4 : 2);
   if (S > lay) S = lay;
   if (S > kDecodeMaxSplits) S = kDecodeMaxSplits;
   // balanced chunks: ceil(N / S) rows per split (rounded up to the 8 rows of a stash line), whatever N is
