@@ -168,7 +168,10 @@ template <int BITS, int W> __device__ inline void fma_piece(float (&o)[16], cons
   for (int t = 0; t < 16; ++t) o[t] = fmaf(wgt, field_f32<BITS, W>(w, t), o[t]);
 }
 
-template <typename T, int D, int KB, int VB, int PASS, bool DYN, int UP>
+// APP (round 5): the MSB pass that also appends the step's row — its own instantiation: carried as a run-time branch the path cost every
+// OTHER caller 0.8-1.0 us per pass (a branch around the new token's loads behind the first tile breaks the exact vmcnt the
+// pipelined tiles rely on: same-call A/B, (4,8) 15.5 vs 14.65 us).
+template <typename T, int D, int KB, int VB, int PASS, bool DYN, int UP, bool APP = false>
 __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams<T> p) {
   constexpr int LPR = D / 16;                    // lanes per row: lane c owns the row's piece c (16 elements)
   constexpr int RPI = kPqvThreads / LPR;         // rows per row-group
@@ -246,9 +249,9 @@ __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams
   // APPEND (round 5, MSB pass): every split's first thread-row requests the new token's K / V pieces and the rotary row of its slot
   // behind the first tile (static addresses); the split that owns row N - 1 rotates, stores the cache rows, packs and stores the row
   // of every plane and scores it FROM ITS REGISTERS as one extra key (the tiles never read it; the refetch pass is another launch)
-  const bool app = PASS == 1 && p.k_new != nullptr;
+  constexpr bool app = APP && PASS == 1;
   typename V8::raw nk_raw[2], nv_raw[2], nr_raw[2];
-  if (app && tid < LPR) {
+  if constexpr (app) {             // (EVERY thread, unconditionally: no control flow between the tile's loads and their first wait)
     const T* kp = p.k_new + b * p.new_sb + hkv * p.new_sh;
     const T* vp = p.v_new + b * p.new_sb + hkv * p.new_sh;
     nk_raw[0] = V8::ldg(kp + 8 * c); nk_raw[1] = V8::ldg(kp + HALF + 8 * c);
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams
 #pragma unroll
   for (int i = 0; i < 16; ++i) o16[i] = 0.f;
 
-  if constexpr (PASS == 1) {
+  if constexpr (app) {
     if (owns_new && tid < LPR) {
       float xlo[8], xhi[8], cc[8], ss[8], ylo[8], yhi[8], va[8], vb[8];
       V8::unpack(nk_raw[0], xlo);
@@ -620,6 +623,7 @@ template <typename K> static int resident_capacity(K kernel) {
 
 template <typename T, int D, int KB, int VB>
 static int launch_pqv(PqvParams<T>& p, int n_active, bool dyn, bool msb_only, int env_poll, hipStream_t st) {
+  const bool app = p.k_new != nullptr;
   constexpr int UP = SPATTEN_PQV_UP;
   const dim3 grid((unsigned)p.S, (unsigned)n_active, (unsigned)p.B), blk(kPqvThreads);
   // (the pass-1 and pass-2 kernels of a profile have different register footprints: the smaller capacity decides)
@@ -629,10 +633,12 @@ static int launch_pqv(PqvParams<T>& p, int n_active, bool dyn, bool msb_only, in
                                       resident_capacity(pqv_decode_kernel<T, D, KB, VB, 2, true, UP>));
   p.poll_merge = (env_poll != 0 && p.S > 1 && (long long)p.S * n_active * p.B <= (dyn ? cap_dyn : cap_static)) ? 1 : 0;
   if (dyn) {
-    hipLaunchKernelGGL((pqv_decode_kernel<T, D, KB, VB, 1, true, UP>), grid, blk, 0, st, p);
+    if (app) hipLaunchKernelGGL((pqv_decode_kernel<T, D, KB, VB, 1, true, UP, true>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((pqv_decode_kernel<T, D, KB, VB, 1, true, UP>), grid, blk, 0, st, p);
     if (!msb_only) hipLaunchKernelGGL((pqv_decode_kernel<T, D, KB, VB, 2, true, UP>), grid, blk, 0, st, p);
   } else {
-    hipLaunchKernelGGL((pqv_decode_kernel<T, D, KB, VB, 1, false, UP>), grid, blk, 0, st, p);
+    if (app) hipLaunchKernelGGL((pqv_decode_kernel<T, D, KB, VB, 1, false, UP, true>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((pqv_decode_kernel<T, D, KB, VB, 1, false, UP>), grid, blk, 0, st, p);
     if (!msb_only) hipLaunchKernelGGL((pqv_decode_kernel<T, D, KB, VB, 2, false, UP>), grid, blk, 0, st, p);
   }
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
