@@ -1489,7 +1489,10 @@ static inline bool flash_pair(int batch, int heads, int q_len, int causal) {
   static int env = -1;
   if (env < 0) { const char* e = getenv("SPATTEN_PREFILL_PAIR"); env = e ? atoi(e) : 2; }   // 0 = off, 1 = forced (A/B), 2 = auto
   if (!causal || q_len % 256 != 0 || q_len < 512 || env == 0) return false;
-  return env == 1 || (long long)batch * heads * (q_len / 256) <= 256;
+  // (r05: also when the 256-row blocks are exactly TWO per CU — q = N = 4096 at 32 heads 235.6 -> 226.2 us, 4096 on 8192 525 -> 519;
+  //  320 workgroups (2560 tokens) 103 -> 122, 640 / 768 / 1024: slower — the dispatch order balances those by itself)
+  const long long items = (long long)batch * heads * (q_len / 256);
+  return env == 1 || items <= 256 || items == 512;
 }
 static inline size_t flash_partial_bytes(int batch, int heads, int head_dim, int q_len, int ks) {
   if (ks <= 1) return 0;
