@@ -499,7 +499,10 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
       const T* vp = vbase + (int64_t)(lo + li) * D;
       tl.v_lo[u] = V8::ldg_stream(vp + 8 * c);
       tl.v_hi[u] = V8::ldg_stream(vp + HALF + 8 * c);
-      tl.pj[u] = (i < n_kept) ? __expf(OKey<T>::to((uint32_t)skey[li]) - mu_g) * rl_g : 0.f;
+      // (computed for every lane — li is always a valid entry — and selected: under the condition the compiler branches around the
+      //  LDS read + exponential, between the value loads, and the loop's vmcnt waits degrade to a full drain per iteration)
+      const float pe = __expf(OKey<T>::to((uint32_t)skey[li]) - mu_g) * rl_g;
+      tl.pj[u] = (i < n_kept) ? pe : 0.f;
     }
   };
   float olo[8], ohi[8];
