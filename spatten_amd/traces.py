@@ -98,7 +98,9 @@ def read_trace(path: str) -> CascadeSchedule:
     iters: Dict[int, Dict[int, LayerStep]] = {}
     with open(path, newline="") as f:
         rd = csv.reader(f)
-        header = next(rd)
+        header = next(rd, None)
+        if header is None:
+            raise ValueError(f"{path}: empty file, not a SpAtten workload trace")
         if [h.strip() for h in header] != COLUMNS:
             raise ValueError(f"{path}: not a SpAtten workload trace (header {header[:3]}...)")
         for row in rd:

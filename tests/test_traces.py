@@ -56,3 +56,12 @@ def test_rejects_other_csv(tmp_path):
     p.write_text("a,b,c\n1,2,3\n")
     with pytest.raises(ValueError):
         read_trace(str(p))
+
+
+def test_an_empty_trace_file_is_refused_with_a_clear_error(tmp_path):
+    import pytest
+    from spatten_amd import traces
+    f = tmp_path / "empty.csv"
+    f.write_text("")
+    with pytest.raises(ValueError, match="empty"):
+        traces.read_trace(str(f))
