@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SPATTEN_ABI_VERSION 4
+#define SPATTEN_ABI_VERSION 5
 
 typedef enum {
   SPATTEN_F32 = 0,
@@ -194,6 +194,57 @@ size_t spatten_decode_qkv_exchange_bytes(int batch, int heads, int head_dim);
  * SPATTEN_ERR_INVALID).  SPATTEN_DECODE_TEAM=256 in the environment sets the initial value. */
 int spatten_decode_set_team(int threads);
 int spatten_decode_qkv_supported(int dtype, int batch, int heads, int kv_heads, int head_dim, int kv_len_layout);
+
+/* ------------------------------------------------------------------------------------------------
+ * The chained decode launch (ABI 5, round 6): the attention step of ALL layers of one token — what the caller's per-layer
+ * loop issues as n_layers spatten_attn_decode_args launches (modify_llama.py:86-147 once per LlamaAttention module) — in ONE
+ * launch.  At batch 1 a layer's launch is latency-bound; a layer's K/V rows depend on nothing upstream, only its query and
+ * appended row do (q_l is a function of out_{l-1}, modify_llama.py:72-92).  One workgroup per (split, head) WALKS the layers:
+ * at the top of a layer's step its waves request their rows of the K/V tile at once; wave 0 alone first waits for the
+ * completion words of the previous layer (one per (batch, head), stored by that unit's merger behind its `out` row), fetches
+ * q / k_new / v_new into LDS for the others, and only then requests its own rows (a wave's loads return in order: a poll behind
+ * the tile would see the flag a whole stream late).  The kernel boundary, the first-byte latency and the ramp of layer l + 1's
+ * stream thereby run under layer l's reduce / publish / merge tail, while the layer dependency of the real model is kept.
+ * Results (`out`, stash, appended rows) are bit-identical to the per-layer launches of the same shape.
+ *   layers          DEVICE table [n_layers] of spatten_chain_layer_t (read by the kernel: a captured graph needs no argument
+ *                   patching; the caller rewrites entries between tokens with ordinary stream operations if pointers move)
+ *   per layer       k_cache (optional) / kr_cache / v_cache [B,H,cap,d] (strides kv_sb, kv_sh: shared by all layers),
+ *                   q [B,H,d] DENSE, k_new / v_new [B,H,d] (strides new_sb, new_sh; read when `append` != 0), out [B,H*d]
+ *                   (stride out_sb), scores optional stash [B,H,>=kv_len] (strides sc_sb, sc_sh), head_ids optional int32
+ *                   [n_active] (head pruning / a head-parallel rank's survivors; NULL = heads 0..n_active-1), n_active heads
+ *                   launched in this layer (0: the layer is skipped, the dependency passes through it)
+ *   kv_len, pos_q, kv_len_layout, step_state, n_splits   as in spatten_decode_args_t — the same for every layer of the token
+ *   max_active      grid columns: max over the layers of n_active (0 = heads)
+ *   depth           lanes of workgroups, 1..4 (0 = 1): lane p serves layers p, p + depth, ... (more than one lane only for
+ *                   the pipelined tiles of long chunks — the single-shot form needs the whole register file of a CU)
+ *   flags           reserved (0).  A completion word is ordered after its `out` row only for observers that wait for the
+ *                   kernel boundary — the launch's own layers need nothing more: they read q, not out (the word stands where a
+ *                   fused producer of q would publish its result).
+ *   workspace       spatten_decode_chain_workspace_bytes(n_layers, batch, heads, head_dim, workspace_splits) bytes,
+ *                   zero-filled once, one per stream; spatten_decode_workspace_status() reports a timed-out wait
+ * MHA, bf16 / f16, head_dim 128, the lean step (no mask / position tensor / cascade accumulation); every workgroup polls, so the
+ * whole grid (splits x max_active x batch x depth) must be co-resident: SPATTEN_ERR_UNSUPPORTED otherwise (launch the layers
+ * one by one), also under spatten_decode_set_team(256).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct spatten_chain_layer {
+  void* k_cache; void* kr_cache; void* v_cache;
+  const void* q; const void* k_new; const void* v_new;
+  void* out; void* scores;
+  const int32_t* head_ids; int32_t n_active; int32_t pad_;
+} spatten_chain_layer_t;                 /* 80 bytes */
+typedef struct spatten_chain_args {
+  uint32_t struct_size;                  /* sizeof(spatten_chain_args_t) of the caller */
+  int32_t dtype;
+  const void* layers;                    /* DEVICE pointer: spatten_chain_layer_t [n_layers] */
+  int32_t n_layers, depth;
+  int64_t kv_sb, kv_sh, new_sb, new_sh, out_sb, sc_sb, sc_sh;
+  const void* cos; const void* sin; int32_t table_rows; int32_t append;
+  void* workspace; int32_t workspace_splits;
+  int32_t batch, heads, head_dim, kv_len, pos_q, n_splits, max_active, flags, kv_len_layout;
+  const void* step_state;
+} spatten_chain_args_t;
+size_t spatten_decode_chain_workspace_bytes(int layers, int batch, int heads, int head_dim, int max_splits);
+int spatten_attn_decode_chain(const spatten_chain_args_t* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Device-resident step state (ABI 3) — what makes a decode step capturable ONCE and replayable for every token of a

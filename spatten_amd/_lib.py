@@ -9,7 +9,7 @@ import ctypes
 import os
 from ctypes import c_char_p, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p, POINTER, c_float
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 DECODE_MAX_SPLITS = 64
 
 
@@ -44,6 +44,31 @@ class DecodeArgs(ctypes.Structure):
         ("qkv_x", c_void_p), ("qkv_weight", c_void_p), ("qkv_w_sn", c_int64), ("qkv_bias", c_void_p),
         ("qkv_exchange", c_void_p), ("qkv_hidden", c_int32), ("pad5_", c_int32),
     ]
+
+class ChainLayer(ctypes.Structure):
+    """``spatten_chain_layer_t`` (include/spatten.h, ABI 5): one entry of the DEVICE table of a chained decode launch."""
+    _fields_ = [
+        ("k_cache", c_void_p), ("kr_cache", c_void_p), ("v_cache", c_void_p),
+        ("q", c_void_p), ("k_new", c_void_p), ("v_new", c_void_p),
+        ("out", c_void_p), ("scores", c_void_p),
+        ("head_ids", c_void_p), ("n_active", c_int32), ("pad_", c_int32),
+    ]
+
+
+class ChainArgs(ctypes.Structure):
+    """``spatten_chain_args_t`` (include/spatten.h, ABI 5): the argument block of ``spatten_attn_decode_chain``."""
+    _fields_ = [
+        ("struct_size", c_uint32), ("dtype", c_int32),
+        ("layers", c_void_p), ("n_layers", c_int32), ("depth", c_int32),
+        ("kv_sb", c_int64), ("kv_sh", c_int64), ("new_sb", c_int64), ("new_sh", c_int64), ("out_sb", c_int64),
+        ("sc_sb", c_int64), ("sc_sh", c_int64),
+        ("cos", c_void_p), ("sin", c_void_p), ("table_rows", c_int32), ("append", c_int32),
+        ("workspace", c_void_p), ("workspace_splits", c_int32),
+        ("batch", c_int32), ("heads", c_int32), ("head_dim", c_int32), ("kv_len", c_int32), ("pos_q", c_int32),
+        ("n_splits", c_int32), ("max_active", c_int32), ("flags", c_int32), ("kv_len_layout", c_int32),
+        ("step_state", c_void_p),
+    ]
+
 
 class PQPlanesDesc(ctypes.Structure):
     """``spatten_pq_planes_t`` (include/spatten.h, ABI 4): profiled key planes + the quantised value plane."""
@@ -81,6 +106,8 @@ class PQDecodeArgs(ctypes.Structure):
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libspatten_hip.so")
+if os.environ.get("SPATTEN_LIB"):          # developer A/B: a variant build of the library (tools/mb/build_variant.sh)
+    LIB_PATH = os.environ["SPATTEN_LIB"]
 
 _lib = None
 
@@ -109,6 +136,10 @@ def _declare(lib):
         i, i, i, i, i, i, i, p]
     lib.spatten_attn_decode_args.restype = c_int
     lib.spatten_attn_decode_args.argtypes = [POINTER(DecodeArgs), p]
+    lib.spatten_decode_chain_workspace_bytes.restype = c_size_t
+    lib.spatten_decode_chain_workspace_bytes.argtypes = [i, i, i, i, i]
+    lib.spatten_attn_decode_chain.restype = c_int
+    lib.spatten_attn_decode_chain.argtypes = [POINTER(ChainArgs), p]
     lib.spatten_decode_qkv_exchange_bytes.restype = c_size_t
     lib.spatten_decode_qkv_exchange_bytes.argtypes = [i, i, i]
     lib.spatten_decode_qkv_supported.restype = c_int

@@ -270,6 +270,96 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: Opti
     return out
 
 
+class DecodeChain:
+    """The attention step of ALL layers of one decode token as ONE launch (``spatten_attn_decode_chain``, include/spatten.h
+    ABI 5): what the caller's layer loop issues as one ``attn_decode`` per LlamaAttention module (modify_llama.py:86-147).
+
+    Built once from the per-layer tensors (their pointers go into a DEVICE table, so a captured graph replays without
+    patching); every layer shares the plane strides, ``kv_len`` / ``pos_q`` (or the device-resident ``step``) and the dtype.
+    ``q`` [B,H,d] dense, ``k_new`` / ``v_new`` [B,H,d] or None (no append), planes [B,H,cap,d], ``out`` [B,H*d], ``scores``
+    [B,H,>=kv_len] or None, ``head_ids`` per layer: int32 tensor (possibly empty) or None.  MHA, bf16 / f16, d = 128."""
+
+    def __init__(self, q, k_cache, kr_cache, v_cache, out, k_new=None, v_new=None, scores=None, head_ids=None,
+                 max_splits: int = 16, depth: int = 0):
+        L = len(q)
+        lib = _lib.load()
+        v0 = v_cache[0]
+        B, H, cap, d = v0.shape
+        self.L, self.B, self.H, self.d, self.cap = L, B, H, d, cap
+        self.dtype = _dt(v0)
+        self.append = k_new is not None
+        tab = (_lib.ChainLayer * L)()
+        self.max_active = 0
+        for l in range(L):
+            ts = [q[l], kr_cache[l], v_cache[l], out[l]] + ([k_cache[l]] if k_cache is not None else []) + \
+                 ([k_new[l], v_new[l]] if self.append else []) + ([scores[l]] if scores is not None else [])
+            _dev(*ts)
+            if v_cache[l].shape != v0.shape or v_cache[l].stride() != v0.stride() or kr_cache[l].stride() != v0.stride() \
+                    or v0.stride(3) != 1 or v0.stride(2) != d or not q[l].is_contiguous() or q[l].shape != (B, H, d) \
+                    or (k_cache is not None and k_cache[l].stride() != v0.stride()) or out[l].stride(-1) != 1 \
+                    or out[l].stride(0) != out[0].stride(0):
+                raise ValueError("chained decode: every layer's planes share shape and strides (rows contiguous), q dense [B,H,d]")
+            if self.append and (k_new[l].shape != (B, H, d) or k_new[l].stride(2) != 1 or k_new[l].stride() != k_new[0].stride()
+                                or v_new[l].stride() != k_new[0].stride()):
+                raise ValueError("chained decode: k_new / v_new [B,H,d] with common strides")
+            if scores is not None and (scores[l].stride(2) != 1 or scores[l].stride() != scores[0].stride()):
+                raise ValueError("chained decode: stash rows contiguous, common strides")
+            e = tab[l]
+            e.k_cache = k_cache[l].data_ptr() if k_cache is not None else None
+            e.kr_cache, e.v_cache = kr_cache[l].data_ptr(), v_cache[l].data_ptr()
+            e.q = q[l].data_ptr()
+            e.k_new = k_new[l].data_ptr() if self.append else None
+            e.v_new = v_new[l].data_ptr() if self.append else None
+            e.out = out[l].data_ptr()
+            e.scores = scores[l].data_ptr() if scores is not None else None
+            ids = None if head_ids is None else head_ids[l]
+            if ids is not None:
+                if ids.dtype != torch.int32 or not ids.is_cuda or ids.dim() != 1:
+                    raise TypeError("head_ids: int32 device vectors")
+                e.head_ids = ids.data_ptr() if ids.numel() else None
+                e.n_active = int(ids.numel())
+            else:
+                e.head_ids, e.n_active = None, H
+            self.max_active = max(self.max_active, e.n_active)
+        raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8)
+        self.table = raw.to(v0.device)
+        self.keep = (q, k_cache, kr_cache, v_cache, out, k_new, v_new, scores, head_ids)      # the table holds raw pointers
+        self.kv_sb, self.kv_sh = v0.stride(0), v0.stride(1)
+        self.new_sb, self.new_sh = (k_new[0].stride(0), k_new[0].stride(1)) if self.append else (0, 0)
+        self.out_sb = out[0].stride(0)
+        self.sc_sb, self.sc_sh = (scores[0].stride(0), scores[0].stride(1)) if scores is not None else (0, 0)
+        self.max_splits, self.depth = max_splits, depth
+        self.ws = torch.zeros(lib.spatten_decode_chain_workspace_bytes(L, B, H, d, max_splits), dtype=torch.uint8, device=v0.device)
+
+    def check(self):
+        """Synchronises the current stream; raises SpattenDeviceTimeout if a wait of an earlier launch gave up."""
+        _lib.check(_lib.load().spatten_decode_workspace_status(self.ws.data_ptr(), _stream()), "decode chain workspace")
+
+    def __call__(self, kv_len: int, cos: torch.Tensor, sin: torch.Tensor, pos_q: int, n_splits: int = 0,
+                 step: Optional["StepState"] = None, layout: int = 0):
+        """One token: every layer's step at cache length ``kv_len`` (counting the appended row) / query position ``pos_q``.
+        Raises NotImplementedError where the chained launch does not apply (launch the layers one by one)."""
+        _dev(cos, sin)
+        if kv_len > self.cap or (step is None and max(kv_len, pos_q + 1) > cos.shape[0]) or cos.shape[1] * 2 != self.d or layout > self.cap:
+            raise ValueError("kv_len exceeds cache capacity or rotary table")
+        a = _lib.ChainArgs()
+        a.struct_size = ctypes.sizeof(_lib.ChainArgs)
+        a.dtype = self.dtype
+        a.layers, a.n_layers, a.depth = self.table.data_ptr(), self.L, self.depth
+        a.kv_sb, a.kv_sh, a.new_sb, a.new_sh, a.out_sb = self.kv_sb, self.kv_sh, self.new_sb, self.new_sh, self.out_sb
+        a.sc_sb, a.sc_sh = self.sc_sb, self.sc_sh
+        a.cos, a.sin, a.table_rows, a.append = cos.data_ptr(), sin.data_ptr(), cos.shape[0], 1 if self.append else 0
+        a.workspace, a.workspace_splits = self.ws.data_ptr(), self.max_splits
+        a.batch, a.heads, a.head_dim, a.kv_len, a.pos_q = self.B, self.H, self.d, int(kv_len), int(pos_q)
+        a.n_splits, a.max_active, a.flags, a.kv_len_layout = int(n_splits), self.max_active, 0, int(layout)
+        a.step_state = None if step is None else step.data_ptr()
+        _pin(self)
+        rc = _lib.load().spatten_attn_decode_chain(ctypes.byref(a), _stream())
+        if rc == -2:
+            raise NotImplementedError("the chained decode launch does not cover this shape (see include/spatten.h)")
+        _lib.check(rc, "spatten_attn_decode_chain")
+
+
 def attn_decode_qkv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], heads: int, k_cache: torch.Tensor,
                     kr_cache: torch.Tensor, v_cache: torch.Tensor, kv_len: int, cos: torch.Tensor, sin: torch.Tensor, pos_q: int,
                     scores: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, n_splits: int = 0,

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, f"declared in include/spatten.h but not exported: {missing}"
     lib.spatten_abi_version.restype = ctypes.c_int
-    assert lib.spatten_abi_version() == 4
+    assert lib.spatten_abi_version() == 5
     lib.spatten_status_string.restype = ctypes.c_char_p
     assert lib.spatten_status_string(-3).decode().startswith("top-k window")
     lib.spatten_decode_workspace_bytes.restype = ctypes.c_size_t
@@ -53,6 +53,25 @@ def test_decode_args_struct_matches_the_header():
         nums = [int(x) for x in subprocess.check_output([exe]).split()]
     assert nums[0] == ctypes.sizeof(DecodeArgs)
     assert nums[1:] == [getattr(DecodeArgs, f).offset for f in fields]
+
+
+def test_chain_structs_match_the_header():
+    """ABI 5: the ctypes mirrors of spatten_chain_layer_t / spatten_chain_args_t have the C compiler's size and offsets."""
+    import subprocess
+    import tempfile
+    from spatten_amd._lib import ChainArgs, ChainLayer
+    for cls, cname in ((ChainLayer, "spatten_chain_layer_t"), (ChainArgs, "spatten_chain_args_t")):
+        fields = [f[0] for f in cls._fields_]
+        prog = '#include <stdio.h>\n#include <stddef.h>\n#include "spatten.h"\nint main(){printf("%zu", sizeof(' + cname + '));' + \
+            "".join(f'printf(" %zu", offsetof({cname}, {f}));' for f in fields) + "return 0;}"
+        with tempfile.TemporaryDirectory() as td:
+            src, exe = os.path.join(td, "s.c"), os.path.join(td, "s")
+            open(src, "w").write(prog)
+            subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+            nums = [int(x) for x in subprocess.check_output([exe]).split()]
+        assert nums[0] == ctypes.sizeof(cls), cname
+        assert nums[1:] == [getattr(cls, f).offset for f in fields], cname
+    assert ctypes.sizeof(ChainLayer) == 80
 
 
 def test_ctypes_layer_declares_every_symbol():
