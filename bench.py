@@ -70,10 +70,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1.  weak (default): B = N sequences, every rank holds H/N heads of each (the 1-GPU KV bytes per "
-                         "rank: per-GPU work fixed).  strong (BASELINE.json configs[2] / [4]): ONE sequence, H/N heads per "
-                         "rank, 4 resp. 5 heads per GPU at N = 8 — latency-floor-bound at the c2 shape")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N > 1.  strong (default; BASELINE.json configs[1] / [2] / [4] and SURVEY 8e: ONE sequence, rank r owns "
+                         "heads [r H/N, (r+1) H/N) — 4 resp. 5 heads per GPU at N = 8): the same workload as the N = 1 line, "
+                         "latency-floor-bound at the c2 shape.  weak: B = N sequences, every rank holds H/N heads of each (the "
+                         "1-GPU KV bytes per rank: per-GPU work fixed) — a batch, not the named config; labelled as such")
+    ap.add_argument("--launch", choices=["auto", "chained", "per-layer"], default="auto",
+                    help="how a token's 32 (40) layer-steps are launched: 'chained' = ONE launch per token "
+                         "(spatten_attn_decode_chain, round 6: a workgroup walks the layers, a layer's K/V tile is requested before "
+                         "the previous layer's completion is waited for; bit-identical results), 'per-layer' = one launch per "
+                         "layer.  auto: chained where it applies (16-bit keys, no collective between the layers), and the "
+                         "per-layer number is measured beside it")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="c2 (default) = BASELINE.json's headline; c3 = + 25 %% head prune (configs[2]); c5 = Llama-2-13B geometry, "
                          "16384 -> 8192 rows, head prune 30 of 40, progressive quantisation k8v8 (configs[4]).  All valid at --gpus 1..8")
@@ -231,15 +238,21 @@ def cpu_baseline_child(L, new_len, lo, hi):
             legs[threads] = {"value": round(mid[0], 4), "ms_per_layer_decode": round(mid[1] * 1e3, 3), "ms_per_layer_prune": round(mid[2] * 1e3, 3),
                              "repetitions": [round(r[0], 4) for r in reps], "spread": round((reps[-1][0] - reps[0][0]) / mid[0], 4),
                              "n_decode": sum(r[3] for r in reps), "n_prune": sum(r[4] for r in reps)}
+    # The REPORTED baseline (round 6): the torch mirror — the reference's own op sequence
+    # (kv_cache_token_pruning.py:42-96 + modify_llama.py:86-147) — on ALL physical cores of one socket, pinned; median of three
+    # repetitions, their spread beside it.  (r05 reported the C port on one thread: the most repeatable leg, but 35x slower than
+    # the socket runs the reference's ops.)  Every other leg stays on the line: by_threads, best_of_thread_counts, one_thread.
     best = max(counts, key=lambda c_: legs[c_]["value"])
-    out = {"value": legs[best]["value"], "unit": "tokens/s", "cores": best, "kind": "port",
-           "sample": f"{legs[best]['n_decode']} decode-attention layer steps at kv_len {n} + {legs[best]['n_prune']} one-layer prune events "
-                     f"({CTX} -> {new_len}) in 3 repetitions (median of the repetitions' medians), torch-CPU mirror of the reference's op "
-                     f"sequence (oracle/torch_mirror.py), extrapolated to {L} layers per token and one prune per {TURN} tokens; process "
-                     f"pinned to {ncpu} physical cores of one socket, OMP_PROC_BIND=close; best of the thread counts {counts}",
-           "ms_per_layer_decode": legs[best]["ms_per_layer_decode"], "ms_per_layer_prune": legs[best]["ms_per_layer_prune"],
-           "spread": legs[best]["spread"],
-           "by_threads": {str(c_): legs[c_] for c_ in counts}, "one_thread": legs[1],
+    full = legs[ncpu]
+    out = {"value": full["value"], "unit": "tokens/s", "cores": ncpu, "kind": "port",
+           "sample": f"{full['n_decode']} decode-attention layer steps at kv_len {n} + {full['n_prune']} one-layer prune events "
+                     f"({CTX} -> {new_len}) in 3 repetitions (median of the repetitions' medians; spread = (max - min) / median), torch-CPU "
+                     f"mirror of the reference's op sequence (oracle/torch_mirror.py), extrapolated to {L} layers per token and one prune "
+                     f"per {TURN} tokens; process pinned to the {ncpu} physical cores of one socket, {ncpu} threads, OMP_PROC_BIND=close",
+           "ms_per_layer_decode": full["ms_per_layer_decode"], "ms_per_layer_prune": full["ms_per_layer_prune"],
+           "spread": full["spread"], "repetitions": full["repetitions"],
+           "best_of_thread_counts": {"threads": best, "value": legs[best]["value"], "spread": legs[best]["spread"]},
+           "by_threads": {str(c_): legs[c_] for c_ in counts}, "one_thread": {"torch_mirror": legs[1]},
            "pinned_cpus": ncpu, "omp_proc_bind": os.environ.get("OMP_PROC_BIND"), "omp_places": os.environ.get("OMP_PLACES")}
     try:      # the C port beside it (-march=native build on this host when gcc is there)
         co.load(native=True)
@@ -268,20 +281,7 @@ def cpu_baseline_child(L, new_len, lo, hi):
                                    "spread": round((reps[-1][0] - reps[0][0]) / mid[0], 4),
                                    "n_decode": sum(r[3] for r in reps), "n_prune": sum(r[4] for r in reps)}
         out["c_port_by_threads"] = cport
-        # The REPORTED baseline (round 5): the C port on ONE pinned thread.  On the driver's shared hosts the
-        # multi-threaded legs swing with the other tenants (torch mirror, best thread count: 12 / 2.6 / 41 / 5.1 / 25 tokens/s over five
-        # hosts; C port on 32 threads 17.6 / 20.7) while this one repeats to < 1 % (0.983 / 0.987) — a baseline has to be the same
-        # number twice.  The faster legs stay on the line beside it.
-        one = cport["1"]
-        out.update({"torch_mirror_best": {"value": out["value"], "cores": out["cores"], "spread": out["spread"], "sample": out["sample"]},
-                    "value": one["value"], "cores": 1, "spread": one["spread"],
-                    "ms_per_layer_decode": one["ms_per_layer_decode"], "ms_per_layer_prune": one["ms_per_layer_prune"],
-                    "sample": f"{one['n_decode']} decode-attention layer steps at kv_len {n} + {one['n_prune']} one-layer prune events ({CTX} -> "
-                              f"{new_len}: window top-k + K and V compaction) in 3 repetitions (median of the repetitions' medians), the C "
-                              f"restatement of the reference's op sequence (oracle/oracle.c, -march=native, pinned to one physical core), "
-                              f"extrapolated to {L} layers per token and one prune per {TURN} tokens; the multi-threaded legs "
-                              f"(c_port_by_threads, by_threads = the torch-CPU mirror) depend on the host's other tenants and are "
-                              f"reported beside it"})
+        out["one_thread"]["c_port"] = cport["1"]       # (oracle/oracle.c, -march=native: repeats to < 1 % across hosts)
     except Exception as e:
         out["c_port_error"] = f"{type(e).__name__}: {e}"
     print("CPU_BASELINE_JSON " + json.dumps(out), flush=True)
@@ -739,7 +739,31 @@ def main():
             ops.attn_decode_pqv(q[l], planes[l], n, cos, sin, n - 1, cfg["pq_threshold"], out=outs2[par][l], need_lsb=need[l],
                                 scores=stash[l], head_ids=ids, workspace=ws, append=(kn[l], vn[l], Kd[l], Krd[l], Vd[l]))
 
+    # ---- round 6: the token's layer-steps as ONE chained launch (ops.DecodeChain) — where no collective sits between layers ----
+    chains = None
+    launch_mode = ["per-layer"]                # what decode_token issues (a list: flipped for the side-by-side measurement)
+    # (a head-parallel run with the dependency-faithful exchange has an all-gather BETWEEN the layers: per-layer launches)
+    want_chain = args.launch != "per-layer" and pq is None and not (dist_on and args.gather == "native" and args.exchange == "per-layer")
+    if want_chain:
+        try:
+            chains = [ops.DecodeChain(q, Kd, Krd, Vd, outs2[par], k_new=kn, v_new=vn, scores=stash,
+                                      head_ids=hid if cfg["head_keep"] else None) for par in range(2)]
+            launch_mode[0] = "chained"
+        except Exception as e:      # noqa: BLE001 - the per-layer launches are always there
+            if rank == 0:
+                print(f"chained launch unavailable ({type(e).__name__}: {e}); per-layer launches", file=sys.stderr)
+            chains = None
+    if args.launch == "chained" and chains is None and rank == 0:
+        print("--launch chained: not applicable here (progressive-quant planes, or a collective between the layers); per-layer launches",
+              file=sys.stderr)
+
     def decode_token(n, par=0):
+        if launch_mode[0] == "chained":
+            try:
+                chains[par](n, cos, sin, n - 1)
+                return
+            except NotImplementedError:
+                launch_mode[0] = "per-layer"
         for l in range(L):
             layer_step(l, n, par)
 
@@ -828,21 +852,34 @@ def main():
 
     # ---- HIP graphs: one per position in the turn (kv_len is a launch parameter) -------------------------
     graphs = None
+    graphs_per_layer = None                    # the same slots with one launch per layer (when `graphs` holds the chained form)
     use_graph = not args.no_graph
+
+    def capture_slots():
+        for s in range(2):
+            run_slot(s)
+        torch.cuda.synchronize()
+        gs = []
+        for slot in range(TURN):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                run_slot(slot)
+            gs.append(g)
+        for g in gs[:2]:                       # a captured collective must also replay
+            g.replay()
+        torch.cuda.synchronize()
+        return gs
     if use_graph:
         try:
-            for s in range(2):
-                run_slot(s)
-            torch.cuda.synchronize()
-            graphs = []
-            for slot in range(TURN):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    run_slot(slot)
-                graphs.append(g)
-            for g in graphs[:2]:               # a captured collective must also replay
-                g.replay()
-            torch.cuda.synchronize()
+            graphs = capture_slots()
+            if launch_mode[0] == "chained":
+                for ch in chains:
+                    ch.check()
+                launch_mode[0] = "per-layer"
+                try:
+                    graphs_per_layer = capture_slots()
+                finally:
+                    launch_mode[0] = "chained"
         except Exception as e:  # e.g. a collective that cannot be captured: fall back to eager launches
             if rank == 0:
                 print(f"graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
@@ -854,15 +891,16 @@ def main():
     # slot of step i: the warm-up ENDS at a turn boundary, so the timed region starts with slot 0 (the prune event)
     base_slot = (-args.warmup) % TURN
 
-    def run_steps(n, first=0):
+    def run_steps(n, first=0, gs=None):
+        gs = graphs if gs is None else gs
         for i in range(first, first + n):
             slot = (base_slot + i) % TURN
             par = slot & 1
             if dist_on and not native and pending[par] is not None:
                 pending[par].wait()            # the gather that still reads this parity's outputs (token i-2)
                 pending[par] = None
-            if graphs is not None:
-                graphs[slot].replay()
+            if gs is not None:
+                gs[slot].replay()
             else:
                 run_slot(slot)
             if dist_on and not native:
@@ -875,6 +913,12 @@ def main():
     run_steps(args.warmup)
     elapsed = time_region(lambda n: run_steps(n, args.warmup), args.steps, dist_on)
     tokens_per_s = B * args.steps / elapsed
+    # the same K steps with one launch per layer (the r01-r05 form) beside the chained value
+    tokens_per_s_per_layer = None
+    if graphs_per_layer is not None:
+        run_steps(args.warmup, 0, graphs_per_layer)
+        el2 = time_region(lambda n: run_steps(n, args.warmup, graphs_per_layer), args.steps, dist_on)
+        tokens_per_s_per_layer = B * args.steps / el2
 
     # ---- what the exchange costs per token (round 4): the same decode-only slots replayed with and without the collectives,
     # as graphs, over the same number of tokens; and — native communicator — the OTHER schedule (flat / per-layer) beside the
@@ -947,8 +991,15 @@ def main():
                    "exchange": (args.exchange if native else args.gather) if dist_on else None,
                    "comm_us_per_token": None if not comm else comm.get("comm_us_per_token"),
                    "rccl_ranks": rccl_ranks if native else (world if dist_on else None),
-                   "launch": "hip-graph" if graphs is not None else "eager"},
+                   "launch": ("hip-graph" if graphs is not None else "eager") +
+                             (", chained: ONE launch per token (spatten_attn_decode_chain; a workgroup walks the layers, layer l+1's "
+                              "K/V tile requested before layer l's completion is waited for; bit-identical to the per-layer launches)"
+                              if launch_mode[0] == "chained" else ", one launch per layer")},
     }
+    if tokens_per_s_per_layer is not None:
+        result["per_layer_launch"] = {"tokens_per_s": round(tokens_per_s_per_layer, 2),
+                                      "chained_over_per_layer": round(tokens_per_s / tokens_per_s_per_layer, 3),
+                                      "note": "the same steps, same graphs-per-position, one launch per layer (the r01-r05 form)"}
 
     if rank == 0:
         # ---- roofline of the dominant kernel (decode attention, HBM-bound) -------------------------------
@@ -977,16 +1028,24 @@ def main():
                 algo_bytes = (B * h_act * n_avg * d * (pq[0] + pq[1]) / 8 + 2 * B * h_act * n_avg * 4 + 2 * B * h_act * d * 2
                               + B * h_act * n_avg * 2 + n_ref * n_avg * d / 2)
             gbs = algo_bytes / us / 1e3
-            # HBM traffic per launch: PMC counters collected in separate rocprofv3 --pmc passes (tools/pmc_decode.sh,
-            # FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md), committed under profiles/
+            chained_now = launch_mode[0] == "chained"
+            layers_per_launch = L if chained_now else 1          # the chained launch IS the token: all layers' bytes, one duration
+            # HBM traffic per launch: PMC counters collected in separate rocprofv3 --pmc passes of THIS command and config
+            # (tools/pmc_bench.sh: FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md), committed under profiles/ as
+            # *pmc_decode_<config>.json; a file measured on the other launch form (or none for this config) gives null
             traffic = None
+            pm = []
             try:
-                pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_decode.json"))
+                pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(f"pmc_decode_{args.config}.json"))
                 if pm:
-                    traffic = int(json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["traffic_bytes_per_launch"])
+                    pj_ = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))
+                    if pj_.get("launch") == launch_mode[0]:
+                        traffic = int(pj_["traffic_bytes_per_launch"])
             except Exception:
                 traffic = None
-            kname = ("decode_lean_kernel<bf16,128,5,...,512> (decode_attn.hip; 512-thread team, two waves per SIMD)" if headline else
+            kname = ("decode_chain_kernel<bf16,128,5,...,512> (decode_chain.hip: decode_body walked over the layers by resident "
+                     "workgroups; ONE launch per token, avg_launch_us and the bytes are the whole token's)" if chained_now else
+                     "decode_lean_kernel<bf16,128,5,...,512> (decode_attn.hip; 512-thread team, two waves per SIMD)" if headline else
                      "decode_lean_hids_kernel<bf16,128,5,...,512> (decode_attn.hip; the lean step over a head list)" if pq is None else
                      "pqv_decode_kernel (pq_decode.hip; the layer-step = MSB pass with the row's append + pack inside (+ LSB refetch): "
                      "avg_launch_us is the whole layer-step)")
@@ -995,10 +1054,22 @@ def main():
                                   "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4), "achievable_GBs": HBM_ACHIEVABLE_GBS,
                                   "traffic": traffic,
                                   "traffic_source": ("committed PMC profile profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                                     "of this command, tools/pmc_decode.sh) - not measured in this run" % pm[-1])
+                                                     "of this command, tools/pmc_bench.sh) - not measured in this run" % pm[-1])
                                   if traffic is not None else None,
-                                  "avg_launch_us": round(us, 3),
-                                  "algorithmic_bytes_per_launch": int(algo_bytes)}
+                                  "avg_launch_us": round(us * layers_per_launch, 3),
+                                  "layers_per_launch": layers_per_launch, "us_per_layer_step": round(us, 3),
+                                  "algorithmic_bytes_per_launch": int(algo_bytes * layers_per_launch)}
+            if graphs_per_layer is not None:      # the per-layer launches of the same steps, same events
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(reps):
+                    for slot in range(1, TURN):
+                        graphs_per_layer[slot].replay()
+                e1.record()
+                torch.cuda.synchronize()
+                us_pl = e0.elapsed_time(e1) * 1e3 / (reps * (TURN - 1) * L)
+                result["per_layer_launch"].update({"avg_launch_us": round(us_pl, 3), "achieved_GBs": round(algo_bytes / us_pl / 1e3, 1),
+                                                   "frac_of_hbm_peak": round(algo_bytes / us_pl / 1e3 / HBM_PEAK_GBS, 4)})
             # the prune event (select + fused gather): separate, informative
             torch.cuda.synchronize()
             e0.record()

@@ -796,7 +796,13 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p, const floa
   if (D > THREADS - kWave && tid >= THREADS - kWave && tid < D) store_granule(part + tid, o_tot, tag);   // D = 256 only
   if (tid == (D < THREADS - kWave ? D : 0)) { store_granule(part + D, m_run, tag); store_granule(part + D + 1, l_tot, tag); }
   if (p.poll_merge) {
-    if (split != p.S - 1) return;
+    if (split != p.S - 1) {
+      // CHAIN: the waves that publish nothing would be back at the top of the next layer's step at once, and their tile requests
+      // (20 KB per wave) would enter the CU's one vector-memory queue in FRONT of this partial's granules — the merger would see
+      // them ~2.5 us late (measured: tools/mb/chain_trace.py).  They wait until the granules have been ISSUED.
+      if (CHAIN) __builtin_amdgcn_s_barrier();
+      return;
+    }
   } else {
     __syncthreads();
     SPATTEN_TSTAMP(3);

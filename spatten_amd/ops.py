@@ -240,8 +240,8 @@ def attn_decode(q: torch.Tensor, k_cache: Optional[torch.Tensor], kr_cache: Opti
     if proj is not None:
         _fill_proj(a, proj, q, B, H * d)
     a.kv_len_layout = int(layout)
-    if layout > cap:
-        raise ValueError("layout length exceeds the cache capacity")
+    # (a static step only lays its splits out for `layout`: every load is clamped to the rows below kv_len, so the layout may
+    #  exceed the capacity — e.g. to give the unit's merging split a short chunk; the device-length form ignores it)
     if step is not None:
         if scores is not None and scores.shape[2] < kv_len:
             raise ValueError("device-length step: the stash row must cover the bound")
@@ -340,7 +340,7 @@ class DecodeChain:
         """One token: every layer's step at cache length ``kv_len`` (counting the appended row) / query position ``pos_q``.
         Raises NotImplementedError where the chained launch does not apply (launch the layers one by one)."""
         _dev(cos, sin)
-        if kv_len > self.cap or (step is None and max(kv_len, pos_q + 1) > cos.shape[0]) or cos.shape[1] * 2 != self.d or layout > self.cap:
+        if kv_len > self.cap or (step is None and max(kv_len, pos_q + 1) > cos.shape[0]) or cos.shape[1] * 2 != self.d or (step is not None and layout > self.cap):
             raise ValueError("kv_len exceeds cache capacity or rotary table")
         a = _lib.ChainArgs()
         a.struct_size = ctypes.sizeof(_lib.ChainArgs)

@@ -29,6 +29,32 @@ def test_bench_emits_one_json_line_with_the_contract_keys():
     assert 0.05 < r["frac"] < 1.0 and (r["traffic"] is None or r["traffic"] > 0.9 * r["algorithmic_bytes_per_launch"])
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    # round 6: `value` is the torch mirror on all pinned cores of one socket (median of three, spread printed), the one-thread
+    # legs of the mirror AND of the C port beside it
+    assert c["cores"] == c["pinned_cpus"] and len(c["repetitions"]) == 3 and c["spread"] >= 0
+    assert c["one_thread"]["torch_mirror"]["value"] > 0 and ("c_port" in c["one_thread"] or "c_port_error" in c)
+    # round 6: the default launch is the chained one (ONE launch per token); the per-layer launches are measured beside it
+    assert "chained" in d["config"]["launch"] and r["layers_per_launch"] == d["config"]["layers"]
+    assert abs(r["avg_launch_us"] - r["us_per_layer_step"] * r["layers_per_launch"]) < 0.05 * r["avg_launch_us"]
+    pl = d["per_layer_launch"]
+    assert pl["tokens_per_s"] > 0 and abs(pl["chained_over_per_layer"] - d["value"] / pl["tokens_per_s"]) < 1e-2
+    assert d["scaling"] == "strong"
+
+
+@pytest.mark.parametrize("config", ["c3", "c5"])
+def test_bench_single_gpu_lines_of_the_other_configs_carry_their_own_roofline(config):
+    """`roofline.traffic` is the PMC figure of THIS config's kernel (profiles/*pmc_decode_<config>.json) or null — never another
+    config's."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "66", "--warmup", "2",
+                          "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    r = d["roofline"]
+    assert d["config"]["name"] == config and 0.05 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"], (r["traffic"], r["algorithmic_bytes_per_launch"])
+    if r["traffic"] is not None:
+        assert f"pmc_decode_{config}.json" in r["traffic_source"]
+    assert ("chained" in d["config"]["launch"]) == (config == "c3")      # c5's quantised-plane steps keep one launch per layer
 
 
 @pytest.mark.parametrize("config", ["c3", "c5"])
@@ -44,6 +70,7 @@ def test_bench_runs_the_8_gpu_configs_of_baseline_json_on_one_rank_through_rccl(
     c = d["config"]
     assert c["name"] == config and "configs[" in c["workload"]
     assert c["rccl_ranks"] == 1 and c["exchange"] == "per-layer" and d["comm"]["comm_us_per_token"] is not None
+    assert d["scaling"] == "strong" and "one launch per layer" in c["launch"]     # (a collective between the layers: no chain)
     kept = c["heads_launched_per_layer_this_rank"]
     assert len(kept) == c["layers"] and all(k == (24 if config == "c3" else 30) for k in kept)
     if config == "c5":
