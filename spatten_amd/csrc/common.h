@@ -484,6 +484,8 @@ struct DecodeCall {
   bool step_oproj_off = false;   // (reserved: keep the output projection a separate launch)
 };
 int decode_rows(const DecodeCall& c, hipStream_t stream);
+// split-N factor of a decode launch over `units` softmax rows (decode_attn.hip); dense_rule = the 16-bit dense step's 8-split rule
+int decode_auto_splits(int units, int d, int kv_len, int elt, bool dense_rule);
 int decode_team();   // threads of the attention team of a single-shot decode step (decode_attn.hip: 512 or 256)
 // y[m, n] = sum_k x[m, k] W[n, k] (+ bias): the weight-streaming kernel of gemv.hip (C++ linkage for the other units)
 int gemv_rows(int dtype, const void* x, int64_t x_sm, const void* W, int64_t w_sn, const void* bias, void* y, int64_t y_sm,

@@ -339,10 +339,10 @@ extern "C" int spatten_decode_set_team(int threads) {
   return prev;
 }
 
-static int auto_splits(int units, int d, int kv_len, int elt = 2) {
-  // one workgroup per CU (256 CUs): measured best at Llama-2-7B decode sizes — more splits shorten each
-  // workgroup's stream but lengthen the merge (a memory round trip per batch of partials)
-  int s = 256 / (units > 0 ? units : 1);
+int decode_auto_splits(int units, int d, int kv_len, int elt, bool dense_rule) {
+  // one workgroup per CU (the device's own count: ADVICE r05): measured best at Llama-2-7B decode sizes — more splits shorten
+  // each workgroup's stream but lengthen the merge (a memory round trip per batch of partials)
+  int s = coresident_workgroups() / (units > 0 ? units : 1);
   static int env_s = -1;
   if (env_s < 0) { const char* e = getenv("SPATTEN_DECODE_SPLITS"); env_s = e ? atoi(e) : 0; }
   if (env_s > 0) s = env_s;
@@ -357,7 +357,8 @@ static int auto_splits(int units, int d, int kv_len, int elt = 2) {
   // larger count — the merge folds up to 8 partials in one thread group (no LDS fold, no barrier) and a fuller tile costs nothing
   // while every load is issued up front: 4 / 8 / 16 / 24 / 28 heads 9.30 / 9.56 / 10.09 / 11.29 / 12.11 -> 8.84 / 9.04 / 9.58 /
   // 10.09 / 10.58 us (32 heads were at 8 already).  Longer rows (pipelined tiles) keep one workgroup per CU.
-  if (env_s <= 0 && elt == 2 && d != 256 && s > 8 && ceil_div(kv_len, 8) <= 10 * decode_group_rows(d)) s = 8;
+  // (dense_rule: measured on the 16-bit dense step only — the quantised-plane passes have other tile sizes and keep their count)
+  if (env_s <= 0 && dense_rule && elt == 2 && d != 256 && s > 8 && ceil_div(kv_len, 8) <= 10 * decode_group_rows(d)) s = 8;
   if (s < 1) s = 1;
   if (s > kDecodeMaxSplits) s = kDecodeMaxSplits;
   return s;
@@ -555,7 +556,7 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   // the length the splits are laid out for: the step's own, or a common layout length of a whole turn (the device-length
   // form is laid out for its bound, kv_len)
   const int lay = (!c.step && c.layout_len > c.kv_len && c.n_q == 1) ? c.layout_len : c.kv_len;
-  int S = c.n_splits > 0 ? c.n_splits : auto_splits(c.batch * n_active * c.n_q, c.head_dim, lay, c.dtype == SPATTEN_F32 ? 4 : 2);
+  int S = c.n_splits > 0 ? c.n_splits : decode_auto_splits(c.batch * n_active * c.n_q, c.head_dim, lay, c.dtype == SPATTEN_F32 ? 4 : 2, c.pq == nullptr);
   if (S > lay) S = lay;
   if (S > kDecodeMaxSplits) S = kDecodeMaxSplits;
   // balanced chunks: ceil(N / S) rows per split (rounded up to the 8 rows of a stash line), whatever N is
@@ -653,7 +654,7 @@ extern "C" size_t spatten_decode_workspace_bytes(int batch, int heads, int head_
 
 extern "C" int spatten_decode_auto_splits(int batch, int heads, int head_dim, int kv_len) {
   if (batch <= 0 || heads <= 0 || kv_len <= 0 || (head_dim != 64 && head_dim != 128 && head_dim != 256)) return 1;
-  return auto_splits(batch * heads, head_dim, kv_len);
+  return decode_auto_splits(batch * heads, head_dim, kv_len, 2, true);
 }
 
 extern "C" size_t spatten_decode_qkv_exchange_bytes(int batch, int heads, int head_dim) {
@@ -666,7 +667,7 @@ extern "C" size_t spatten_decode_qkv_exchange_bytes(int batch, int heads, int he
 extern "C" int spatten_decode_qkv_supported(int dtype, int batch, int heads, int kv_heads, int head_dim, int kv_len_layout) {
   if (dtype != SPATTEN_F16 && dtype != SPATTEN_BF16) return 0;
   if (batch != 1 || heads <= 0 || heads != kv_heads || head_dim != 128 || kv_len_layout <= 0) return 0;
-  int S = auto_splits(batch * heads, head_dim, kv_len_layout);
+  int S = decode_auto_splits(batch * heads, head_dim, kv_len_layout, 2, true);
   if (S > kv_len_layout) S = kv_len_layout;
   const int chunk = ceil_div(ceil_div(kv_len_layout, S), 8) * 8;
   S = ceil_div(kv_len_layout, chunk);

@@ -179,7 +179,8 @@ __global__ __launch_bounds__(kLvThreads) void local_v_kernel(const LvParams<T> p
   __builtin_amdgcn_sched_barrier(0);
   const int N = DYN ? __builtin_amdgcn_readfirstlane(n_dyn) : p.N;
   const int hi = min(lo + p.chunk, N);
-  const bool owns_new = app && lo <= N - 1 && N - 1 < hi;       // (wave-uniform)
+  // (DYN: p.N is the launch's BOUND = the planes' capacity — a replay past it must not write beyond the planes: ADVICE r05)
+  const bool owns_new = app && lo <= N - 1 && N - 1 < hi && (!DYN || N <= p.N);       // (wave-uniform)
   const int hi_t = owns_new ? hi - 1 : hi;                       // rows the key tiles score
   typename D8::packed nk_lo, nk_hi;                              // the appended key, rotated (owner's first thread-row)
   if (owns_new && tid < LPR) {
@@ -627,14 +628,17 @@ static int local_v_launch(int dtype, const void* q, int64_t q_sb, int64_t q_sh, 
   if (!step_state && (pos_q < 0 || pos_q >= table_rows)) return SPATTEN_ERR_INVALID;
   const int lay = (!step_state && kv_len_layout > kv_len) ? kv_len_layout : kv_len;
   const long long units = (long long)batch * heads;
-  const int resident = coresident_workgroups();      // the splits of a head poll each other: the whole grid must be resident
-  if (units > resident) return SPATTEN_ERR_UNSUPPORTED;   // (cascade.local_v_decode falls back to the three-launch path)
+  // the splits of a head poll each other: a MULTI-split grid must be resident at once.  More units than CUs run with one split per
+  // head — that kernel path polls nobody (refusing it sent B*H > CU-count launches to the slower three-launch form
+  // and made the graph step raise)
+  const int resident = coresident_workgroups();
   int S = (int)std::max(1LL, resident / units);
   if (S > kLvMaxSplits) S = kLvMaxSplits;
   const int min_rows = 256;                          // a split shorter than this is all latency
   if (S > std::max(1, lay / min_rows)) S = std::max(1, lay / min_rows);
   const int chunk = ceil_div(ceil_div(lay, S), 8) * 8;
   S = ceil_div(lay, chunk);
+  if (S > 1 && (long long)S * units > resident) return SPATTEN_ERR_UNSUPPORTED;   // (cascade.local_v_decode: the three-launch path)
   const size_t key_b = dtype == SPATTEN_F32 ? 4 : 2;
   const size_t lds = ((size_t)chunk * key_b + 15) / 16 * 16 + (size_t)chunk * 2;
   if (chunk > 16384 || lds > 120 * 1024) return SPATTEN_ERR_UNSUPPORTED;   // (the three-launch path covers longer chunks)

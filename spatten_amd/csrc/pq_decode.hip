@@ -264,7 +264,8 @@ __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams
 
   const int N = DYN ? __builtin_amdgcn_readfirstlane(n_dyn) : p.N;
   const int hi_all = min(lo + p.chunk, N);
-  const bool owns_new = app && lo <= N - 1 && N - 1 < hi_all;      // (wave-uniform)
+  // (DYN: p.N is the launch's BOUND = the planes' capacity — a replay past it must not write beyond the planes: ADVICE r05)
+  const bool owns_new = app && lo <= N - 1 && N - 1 < hi_all && (!DYN || N <= p.N);      // (wave-uniform)
   const int hi = owns_new ? hi_all - 1 : hi_all;                   // rows the tiles score
 
   // ---- the rotated query: fp32 values (they ARE model-dtype values: rope_pair rounds) in piece order; for the nibble planes
@@ -652,7 +653,7 @@ static int run_pqv(const spatten_pq_decode_args_t* a, const PlanesDev& pd, hipSt
   const int units = a->batch * a->heads;
   const int ws_splits = a->workspace_splits > 0 ? a->workspace_splits : kDecodeMaxSplits;
   const int lay = (!a->step_state && a->kv_len_layout > a->kv_len) ? a->kv_len_layout : a->kv_len;
-  int S = a->n_splits > 0 ? a->n_splits : spatten_decode_auto_splits(a->batch, n_active, d, lay);
+  int S = a->n_splits > 0 ? a->n_splits : decode_auto_splits(a->batch * n_active, d, lay, 2, false);
   if (S > lay) S = lay;
   if (S > kDecodeMaxSplits) S = kDecodeMaxSplits;
   const int chunk = ceil_div(ceil_div(lay, S), 8) * 8;

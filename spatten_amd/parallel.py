@@ -176,11 +176,24 @@ class HeadParallel:
         lib = _lib.load()
         peer = ctypes.c_void_p()
         mine = ctypes.create_string_buffer(64)
-        _lib.check(lib.spatten_peer_create(ctypes.byref(peer), self.rank, self.world, int(max_bytes_per_rank), mine), "spatten_peer_create")
-        handles = list(exchange_handles(mine.raw)) if exchange_handles is not None else self.gather_handles(mine.raw)
+        rc = lib.spatten_peer_create(ctypes.byref(peer), self.rank, self.world, int(max_bytes_per_rank), mine)
+        if self.world == 1:
+            _lib.check(rc, "spatten_peer_create")
+        # A rank whose window could not be created (no fine-grained memory, no IPC handle) still takes part in the exchange — with
+        # an all-zero handle — so that EVERY rank sees the failure and falls back together; raising before the collective would
+        # leave the others blocked in it.
+        raw = mine.raw if rc == 0 else bytes(64)
+        handles = list(exchange_handles(raw)) if exchange_handles is not None else self.gather_handles(raw)
         if len(handles) != self.world or any(len(h) != 64 for h in handles):
-            lib.spatten_peer_destroy(peer)
+            if rc == 0:
+                lib.spatten_peer_destroy(peer)
             raise ValueError("peer-store: the handle exchange must return one 64-byte handle per rank, rank-major")
+        failed = [r for r, h in enumerate(handles) if bytes(h) == bytes(64)] if self.world > 1 else []
+        if failed:
+            if rc == 0:
+                lib.spatten_peer_destroy(peer)
+            _lib.check(rc, "spatten_peer_create")            # this rank's own error, if it is one of them
+            raise NotImplementedError(f"peer-store: receive window unavailable on rank(s) {failed}; every rank keeps RCCL")
         blob = ctypes.create_string_buffer(b"".join(handles), 64 * self.world)
         try:
             _lib.check(lib.spatten_peer_connect(peer, blob), "spatten_peer_connect")

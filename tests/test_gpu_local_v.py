@@ -158,3 +158,28 @@ def test_append_inside_the_launch_equals_append_then_launch(dt, d, B, H, Hkv, P,
     assert torch.equal(ka, kc_) and torch.equal(kra, krc) and torch.equal(va, vc_) and torch.equal(sa, sc)
     if int(np.ceil(frac * N)) == keep:
         assert torch.equal(ob, oc) and torch.equal(lb, lc)
+
+
+def test_more_units_than_cus_run_one_split_per_head_eager_and_device_length():
+    """batch x heads above the CU count runs with ONE split per head (that path polls no sibling split) — the
+    one-launch call must not be refused (-2) there, in its static form or in the device-length form a captured step uses."""
+    from spatten_amd import ops
+    from spatten_amd.cascade import local_v_decode
+    dt, d, B, H, P = "bf16", 128, 9, 32, 600                   # 288 units > 256 CUs
+    q, kc, vc, stash, (qd, krd, vd, cos, sin, N) = setup_decode(B, H, H, d, P, dt, 77)
+    keep = int(np.ceil(0.3 * N))
+    st1 = torch.zeros(B, H, N, dtype=TORCH_DT[dt], device="cuda")
+    o1 = ops.attn_decode_local_v(qd, krd, vd, N, cos, sin, N - 1, keep, st1)     # raises NotImplementedError if refused
+    o3, s3 = local_v_decode(qd, krd, vd, N, cos, sin, N - 1, keep, three_launches=True)
+    torch.cuda.synchronize()
+    assert torch.equal(st1[:, :, :N], s3[:, :, :N])
+    np.testing.assert_allclose(host(o1), host(o3), **OUT_TOL[dt])
+    # device-length form (what extensions.py's graph step launches): the same step with the length in the step state
+    step = ops.StepState(cos, sin)
+    step.set(N - 1, N - 2)
+    step.advance()
+    st2 = torch.zeros(B, H, krd.shape[2], dtype=TORCH_DT[dt], device="cuda")
+    o2 = ops.attn_decode_local_v(qd, krd, vd, krd.shape[2], cos, sin, 0, 1, st2, keep_fraction=0.3, step=step)
+    torch.cuda.synchronize()
+    assert torch.equal(st2[:, :, :N], st1[:, :, :N])
+    np.testing.assert_allclose(host(o2), host(o1), **OUT_TOL[dt])
