@@ -84,6 +84,12 @@ def parse():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="c2 (default) = BASELINE.json's headline; c3 = + 25 %% head prune (configs[2]); c5 = Llama-2-13B geometry, "
                          "16384 -> 8192 rows, head prune 30 of 40, progressive quantisation k8v8 (configs[4]).  All valid at --gpus 1..8")
+    ap.add_argument("--pq-confidence", choices=["trace", "uniform"], default="trace",
+                    help="c5 only — how confident the synthetic heads are.  trace (default): queries PEAKED on the step's newest key "
+                         "for ~93 %% of the (layer, head) pairs, so that ~7 %% fall below the 0.05 max-probability threshold and refetch "
+                         "the LSB plane — the rate of the reference's traces (323 of 4,608 head-requests, workloads/summary-gpt2-small-"
+                         "wikitext2-per8.csv: auto_requant_thres / if_requant).  uniform: unit-variance logits over 8192 keys — EVERY head "
+                         "is flagged, the worst case of the feature (the r05 line); measured beside the default under `extras`")
     ap.add_argument("--batch", type=int, default=0,
                     help="sequences per step (default: 1, or N under --scaling weak); lets ONE rank run the per-rank shape of a weak-"
                          "scaling run (testing)")
@@ -674,6 +680,17 @@ def main():
     q = [rnd(B, Hl, d) for _ in range(L)]
     kn = [rnd(B, Hl, d) for _ in range(L)]
     vn = [rnd(B, Hl, d) for _ in range(L)]
+    kn_uniform = None
+    if cfg["pq"] is not None:
+        # trace-like confidence: a confident head's NEWEST key is 0.9 x its query — relative rotary position 0, so
+        # the step's logit of that key is 0.9 |q|^2 / sqrt(d) ~ 10 whatever the position, max probability ~ 0.6 >> 0.05; the other
+        # ~7 % keep a random newest key: max probability ~ 1e-3 over 8192 unit-variance logits -> flagged -> LSB refetch
+        kn_uniform = [x.clone() for x in kn]
+        conf = [torch.rand(B, Hl, device=dev, generator=gen) < 0.93 for _ in range(L)]
+        kn_trace = [torch.where(conf[l][:, :, None], (0.9 * q[l].float()).to(dt), kn[l]) for l in range(L)]
+        if args.pq_confidence == "trace":
+            for l in range(L):
+                kn[l].copy_(kn_trace[l])
     ws = ops.DecodeWorkspace(B, Hl, d, dev)
     stash_full = [torch.empty(B, Hl, 1, CTX, dtype=dt, device=dev) for _ in range(L)]
     Krp = []
@@ -913,6 +930,51 @@ def main():
     run_steps(args.warmup)
     elapsed = time_region(lambda n: run_steps(n, args.warmup), args.steps, dist_on)
     tokens_per_s = B * args.steps / elapsed
+    # c5: the refetch rate of the timed run, and the OTHER confidence setting beside it (same graphs: the new rows are read through
+    # fixed tensors)
+    pq_side = None
+    if pq is not None and graphs is not None:
+        torch.cuda.synchronize()
+        frac_of = lambda: float(sum(float(need[l][hid[l].long()].float().mean().item()) if hid[l] is not None and hid[l].numel() else
+                                    float(need[l].float().mean().item()) for l in range(L)) / L)
+        pq_side = {"confidence": args.pq_confidence, "refetch_fraction": round(frac_of(), 4)}
+        other = "uniform" if args.pq_confidence == "trace" else "trace"
+        for l in range(L):
+            kn[l].copy_(kn_uniform[l] if other == "uniform" else kn_trace[l])
+        run_steps(args.warmup)
+        el_o = time_region(lambda n: run_steps(n, args.warmup), args.steps, dist_on)
+        torch.cuda.synchronize()
+        pq_side.update({f"{other}_tokens_per_s": round(B * args.steps / el_o, 2), f"{other}_refetch_fraction": round(frac_of(), 4)})
+        for l in range(L):
+            kn[l].copy_(kn_trace[l] if args.pq_confidence == "trace" else kn_uniform[l])
+        # ... and the same layer-steps over 16-BIT keys and values (the lean head-list step on the rotated shadow): what MSB-first buys
+        try:
+            gb = torch.cuda.CUDAGraph()
+            nb = new_len + TURN // 2
+
+            def bf16_token():
+                for l in range(L):
+                    if hid[l] is not None and hid[l].numel() == 0:
+                        continue
+                    ops.attn_decode(q[l], Kd[l], Krd[l], Vd[l], nb, cos, sin, nb - 1, k_new=kn[l], v_new=vn[l], scores=stash[l],
+                                    out=outs2[0][l], workspace=ws, head_ids=hid[l])
+            bf16_token()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(gb):
+                bf16_token()
+            for _ in range(3):
+                gb.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                gb.replay()
+            torch.cuda.synchronize()
+            us_b = (time.perf_counter() - t0) / 30 * 1e6
+            pq_side["bf16_keys_same_steps_us_per_layer"] = round(us_b / L, 2)
+            pq_side["bf16_keys_same_steps_tokens_per_s_decode_only"] = round(1e6 / us_b, 2)
+        except Exception as e:      # noqa: BLE001
+            pq_side["bf16_keys_error"] = f"{type(e).__name__}: {e}"
+        prune()                     # (the 16-bit steps appended rows: restore the turn's start)
     # the same K steps with one launch per layer (the r01-r05 form) beside the chained value
     tokens_per_s_per_layer = None
     if graphs_per_layer is not None:
@@ -996,6 +1058,9 @@ def main():
                               "K/V tile requested before layer l's completion is waited for; bit-identical to the per-layer launches)"
                               if launch_mode[0] == "chained" else ", one launch per layer")},
     }
+    if pq_side is not None:
+        pq_side["pq_us_per_layer_this_run"] = round(elapsed / args.steps * 1e6 / L, 2)
+        result["config"]["pq_confidence"] = pq_side
     if tokens_per_s_per_layer is not None:
         result["per_layer_launch"] = {"tokens_per_s": round(tokens_per_s_per_layer, 2),
                                       "chained_over_per_layer": round(tokens_per_s / tokens_per_s_per_layer, 3),
@@ -1221,14 +1286,16 @@ def main():
                 cp, sp = ops.rope_table(Np, d, dt, dev)
                 Krp2 = ops.rope_single(Kp2, cp, sp)
                 op = torch.empty(1, Np, HEADS * d, dtype=dt, device=dev)
+                # (reference numerics: both 16-bit roundings of every logit, modify_llama.py:111-113 — what a stash-producing
+                #  forward runs; round 6: a forward WITHOUT a stash defaults to fp32 logits, measured below as ..._fast_numerics)
                 for _ in range(3):
-                    ops.attn_prefill(Qp, Krp2, Vp2, Np, cp, sp, 0, causal=True, out=op)
+                    ops.attn_prefill(Qp, Krp2, Vp2, Np, cp, sp, 0, causal=True, out=op, numerics="reference")
                 torch.cuda.synchronize()
                 blocks = []             # median of three blocks of 8 calls (one run showed a 5x outlier block on a shared host)
                 for _ in range(3):
                     t0 = time.perf_counter()
                     for _ in range(8):
-                        ops.attn_prefill(Qp, Krp2, Vp2, Np, cp, sp, 0, causal=True, out=op)
+                        ops.attn_prefill(Qp, Krp2, Vp2, Np, cp, sp, 0, causal=True, out=op, numerics="reference")
                     torch.cuda.synchronize()
                     blocks.append((time.perf_counter() - t0) / 8)
                 tp = sorted(blocks)[1]
@@ -1280,7 +1347,7 @@ def main():
                 c2, s2 = cp[:N2], sp[:N2]
                 o2 = torch.empty(1, N2, HEADS * d, dtype=dt, device=dev)
                 Q2, K2, V2 = Qp[:, :, :N2].contiguous(), Krp2[:, :, :N2].contiguous(), Vp2[:, :, :N2].contiguous()
-                run2 = lambda: ops.attn_prefill(Q2, K2, V2, N2, c2, s2, 0, causal=True, out=o2)
+                run2 = lambda: ops.attn_prefill(Q2, K2, V2, N2, c2, s2, 0, causal=True, out=o2, numerics="reference")
                 for _ in range(3):
                     run2()
                 torch.cuda.synchronize()

@@ -25,7 +25,7 @@ _FAMILIES: Dict[str, Callable] = {"llama": _patch_llama}
 
 def enable_spatten_llm(model, start_size, important_size, recent_size, importance_mode="reference",
                        prefill_stash=True, assume_causal=False, head_keep=None, pq_threshold=None, local_v_keep=None,
-                       layer_keep=None, fuse_qkv=False, native_gemv=False, head_parallel=None, numerics="reference",
+                       layer_keep=None, fuse_qkv=False, native_gemv=False, head_parallel=None, numerics="auto",
                        auto_graph=False, pq_profile=None, fused_step=False, token_scope="head"):
     """The reference's four positional arguments (enable_spatten_llm.py:5) plus opt-in extensions:
 
@@ -58,9 +58,11 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
     (run_spatten_llama.py:27-35), unchanged, replays one captured HIP graph of the whole patched stack per token
     (spatten_amd/graph.py:auto_graph) — the zero-change form of ``DecodeGraph``.
 
-    ``numerics="fast"``: multi-token forwards that materialise no stash (``prefill_stash=False``) keep their logits in
-    fp32 instead of reproducing the reference's two 16-bit roundings per logit (modify_llama.py:111-113) — a faster
-    prefill whose output leaves the stated tolerance only where logits are large.
+    ``numerics``: "auto" (default, round 6) — multi-token forwards that materialise NO stash (``prefill_stash=False``) keep
+    their logits in fp32 instead of reproducing the reference's two 16-bit roundings per logit (modify_llama.py:111-113): the
+    roundings are then unobservable except through the output, which stays inside the stated tolerance (it leaves it only
+    where logits are large); forwards that do stash always reproduce them.  "reference": always both roundings.
+    "fast": as auto.
     ``head_parallel=HeadParallel(H, Hkv)`` (spatten_amd/parallel.py; one process per GPU): this rank's modules project,
     cache, attend and prune only its H/G heads (column-sharded q/k/v projections; ``past_key_values`` and ``attn_scores``
     hold the local heads) and all-gather the attention outputs [B, q, H/G*d] in front of the full ``o_proj``
@@ -117,8 +119,8 @@ def enable_spatten_llm(model, start_size, important_size, recent_size, importanc
         m._spatten_qkv = None
         m.__dict__["_spatten_gemv"] = bool(native_gemv)
         m.__dict__["_spatten_fused_step"] = bool(fused_step)
-        if numerics not in ("reference", "fast"):
-            raise ValueError("numerics must be 'reference' or 'fast'")
+        if numerics not in ("auto", "reference", "fast"):
+            raise ValueError("numerics must be 'auto', 'reference' or 'fast'")
         m.__dict__["_spatten_numerics"] = numerics
         m.__dict__.pop("_spatten_hp", None)
         if head_parallel is not None:

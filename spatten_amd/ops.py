@@ -678,15 +678,20 @@ def attn_prefill(q: torch.Tensor, kr_cache: torch.Tensor, v_cache: torch.Tensor,
                  position_ids: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
                  out: Optional[torch.Tensor] = None, scores: Optional[torch.Tensor] = None,
                  col_importance: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,
-                 numerics: str = "reference") -> torch.Tensor:
+                 numerics: str = "auto") -> torch.Tensor:
     """Flash-style prefill (modify_llama.py:86-147 at q_len>1).  q [B,H,q,d] un-rotated (any strides with d
     contiguous); kr_cache = ROTATED shadow of the keys, v_cache values, both already holding the q new rows
     at [kv_len-q, kv_len); mask additive [B,q,kv_len]; position_ids int64 [B,q]; lse optional fp32 [B,H,q,2] output
     (row reference max, sum exp): the softmax statistics.  ``numerics="fast"``: fp32 logits without the reference's two
-    16-bit roundings (include/spatten.h, SPATTEN_PREFILL_FAST_NUMERICS) where no by-product needs them.
+    16-bit roundings (include/spatten.h, SPATTEN_PREFILL_FAST_NUMERICS) where no by-product needs them; ``"reference"``: both
+    roundings of every logit (modify_llama.py:111-113); ``"auto"`` (default, round 6): fast when NOTHING that is defined on the
+    rounded logits is requested (no stash, column importance, row statistics or mask) — the roundings are then observable only
+    through the output, which stays inside the stated tolerance (tests/util.py) — reference otherwise.
     Returns out [B, q, H*d]."""
-    if numerics not in ("reference", "fast"):
-        raise ValueError("numerics must be 'reference' or 'fast'")
+    if numerics not in ("auto", "reference", "fast"):
+        raise ValueError("numerics must be 'auto', 'reference' or 'fast'")
+    if numerics == "auto":
+        numerics = "fast" if (scores is None and col_importance is None and lse is None and mask is None) else "reference"
     _dev(q, kr_cache, v_cache, cos, sin, out, scores, col_importance, position_ids, mask, lse)
     if lse is not None and (lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != q.shape[0] * q.shape[1] * q.shape[2] * 2):
         raise ValueError("lse must be a contiguous fp32 [B,H,q,2] tensor")

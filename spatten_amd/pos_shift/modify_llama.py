@@ -304,7 +304,7 @@ def llama_pos_shift_attention_forward(
                     stash = None
             attn_output = ops.attn_prefill(q4, slab.kr, slab.v, kv_seq_len, cos, sin, past_len, causal=causal,
                                            position_ids=position_ids, mask=pmask, scores=stash, lse=lse_pf,
-                                           numerics=self.__dict__.get("_spatten_numerics", "reference"))
+                                           numerics=self.__dict__.get("_spatten_numerics", "auto"))
         if ext is not None:
             ext[0].after_prefill(ext[1], attn_output, stash, pmask, num_heads, causal, q4=q4, slab=slab, kv_len=kv_seq_len,
                                  cos=cos, sin=sin, past_len=past_len, position_ids=position_ids,

@@ -55,6 +55,11 @@ def test_bench_single_gpu_lines_of_the_other_configs_carry_their_own_roofline(co
     if r["traffic"] is not None:
         assert f"pmc_decode_{config}.json" in r["traffic_source"]
     assert ("chained" in d["config"]["launch"]) == (config == "c3")      # c5's quantised-plane steps keep one launch per layer
+    if config == "c5":      # round 6: the default c5 line runs at the traces' refetch rate (~7 % of the heads), the worst case beside it
+        pc = d["config"]["pq_confidence"]
+        assert pc["confidence"] == "trace" and 0.03 <= pc["refetch_fraction"] <= 0.12, pc
+        assert pc["uniform_refetch_fraction"] == 1.0 and pc["uniform_tokens_per_s"] < d["value"]
+        assert pc["bf16_keys_same_steps_us_per_layer"] > 0
 
 
 @pytest.mark.parametrize("config", ["c3", "c5"])

@@ -266,3 +266,37 @@ def test_profile_c4_c5_scale_decode_vs_oracle():
         ok = got == need
         np.testing.assert_allclose(host(out).reshape(B, H, d)[ok], orc.round_dt(want, dt)[ok], **OUT_TOL[dt])
         assert 0 < need.sum() < need.size
+
+
+def test_c5_geometry_at_a_trace_like_refetch_rate_flags_exactly_the_oracles_heads():
+    """the reference's traces refetch 323 of 4,608 head-requests (~7 %:
+    workloads/summary-gpt2-small-wikitext2-per8.csv, columns auto_requant_thres / if_requant).  C5 geometry (H = 40, d = 128,
+    8192 rows, (8, 8) planes, threshold 0.05) with queries PEAKED on the newest key for 37 of the 40 heads (bench.py
+    --pq-confidence trace builds its inputs the same way): the MSB pass must flag exactly the 3 unpeaked heads — the set the
+    oracle flags — refetch only those, and leave the outputs within tolerance."""
+    from spatten_amd import ops
+    from tests.util import attn_inputs
+    dt, d, B, H, P, kb, vb, thr = "bf16", 128, 1, 40, 8191, 8, 8, 0.05
+    q, k, v, past = attn_inputs(B, H, H, d, P + 1, 1, dt, 61)
+    kc, vc = past
+    N = P + 1
+    flagged = (5, 17, 33)                                               # 3 of 40 = 7.5 %
+    for h in range(H):
+        if h not in flagged:      # the newest key = 0.9 x the query: relative position 0, logit ~ 0.9 |q|^2 / sqrt(d) ~ 10
+            kc[:, h, N - 1] = orc.round_dt(np.float32(0.9) * q[:, h, 0], dt)
+    c, s = orc.rope_table(N, d, dt)
+    cos, sin = dev(c[:, : d // 2], dt), dev(s[:, : d // 2], dt)
+    kd, vd = dev(kc, dt), dev(vc, dt)
+    krd = ops.rope_single(kd, cos, sin)
+    planes = ops.PQProfilePlanes(B, H, H, N, d, "cuda", key_bits=kb, value_bits=vb)
+    ops.pq_pack_planes(krd, vd, planes, 0, N)
+    msb, lsb, scale, qv, vscale = _oracle_planes(host(krd), host(vd), kb, vb)
+    qr = orc.apply_rotary_pos_emb_single(q, c, s, np.full((B, 1), N - 1), dt)[:, :, 0]
+    want, need, _ = orc.pq_decode_attention_profile(qr, msb, lsb, scale, qv, vscale, thr)
+    assert sorted(np.nonzero(need[0])[0].tolist()) == list(flagged)      # the oracle: exactly the unpeaked heads
+    need_dev = torch.full((B * H,), -1, dtype=torch.int32, device="cuda")
+    out = ops.attn_decode_pqv(dev(q[:, :, 0], dt), planes, N, cos, sin, N - 1, thr, need_lsb=need_dev)
+    torch.cuda.synchronize()
+    got = need_dev.cpu().numpy().reshape(B, H).astype(bool)
+    assert np.array_equal(got, need)
+    np.testing.assert_allclose(host(out).reshape(B, H, d), orc.round_dt(want, dt), **OUT_TOL[dt])

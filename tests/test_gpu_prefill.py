@@ -500,6 +500,13 @@ def test_prefill_fast_numerics_stays_within_the_stated_tolerance(dt, d, P, ql):
     check_stash(stash, stash_ref, dt, "fast numerics with a stash")
     with pytest.raises(ValueError):
         run_prefill(q, k, v, past, dt, causal=True, stash=False, numerics="sloppy")
+    # round 6: numerics="auto" (the default of ops.attn_prefill and of the plugin) = fast exactly when nothing defined on the
+    # rounded logits is requested, reference otherwise — bit for bit the explicit forms
+    o_auto, _, _ = run_prefill(q, k, v, past, dt, causal=True, stash=False, numerics="auto")
+    assert np.array_equal(o_auto, o_fast)
+    o_auto_st, stash_auto, _ = run_prefill(q, k, v, past, dt, causal=True, stash=True, numerics="auto")
+    o_ref_st, stash_r, _ = run_prefill(q, k, v, past, dt, causal=True, stash=True, numerics="reference")
+    assert np.array_equal(o_auto_st, o_ref_st) and np.array_equal(stash_auto, stash_r)
 
 
 @pytest.mark.parametrize("case", [("bf16", 1, 8, 8, 2000, 64), ("f16", 2, 4, 2, 700, 300), ("bf16", 1, 4, 4, 0, 512), ("bf16", 1, 4, 1, 3000, 17),
