@@ -1104,7 +1104,8 @@ def main():
                 pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(f"pmc_decode_{args.config}.json"))
                 if pm:
                     pj_ = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))
-                    if pj_.get("launch") == launch_mode[0]:
+                    # (c5: measured at the same confidence setting — the refetch pass re-streams V for the flagged heads)
+                    if pj_.get("launch") == launch_mode[0] and (pq is None or pj_.get("pq_confidence") == args.pq_confidence):
                         traffic = int(pj_["traffic_bytes_per_launch"])
             except Exception:
                 traffic = None
@@ -1423,6 +1424,17 @@ def main():
                         q[i % L][:, :hg], None, Krd[i % L][:, :hg], Vd[i % L][:, :hg], new_len, cos, sin, new_len - 1, out=og, workspace=wsg), n=L), 2)
                 prl["c2_32_heads"] = extras["c2_decode_2048_32_heads_us"]
                 extras["per_rank_launch_us"] = prl
+                # round 6: the same per-rank shapes through the CHAINED launch (one launch per token over the rank's heads), per layer
+                try:
+                    prc = {}
+                    for hg in (32, 16, 8, 4):
+                        og = [torch.empty(1, hg * d, dtype=dt, device=dev) for _ in range(L)]
+                        chg = ops.DecodeChain([x[:, :hg] for x in q], None, [x[:, :hg] for x in Krd], [x[:, :hg] for x in Vd], og)
+                        prc[f"c2_{hg}_heads"] = round(_time(lambda i: chg(new_len, cos, sin, new_len - 1), n=1, reps=20) / L, 2)
+                        del chg
+                    extras["per_rank_chained_us_per_layer"] = prc
+                except Exception as e:      # noqa: BLE001
+                    extras["per_rank_chained_error"] = f"{type(e).__name__}: {e}"
                 # batched decode (the C ABI takes a batch): B sequences on their own pruned 2048-row caches — the
                 # launch's fixed costs (boundary, ramp, split merge) amortise over B x the bytes
                 for Bb in (4, 8):

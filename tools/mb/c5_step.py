@@ -27,6 +27,11 @@ for l in range(L):
     need.append(torch.zeros(B * H, dtype=torch.int32, device=dev))
     q.append(rnd(B, H, d)); kn.append(rnd(B, H, d)); vn.append(rnd(B, H, d))
     out.append(torch.zeros(B, H * d, dtype=dt, device=dev)); stash.append(torch.zeros(B, H, cap, dtype=dt, device=dev))
+CONF = sys.argv[1] if len(sys.argv) > 1 else "trace"       # trace: ~7 % of the heads refetch (bench.py --pq-confidence trace); uniform: all
+if CONF == "trace":
+    for l in range(L):
+        conf = torch.rand(B, H, device=dev, generator=g) < 0.93
+        kn[l] = torch.where(conf[:, :, None], (0.9 * q[l].float()).to(dt), kn[l])
 ws = ops.DecodeWorkspace(B, H, d, dev)
 steps = 24
 for t in range(steps):
@@ -38,5 +43,5 @@ torch.cuda.synchronize()
 n_avg = n0 + (steps + 1) / 2.0
 n_ref = float(sum(int(x.sum().item()) for x in need)) / L
 algo = (B * keepH * n_avg * d * (8 + 8) / 8 + 2 * B * keepH * n_avg * 4 + 2 * B * keepH * d * 2 + B * keepH * n_avg * 2 + n_ref * n_avg * d / 2)
-print("C5_STEP_JSON " + json.dumps({"layer_steps": steps * L, "heads_launched": keepH, "heads_refetched_per_step": n_ref,
+print("C5_STEP_JSON " + json.dumps({"pq_confidence": CONF, "refetch_fraction": n_ref / keepH, "layer_steps": steps * L, "heads_launched": keepH, "heads_refetched_per_step": n_ref,
                                     "avg_rows": n_avg, "algorithmic_bytes_per_layer_step": algo}))

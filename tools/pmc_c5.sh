@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmcc5_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmcc5_$c -o p -- python $R/tools/mb/c5_step.py > $R/gpurun_out/pmcc5_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmcc5_$c -o p -- python $R/tools/mb/c5_step.py ${1:-trace} > $R/gpurun_out/pmcc5_$c.log 2>&1
 done
 python3 - $R <<'PY'
 import csv, glob, json, sys
@@ -25,5 +25,6 @@ out["traffic_bytes_per_launch"] = out["fetch_bytes_corrected_x2"] + out["write_b
 out["algorithmic_bytes_per_launch"] = info["algorithmic_bytes_per_layer_step"]
 out["traffic_over_algorithmic"] = out["traffic_bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
 json.dump(out, open(f"{R}/gpurun_out/pmc_decode_c5.json", "w"), indent=1)
+json.dump(out, open(f"{R}/gpurun_out/pmc_decode_c5_{info['pq_confidence']}.json", "w"), indent=1)
 print(json.dumps(out))
 PY
