@@ -49,6 +49,10 @@ struct PqvParams {
   // the step's APPEND inside the MSB pass (round 5, optional): row N - 1 of kc (optional) / krc / vc <- k_new / v_new [B,Hkv,d]
   // (modify_llama.py:95-104; the key rotated with rotary row nr_row of cos / sin) and that row of every plane
   const T* k_new; const T* v_new; int64_t new_sb, new_sh; T* kc; T* krc; T* vc; int64_t kv_sb, kv_sh; int nr_row;
+  // the refetch pass over the FLAGGED heads only (round 6): blockIdx.y = rank among the flagged heads of the launch's n_act heads
+  // (every workgroup derives the list itself from `need`: one wave load + ballot, no counter to reset), S / chunk of this pass are
+  // its own — many short splits, so that two or three flagged heads are spread over the chip instead of over 8 CUs each
+  int compact, n_act;
 };
 
 #ifndef SPATTEN_PQV_UP
@@ -195,8 +199,17 @@ __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams
   const int lane = tid % kWave;
 
   const int split = blockIdx.x;
-  const int h = p.head_ids ? p.head_ids[blockIdx.y] : (int)blockIdx.y;
   const int b = blockIdx.z;
+  int y = blockIdx.y;
+  if (PASS == 2 && p.compact) {
+    int f = 0;
+    if (lane < p.n_act) f = p.need[b * p.H + (p.head_ids ? p.head_ids[lane] : lane)] != 0;
+    unsigned long long m = __ballot(f);
+    if ((int)blockIdx.y >= __popcll(m)) return;      // fewer flagged heads than this row of the grid
+    for (int i = 0; i < (int)blockIdx.y; ++i) m &= m - 1ull;
+    y = __builtin_ctzll(m);
+  }
+  const int h = p.head_ids ? p.head_ids[y] : y;
   const int hkv = (p.Hkv == p.H) ? h : h / (p.H / p.Hkv);
   const int unit = b * p.H + h;
   if (PASS == 2 && p.need[unit] == 0) return;    // confident head: pass 1 already produced its output
@@ -633,14 +646,33 @@ static int launch_pqv(PqvParams<T>& p, int n_active, bool dyn, bool msb_only, in
   static const int cap_dyn = std::min(resident_capacity(pqv_decode_kernel<T, D, KB, VB, 1, true, UP>),
                                       resident_capacity(pqv_decode_kernel<T, D, KB, VB, 2, true, UP>));
   p.poll_merge = (env_poll != 0 && p.S > 1 && (long long)p.S * n_active * p.B <= (dyn ? cap_dyn : cap_static)) ? 1 : 0;
+  // ---- the refetch pass (round 6): at the reference traces' rate 2-3 of 30 heads are flagged per layer-step; laid out like pass 1
+  // their rows sit on S CUs each and the pass takes as long as if every head were flagged (a CU streams at ~21 B/ns).  So pass 2
+  // gets its own, finer split-N (~256-row chunks, <= 64 splits) over a grid whose rows are the RANKS of the flagged heads: a few
+  // flagged heads spread over the whole chip, unflagged rows of the grid exit at once.  The merge polls: workgroups are dispatched
+  // in order, a head's merging (last) split after its siblings, and no other workgroup ever waits — safe beyond residency.
+  PqvParams<T> p2 = p;
+  static int env_c = -1;
+  if (env_c < 0) { const char* e = getenv("SPATTEN_PQV_COMPACT"); env_c = e ? atoi(e) : 1; }
+  if (env_c && !msb_only && n_active <= 64) {
+    const int lay = p.S * p.chunk;                       // the layout length pass 1 was laid out for
+    const int ws_splits = (int)(p.ws_unit / (D + 2));
+    const int rows2 = env_c >= 64 ? env_c : 256;          // (SPATTEN_PQV_COMPACT=rows: A/B of the chunk length)
+    int S2 = std::min({kDecodeMaxSplits, ws_splits, std::max(p.S, ceil_div(lay, rows2))});
+    const int chunk2 = ceil_div(ceil_div(lay, S2), 8) * 8;
+    S2 = ceil_div(lay, chunk2);
+    p2.S = S2; p2.chunk = chunk2; p2.compact = 1; p2.n_act = n_active;
+    p2.poll_merge = (env_poll != 0 && S2 > 1) ? 1 : 0;
+  }
+  const dim3 grid2((unsigned)p2.S, (unsigned)n_active, (unsigned)p.B);
   if (dyn) {
     if (app) hipLaunchKernelGGL((pqv_decode_kernel<T, D, KB, VB, 1, true, UP, true>), grid, blk, 0, st, p);
     else hipLaunchKernelGGL((pqv_decode_kernel<T, D, KB, VB, 1, true, UP>), grid, blk, 0, st, p);
-    if (!msb_only) hipLaunchKernelGGL((pqv_decode_kernel<T, D, KB, VB, 2, true, UP>), grid, blk, 0, st, p);
+    if (!msb_only) hipLaunchKernelGGL((pqv_decode_kernel<T, D, KB, VB, 2, true, UP>), grid2, blk, 0, st, p2);
   } else {
     if (app) hipLaunchKernelGGL((pqv_decode_kernel<T, D, KB, VB, 1, false, UP, true>), grid, blk, 0, st, p);
     else hipLaunchKernelGGL((pqv_decode_kernel<T, D, KB, VB, 1, false, UP>), grid, blk, 0, st, p);
-    if (!msb_only) hipLaunchKernelGGL((pqv_decode_kernel<T, D, KB, VB, 2, false, UP>), grid, blk, 0, st, p);
+    if (!msb_only) hipLaunchKernelGGL((pqv_decode_kernel<T, D, KB, VB, 2, false, UP>), grid2, blk, 0, st, p2);
   }
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 }
@@ -682,6 +714,7 @@ static int run_pqv(const spatten_pq_decode_args_t* a, const PlanesDev& pd, hipSt
   p.ws_unit = (int64_t)ws_splits * (d + 2);
   p.B = a->batch; p.H = a->heads; p.Hkv = a->kv_heads; p.N = a->kv_len; p.S = S; p.chunk = chunk;
   p.poll_merge = 0;      // decided per instantiation in launch_pqv (co-residency of the whole grid)
+  p.compact = 0; p.n_act = n_active;
   p.sqrt_d = sqrtf((float)d);
   p.k_new = (const T*)a->k_new; p.v_new = (const T*)a->v_new; p.new_sb = a->new_sb; p.new_sh = a->new_sh;
   p.kc = (T*)a->k_cache; p.krc = (T*)a->kr_cache; p.vc = (T*)a->v_cache; p.kv_sb = a->kv_sb; p.kv_sh = a->kv_sh;
