@@ -52,7 +52,7 @@ struct PqvParams {
   // the refetch pass over the FLAGGED heads only (round 6): blockIdx.y = rank among the flagged heads of the launch's n_act heads
   // (every workgroup derives the list itself from `need`: one wave load + ballot, no counter to reset), S / chunk of this pass are
   // its own — many short splits, so that two or three flagged heads are spread over the chip instead of over 8 CUs each
-  int compact, n_act;
+  int compact, n_act, S1, chunk1;                // (S1 / chunk1: pass 1's layout, taken when most heads are flagged)
 };
 
 #ifndef SPATTEN_PQV_UP
@@ -176,7 +176,8 @@ template <int BITS, int W> __device__ inline void fma_piece(float (&o)[16], cons
 // OTHER caller 0.8-1.0 us per pass (a branch around the new token's loads behind the first tile breaks the exact vmcnt the
 // pipelined tiles rely on: same-call A/B, (4,8) 15.5 vs 14.65 us).
 template <typename T, int D, int KB, int VB, int PASS, bool DYN, int UP, bool APP = false>
-__global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams<T> p) {
+__global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams<T> p_in) {
+  PqvParams<T> p = p_in;                         // (the compact refetch pass picks its split layout by the number of flagged heads)
   constexpr int LPR = D / 16;                    // lanes per row: lane c owns the row's piece c (16 elements)
   constexpr int RPI = kPqvThreads / LPR;         // rows per row-group
   constexpr int TILE = RPI * UP;
@@ -198,15 +199,26 @@ __global__ __launch_bounds__(kPqvThreads) void pqv_decode_kernel(const PqvParams
   const int wave = tid / kWave;
   const int lane = tid % kWave;
 
-  const int split = blockIdx.x;
+  int split = blockIdx.x;
   const int b = blockIdx.z;
   int y = blockIdx.y;
   if (PASS == 2 && p.compact) {
     int f = 0;
     if (lane < p.n_act) f = p.need[b * p.H + (p.head_ids ? p.head_ids[lane] : lane)] != 0;
     unsigned long long m = __ballot(f);
-    if ((int)blockIdx.y >= __popcll(m)) return;      // fewer flagged heads than this row of the grid
-    for (int i = 0; i < (int)blockIdx.y; ++i) m &= m - 1ull;
+    const int cnt = __popcll(m);
+    int rank = blockIdx.y;
+    if (2 * cnt > p.n_act) {
+      // MANY flagged heads (the every-head-flagged worst case): the fine layout would be 4x the workgroups and 32 partials per
+      // merge — the first S1 x cnt workgroups of the grid take pass 1's coarser layout instead, the rest leave
+      const int lin = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+      if (lin >= p.S1 * cnt) return;
+      rank = lin / p.S1; split = lin - rank * p.S1;
+      p.S = p.S1; p.chunk = p.chunk1;
+    } else if (rank >= cnt) {
+      return;                                        // fewer flagged heads than this row of the grid
+    }
+    for (int i = 0; i < rank; ++i) m &= m - 1ull;
     y = __builtin_ctzll(m);
   }
   const int h = p.head_ids ? p.head_ids[y] : y;
@@ -661,7 +673,7 @@ static int launch_pqv(PqvParams<T>& p, int n_active, bool dyn, bool msb_only, in
     int S2 = std::min({kDecodeMaxSplits, ws_splits, std::max(p.S, ceil_div(lay, rows2))});
     const int chunk2 = ceil_div(ceil_div(lay, S2), 8) * 8;
     S2 = ceil_div(lay, chunk2);
-    p2.S = S2; p2.chunk = chunk2; p2.compact = 1; p2.n_act = n_active;
+    p2.S = S2; p2.chunk = chunk2; p2.compact = 1; p2.n_act = n_active; p2.S1 = p.S; p2.chunk1 = p.chunk;
     p2.poll_merge = (env_poll != 0 && S2 > 1) ? 1 : 0;
   }
   const dim3 grid2((unsigned)p2.S, (unsigned)n_active, (unsigned)p.B);
@@ -714,7 +726,7 @@ static int run_pqv(const spatten_pq_decode_args_t* a, const PlanesDev& pd, hipSt
   p.ws_unit = (int64_t)ws_splits * (d + 2);
   p.B = a->batch; p.H = a->heads; p.Hkv = a->kv_heads; p.N = a->kv_len; p.S = S; p.chunk = chunk;
   p.poll_merge = 0;      // decided per instantiation in launch_pqv (co-residency of the whole grid)
-  p.compact = 0; p.n_act = n_active;
+  p.compact = 0; p.n_act = n_active; p.S1 = S; p.chunk1 = chunk;
   p.sqrt_d = sqrtf((float)d);
   p.k_new = (const T*)a->k_new; p.v_new = (const T*)a->v_new; p.new_sb = a->new_sb; p.new_sh = a->new_sh;
   p.kc = (T*)a->k_cache; p.krc = (T*)a->kr_cache; p.vc = (T*)a->v_cache; p.kv_sb = a->kv_sb; p.kv_sh = a->kv_sh;

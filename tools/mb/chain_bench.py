@@ -10,6 +10,7 @@ H = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2081
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 depth = int(os.environ.get("CHAIN_DEPTH", "0"))
+NS = int(os.environ.get("CHAIN_SPLITS", "0"))      # n_splits of BOTH forms (0 = each form's default)
 LAY = int(os.environ.get("CHAIN_LAYOUT", "0"))      # kv_len_layout of BOTH forms (0 = equal chunks)
 B, d, dt = 1, 128, torch.bfloat16
 cap = (N + 64 + 127) // 128 * 128
@@ -37,11 +38,11 @@ chain = ops.DecodeChain(q, K, Kr, V, out_b, k_new=kn, v_new=vn, scores=st_b, dep
 
 def per_layer():
     for l in range(L):
-        ops.attn_decode(q[l], K[l], Kr[l], V[l], N, cos, sin, N - 1, k_new=kn[l], v_new=vn[l], scores=st[l], out=out_a[l], workspace=ws, layout=LAY)
+        ops.attn_decode(q[l], K[l], Kr[l], V[l], N, cos, sin, N - 1, k_new=kn[l], v_new=vn[l], scores=st[l], out=out_a[l], workspace=ws, layout=LAY, n_splits=NS)
 
 
 def chained():
-    chain(N, cos, sin, N - 1, layout=LAY)
+    chain(N, cos, sin, N - 1, layout=LAY, n_splits=NS)
 
 
 def graph_of(fn):
@@ -78,5 +79,5 @@ for rep in range(3):
 chain.check()
 bytes_layer = 2 * B * H * N * d * 2 + 2 * B * H * d * 2 + B * H * N * 2
 for ta, tb in res:
-    print(f"H={H} N={N} L={L} layout={LAY}: per-layer {ta:8.1f} us/token = {ta / L:6.2f} us/layer ({bytes_layer / (ta / L) / 1e6:.2f} TB/s) | "
+    print(f"H={H} N={N} L={L} layout={LAY} n_splits={NS}: per-layer {ta:8.1f} us/token = {ta / L:6.2f} us/layer ({bytes_layer / (ta / L) / 1e6:.2f} TB/s) | "
           f"chained {tb:8.1f} us/token = {tb / L:6.2f} us/layer ({bytes_layer / (tb / L) / 1e6:.2f} TB/s) | x{ta / tb:.3f} | bit-identical {same}")
