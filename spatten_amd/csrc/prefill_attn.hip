@@ -141,7 +141,9 @@ struct FlashParams {
 #define SPATTEN_PF_EXPMODE 0    // results: anatomy only); 4 = DMA_MODE 2; 16 = no exp2 in the softmax (wrong results)
 #endif
 #ifndef SPATTEN_PF_DMA_MODE     // who issues a stage's LDS-DMA: 0 half 0 in its matrix / half 1 in its vector phase (r01, 762);
-#define SPATTEN_PF_DMA_MODE ((SPATTEN_PF_EXPMODE & 4) ? 2 : 1)   // 1 both in their matrix phase (r02, 810); 2 both in their vector phase (743)
+#define SPATTEN_PF_DMA_MODE 2   // 1 both in their matrix phase (r02: 810 against 743 for 2); 2 both in their vector phase — r06, after the r05 softmax
+                                // diet: 2 is +1.5-2.4 % in both numerics (four alternations on two boxes: 882 / 991-1,022 against 870 / 973-998 TFLOP/s);
+                                // 3 = K pieces from the matrix, V pieces from the vector phase: as 1
 #endif
 // FAST (template flag of prefill_pp128_kernel; run-time opt-in SPATTEN_PREFILL_FAST_NUMERICS of spatten_attn_prefill):
 // logits kept in fp32 — no reference roundings (matmul -> dtype, / sqrt(d) -> dtype) — with the scale folded into the
@@ -828,6 +830,8 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     if (j + 1 < n_tiles) dma_k(j + 1, k_area(j));
     if (j < n_att_tiles) dma_v(j, v_area(j));
   };
+  [[maybe_unused]] auto dma_stage_k = [&](int j) { if (j + 1 < n_tiles) dma_k(j + 1, k_area(j)); };   // (DMA_MODE 3: the stage's two halves
+  [[maybe_unused]] auto dma_stage_v = [&](int j) { if (j < n_att_tiles) dma_v(j, v_area(j)); };       //  go out in different phases)
 
   f32x16 s[NKB];
   frag pf[NKB][2];
@@ -1099,6 +1103,11 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     PF_STAMP(6);           // (the stage's LDS-DMA pieces issued)
 #elif SPATTEN_PF_DMA_MODE == 0
     if (grp == 0 && t >= T0 + 1 && t + 1 < n_tiles) dma_stage(t + 1);
+#elif SPATTEN_PF_DMA_MODE == 3
+    // round 6: the stage's K pieces from the matrix phase (as mode 1), its V pieces from the vector phase (as mode 2): four DMA
+    // instructions per wave in each phase instead of eight in one — each costs ~115-125 cycles of the wave's issue whichever phase
+    // it sits in, and the phase that carries all eight is the longer one of the step (matrix phase in fast numerics)
+    if (!(SPATTEN_PF_EXPMODE & 2) && t >= T0 + 1 && t + 1 < n_tiles) dma_stage_k(t + 1);
 #endif
     __builtin_amdgcn_sched_barrier(0);
     bool rounded = false;
@@ -1130,6 +1139,9 @@ __global__ __launch_bounds__(512, 1) void prefill_pp128_kernel(const FlashParams
     // its vector phase of iteration t-1 during 2t, half 0 in its vector phase of iteration t during 2t+1)
     if (grp == 0 && t >= T0 + 1 && t + 1 < n_tiles) dma_stage(t + 1);
     if (grp == 1 && t + 2 < n_tiles) dma_stage(t + 2);
+#elif SPATTEN_PF_DMA_MODE == 3
+    if (grp == 0 && t >= T0 + 1 && t + 1 < n_tiles) dma_stage_v(t + 1);
+    if (grp == 1 && t + 2 < n_tiles) dma_stage_v(t + 2);
 #endif
     PF_STAMP(3);
     if (!(SPATTEN_PF_EXPMODE & 8) && t + 1 < wave_tiles) softmax_tile(t + 1, rounded);
