@@ -221,7 +221,9 @@ int spatten_decode_qkv_supported(int dtype, int batch, int heads, int kv_heads, 
  *                   kernel boundary — the launch's own layers need nothing more: they read q, not out (the word stands where a
  *                   fused producer of q would publish its result).
  *   workspace       spatten_decode_chain_workspace_bytes(n_layers, batch, heads, head_dim, workspace_splits) bytes,
- *                   zero-filled once, one per stream; spatten_decode_workspace_status() reports a timed-out wait
+ *                   zero-filled once, one per stream; spatten_decode_workspace_status() reports a timed-out wait (the
+ *                   launch then ran to its end on incomplete data: zero-fill the workspace again before the next token — the
+ *                   token epoch did not advance)
  * MHA, bf16 / f16, head_dim 128, the lean step (no mask / position tensor / cascade accumulation); every workgroup polls, so the
  * whole grid (splits x max_active x batch x depth) must be co-resident: SPATTEN_ERR_UNSUPPORTED otherwise (launch the layers
  * one by one), also under spatten_decode_set_team(256).
