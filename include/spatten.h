@@ -194,6 +194,13 @@ size_t spatten_decode_qkv_exchange_bytes(int batch, int heads, int head_dim);
  * SPATTEN_ERR_INVALID).  SPATTEN_DECODE_TEAM=256 in the environment sets the initial value. */
 int spatten_decode_set_team(int threads);
 int spatten_decode_qkv_supported(int dtype, int batch, int heads, int kv_heads, int head_dim, int kv_len_layout);
+/* Grouped-query models (heads > kv_heads; modify_llama.py:106-108 repeat_kv), round 6: the single-row step of bf16 / f16, head_dim
+ * 128, without mask / head list / cascade accumulation / quantised keys streams a KV head's rows ONCE for its whole query group and
+ * scores them on the matrix cores (csrc/decode_gqa.hip) instead of once per query head.  mode: -1 = from 1024 rows on (the default),
+ * 0 = never, 1 = whenever the step is eligible.  Process-wide; outputs of the two forms differ in summation order (low bits), both
+ * inside the stated tolerance.  Returns the previous mode + 1 (0..2), or SPATTEN_ERR_INVALID.  SPATTEN_DECODE_GQA in the
+ * environment sets the initial mode. */
+int spatten_decode_set_gqa(int mode);
 
 /* ------------------------------------------------------------------------------------------------
  * The chained decode launch (ABI 5, round 6): the attention step of ALL layers of one token — what the caller's per-layer

@@ -484,6 +484,9 @@ struct DecodeCall {
   bool step_oproj_off = false;   // (reserved: keep the output projection a separate launch)
 };
 int decode_rows(const DecodeCall& c, hipStream_t stream);
+// the grouped-query single-row step on the matrix cores (decode_gqa.hip): SPATTEN_OK after launching it, SPATTEN_ERR_UNSUPPORTED when
+// the launch is not one it serves (nothing launched; decode_rows then takes the per-query-head kernel)
+int decode_gqa_rows(const DecodeCall& c, hipStream_t stream);
 // split-N factor of a decode launch over `units` softmax rows (decode_attn.hip); dense_rule = the 16-bit dense step's 8-split rule
 int decode_auto_splits(int units, int d, int kv_len, int elt, bool dense_rule);
 int decode_team();   // threads of the attention team of a single-shot decode step (decode_attn.hip: 512 or 256)

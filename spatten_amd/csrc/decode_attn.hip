@@ -580,6 +580,15 @@ int decode_rows(const DecodeCall& c, hipStream_t stream) {
   const bool want_proj = c.proj_w != nullptr;
   if (want_proj && (!c.proj_out || c.proj_n <= 0 || c.n_q != 1 || scores_only || c.proj_w_sn < (int64_t)c.heads * c.head_dim))
     return SPATTEN_ERR_INVALID;
+  // grouped-query step on the matrix cores (decode_gqa.hip, round 6): a kv head's rows streamed once for its whole query group
+  {
+    const int rc_g = decode_gqa_rows(c, stream);
+    if (rc_g == SPATTEN_OK)
+      return want_proj ? gemv_rows(c.dtype, c.out, c.out_sb, c.proj_w, c.proj_w_sn, c.proj_bias, c.proj_out, c.proj_out_sb, c.batch,
+                                   c.proj_n, c.heads * c.head_dim, stream)
+                       : SPATTEN_OK;
+    if (rc_g != SPATTEN_ERR_UNSUPPORTED) return rc_g;
+  }
   // the output projection INSIDE the fused projection + attention launch (round 4): when that launch runs at all, its grid has
   // one workgroup per 16 output rows (gemv.hip's mapping) and the contraction is one 4096-column pass
   static int env_oproj = -1;

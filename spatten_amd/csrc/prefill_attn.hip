@@ -25,10 +25,10 @@
 #include <type_traits>
 
 #include "common.h"
+#include "mfma_tiles.h"
 
 namespace spatten {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifdef SPATTEN_PF_TRACE   // developer instrumentation (tools/probe_pf_trace.py): phase timestamps of workgroup 0
 __device__ unsigned long long* g_pf_trace = nullptr;
 #define PF_STAMP(slot)                                                                                   \
@@ -41,15 +41,6 @@ __device__ unsigned long long* g_pf_trace = nullptr;
 #endif
 
 
-template <typename T> struct Mfma;
-template <> struct Mfma<bf16_t> {
-  typedef bf16_t frag __attribute__((ext_vector_type(8)));
-  __device__ static inline f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-};
-template <> struct Mfma<f16_t> {
-  typedef f16_t frag __attribute__((ext_vector_type(8)));
-  __device__ static inline f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-};
 
 // position of key (0..31, within its 32-key block) in a Vt row: the order in which the Q·K^T accumulator
 // registers of a lane enumerate keys:  key = (r&3) + 8*(r>>2) + 4*hi  for register r (0..15), half hi.
@@ -599,15 +590,7 @@ __global__ __launch_bounds__(512, 1) void prefill_pp_kernel(const FlashParams<T>
 // A DMA instruction writes 1 KiB of LDS linearly (lane l -> +16 l), so the XOR swizzle of the 16-byte slots is applied
 // on the GLOBAL side: lane (row, p) fetches logical slot p ^ f(row) of its row.
 // ------------------------------------------------------------------------------------------------
-// buffer-descriptor LDS-DMA helpers (device-only functions: the host pass of a __global__ template must not see the
-// target builtins)
-// lane l fetches 16 bytes at base + soff + voff(l) into lds_dst + 16 l (lds_dst wave-uniform); bytes beyond `bytes`
-// read as zero.  The descriptor is rebuilt from wave-uniform values at every call (a few SALU moves).
-__device__ inline void dma16(const void* base, int64_t bytes, char* lds_dst, int voff, int soff) {
-  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0,
-                                                                     (int)(bytes < 0x7FFFFFFF ? bytes : 0x7FFFFFFF), 0x00020000);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
-}
+// (the LDS-DMA helper dma16 and the MFMA wrappers: mfma_tiles.h)
 
 template <int ROWB> __device__ inline int swz_slot(int row, int p) {   // logical slot stored at physical slot p
   return ROWB == 256 ? (p ^ (row & 15)) : (p ^ ((row >> 1) & 7));

@@ -592,6 +592,15 @@ def set_decode_team(threads: int) -> int:
     return prev
 
 
+def set_decode_gqa(mode: int) -> int:
+    """Grouped-query decode steps on the matrix cores (include/spatten.h: spatten_decode_set_gqa): -1 = from 1024 rows on (default),
+    0 = never (one workgroup column per query head), 1 = whenever the step is eligible.  Process-wide; returns the previous mode."""
+    prev = _lib.load().spatten_decode_set_gqa(int(mode))
+    if prev < 0:
+        raise ValueError("decode gqa mode: -1, 0 or 1")
+    return prev - 1
+
+
 def gemv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``torch.nn.functional.linear(x, weight, bias)`` for single-token rows: x [..., K] with few rows (a decode step),

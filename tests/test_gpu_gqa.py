@@ -1,0 +1,150 @@
+"""The grouped-query decode step on the matrix cores (csrc/decode_gqa.hip, round 6): a KV head's rows streamed once for its whole
+query group (modify_llama.py:106-108 repeat_kv + :111-147) — against the oracle at ragged lengths and group sizes, against the
+per-query-head kernel (same stash bits up to the stated fraction, caches bit for bit), in the device-length form and at the size
+VERDICT r05 #8 names (32 / 8 heads, 16384 rows).  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import spatten_oracle as orc
+from tests.test_gpu_decode import oracle_table, run_decode
+from tests.util import OUT_TOL, STASH_TOL, TORCH_DT, attn_inputs, dev, host
+
+pytestmark = pytest.mark.gpu
+
+
+def check_stash(got, want, dt, name=""):
+    """tests.util.check_stash with a floor on the count: at a handful of rows ONE logit on a rounding boundary (the matrix cores
+    sum a row's 128 products in another order than the oracle) is already more than 2 % of the stash."""
+    np.testing.assert_allclose(got, want, err_msg=f"stash {name}", **STASH_TOL[dt])
+    bad = int(np.sum(got != want))
+    assert bad <= max(2, 0.02 * got.size), (name, bad, got.size)
+
+
+@pytest.fixture
+def gqa_forced():
+    from spatten_amd import ops
+    prev = ops.set_decode_gqa(1)
+    yield
+    ops.set_decode_gqa(prev)
+
+
+def test_gqa_mode_setter_validates():
+    from spatten_amd import ops
+    prev = ops.set_decode_gqa(0)
+    try:
+        assert ops.set_decode_gqa(1) == 0 and ops.set_decode_gqa(-1) == 1
+        with pytest.raises(ValueError):
+            ops.set_decode_gqa(2)
+    finally:
+        ops.set_decode_gqa(prev)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(2, 8, 2), (1, 32, 8), (1, 16, 1), (2, 12, 4), (1, 64, 2)])
+@pytest.mark.parametrize("P", [0, 5, 31, 32, 33, 127, 128, 333, 1500, 2100])
+def test_gqa_mfma_vs_oracle_ragged_lengths(gqa_forced, dt, shape, P):
+    B, H, Hkv = shape
+    d = 128
+    q, k, v, past = attn_inputs(B, H, Hkv, d, P, 1, dt, seed=500 + P + H)
+    o, stash, (kc_ref, vc_ref) = orc.attention_core(q, k, v, None if past is None else past[0], None if past is None else past[1],
+                                                    np.full((B, 1), P), None, dt)
+    for ns in (0, 1, 3, 7):
+        out, st, kc, vc, lse = run_decode(q, k, v, past, dt, n_splits=ns)
+        np.testing.assert_allclose(out, o, err_msg=f"ns={ns}", **OUT_TOL[dt])
+        check_stash(st, stash, dt, f"ns={ns}")
+        assert np.array_equal(kc, kc_ref) and np.array_equal(vc, vc_ref)
+        p = orc.softmax_probs(stash)
+        np.testing.assert_allclose(1.0 / lse[:, :, 1], p[:, :, 0].max(-1), rtol=2e-2)
+
+
+def test_gqa_mfma_agrees_with_the_per_query_head_kernel(gqa_forced):
+    """Same inputs through both forms: caches bit for bit, stash within the oracle's fraction of each other, outputs to rounding;
+    arbitrary query position from a tensor."""
+    from spatten_amd import ops
+    dt, B, H, Hkv, d, P = "bf16", 2, 16, 4, 128, 1100
+    q, k, v, past = attn_inputs(B, H, Hkv, d, P, 1, dt, seed=77)
+    a = run_decode(q, k, v, past, dt, pos_q=P + 9, use_pos_tensor=True)
+    ops.set_decode_gqa(0)
+    b_ = run_decode(q, k, v, past, dt, pos_q=P + 9, use_pos_tensor=True)
+    ops.set_decode_gqa(1)
+    np.testing.assert_allclose(a[0], b_[0], **OUT_TOL[dt])
+    assert float(np.mean(a[1] != b_[1])) < 0.02
+    assert np.array_equal(a[2], b_[2]) and np.array_equal(a[3], b_[3])
+
+
+def _dyn_pair(B, H, Hkv, P, cap, dt, steps, graph):
+    """`steps` tokens through the static launches (set A) and the device-length form (set B, optionally ONE captured graph)."""
+    from spatten_amd import ops
+    d, tdt = 128, TORCH_DT[dt]
+    cos, sin = ops.rope_table(cap + 8, d, tdt, "cuda")
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, device="cuda", dtype=torch.float32, generator=g).to(tdt)
+    kc = torch.full((B, Hkv, cap, d), float("nan"), dtype=tdt, device="cuda")
+    vc, krc = kc.clone(), kc.clone()
+    kc[:, :, :P], vc[:, :, :P] = rnd(B, Hkv, P, d), rnd(B, Hkv, P, d)
+    ops.build_shadow(kc, krc, 0, P, cos, sin)
+    A = (kc, krc, vc)
+    Bs = tuple(t.clone() for t in A)
+    q, kn, vn = rnd(B, H, d), rnd(B, Hkv, d), rnd(B, Hkv, d)
+    out_a, out_b = torch.zeros(B, H * d, dtype=tdt, device="cuda"), torch.zeros(B, H * d, dtype=tdt, device="cuda")
+    st_a, st_b = torch.zeros(B, H, cap, dtype=tdt, device="cuda"), torch.zeros(B, H, cap, dtype=tdt, device="cuda")
+    ws = ops.DecodeWorkspace(B, H, d, "cuda")
+    step = ops.StepState(cos, sin)
+    step.set(P, P - 1)
+
+    def dyn():
+        step.advance()
+        ops.attn_decode(q, Bs[0], Bs[1], Bs[2], cap, cos, sin, 0, k_new=kn, v_new=vn, scores=st_b, out=out_b, workspace=ws, step=step)
+
+    gr = None
+    if graph:
+        dyn()
+        torch.cuda.synchronize()
+        for a, b_ in zip(A, Bs):
+            b_.copy_(a)
+        st_b.zero_()
+        step.set(P, P - 1)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            dyn()
+    for t in range(steps):
+        n = P + t + 1
+        q.copy_(rnd(B, H, d)); kn.copy_(rnd(B, Hkv, d)); vn.copy_(rnd(B, Hkv, d))
+        ops.attn_decode(q, A[0], A[1], A[2], n, cos, sin, n - 1, k_new=kn, v_new=vn, scores=st_a, out=out_a, workspace=ws)
+        if gr is not None:
+            gr.replay()
+        else:
+            dyn()
+        torch.cuda.synchronize()
+        ws.check()
+        # the device-length form lays its splits out for the bound: another summation grouping (low bits of `out`), same logits
+        np.testing.assert_allclose(host(out_a), host(out_b), **OUT_TOL[dt])
+        assert torch.equal(st_a[:, :, :n], st_b[:, :, :n]), t
+        for a, b_ in zip(A, Bs):
+            assert torch.equal(a[:, :, :n], b_[:, :, :n]), t
+            assert torch.isnan(b_[:, :, n:].float()).all(), "written past the live length"
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_gqa_mfma_device_length_form_equals_the_static_launches(gqa_forced, graph):
+    # lengths that cross a tile and a split boundary while the steps run; stale rows beyond the live length are NaN
+    _dyn_pair(1, 32, 8, 2045, 2304, "bf16", steps=6, graph=graph)
+    _dyn_pair(2, 8, 2, 60, 512, "f16", steps=5, graph=graph)
+
+
+def test_gqa_mfma_at_16384_rows_32_over_8_heads():
+    """The size the verdict names; the default mode must pick the matrix-core form here (>= 1024 rows) — checked through the
+    result: both forms are run and must agree with the oracle; more splits than the chip has CUs (ticket merge) as well."""
+    from spatten_amd import ops
+    dt, B, H, Hkv, d, P = "bf16", 1, 32, 8, 128, 16383
+    q, k, v, past = attn_inputs(B, H, Hkv, d, P, 1, dt, seed=9)
+    o, stash, _ = orc.attention_core(q, k, v, past[0], past[1], np.full((B, 1), P), None, dt)
+    prev = ops.set_decode_gqa(-1)
+    try:
+        for ns in (0, 48):
+            out, st, _, _, _ = run_decode(q, k, v, past, dt, n_splits=ns)
+            np.testing.assert_allclose(out, o, **OUT_TOL[dt])
+            check_stash(st, stash, dt)
+    finally:
+        ops.set_decode_gqa(prev)
