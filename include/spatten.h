@@ -196,8 +196,10 @@ int spatten_decode_set_team(int threads);
 int spatten_decode_qkv_supported(int dtype, int batch, int heads, int kv_heads, int head_dim, int kv_len_layout);
 /* Grouped-query models (heads > kv_heads; modify_llama.py:106-108 repeat_kv), round 6: the single-row step of bf16 / f16, head_dim
  * 128, without mask / head list / cascade accumulation / quantised keys streams a KV head's rows ONCE for its whole query group and
- * scores them on the matrix cores (csrc/decode_gqa.hip) instead of once per query head.  mode: -1 = from 1024 rows on (the default),
- * 0 = never, 1 = whenever the step is eligible.  Process-wide; outputs of the two forms differ in summation order (low bits), both
+ * scores them on the matrix cores (csrc/decode_gqa.hip) instead of once per query head.  mode: -1 = where that form measured faster
+ * (the default: batch x kv_heads x rows x (0.047 group - 0.0625) >= 5.3 x 1024 — 32 / 8 heads from ~5.4k rows, 64 / 8 from ~2.2k; the
+ * layout length decides, so a static launch and the device-length form of one step take the same kernel), 0 = never, 1 = whenever the
+ * step is eligible.  Process-wide; outputs of the two forms differ in summation order (low bits), both
  * inside the stated tolerance.  Returns the previous mode + 1 (0..2), or SPATTEN_ERR_INVALID.  SPATTEN_DECODE_GQA in the
  * environment sets the initial mode. */
 int spatten_decode_set_gqa(int mode);

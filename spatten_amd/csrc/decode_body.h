@@ -34,10 +34,17 @@ static __device__ unsigned long long* g_chain_trace = nullptr;
   do {                                                                                                                  \
     if (CHAIN && g_chain_trace && threadIdx.x == 0)                                                                     \
       g_chain_trace[((size_t)p.ch_layer * (gridDim.x * gridDim.y * gridDim.z) +                                         \
-                     ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); \
+                     ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (slot)] = wall_clock64(); \
+  } while (0)
+#define SPATTEN_CSTAMP_L(layer, slot)     /* outside decode_body (the chain loop): the layer is named */                \
+  do {                                                                                                                  \
+    if (g_chain_trace && threadIdx.x == 0)                                                                              \
+      g_chain_trace[((size_t)(layer) * (gridDim.x * gridDim.y * gridDim.z) +                                            \
+                     ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (slot)] = wall_clock64(); \
   } while (0)
 #else
 #define SPATTEN_CSTAMP(slot)
+#define SPATTEN_CSTAMP_L(layer, slot)
 #endif
 
 namespace spatten {
@@ -303,7 +310,10 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p, const floa
     // its polls for the partials never queue behind the next layer's tile either.
     // (Measured and dropped: the MERGING workgroup — which comes out of the previous layer's merge with the completion words
     //  set — requesting its whole tile behind the barrier, so that wave 0's poll does not queue behind the other waves' 140 KB in
-    //  the CU's one vector-memory queue: 9.9 us per layer against 9.3, its stream then starts 1 us later still.)
+    //  the CU's one vector-memory queue: 9.9 us per layer against 9.3, its stream then starts 1 us later still.  And, late in
+    //  round 6: only the merger's first poll ISSUED in front of them — one bare barrier more in that workgroup: 10.5-10.6 against
+    //  9.35-9.4; the other splits' granules requested before the merger's own reduction: 9.65 against 9.35; the merger folding its
+    //  own partial from registers instead of publishing it and reading it back: 9.5-9.55 against 9.36-9.44.  HISTORY.md §0.)
     const bool w0 = __builtin_amdgcn_readfirstlane(wave) == 0;
     const bool late = w0;
     if (!late) {
@@ -800,7 +810,9 @@ __device__ __forceinline__ void decode_body(const DecodeParams<T>& p, const floa
       // CHAIN: the waves that publish nothing would be back at the top of the next layer's step at once, and their tile requests
       // (20 KB per wave) would enter the CU's one vector-memory queue in FRONT of this partial's granules — the merger would see
       // them ~2.5 us late (measured: tools/mb/chain_trace.py).  They wait until the granules have been ISSUED.
+      SPATTEN_CSTAMP(8);
       if (CHAIN) __builtin_amdgcn_s_barrier();
+      SPATTEN_CSTAMP(9);
       return;
     }
   } else {

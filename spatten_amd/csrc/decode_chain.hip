@@ -143,8 +143,10 @@ __global__ __launch_bounds__(THREADS) void decode_chain_kernel(const ChainLayerD
   const unsigned tag = c.hdr[1] + 1u;   // (the epoch only moves when every workgroup has passed this load: chain_complete)
   chain_stage_table(table, c.n_layers, s_tab);
   for (int l = lane_id; l < c.n_layers; l += c.depth) {
+    SPATTEN_CSTAMP_L(l, 10);
     DecodeParams<T> p = c.base;
     if ((int)blockIdx.y >= chain_fill<T>(p, c, s_tab, l, tag)) continue;
+    SPATTEN_CSTAMP_L(l, 11);
     // (Measured and dropped: a SHORT last split — a layout that gives the unit's merging split, which starts its stream last, fewer
     //  rows, run through a second instantiation with fewer row-groups per tile so that it requests nothing it does not have: 9.5 us
     //  per layer against 9.3 — the doubled loop body costs more than the shorter stream brings.)

@@ -36,6 +36,13 @@ static __device__ unsigned long long* g_gqa_trace = nullptr;
 #define SPATTEN_GSTAMP(slot)
 #endif
 
+#ifndef SPATTEN_GQA_NT             // A/B: non-temporal LDS-DMA requests
+#define SPATTEN_GQA_NT 1
+#endif
+#ifndef SPATTEN_GQA_SPLIT_REFILL   // A/B: a consumed stage is refilled in two halves (keys behind S, values behind P·V)
+#define SPATTEN_GQA_SPLIT_REFILL 1
+#endif
+
 namespace spatten {
 
 template <typename T>
@@ -103,21 +110,33 @@ __global__ __launch_bounds__(256, 1) void decode_gqa_kernel(const GqaParams<T> p
   const i32x4 k_rsrc = rsrc_of(krb), v_rsrc = rsrc_of(vb);
   const unsigned lds_wbuf = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds + (unsigned)wave * WBUF;
   auto dma16a = [&](const i32x4& rsrc, unsigned lds_dst, int voff, int soff) {
+#if SPATTEN_GQA_NT      // non-temporal: every K / V byte is used once per launch
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds"
+                 :: "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+#else
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+#endif
   };
-  auto dma_tile = [&](int tile, int stage) {
+  auto dma_keys = [&](int tile, int stage) {
     const int ln = opaque_lane(lane);
     const int lr = ln >> 4, ps = ln & 15;
     const int kbase = lr * 256 + ((ps ^ lr) << 4);
-    const int vbase = lr * 256 + ((ps ^ (4 * lr)) << 4);
-    const unsigned ka = lds_wbuf + stage * STAGE, va = ka + KBYTES;
+    const unsigned ka = lds_wbuf + stage * STAGE;
     const int soff = __builtin_amdgcn_readfirstlane((lo + tile * KT) * (D * 2));
 #pragma unroll
     for (int i = 0; i < NK; ++i) dma16a(k_rsrc, ka + i * 1024, kbase ^ (((i * 4) & 15) << 4), soff + i * 1024);
+  };
+  auto dma_values = [&](int tile, int stage) {
+    const int ln = opaque_lane(lane);
+    const int lr = ln >> 4, ps = ln & 15;
+    const int vbase = lr * 256 + ((ps ^ (4 * lr)) << 4);
+    const unsigned va = lds_wbuf + stage * STAGE + KBYTES;
+    const int soff = __builtin_amdgcn_readfirstlane((lo + tile * KT) * (D * 2));
 #pragma unroll
     for (int i = 0; i < NK; ++i) dma16a(v_rsrc, va + i * 1024, vbase, soff + i * 1024);
   };
+  auto dma_tile = [&](int tile, int stage) { dma_keys(tile, stage); dma_values(tile, stage); };
   // ---- the group's queries as B operands: column g = head hkv G + g, fragment kk holds elements [16 kk + 8 hi, +8), so kk and
   // kk + KK/2 are the (x[i], x[i + d/2]) pairs RoPE combines.  Columns >= G: zeros.  Their rows are requested FIRST (a wave's loads
   // return in order: behind the tile the rotation would wait for the tile), then the first tile, then the rotation.
@@ -196,6 +215,7 @@ __global__ __launch_bounds__(256, 1) void decode_gqa_kernel(const GqaParams<T> p
   for (int i = wave, k = 0; i < nt; i += NW, ++k) {
     const int stage = k & 1;
     const bool more = i + NW < nt;                    // this wave's next tile is in flight behind this one
+    const bool more2 = i + 2 * NW < nt;               // ... and the tile after next is requested during this one
     const int row0 = lo + i * KT;
     const bool edge = row0 + KT > n_cached;           // the tile holds rows the caches do not: past the length, or the new token's
     // loads return in order: "at most X outstanding" with X = the requests issued behind the wanted ones proves those have landed
@@ -256,6 +276,14 @@ __global__ __launch_bounds__(256, 1) void decode_gqa_kernel(const GqaParams<T> p
         s = Mfma<T>::mma(a, qf[kk], s);
       }
     }
+#if SPATTEN_GQA_SPLIT_REFILL
+    // the stage's KEY half is consumed (the reads that fed the products above have returned): the keys of the tile after next go
+    // out now, a softmax and a P·V earlier than the stage's value half — a wave's requests then enter the CU's memory queue in two
+    // bursts of 8 KiB per tile instead of one of 16
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) dma_keys(i + 2 * NW, stage);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     // both reference roundings of every logit (matmul -> dtype, "/ sqrt(d)" -> dtype, modify_llama.py:111-113)
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
@@ -322,7 +350,11 @@ __global__ __launch_bounds__(256, 1) void decode_gqa_kernel(const GqaParams<T> p
     }
     // ---- O^T += Vt · P^T: the tile's value rows have landed ------------------------------------------------------------------------
     __builtin_amdgcn_sched_barrier(0);
+#if SPATTEN_GQA_SPLIT_REFILL
+    if (!edge) { if (more2) wait_vm<3 * NK>(); else if (more) wait_vm<2 * NK>(); else wait_vm<0>(); }   // (behind V: K, V of the next tile, K of the one after)
+#else
     if (!edge) { if (more) wait_vm<2 * NK>(); else wait_vm<0>(); }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     {
       // lane (col, hi) needs, for d = 32 db + col, the 8 keys its P fragment holds — elements 0..3: keys 16 t + 4 hi + 0..3,
@@ -344,7 +376,11 @@ __global__ __launch_bounds__(256, 1) void decode_gqa_kernel(const GqaParams<T> p
     // the stage is consumed (its last read fed the last product): request the tile after next into it
     __builtin_amdgcn_sched_barrier(0);
     if (k == 0) SPATTEN_GSTAMP(4);   // first tile consumed
-    if (i + 2 * NW < nt) dma_tile(i + 2 * NW, stage);
+#if SPATTEN_GQA_SPLIT_REFILL
+    if (more2) dma_values(i + 2 * NW, stage);
+#else
+    if (more2) dma_tile(i + 2 * NW, stage);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if (k == 0) SPATTEN_GSTAMP(6);   // its refill requested
   }
@@ -490,7 +526,7 @@ __global__ __launch_bounds__(256, 1) void decode_gqa_kernel(const GqaParams<T> p
   if (!p.poll_merge && tid == 0) __hip_atomic_store(p.ws_cnt + 2 * unit0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
 }
 
-// 0 = never, 1 = whenever the launch is eligible, -1 (default) = eligible launches from kGqaMinRows rows on
+// 0 = never, 1 = whenever the launch is eligible, -1 (default) = eligible launches where the form measured faster (gqa_pays)
 static std::atomic<int> g_gqa_mode{-2};
 static int gqa_mode() {
   int m = g_gqa_mode.load(std::memory_order_relaxed);
@@ -502,7 +538,14 @@ static int gqa_mode() {
   }
   return m;
 }
-constexpr int kGqaMinRows = 1024;
+// Default mode: the matrix-core form where it measured faster than one workgroup column per query head (tools/mb/gqa_bench.py,
+// 12 shapes, round 6): the per-query-head step costs ~6.3 us + 0.047 us per 1024 (query head x row), this one ~11.6 us + 0.0625 us
+// per 1024 (kv head x row) — its fixed part is the larger one (four waves' LDS rings to fill, a two-level fold), its slope does
+// not grow with the group.  Crossover: B Hkv N (0.047 G - 0.0625) = 5.3 x 1024, e.g. 32 / 8 heads from ~5.4k rows, 64 / 8 from ~2.2k,
+// 16 / 8 from ~21k (measured: 4096 -> 6144, 2048 -> 4096, ~16k).
+static inline bool gqa_pays(int batch, int kv_heads, int group, int rows) {
+  return (long long)batch * kv_heads * rows * (47 * group - 62) >= 5400000ll;
+}
 
 // The grouped-query step on the matrix cores, when the launch is one this kernel serves: SPATTEN_OK after launching,
 // SPATTEN_ERR_UNSUPPORTED (nothing launched: the caller takes the per-query-head kernel) otherwise.
@@ -510,16 +553,19 @@ int decode_gqa_rows(const DecodeCall& c, hipStream_t stream) {
   const int mode = gqa_mode();
   if (mode == 0 || c.heads == c.kv_heads || c.head_dim != 128 || (c.dtype != SPATTEN_BF16 && c.dtype != SPATTEN_F16)) return SPATTEN_ERR_UNSUPPORTED;
   if (c.n_q != 1 || c.mask || c.pq || c.acc || c.prev_scores || c.qkv_x || c.head_ids || c.head_abs || c.flags != 0 || c.causal ||
-      !c.q || !c.kr_cache || !c.v_cache || !c.out || c.layout_len > c.kv_len)
+      !c.q || !c.kr_cache || !c.v_cache || !c.out)
     return SPATTEN_ERR_UNSUPPORTED;
   const int G = c.heads / c.kv_heads;
   if (G > 32 || c.lse_q > 1) return SPATTEN_ERR_UNSUPPORTED;
-  if (mode < 0 && c.kv_len < kGqaMinRows) return SPATTEN_ERR_UNSUPPORTED;
+  // the split layout follows the LAYOUT length (a static launch laid out for a longer cache: the decomposition — and with it
+  // every bit of `out` — of the device-length form whose bound is that length); so does the choice of the kernel, or a static
+  // launch and the device-length form of the same step could take different kernels around the threshold
+  const int lay = (!c.step && c.layout_len > c.kv_len) ? c.layout_len : c.kv_len;
+  if (mode < 0 && !gqa_pays(c.batch, c.kv_heads, G, lay)) return SPATTEN_ERR_UNSUPPORTED;
   if ((int64_t)c.kv_len * 256 >= 0x7FFFFFFFll) return SPATTEN_ERR_UNSUPPORTED;          // 32-bit byte offsets inside a plane
   if ((c.kv_sb | c.kv_sh) % 8 != 0 || (c.q_sb | c.q_sh) % 8 != 0 || (c.k_new && (c.new_sb | c.new_sh) % 8 != 0)) return SPATTEN_ERR_UNSUPPORTED;
   const int units = c.batch * c.heads;
   const int ws_splits = c.ws_splits > 0 ? c.ws_splits : kDecodeMaxSplits;
-  const int lay = c.kv_len;
   const int cols = c.batch * c.kv_heads;
   // one workgroup per CU (128 KiB of LDS each); a wave wants at least two tiles
   int S = c.n_splits > 0 ? c.n_splits : std::max(1, coresident_workgroups() / cols);

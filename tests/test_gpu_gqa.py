@@ -73,8 +73,9 @@ def test_gqa_mfma_agrees_with_the_per_query_head_kernel(gqa_forced):
     assert np.array_equal(a[2], b_[2]) and np.array_equal(a[3], b_[3])
 
 
-def _dyn_pair(B, H, Hkv, P, cap, dt, steps, graph):
-    """`steps` tokens through the static launches (set A) and the device-length form (set B, optionally ONE captured graph)."""
+def _dyn_pair(B, H, Hkv, P, cap, dt, steps, graph, same_layout=False):
+    """`steps` tokens through the static launches (set A) and the device-length form (set B, optionally ONE captured graph);
+    same_layout: the static launches are laid out for the bound (`layout=cap`) — then `out` must agree bit for bit."""
     from spatten_amd import ops
     d, tdt = 128, TORCH_DT[dt]
     cos, sin = ops.rope_table(cap + 8, d, tdt, "cuda")
@@ -111,7 +112,8 @@ def _dyn_pair(B, H, Hkv, P, cap, dt, steps, graph):
     for t in range(steps):
         n = P + t + 1
         q.copy_(rnd(B, H, d)); kn.copy_(rnd(B, Hkv, d)); vn.copy_(rnd(B, Hkv, d))
-        ops.attn_decode(q, A[0], A[1], A[2], n, cos, sin, n - 1, k_new=kn, v_new=vn, scores=st_a, out=out_a, workspace=ws)
+        ops.attn_decode(q, A[0], A[1], A[2], n, cos, sin, n - 1, k_new=kn, v_new=vn, scores=st_a, out=out_a, workspace=ws,
+                        **({"layout": cap} if same_layout else {}))
         if gr is not None:
             gr.replay()
         else:
@@ -120,6 +122,8 @@ def _dyn_pair(B, H, Hkv, P, cap, dt, steps, graph):
         ws.check()
         # the device-length form lays its splits out for the bound: another summation grouping (low bits of `out`), same logits
         np.testing.assert_allclose(host(out_a), host(out_b), **OUT_TOL[dt])
+        if same_layout:
+            assert torch.equal(out_a, out_b), t
         assert torch.equal(st_a[:, :, :n], st_b[:, :, :n]), t
         for a, b_ in zip(A, Bs):
             assert torch.equal(a[:, :, :n], b_[:, :, :n]), t
@@ -131,10 +135,14 @@ def test_gqa_mfma_device_length_form_equals_the_static_launches(gqa_forced, grap
     # lengths that cross a tile and a split boundary while the steps run; stale rows beyond the live length are NaN
     _dyn_pair(1, 32, 8, 2045, 2304, "bf16", steps=6, graph=graph)
     _dyn_pair(2, 8, 2, 60, 512, "f16", steps=5, graph=graph)
+    # laid out for the bound, the static launch IS the device-length form: same splits, same bits (and the same kernel on both
+    # sides of the 1024-row threshold of the default mode: tests/test_gpu_gemv.py, 900 live rows under a 1024-row bound)
+    _dyn_pair(1, 32, 8, 2045, 2304, "bf16", steps=3, graph=graph, same_layout=True)
+    _dyn_pair(1, 16, 4, 700, 1280, "f16", steps=3, graph=graph, same_layout=True)
 
 
 def test_gqa_mfma_at_16384_rows_32_over_8_heads():
-    """The size the verdict names; the default mode must pick the matrix-core form here (>= 1024 rows) — checked through the
+    """The size the verdict names; the default mode must pick the matrix-core form here (its measured crossover at 32 / 8 heads is ~5.4k rows) — checked through the
     result: both forms are run and must agree with the oracle; more splits than the chip has CUs (ticket merge) as well."""
     from spatten_amd import ops
     dt, B, H, Hkv, d, P = "bf16", 1, 32, 8, 128, 16383

@@ -32,7 +32,7 @@ chain = ops.DecodeChain(q, K, Kr, V, out, k_new=kn, v_new=vn, scores=st)
 lib = _lib.load()
 S = lib.spatten_decode_auto_splits(B, H, d, N)
 nwg = S * H * B * (2 if N > 8 * 320 else 1)
-buf = torch.zeros(L * nwg * 8, dtype=torch.int64, device=dev)
+buf = torch.zeros(L * nwg * 16, dtype=torch.int64, device=dev)
 for _ in range(3):
     chain(N, cos, sin, N - 1)
 torch.cuda.synchronize()
@@ -41,11 +41,11 @@ assert lib.spatten_debug_set_chain_trace(buf.data_ptr()) == 0
 chain(N, cos, sin, N - 1)
 torch.cuda.synchronize()
 lib.spatten_debug_set_chain_trace(None)
-t = buf.cpu().numpy().reshape(L, nwg, 8).astype(np.float64) * 0.01      # us
+t = buf.cpu().numpy().reshape(L, nwg, 16).astype(np.float64) * 0.01      # us
 names = ["step start", "flag seen (wave 0)", "q staged (barrier passed)", "q rotated, next keys requested", "tile done",
-         "workgroup reduced", "merger: partials landed", "step end (flag stored)", "next keys issued", "scores done",
-         "next values issued", "-"]
-order = [0, 1, 2, 3, 4, 5, 6, 7]
+         "workgroup reduced", "merger: partials landed", "step end (flag stored)", "non-merger: granules issued",
+         "non-merger: end barrier passed", "loop top (this layer)", "layer table entry read"]
+order = [10, 11, 0, 1, 2, 3, 4, 5, 8, 9, 6, 7]
 t0 = t[t > 0].min()
 print(f"H={H} N={N} L={L} S={S}: layer period (flag-stored of the last unit, layer to layer):")
 ends = np.array([t[l, :, 7].max() for l in range(L)])

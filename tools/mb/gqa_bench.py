@@ -10,6 +10,8 @@ from spatten_amd import ops
 
 H, Hkv, N = (int(x) for x in (sys.argv[1:4] if len(sys.argv) >= 4 else (32, 8, 16384)))
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+NS = int(os.environ.get("GQA_NS", "0"))          # forced split count (0 = the launch's own choice)
+MODES = tuple(int(x) for x in os.environ.get("GQA_MODES", "0,1,0,1").split(","))
 d, tdt = 128, torch.bfloat16
 cap = N + 64
 plane = B * Hkv * cap * d * 2
@@ -26,12 +28,12 @@ out = torch.zeros(B, H * d, dtype=tdt, device="cuda")
 st = torch.zeros(B, H, cap, dtype=tdt, device="cuda")
 ws = ops.DecodeWorkspace(B, H, d, "cuda")
 res = {}
-for mode in (0, 1, 0, 1):
+for mode in MODES:
     ops.set_decode_gqa(mode)
 
     def token():
         for kc, krc, vc in planes:
-            ops.attn_decode(q, kc, krc, vc, N, cos, sin, N - 1, k_new=kn, v_new=vn, scores=st, out=out, workspace=ws)
+            ops.attn_decode(q, kc, krc, vc, N, cos, sin, N - 1, k_new=kn, v_new=vn, scores=st, out=out, workspace=ws, n_splits=NS)
 
     token()
     torch.cuda.synchronize()
@@ -51,6 +53,6 @@ for mode in (0, 1, 0, 1):
     us = e0.elapsed_time(e1) * 1e3 / (reps * L)
     uniq = B * Hkv * N * d * 2 * 2
     res.setdefault(mode, []).append(us)
-    print(f"H={H} Hkv={Hkv} N={N} B={B} layers={L} mode={mode}: {us:7.2f} us/step  unique K/V {uniq / us / 1e6:6.2f} TB/s "
+    print(f"H={H} Hkv={Hkv} N={N} B={B} layers={L} ns={NS} mode={mode}: {us:7.2f} us/step  unique K/V {uniq / us / 1e6:6.2f} TB/s "
           f"({uniq / us / 1e6 / 8.0:.3f} of peak)", flush=True)
     ws.check()
