@@ -1521,6 +1521,33 @@ def main():
                     q5, K6[i % 2], V6[i % 2], 2 * N5, c5, s5, 2 * N5 - 1, keep5, st5, out=o5, k_new=kn5, v_new=vn5, k_cache=ku6)), 2)
                 extras["c5_local_v_30pct_vs_plain_decode_with_append"] = round(
                     extras["c5_decode_13b_16384_local_v_30pct_with_append_us"] / extras["c5_decode_13b_16384_dense_with_append_us"], 3)
+                del K6, V6, K5, V5, ku6, st5
+                # round 6: a grouped-query model's step (32 query heads on 8 kv heads, modify_llama.py:106-108 repeat_kv; not among
+                # BASELINE's configs): one workgroup column per query head against a kv head's rows streamed once and scored for the
+                # whole group on the matrix cores (csrc/decode_gqa.hip); "unique" = K/V bytes counted once
+                Hq, Hk = 32, 8
+                for Ng in (16384, 4096):
+                    capg = Ng + 64
+                    cg, sg = ops.rope_table(capg + 8, d, dt, dev)
+                    Lg = max(4, int(600e6 // (2 * Hk * capg * d * 2)) + 1)
+                    Kg = [rnd(1, Hk, capg, d) for _ in range(Lg)]
+                    Vg = [rnd(1, Hk, capg, d) for _ in range(Lg)]
+                    Kug = torch.zeros_like(Kg[0])
+                    qg_, kng, vng = rnd(1, Hq, d), rnd(1, Hk, d), rnd(1, Hk, d)
+                    og_ = torch.empty(1, Hq * d, dtype=dt, device=dev)
+                    wsg_ = ops.DecodeWorkspace(1, Hq, d, dev)
+                    prev_mode = ops.set_decode_gqa(-1)
+                    try:
+                        for mode, tag in ((0, "per_query_head"), (1, "matrix_core"), (-1, "default")):
+                            ops.set_decode_gqa(mode)
+                            extras[f"gqa_32over8_{Ng}_{tag}_us"] = round(_time(lambda i: ops.attn_decode(
+                                qg_, Kug, Kg[i % Lg], Vg[i % Lg], Ng, cg, sg, Ng - 1, k_new=kng, v_new=vng, out=og_, workspace=wsg_), n=Lg), 2)
+                    finally:
+                        ops.set_decode_gqa(prev_mode)
+                    if Ng == 16384:
+                        extras["gqa_32over8_16384_matrix_core_unique_frac_of_hbm_peak"] = round(
+                            2 * Hk * Ng * d * 2 / (extras["gqa_32over8_16384_matrix_core_us"] * 1e-6) / 8e12, 3)
+                    del Kg, Vg, Kug
             except Exception as e:  # the headline number must not depend on the side measurements
                 extras["side_measurements_error"] = f"{type(e).__name__}: {e}"
             result["extras"] = extras

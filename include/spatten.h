@@ -197,8 +197,8 @@ int spatten_decode_qkv_supported(int dtype, int batch, int heads, int kv_heads, 
 /* Grouped-query models (heads > kv_heads; modify_llama.py:106-108 repeat_kv), round 6: the single-row step of bf16 / f16, head_dim
  * 128, without mask / head list / cascade accumulation / quantised keys streams a KV head's rows ONCE for its whole query group and
  * scores them on the matrix cores (csrc/decode_gqa.hip) instead of once per query head.  mode: -1 = where that form measured faster
- * (the default: batch x kv_heads x rows x (0.047 group - 0.0625) >= 5.3 x 1024 — 32 / 8 heads from ~5.4k rows, 64 / 8 from ~2.2k; the
- * layout length decides, so a static launch and the device-length form of one step take the same kernel), 0 = never, 1 = whenever the
+ * (the default: a cost model fitted to 27 measured shapes, csrc/decode_gqa.hip gqa_pays — 32 / 8 heads from ~3k rows, 64 / 8 from
+ * ~1.5k; the layout length decides, so a static launch and the device-length form of one step take the same kernel), 0 = never, 1 = whenever the
  * step is eligible.  Process-wide; outputs of the two forms differ in summation order (low bits), both
  * inside the stated tolerance.  Returns the previous mode + 1 (0..2), or SPATTEN_ERR_INVALID.  SPATTEN_DECODE_GQA in the
  * environment sets the initial mode. */

@@ -539,12 +539,16 @@ static int gqa_mode() {
   return m;
 }
 // Default mode: the matrix-core form where it measured faster than one workgroup column per query head (tools/mb/gqa_bench.py,
-// 12 shapes, round 6): the per-query-head step costs ~6.3 us + 0.047 us per 1024 (query head x row), this one ~11.6 us + 0.0625 us
-// per 1024 (kv head x row) — its fixed part is the larger one (four waves' LDS rings to fill, a two-level fold), its slope does
-// not grow with the group.  Crossover: B Hkv N (0.047 G - 0.0625) = 5.3 x 1024, e.g. 32 / 8 heads from ~5.4k rows, 64 / 8 from ~2.2k,
-// 16 / 8 from ~21k (measured: 4096 -> 6144, 2048 -> 4096, ~16k).
-static inline bool gqa_pays(int batch, int kv_heads, int group, int rows) {
-  return (long long)batch * kv_heads * rows * (47 * group - 62) >= 5400000ll;
+// 12 + 15 shapes, round 6).  The per-query-head step costs ~6.3 us + 0.047 us per 1024 (query head x row); this one a fixed part
+// + 0.0625 us per 1024 (kv head x row): its slope does not grow with the group, its fixed part is the larger one — ~9.4 us while
+// a split's chunk is one tile per wave (128 rows: short caches spread over many splits), ~11.6 us from two tiles per wave on
+// (four waves' rings to fill twice over, the longer fold).  32 / 8 heads: from ~3k rows (4096: 11.6 against 12.4; 2048: 10.45
+// against 9.44), 64 / 8 from ~1.5k (2048: 11.1 against 12.2), 16 / 8 only around 16k.
+static inline bool gqa_pays(int batch, int heads, int kv_heads, int rows, int chunk) {
+  const float n = (float)rows * (1.0f / 1024.0f) * (float)batch;
+  const float per_query_head = 6.3f + 0.047f * (float)heads * n;
+  const float fixed = chunk <= 128 ? 9.4f : chunk >= 256 ? 11.6f : 9.4f + 2.2f * (float)(chunk - 128) * (1.0f / 128.0f);
+  return fixed + 0.0625f * (float)kv_heads * n < per_query_head;
 }
 
 // The grouped-query step on the matrix cores, when the launch is one this kernel serves: SPATTEN_OK after launching,
@@ -561,19 +565,22 @@ int decode_gqa_rows(const DecodeCall& c, hipStream_t stream) {
   // every bit of `out` — of the device-length form whose bound is that length); so does the choice of the kernel, or a static
   // launch and the device-length form of the same step could take different kernels around the threshold
   const int lay = (!c.step && c.layout_len > c.kv_len) ? c.layout_len : c.kv_len;
-  if (mode < 0 && !gqa_pays(c.batch, c.kv_heads, G, lay)) return SPATTEN_ERR_UNSUPPORTED;
   if ((int64_t)c.kv_len * 256 >= 0x7FFFFFFFll) return SPATTEN_ERR_UNSUPPORTED;          // 32-bit byte offsets inside a plane
   if ((c.kv_sb | c.kv_sh) % 8 != 0 || (c.q_sb | c.q_sh) % 8 != 0 || (c.k_new && (c.new_sb | c.new_sh) % 8 != 0)) return SPATTEN_ERR_UNSUPPORTED;
   const int units = c.batch * c.heads;
   const int ws_splits = c.ws_splits > 0 ? c.ws_splits : kDecodeMaxSplits;
   const int cols = c.batch * c.kv_heads;
-  // one workgroup per CU (128 KiB of LDS each); a wave wants at least two tiles
+  // one workgroup per CU (128 KiB of LDS each); a split gets at least one tile per wave (128 rows: 2048 rows x 32 / 8 heads 12.6 ->
+  // 10.45 us, 4096 rows 13.2 -> 11.6 against two tiles per wave; 64 rows: as 128)
   int S = c.n_splits > 0 ? c.n_splits : std::max(1, coresident_workgroups() / cols);
-  S = std::min(S, std::max(1, lay / 256));
+  static int min_chunk = -1;                  // (SPATTEN_GQA_MIN_CHUNK: A/B of the shortest chunk a split may get)
+  if (min_chunk < 0) { const char* e = getenv("SPATTEN_GQA_MIN_CHUNK"); min_chunk = e ? std::max(32, atoi(e)) : 128; }
+  S = std::min(S, std::max(1, lay / min_chunk));
   S = std::min(S, std::min(ws_splits, kDecodeMaxSplits));
   const int chunk = (lay + S - 1) / S;
   const int chunk32 = (chunk + 31) / 32 * 32;
   S = (lay + chunk32 - 1) / chunk32;
+  if (mode < 0 && !gqa_pays(c.batch, c.heads, c.kv_heads, lay, chunk32)) return SPATTEN_ERR_UNSUPPORTED;
   if (S > 1 && (!c.workspace || (size_t)units > c.ws_units)) return SPATTEN_ERR_UNSUPPORTED;
   static int env_poll = -1;
   if (env_poll < 0) { const char* e = getenv("SPATTEN_DECODE_POLL"); env_poll = e ? atoi(e) : 1; }

@@ -594,7 +594,7 @@ def set_decode_team(threads: int) -> int:
 
 def set_decode_gqa(mode: int) -> int:
     """Grouped-query decode steps on the matrix cores (include/spatten.h: spatten_decode_set_gqa): -1 = where it measured faster
-    (default: long caches / large groups, e.g. 32 / 8 heads from ~5.4k rows), 0 = never (one workgroup column per query head), 1 = whenever the step is eligible.  Process-wide; returns the previous mode."""
+    (default: long caches / large groups, e.g. 32 / 8 heads from ~3k rows), 0 = never (one workgroup column per query head), 1 = whenever the step is eligible.  Process-wide; returns the previous mode."""
     prev = _lib.load().spatten_decode_set_gqa(int(mode))
     if prev < 0:
         raise ValueError("decode gqa mode: -1, 0 or 1")

@@ -142,7 +142,7 @@ def test_gqa_mfma_device_length_form_equals_the_static_launches(gqa_forced, grap
 
 
 def test_gqa_mfma_at_16384_rows_32_over_8_heads():
-    """The size the verdict names; the default mode must pick the matrix-core form here (its measured crossover at 32 / 8 heads is ~5.4k rows) — checked through the
+    """The size the verdict names; the default mode must pick the matrix-core form here (its measured crossover at 32 / 8 heads is ~3k rows) — checked through the
     result: both forms are run and must agree with the oracle; more splits than the chip has CUs (ticket merge) as well."""
     from spatten_amd import ops
     dt, B, H, Hkv, d, P = "bf16", 1, 32, 8, 128, 16383
