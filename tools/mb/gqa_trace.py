@@ -27,7 +27,7 @@ ops.set_decode_gqa(1)
 lib = _lib.load()
 lib.spatten_debug_set_gqa_trace.argtypes = [ctypes.c_void_p]
 nwg = 64 * Hkv * B
-buf = torch.zeros(nwg * 4 * 16, dtype=torch.int64, device="cuda")
+buf = torch.zeros(nwg * 4 * 48, dtype=torch.int64, device="cuda")
 
 
 def token(n=L):
@@ -41,7 +41,7 @@ assert lib.spatten_debug_set_gqa_trace(buf.data_ptr()) == 0
 token(3)            # the stamps of the LAST launch survive (back-to-back launches: a warm pipeline)
 torch.cuda.synchronize()
 lib.spatten_debug_set_gqa_trace(None)
-t = buf.cpu().numpy().reshape(-1, 4, 16).astype(np.float64) * 0.01
+t = buf.cpu().numpy().reshape(-1, 4, 48).astype(np.float64) * 0.01
 live = t[:, 0, 0] > 0
 t = t[live]
 t0 = t[:, :, 0][t[:, :, 0] > 0].min()
@@ -53,3 +53,13 @@ for s_, nm in enumerate(names):
     x = x[x > 0] - t0
     if x.size:
         print(f"  {nm:28s} {x.min():7.2f} {np.median(x):7.2f} {x.max():7.2f}   (n={x.size})")
+
+it_names = ["keys ready", "S done", "key refill issued", "softmax done", "values ready", "P.V done", "value refill issued"]
+print("per tile of a wave (k = 0..3): median us after the first wave start")
+for k in range(4):
+    row = []
+    for j, nm in enumerate(it_names):
+        x = t[:, :, 12 + 8 * k + j]
+        x = x[x > 0] - t0
+        row.append(f"{nm} {np.median(x):6.2f}" if x.size else f"{nm}    -- ")
+    print(f"  k={k}: " + " | ".join(row))
