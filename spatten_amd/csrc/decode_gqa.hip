@@ -21,8 +21,6 @@
 // and the error word are shared with the per-query-head kernels, so launches of both kinds may alternate on one workspace.
 #include <stdlib.h>
 
-#include <type_traits>
-
 #include "common.h"
 #include "decode_body.h"
 #include "mfma_tiles.h"
@@ -37,11 +35,9 @@ static __device__ unsigned long long* g_gqa_trace = nullptr;
 #else
 #define SPATTEN_GSTAMP(slot)
 #endif
-#define SPATTEN_GSTAMP_IT(k, j) do { if ((k) < 4) SPATTEN_GSTAMP(12 + 8 * (k) + (j)); } while (0)   /* per tile: 0 keys ready, 1 S done, 2 key refill issued, 3 softmax done, 4 values ready, 5 P.V done, 6 value refill issued */
+// per tile k < 4 of a wave: 0 keys ready, 1 S done, 2 key refill issued, 3 softmax done, 4 values ready, 5 P.V done, 6 value refill issued
+#define SPATTEN_GSTAMP_IT(k, j) do { if ((k) < 4) SPATTEN_GSTAMP(12 + 8 * (k) + (j)); } while (0)
 
-#ifndef SPATTEN_GQA_REGT_DEFAULT   // which fill path a launch takes unless SPATTEN_GQA_REGT says otherwise
-#define SPATTEN_GQA_REGT_DEFAULT 0
-#endif
 #ifndef SPATTEN_GQA_NT             // A/B: non-temporal LDS-DMA requests
 #define SPATTEN_GQA_NT 1
 #endif
@@ -73,11 +69,7 @@ template <int N> __device__ inline void wait_vm() {
   __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
 }
 
-// REGT (round 6, third session): the tiles travel through REGISTERS instead of LDS-DMA rings — three register tiles per wave in
-// flight (48 KiB), each written to the wave's ONE LDS stage when it has landed and re-requested at once for the tile three ahead:
-// a refill no longer waits for the consumption of its stage (the DMA ring keeps one to two tiles per wave in flight and streams at
-// ~13 B/ns per CU in the steady state; the requests here are plain buffer loads whose waits the compiler counts exactly).
-template <typename T, bool DYN, bool REGT>
+template <typename T, bool DYN>
 __global__ __launch_bounds__(256, 1) void decode_gqa_kernel(const GqaParams<T> p) {
   constexpr int D = 128, KK = D / 16, DB = D / 32, KT = 32, NW = 4;
   constexpr int KBYTES = KT * D * 2;                  // a tile's key rows (8 KiB); as many value rows
@@ -147,34 +139,6 @@ __global__ __launch_bounds__(256, 1) void decode_gqa_kernel(const GqaParams<T> p
     for (int i = 0; i < NK; ++i) dma16a(v_rsrc, va + i * 1024, vbase, soff + i * 1024);
   };
   auto dma_tile = [&](int tile, int stage) { dma_keys(tile, stage); dma_values(tile, stage); };
-  // REGT: the same pieces (same global-side swizzle: the LDS image is the DMA's) as 16-byte buffer loads; a tile past the plane's
-  // bound reads as zeros without touching memory, so every request is unconditional
-  struct RegTile { u32x4 k[NK], v[NK]; };
-  RegTile regs[REGT ? 3 : 1];
-  const __amdgpu_buffer_rsrc_t k_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(krb), 0, (int)(plane_bytes < 0x7FFFFFFF ? plane_bytes : 0x7FFFFFFF), 0x00020000);
-  const __amdgpu_buffer_rsrc_t v_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(vb), 0, (int)(plane_bytes < 0x7FFFFFFF ? plane_bytes : 0x7FFFFFFF), 0x00020000);
-  const int r_lr = lane >> 4, r_ps = lane & 15;
-  const int r_kbase = r_lr * 256 + ((r_ps ^ r_lr) << 4), r_vbase = r_lr * 256 + ((r_ps ^ (4 * r_lr)) << 4);
-  auto tile_soff = [&](int tile) {   // (a tile index past the split: an offset past every plane — zeros, no memory access)
-    const long long o = (long long)(lo + tile * KT) * (D * 2);
-    return __builtin_amdgcn_readfirstlane((int)(o < 0x7FFFF000ll ? o : 0x7FFFF000ll));
-  };
-  auto ld_keys = [&](RegTile& rt, int tile) {
-    const int soff = tile_soff(tile);
-#pragma unroll
-    for (int i = 0; i < NK; ++i) {
-      const auto x = __builtin_amdgcn_raw_buffer_load_b128(k_res, r_kbase ^ (((i * 4) & 15) << 4), soff + i * 1024, 2);
-      rt.k[i] = u32x4{x[0], x[1], x[2], x[3]};
-    }
-  };
-  auto ld_values = [&](RegTile& rt, int tile) {
-    const int soff = tile_soff(tile);
-#pragma unroll
-    for (int i = 0; i < NK; ++i) {
-      const auto x = __builtin_amdgcn_raw_buffer_load_b128(v_res, r_vbase, soff + i * 1024, 2);
-      rt.v[i] = u32x4{x[0], x[1], x[2], x[3]};
-    }
-  };
   // ---- the group's queries as B operands: column g = head hkv G + g, fragment kk holds elements [16 kk + 8 hi, +8), so kk and
   // kk + KK/2 are the (x[i], x[i + d/2]) pairs RoPE combines.  Columns >= G: zeros.  Their rows are requested FIRST (a wave's loads
   // return in order: behind the tile the rotation would wait for the tile), then the first tile, then the rotation.
@@ -199,15 +163,9 @@ __global__ __launch_bounds__(256, 1) void decode_gqa_kernel(const GqaParams<T> p
   __builtin_amdgcn_sched_barrier(0);
   // the first tile goes out before anything is waited for (laid out for the bound: a device-length step may find it past its length)
   const int nt_bound = (min(lo + p.chunk, p.N) - lo + KT - 1) / KT;
-  if constexpr (REGT) {
-    ld_keys(regs[0], wave); ld_values(regs[0], wave);
-    ld_keys(regs[REGT ? 1 : 0], wave + NW); ld_values(regs[REGT ? 1 : 0], wave + NW);
-    ld_keys(regs[REGT ? 2 : 0], wave + 2 * NW); ld_values(regs[REGT ? 2 : 0], wave + 2 * NW);
-  } else {
-    if (wave < nt_bound) dma_tile(wave, 0);
-    if (wave + NW < nt_bound) dma_tile(wave + NW, 1);
-  }
-  SPATTEN_GSTAMP(1);          // two (REGT: three) tiles requested
+  if (wave < nt_bound) dma_tile(wave, 0);
+  if (wave + NW < nt_bound) dma_tile(wave + NW, 1);
+  SPATTEN_GSTAMP(1);          // two tiles requested
   __builtin_amdgcn_sched_barrier(0);
   frag qf[KK];                                        // rotated (modify_llama.py:92: three rounded ops)
   {
@@ -256,34 +214,16 @@ __global__ __launch_bounds__(256, 1) void decode_gqa_kernel(const GqaParams<T> p
 
   const unsigned lds0 = (unsigned)(wbuf - lds);
   const int li = lane & 15, kr = li >> 2;
-  // one tile: `slot_c` names the register tile that holds it (REGT; a compile-time index — the loop below is unrolled by three)
-  auto tile_step = [&](const int i, const int k, auto slot_c) {
-    constexpr int SLOT = REGT ? decltype(slot_c)::value : 0;
-    const int stage = REGT ? 0 : (k & 1);             // (REGT: one LDS stage per wave — the ring is the register tiles)
+  for (int i = wave, k = 0; i < nt; i += NW, ++k) {
+    const int stage = k & 1;
     const bool more = i + NW < nt;                    // this wave's next tile is in flight behind this one
     const bool more2 = i + 2 * NW < nt;               // ... and the tile after next is requested during this one
     const int row0 = lo + i * KT;
     const bool edge = row0 + KT > n_cached;           // the tile holds rows the caches do not: past the length, or the new token's
     // loads return in order: "at most X outstanding" with X = the requests issued behind the wanted ones proves those have landed
     // whatever the stash stores in between do (they may only make the wait longer)
-    if constexpr (REGT) {     // the tile's key rows: registers -> the LDS stage (the compiler's own wait: exactly these eight loads),
-                              // and the registers are requested again at once, for the tile three ahead
-      char* ka = wbuf + stage * STAGE;
-#pragma unroll
-      for (int j = 0; j < NK; ++j) *reinterpret_cast<u32x4*>(ka + j * 1024 + lane * 16) = regs[SLOT].k[j];
-      ld_keys(regs[SLOT], i + 3 * NW);
-    }
-    auto commit_values = [&]() {
-      if constexpr (REGT) {
-        char* va = wbuf + stage * STAGE + KBYTES;
-#pragma unroll
-        for (int j = 0; j < NK; ++j) *reinterpret_cast<u32x4*>(va + j * 1024 + lane * 16) = regs[SLOT].v[j];
-        ld_values(regs[SLOT], i + 3 * NW);
-      }
-    };
     if (edge) {
-      if constexpr (REGT) commit_values();            // (an edge tile patches both halves below: its values go to LDS now)
-      else { if (more) wait_vm<2 * NK>(); else wait_vm<0>(); }
+      if (more) wait_vm<2 * NK>(); else wait_vm<0>();
       // value rows the cache does not hold: zero (their P is 0, but 0 x stale bits may be NaN); then the new token's rows
       char* va = wbuf + stage * STAGE + KBYTES;
 #pragma unroll
@@ -319,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void decode_gqa_kernel(const GqaParams<T> p
           V8::stg(p.vc + b * p.kv_sb + hkv * p.kv_sh + (int64_t)jn * D + 8 * (lane & 15), nv_raw);
         }
       }
-    } else if constexpr (!REGT) {
+    } else {
       if (more) wait_vm<3 * NK>(); else wait_vm<NK>();            // the tile's key rows have landed
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -341,14 +281,12 @@ __global__ __launch_bounds__(256, 1) void decode_gqa_kernel(const GqaParams<T> p
     }
     SPATTEN_GSTAMP_IT(k, 1);
 #if SPATTEN_GQA_SPLIT_REFILL
-    if constexpr (!REGT) {
     // the stage's KEY half is consumed (the reads that fed the products above have returned): the keys of the tile after next go
     // out now, a softmax and a P·V earlier than the stage's value half — a wave's requests then enter the CU's memory queue in two
     // bursts of 8 KiB per tile instead of one of 16
     __builtin_amdgcn_sched_barrier(0);
     if (more2) dma_keys(i + 2 * NW, stage);
     __builtin_amdgcn_sched_barrier(0);
-    }
 #endif
     SPATTEN_GSTAMP_IT(k, 2);
     // both reference roundings of every logit (matmul -> dtype, "/ sqrt(d)" -> dtype, modify_llama.py:111-113)
@@ -415,11 +353,8 @@ __global__ __launch_bounds__(256, 1) void decode_gqa_kernel(const GqaParams<T> p
         }
       l_run += ls[0] + ls[1];
     }
-    // ---- O^T += Vt · P^T: the tile's value rows have landed ------------------------------------------------------------------------
     SPATTEN_GSTAMP_IT(k, 3);
-    if constexpr (REGT) {
-      if (!edge) commit_values();
-    } else {
+    // ---- O^T += Vt · P^T: the tile's value rows have landed ------------------------------------------------------------------------
     __builtin_amdgcn_sched_barrier(0);
 #if SPATTEN_GQA_SPLIT_REFILL
     if (!edge) { if (more2) wait_vm<3 * NK>(); else if (more) wait_vm<2 * NK>(); else wait_vm<0>(); }   // (behind V: K, V of the next tile, K of the one after)
@@ -427,7 +362,6 @@ __global__ __launch_bounds__(256, 1) void decode_gqa_kernel(const GqaParams<T> p
     if (!edge) { if (more) wait_vm<2 * NK>(); else wait_vm<0>(); }
 #endif
     __builtin_amdgcn_sched_barrier(0);
-    }
     SPATTEN_GSTAMP_IT(k, 4);
     {
       // lane (col, hi) needs, for d = 32 db + col, the 8 keys its P fragment holds — elements 0..3: keys 16 t + 4 hi + 0..3,
@@ -447,30 +381,17 @@ __global__ __launch_bounds__(256, 1) void decode_gqa_kernel(const GqaParams<T> p
         }
     }
     // the stage is consumed (its last read fed the last product): request the tile after next into it
+    __builtin_amdgcn_sched_barrier(0);
     if (k == 0) SPATTEN_GSTAMP(4);   // first tile consumed
     SPATTEN_GSTAMP_IT(k, 5);
-    if constexpr (!REGT) {
-    __builtin_amdgcn_sched_barrier(0);
 #if SPATTEN_GQA_SPLIT_REFILL
     if (more2) dma_values(i + 2 * NW, stage);
 #else
     if (more2) dma_tile(i + 2 * NW, stage);
 #endif
     __builtin_amdgcn_sched_barrier(0);
-    }
     if (k == 0) SPATTEN_GSTAMP(6);   // its refill requested
     SPATTEN_GSTAMP_IT(k, 6);
-  };
-  if constexpr (REGT) {
-    for (int i = wave, k = 0; i < nt;) {
-      tile_step(i, k, std::integral_constant<int, 0>{}); i += NW; ++k;
-      if (i >= nt) break;
-      tile_step(i, k, std::integral_constant<int, 1>{}); i += NW; ++k;
-      if (i >= nt) break;
-      tile_step(i, k, std::integral_constant<int, 2>{}); i += NW; ++k;
-    }
-  } else {
-    for (int i = wave, k = 0; i < nt; i += NW, ++k) tile_step(i, k, std::integral_constant<int, 0>{});
   }
 
   // ---- the four waves' partials -> LDS (each wave into its own ring: all its requests have landed and been consumed) ----------------
@@ -674,9 +595,6 @@ int decode_gqa_rows(const DecodeCall& c, hipStream_t stream) {
   if (env_poll < 0) { const char* e = getenv("SPATTEN_DECODE_POLL"); env_poll = e ? atoi(e) : 1; }
   const int poll_merge = (env_poll != 0 && S > 1 && (long long)S * cols <= coresident_workgroups()) ? 1 : 0;
   const size_t cnt_bytes = decode_cnt_bytes(c.ws_units);
-  static int env_regt = -1;                   // (SPATTEN_GQA_REGT: A/B of the fill path — 1 = register tiles, 0 = LDS-DMA rings)
-  if (env_regt < 0) { const char* e = getenv("SPATTEN_GQA_REGT"); env_regt = e ? atoi(e) : SPATTEN_GQA_REGT_DEFAULT; }
-  const bool regt = env_regt != 0;
 
 #define SPATTEN_GQA_FILL(T)                                                                                      \
   GqaParams<T> p;                                                                                                \
@@ -703,13 +621,8 @@ int decode_gqa_rows(const DecodeCall& c, hipStream_t stream) {
   p.B = c.batch; p.H = c.heads; p.Hkv = c.kv_heads; p.G = G; p.N = c.kv_len; p.S = S; p.chunk = chunk32;         \
   p.poll_merge = poll_merge; p.sqrt_d = sqrtf((float)c.head_dim);                                                \
   const dim3 grid(S, c.kv_heads, c.batch);                                                                       \
-  if (regt) {                                                                                                    \
-    if (c.step) hipLaunchKernelGGL((decode_gqa_kernel<T, true, true>), grid, dim3(256), 0, stream, p);           \
-    else hipLaunchKernelGGL((decode_gqa_kernel<T, false, true>), grid, dim3(256), 0, stream, p);                 \
-  } else {                                                                                                       \
-    if (c.step) hipLaunchKernelGGL((decode_gqa_kernel<T, true, false>), grid, dim3(256), 0, stream, p);          \
-    else hipLaunchKernelGGL((decode_gqa_kernel<T, false, false>), grid, dim3(256), 0, stream, p);                \
-  }                                                                                                              \
+  if (c.step) hipLaunchKernelGGL((decode_gqa_kernel<T, true>), grid, dim3(256), 0, stream, p);                   \
+  else hipLaunchKernelGGL((decode_gqa_kernel<T, false>), grid, dim3(256), 0, stream, p);                         \
   return hipGetLastError() == hipSuccess ? SPATTEN_OK : SPATTEN_ERR_LAUNCH;
 
   if (c.dtype == SPATTEN_F16) { SPATTEN_GQA_FILL(f16_t) }
