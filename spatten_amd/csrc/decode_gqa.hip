@@ -12,7 +12,8 @@
 // Mapping: grid = (S splits, Hkv, B), 256 threads = 4 waves, ONE wave per SIMD, one workgroup per CU (128 KiB of LDS).  A split owns
 // `chunk` consecutive rows; its 32-row tiles go round-robin to the four waves, which never synchronise inside the stream: every wave
 // has a private two-stage LDS ring of { K tile, V tile } (8 + 8 KiB) filled by LDS-DMA (buffer_load_dwordx4 ... lds: no staging
-// registers): a stage is refilled with the tile after next as soon as it is consumed, so two tiles (32 KiB) per wave are in flight.  K tiles
+// registers; non-temporal): a stage is refilled with the tile after next in two halves — its keys behind S, its values behind P·V — so one to
+// two tiles (16-32 KiB) per wave are in flight.  A split's chunk is at least one tile per wave (128 rows).  K tiles
 // are XOR-swizzled on the global side for conflict-free ds_read_b128 A-operands; V tiles stay row-major and are read with gfx950's
 // transposing ds_read_b64_tr_b16 (the contraction index of P·V is the key = the row).
 // The appended token (k_new / v_new, modify_llama.py:95-100) is written INTO the LDS tile that holds row N-1 (and to the caches), so
