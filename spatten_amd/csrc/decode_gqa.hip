@@ -57,7 +57,7 @@ struct GqaParams {
   const int64_t* pos_ids; int64_t pos_sb; int pos_q;
   const int32_t* step;                                      // device-length form: word 0 = the live length (N is then the bound)
   T* out; int64_t out_sb;
-  T* scores; int64_t sc_sb, sc_sh; int sc_vec;              // sc_vec: stash rows 8-byte aligned -> four logits per store
+  T* scores; int64_t sc_sb, sc_sh; int sc_vec;              // sc_vec: stash rows 8-byte aligned -> four logits per store; 2: 16-byte aligned -> eight
   float* lse;
   unsigned* ws_err; unsigned* ws_cnt; unsigned long long* ws_part; int64_t ws_unit;
   int B, H, Hkv, G, N, S, chunk, poll_merge;
@@ -299,7 +299,30 @@ __global__ __launch_bounds__(256, 1) void decode_gqa_kernel(const GqaParams<T> p
       s[r + 1] = v[1];
     }
     // the stash (pre-mask logits, :116-119): register r is key row0 + (r & 3) + 8 (r >> 2) + 4 hi
-    if (stashp != nullptr) {
+    if (stashp != nullptr && p.sc_vec == 2 && row0 + KT <= N) {
+      // a whole tile, 16-byte aligned rows: lanes col and col + 32 exchange halves (v_permlane32_swap: 4 per tile) so that each
+      // holds 16 CONSECUTIVE keys — two 16-byte stores per tile instead of four 8-byte ones (a store takes a slot of the CU's
+      // memory queue like a 1-KiB request does)
+      uint32_t w[4][2];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const T x0 = DT<T>::from_f32(s[4 * q4 + 2 * j]), x1 = DT<T>::from_f32(s[4 * q4 + 2 * j + 1]);
+          w[q4][j] = (uint32_t)*reinterpret_cast<const unsigned short*>(&x0) | ((uint32_t)*reinterpret_cast<const unsigned short*>(&x1) << 16);
+        }
+      u32x4 lo8, hi8;                                 // keys [16 hi, +8) and [16 hi + 8, +8) of the tile
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const auto ra = __builtin_amdgcn_permlane32_swap(w[0][j], w[2][j], false, false);
+        lo8[j] = ra[0]; lo8[2 + j] = ra[1];
+        const auto rb = __builtin_amdgcn_permlane32_swap(w[1][j], w[3][j], false, false);
+        hi8[j] = rb[0]; hi8[2 + j] = rb[1];
+      }
+      T* dst = stashp + row0 + 16 * hi;
+      *reinterpret_cast<u32x4*>(dst) = lo8;
+      *reinterpret_cast<u32x4*>(dst + 8) = hi8;
+    } else if (stashp != nullptr) {
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         const int key = row0 + 8 * q4 + 4 * hi;
@@ -614,6 +637,7 @@ int decode_gqa_rows(const DecodeCall& c, hipStream_t stream) {
   p.out = (T*)c.out; p.out_sb = c.out_sb;                                                                        \
   p.scores = (T*)c.scores; p.sc_sb = c.sc_sb; p.sc_sh = c.sc_sh;                                                 \
   p.sc_vec = (c.scores && ((uintptr_t)c.scores % 8 == 0) && c.sc_sb % 4 == 0 && c.sc_sh % 4 == 0) ? 1 : 0;      \
+  if (p.sc_vec && (uintptr_t)c.scores % 16 == 0 && c.sc_sb % 8 == 0 && c.sc_sh % 8 == 0 && sizeof(T) == 2) p.sc_vec = 2; \
   p.lse = c.lse;                                                                                                 \
   p.ws_err = (unsigned*)c.workspace;                                                                             \
   p.ws_cnt = c.workspace ? (unsigned*)((char*)c.workspace + kDecodeWsHeader) : nullptr;                          \

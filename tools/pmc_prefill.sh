@@ -7,14 +7,21 @@ timeout 250 rocprofv3 --pmc SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INS
 python3 - $R <<'PY'
 import csv, glob, sys, collections
 R = sys.argv[1]
+# the q = N = 8192 launches of the flash kernel (grid 64 x 32 workgroups of 256 threads), grouped by instantiation: the probe runs the
+# reference-numerics and the fp32-logit ("fast") instantiations back to back
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ("pmc_pf", "pmc_pf2", "pmc_pf3"):
     fs = glob.glob(f"{R}/gpurun_out/{d}/**/*counter_collection.csv", recursive=True)
     if not fs:
         print(d, "no output"); continue
-    acc = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        if "prefill_pp128_kernel" in r["Kernel_Name"] and ("Lb0ELi0ELb0ELb0ELb0EEEv" in r["Kernel_Name"] or "Lb0ELi0ELb0ELb0EEEv" in r["Kernel_Name"] or ", false, 0>" in r["Kernel_Name"]) and r["Grid_Size"] == str(64*32*256):
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in sorted(acc.items()):
-        print(f"{k:34s} {len(v):3d} {sum(v) / len(v):16.0f}  per wave-tile {sum(v) / len(v) / 266240:9.1f}")
+        if "prefill_pp128_kernel" in r["Kernel_Name"] and r["Grid_Size"] == str(64 * 32 * 256):
+            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for kn, cs in acc.items():
+    print("kernel:", kn[:160])
+    avg = {k: sum(v) / len(v) for k, v in cs.items()}
+    if "SQ_INSTS_VALU" in avg and avg.get("SQ_INSTS_MFMA"):
+        print(f"  SQ_INSTS_VALU / SQ_INSTS_MFMA = {avg['SQ_INSTS_VALU'] / 266240:.1f} / {avg['SQ_INSTS_MFMA'] / 266240:.1f} = {avg['SQ_INSTS_VALU'] / avg['SQ_INSTS_MFMA']:.2f}")
+    for k, v in sorted(cs.items()):
+        print(f"  {k:34s} {len(v):3d} {sum(v) / len(v):16.0f}  per wave-tile {sum(v) / len(v) / 266240:9.1f}")
 PY

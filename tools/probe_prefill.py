@@ -12,7 +12,7 @@ for N in (2048, 8192):
     cos, sin = ops.rope_table(N, d, dt, "cuda")
     kr = ops.rope_single(k, cos, sin)
     out = torch.empty(B, N, H * d, device="cuda", dtype=dt)
-    for name, kw in (("causal", dict(causal=True)), ("causal fast", dict(causal=True, numerics="fast")),
+    for name, kw in (("causal", dict(causal=True, numerics="reference")), ("causal fast", dict(causal=True, numerics="fast")),
                      ("causal+colimp", dict(causal=True, col_importance=torch.zeros(B, H, N, device="cuda")))):
         reps = 20 if name.startswith("causal") and "colimp" not in name else 5
         for _ in range(3):
