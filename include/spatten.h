@@ -203,6 +203,11 @@ int spatten_decode_qkv_supported(int dtype, int batch, int heads, int kv_heads, 
  * inside the stated tolerance.  Returns the previous mode + 1 (0..2), or SPATTEN_ERR_INVALID.  SPATTEN_DECODE_GQA in the
  * environment sets the initial mode. */
 int spatten_decode_set_gqa(int mode);
+/* 1 when a plain single-row step of this geometry (dtype bf16 / f16, head_dim 128, heads > kv_heads, kv_len_layout = the layout length:
+ * the cache length of a static launch, the bound of the device-length form) is launched in the matrix-core form under the current
+ * mode, 0 otherwise (also for geometries the form does not serve).  No stream operation; the default mode's answer follows the
+ * device's CU count. */
+int spatten_decode_gqa_selected(int dtype, int batch, int heads, int kv_heads, int head_dim, int kv_len_layout);
 
 /* ------------------------------------------------------------------------------------------------
  * The chained decode launch (ABI 5, round 6): the attention step of ALL layers of one token — what the caller's per-layer

@@ -250,6 +250,8 @@ def _declare(lib):
     lib.spatten_decode_set_team.argtypes = [c_int]
     lib.spatten_decode_set_gqa.restype = c_int
     lib.spatten_decode_set_gqa.argtypes = [c_int]
+    lib.spatten_decode_gqa_selected.restype = c_int
+    lib.spatten_decode_gqa_selected.argtypes = [i, i, i, i, i, i]
     lib.spatten_prune_layer_cascade.restype = c_int
     lib.spatten_prune_layer_cascade.argtypes = [i, i, i, p, p, p, p, p, p, p, p, p, p, p, p, i, p, i, p, i64, p, p, i, i, i, i, p]
 def load():

@@ -584,6 +584,19 @@ static inline bool gqa_pays(int batch, int heads, int kv_heads, int rows, int ch
   return fixed + 0.0625f * (float)kv_heads * n < per_query_head;
 }
 
+// The split layout of a launch: one workgroup per CU (128 KiB of LDS each); a split gets at least one tile per wave (128 rows: 2048
+// rows x 32 / 8 heads 12.6 -> 10.45 us, 4096 rows 13.2 -> 11.6 against two tiles per wave; 64 rows: as 128); chunks are whole tiles.
+static inline void gqa_layout(int cols, int lay, int n_splits, int ws_splits, int& S, int& chunk32) {
+  S = n_splits > 0 ? n_splits : std::max(1, coresident_workgroups() / cols);
+  static int min_chunk = -1;                  // (SPATTEN_GQA_MIN_CHUNK: A/B of the shortest chunk a split may get)
+  if (min_chunk < 0) { const char* e = getenv("SPATTEN_GQA_MIN_CHUNK"); min_chunk = e ? std::max(32, atoi(e)) : 128; }
+  S = std::min(S, std::max(1, lay / min_chunk));
+  S = std::min(S, std::min(ws_splits, kDecodeMaxSplits));
+  const int chunk = (lay + S - 1) / S;
+  chunk32 = (chunk + 31) / 32 * 32;
+  S = (lay + chunk32 - 1) / chunk32;
+}
+
 // The grouped-query step on the matrix cores, when the launch is one this kernel serves: SPATTEN_OK after launching,
 // SPATTEN_ERR_UNSUPPORTED (nothing launched: the caller takes the per-query-head kernel) otherwise.
 int decode_gqa_rows(const DecodeCall& c, hipStream_t stream) {
@@ -603,16 +616,8 @@ int decode_gqa_rows(const DecodeCall& c, hipStream_t stream) {
   const int units = c.batch * c.heads;
   const int ws_splits = c.ws_splits > 0 ? c.ws_splits : kDecodeMaxSplits;
   const int cols = c.batch * c.kv_heads;
-  // one workgroup per CU (128 KiB of LDS each); a split gets at least one tile per wave (128 rows: 2048 rows x 32 / 8 heads 12.6 ->
-  // 10.45 us, 4096 rows 13.2 -> 11.6 against two tiles per wave; 64 rows: as 128)
-  int S = c.n_splits > 0 ? c.n_splits : std::max(1, coresident_workgroups() / cols);
-  static int min_chunk = -1;                  // (SPATTEN_GQA_MIN_CHUNK: A/B of the shortest chunk a split may get)
-  if (min_chunk < 0) { const char* e = getenv("SPATTEN_GQA_MIN_CHUNK"); min_chunk = e ? std::max(32, atoi(e)) : 128; }
-  S = std::min(S, std::max(1, lay / min_chunk));
-  S = std::min(S, std::min(ws_splits, kDecodeMaxSplits));
-  const int chunk = (lay + S - 1) / S;
-  const int chunk32 = (chunk + 31) / 32 * 32;
-  S = (lay + chunk32 - 1) / chunk32;
+  int S, chunk32;
+  gqa_layout(cols, lay, c.n_splits, ws_splits, S, chunk32);
   if (mode < 0 && !gqa_pays(c.batch, c.heads, c.kv_heads, lay, chunk32)) return SPATTEN_ERR_UNSUPPORTED;
   if (S > 1 && (!c.workspace || (size_t)units > c.ws_units)) return SPATTEN_ERR_UNSUPPORTED;
   static int env_poll = -1;
@@ -662,6 +667,17 @@ extern "C" int spatten_debug_set_gqa_trace(unsigned long long* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_gqa_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
 }
 #endif
+
+extern "C" int spatten_decode_gqa_selected(int dtype, int batch, int heads, int kv_heads, int head_dim, int kv_len_layout) {
+  if (dtype != SPATTEN_F16 && dtype != SPATTEN_BF16) return 0;
+  if (batch <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads != 0 || heads == kv_heads || heads / kv_heads > 32) return 0;
+  if (head_dim != 128 || kv_len_layout <= 0 || (int64_t)kv_len_layout * 256 >= 0x7FFFFFFFll) return 0;
+  const int mode = spatten::gqa_mode();
+  if (mode >= 0) return mode;
+  int S, chunk32;
+  spatten::gqa_layout(batch * kv_heads, kv_len_layout, 0, spatten::kDecodeMaxSplits, S, chunk32);
+  return spatten::gqa_pays(batch, heads, kv_heads, kv_len_layout, chunk32) ? 1 : 0;
+}
 
 extern "C" int spatten_decode_set_gqa(int mode) {
   if (mode < -1 || mode > 1) return SPATTEN_ERR_INVALID;

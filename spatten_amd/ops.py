@@ -601,6 +601,12 @@ def set_decode_gqa(mode: int) -> int:
     return prev - 1
 
 
+def decode_gqa_selected(dtype: torch.dtype, batch: int, heads: int, kv_heads: int, head_dim: int, kv_len_layout: int) -> bool:
+    """Would a plain single-row step of this geometry run in the matrix-core grouped-query form under the current mode
+    (spatten_decode_gqa_selected)?  `kv_len_layout`: the cache length of a static launch / the bound of the device-length form."""
+    return bool(_lib.load().spatten_decode_gqa_selected(_DT.get(dtype, -1), int(batch), int(heads), int(kv_heads), int(head_dim), int(kv_len_layout)))
+
+
 def gemv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``torch.nn.functional.linear(x, weight, bias)`` for single-token rows: x [..., K] with few rows (a decode step),

@@ -148,3 +148,33 @@ def test_decode_team_option_is_a_validated_process_wide_setting():
             ops.set_decode_team(128)
     finally:
         ops.set_decode_team(prev)
+
+
+def test_grouped_query_form_is_selected_by_the_documented_rule():
+    """spatten_decode_gqa_selected (no GPU needed: the rule is host arithmetic on the geometry and the CU count): never for MHA /
+    other head dims / fp32; under the default mode where the cost model says the matrix-core form is faster — monotone in the
+    cache length, earlier for larger groups; forced modes answer for every eligible geometry."""
+    import torch
+    from spatten_amd import ops
+    prev = ops.set_decode_gqa(-1)
+    try:
+        bf = torch.bfloat16
+        assert not ops.decode_gqa_selected(bf, 1, 32, 32, 128, 16384)            # not grouped
+        assert not ops.decode_gqa_selected(bf, 1, 32, 8, 64, 16384)              # head_dim 128 only
+        assert not ops.decode_gqa_selected(torch.float32, 1, 32, 8, 128, 16384)  # 16-bit dtypes only
+        assert not ops.decode_gqa_selected(bf, 1, 32, 8, 128, 1024)              # short cache: one workgroup column per query head
+        assert ops.decode_gqa_selected(bf, 1, 32, 8, 128, 16384)
+        assert ops.decode_gqa_selected(torch.float16, 1, 64, 8, 128, 4096)
+        first = {}
+        for heads in (16, 32, 64):
+            sel = [ops.decode_gqa_selected(bf, 1, heads, 8, 128, n) for n in range(512, 65536 + 1, 512)]
+            assert sel == sorted(sel), heads                                     # once selected, selected for every longer cache
+            first[heads] = sel.index(True)
+        assert first[64] < first[32] < first[16]                                  # a larger group pays earlier
+        assert ops.decode_gqa_selected(bf, 4, 32, 8, 128, 2048)                  # a batch counts like a longer cache
+        ops.set_decode_gqa(0)
+        assert not ops.decode_gqa_selected(bf, 1, 32, 8, 128, 16384)
+        ops.set_decode_gqa(1)
+        assert ops.decode_gqa_selected(bf, 1, 32, 8, 128, 512)
+    finally:
+        ops.set_decode_gqa(prev)

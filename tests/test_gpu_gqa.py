@@ -156,3 +156,25 @@ def test_gqa_mfma_at_16384_rows_32_over_8_heads():
             check_stash(st, stash, dt)
     finally:
         ops.set_decode_gqa(prev)
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 8, 1500), (1, 32, 8, 6000), (1, 64, 8, 2500), (2, 16, 8, 3000)])
+def test_the_query_entry_point_names_the_form_the_default_mode_launches(shape):
+    """ops.decode_gqa_selected (spatten_decode_gqa_selected) against the dispatch itself: the default mode's output must be the FORCED
+    output of the form the query names, bit for bit (the two forms differ in their low bits), and not the other one's."""
+    from spatten_amd import ops
+    B, H, Hkv, P = shape
+    dt, d = "bf16", 128
+    q, k, v, past = attn_inputs(B, H, Hkv, d, P, 1, dt, seed=31 + P)
+    prev = ops.set_decode_gqa(-1)
+    try:
+        picked = ops.decode_gqa_selected(TORCH_DT[dt], B, H, Hkv, d, P + 1)
+        default = run_decode(q, k, v, past, dt)[0]
+        ops.set_decode_gqa(1)
+        mfma = run_decode(q, k, v, past, dt)[0]
+        ops.set_decode_gqa(0)
+        per_head = run_decode(q, k, v, past, dt)[0]
+    finally:
+        ops.set_decode_gqa(prev)
+    assert not np.array_equal(mfma, per_head)              # (else the test could not tell them apart)
+    assert np.array_equal(default, mfma if picked else per_head), (shape, picked)
