@@ -178,3 +178,24 @@ def test_the_query_entry_point_names_the_form_the_default_mode_launches(shape):
         ops.set_decode_gqa(prev)
     assert not np.array_equal(mfma, per_head)              # (else the test could not tell them apart)
     assert np.array_equal(default, mfma if picked else per_head), (shape, picked)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_gqa_mfma_random_configs(gqa_forced, seed):
+    """Seeded sweep of the matrix-core form against the oracle: group sizes that are not powers of two, batches, lengths that align
+    with no tile, wave or split boundary, forced split counts (incl. more splits than the workspace default merges in one round)."""
+    rng = np.random.default_rng(4000 + seed)
+    dt = str(rng.choice(["bf16", "f16"]))
+    Hkv = int(rng.choice([1, 2, 3, 8]))
+    G = int(rng.choice([2, 3, 4, 7, 8, 16]))
+    B = int(rng.choice([1, 2, 3]))
+    P = int(rng.integers(0, 5000))
+    q, k, v, past = attn_inputs(B, G * Hkv, Hkv, 128, P, 1, dt, seed=6000 + seed)
+    o, stash, (kc, vc) = orc.attention_core(q, k, v, None if past is None else past[0], None if past is None else past[1],
+                                            np.full((B, 1), P), None, dt)
+    splits = int(rng.choice([0, 0, 1, 2, 5, 11, 33]))
+    out, st, kc_g, vc_g, _ = run_decode(q, k, v, past, dt, n_splits=splits)
+    msg = f"{dt} H{G * Hkv}/{Hkv} B{B} P{P} S{splits}"
+    np.testing.assert_allclose(out, o, err_msg=msg, **OUT_TOL[dt])
+    check_stash(st, stash, dt, msg)
+    assert np.array_equal(kc_g, kc) and np.array_equal(vc_g, vc), msg
