@@ -91,6 +91,55 @@ def test_head_parallel_world2_gloo():
     assert dict(ret) == {0: 1, 1: 1}
 
 
+def _worker_c5(rank, world, port, ret):
+    """BASELINE.json configs[4] partition on EIGHT ranks: 40 heads, 5 per rank, cascade head pruning to 30 with static ownership —
+    the per-rank head lists `bench.py --config c5 --gpus 8` launches — plus the gather layout at world 8."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from spatten_amd.parallel import HeadParallel
+        B, H, d, P, dt = 1, 40, 16, 37, "f32"
+        q = orc.synth_normal(15, 0, (B, H, 1, d), dt)
+        k = orc.synth_normal(15, 1, (B, H, 1, d), dt)
+        v = orc.synth_normal(15, 2, (B, H, 1, d), dt)
+        pk = orc.synth_normal(15, 3, (B, H, P, d), dt)
+        pv = orc.synth_normal(15, 4, (B, H, P, d), dt)
+        pos = np.full((B, 1), P)
+        full_o, _, _ = orc.attention_core(q, k, v, pk, pv, pos, None, dt)
+        hp = HeadParallel(H)
+        assert hp.world == world == 8 and hp.local_heads == 5
+        lo, hi = hp.head_range()
+        assert (lo, hi) == (5 * rank, 5 * rank + 5)
+        sh = lambda x: x[:, lo:hi]
+        o_loc, _, _ = orc.attention_core(sh(q), sh(k), sh(v), sh(pk), sh(pv), pos, None, dt)
+        full, _ = hp.gather_heads(torch.from_numpy(o_loc))
+        np.testing.assert_allclose(full.numpy(), full_o, rtol=1e-5, atol=1e-6)          # rank-major = head-major
+        # head scores of three layers, pruned 40 -> 30 -> 30 -> 24 (cumulative: a pruned head stays pruned)
+        rng = np.random.default_rng(7)
+        sc_full = rng.random((3, H)).astype(np.float32)
+        keep = [30, 30, 24]
+        want = orc.head_prune_cascade(list(sc_full), keep)
+        got = hp.surviving_local_heads(torch.from_numpy(sc_full[:, lo:hi].copy()), keep)
+        counts = []
+        for l in range(3):
+            mine = [int(h) - lo for h in want[l] if lo <= h < hi]
+            assert got[l].tolist() == mine, (rank, l, got[l].tolist(), mine)
+            counts.append(len(mine))
+        tot = torch.tensor(counts)
+        dist.all_reduce(tot)
+        assert tot.tolist() == keep                                                       # every survivor has exactly one owner
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_head_parallel_world8_c5_partition_gloo():
+    world, port = 8, _free_port()
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_worker_c5, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: 1 for r in range(8)}
+
+
 def _plugin_worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
